@@ -1,0 +1,122 @@
+"""ctypes binding of libabr_iod_hip.so (C ABI declared in include/abr_iod_hip.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every op on the hot path is a HIP kernel
+behind the C ABI.  There is NO fallback: if the library is missing or a call fails this raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libabr_iod_hip.so")
+
+NCHW, NHWC = 0, 1
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+
+class ConvDesc(C.Structure):
+    """abr_conv_desc (include/abr_iod_hip.h section 3)."""
+
+    _fields_ = [
+        ("B", _i), ("H", _i), ("W", _i), ("Cin", _i),
+        ("Cout", _i), ("R", _i), ("S", _i),
+        ("stride", _i), ("pad", _i),
+        ("Ho", _i), ("Wo", _i),
+        ("scale", _vp), ("bias", _vp), ("residual", _vp), ("mask", _vp),
+        ("relu", _i),
+        ("out_H", _i), ("out_W", _i), ("out_sh", _i), ("out_sw", _i),
+    ]
+
+
+_SIGS = {
+    "abr_version": (_i, []),
+    "abr_device_info": (_i, [_vp]),
+    "abr_roi_align_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp]),
+    "abr_roi_align_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "abr_roi_align_taps": (_i, [_vp, _i, _i, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "abr_nms_workspace_bytes": (_i64, [_i, _i]),
+    "abr_nms_sorted_batched": (_i, [_vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _i64, _vp]),
+    "abr_sigmoid_focal_forward": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    "abr_sigmoid_focal_backward": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    "abr_ard_forward": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "abr_ard_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp]),
+    "abr_smooth_l1": (_i, [_vp, _vp, _i64, _f, _f, _vp, _f, _vp, _vp]),
+    "abr_smooth_l1_rows": (_i, [_vp, _i, _vp, _vp, _vp, _i, _f, _f, _vp, _f, _vp, _vp]),
+    "abr_softmax_ce": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp]),
+    "abr_roi_distill": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp]),
+    "abr_bce_logits_gather": (_i, [_vp, _vp, _vp, _i, _vp, _f, _vp, _vp]),
+    "abr_conv_forward": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "abr_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "abr_conv_dgrad_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "abr_bias_grad": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "abr_nchw_to_nhwc_pad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "abr_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "abr_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "abr_maxpool3x3s2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "abr_avgpool_forward": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "abr_avgpool_backward": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "abr_relu_backward": (_i, [_vp, _vp, _i64, _vp]),
+    "abr_add_inplace": (_i, [_vp, _vp, _i64, _vp]),
+    "abr_grid_anchors": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "abr_rpn_decode_clip": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _f, _f, _f, _f, _vp, _vp]),
+    "abr_match_workspace_bytes": (_i64, [_i, _i]),
+    "abr_match_encode": (_i, [_vp, _i, _vp, _vp, _i, _vp, _f, _f, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "abr_sgd_momentum": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _f, _i, _vp]),
+}
+
+# every symbol include/abr_iod_hip.h declares (tests/test_abi.py checks the library exports them all)
+EXPORTS = sorted(list(_SIGS) + ["abr_last_error"])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  abr_iod_amd has no CPU/eager fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        L.abr_last_error.restype = C.c_char_p
+        L.abr_last_error.argtypes = []
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().abr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"abr_iod_hip {what} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("abr_iod_amd ops need device tensors (MI355X); there is no CPU path — "
+                               "the CPU oracle lives in oracle/ and is test infrastructure only")
+
+
+def f32c(t):
+    """contiguous fp32 view/copy (the reference kernels call .contiguous() too, ROIAlign_cuda.cu:286)."""
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()

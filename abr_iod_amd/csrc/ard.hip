@@ -1,0 +1,181 @@
+// Attentive RoI Distillation (ARD) loss, fused.
+//
+// Reference: maskrcnn_benchmark/distillation/distillation.py:86-130, called as
+//   calculate_attentive_roi_feature_distillation(roi_align_features_source, roi_align_features_target, gamma)
+// (tools/train_incremental.py:115).  With F_s = source (frozen), F_t = target, per RoI n:
+//   m_x[hw] = mean_c F_x^2 ;  A_x = HW * softmax_hw(m_x)              (activation_at, :121-130; temp unused)
+//   pad = mean_{n,hw} |A_t - A_s|                                      (pad_loss, :114-118)
+//   afd = mean_{n,c,hw} (F_s*sqrt(A_s) - F_t*sqrt(A_s))^2 = mean A_s * (F_s - F_t)^2     (afd_loss, :103-111)
+//   loss = afd + gamma * pad ; gradient only into F_t (source runs under no_grad, train_incremental.py:83).
+// The reference runs ~12 ATen kernels making 3+ passes over both [64B,1024,7,7] maps.  Here:
+//   forward  = ONE pass: each wave owns HW positions, lanes stride the channel axis with 16 B loads and
+//              reduce {sum F_s^2, sum F_t^2, sum (F_s-F_t)^2} with wavefront shuffles; wave 0 then does the
+//              two 49-way softmaxes in registers and emits the per-position coefficients the backward needs;
+//   backward = ONE elementwise pass: g = -2 A_s (F_s-F_t)/(N C HW) + gamma * dPad/dm_t * 2 F_t / C.
+// Bound: HBM.  Algorithmic bytes: fwd reads both maps (25.7 MB/img), bwd re-reads both + writes one (38.5 MB/img).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxHW = 1024;
+
+// element (n, hw, c) at base + hw*sHW + c*sC
+template <bool VEC4>
+__global__ __launch_bounds__(256) void ard_fwd_kernel(const float* __restrict__ f_src, const float* __restrict__ f_tgt,
+                                                       int N, int C, int HW, int sHW, int sC, float gamma,
+                                                       float* __restrict__ coef, float* __restrict__ loss_out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // ms[HW], mt[HW], d2[HW], red[8]
+    float* ms = sm;
+    float* mt = sm + HW;
+    float* d2 = sm + 2 * HW;
+    const int n = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* ps = f_src + (size_t)n * HW * C;
+    const float* pt = f_tgt + (size_t)n * HW * C;
+    for (int hw = wave; hw < HW; hw += 4) {
+        float a = 0.f, b = 0.f, d = 0.f;
+        if (VEC4) {
+            const float4* rs = reinterpret_cast<const float4*>(ps + (size_t)hw * sHW);
+            const float4* rt = reinterpret_cast<const float4*>(pt + (size_t)hw * sHW);
+            for (int c = lane; c < C / 4; c += 64) {
+                const float4 s = rs[c], t = rt[c];
+                a += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+                b += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+                const float e0 = s.x - t.x, e1 = s.y - t.y, e2 = s.z - t.z, e3 = s.w - t.w;
+                d += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+            }
+        } else {
+            for (int c = lane; c < C; c += 64) {
+                const float s = ps[(size_t)hw * sHW + (size_t)c * sC], t = pt[(size_t)hw * sHW + (size_t)c * sC];
+                a += s * s;
+                b += t * t;
+                d += (s - t) * (s - t);
+            }
+        }
+        a = abr::wave_sum(a);
+        b = abr::wave_sum(b);
+        d = abr::wave_sum(d);
+        if (lane == 0) { ms[hw] = a / (float)C; mt[hw] = b / (float)C; d2[hw] = d; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float mxs = -INFINITY, mxt = -INFINITY;
+        for (int j = lane; j < HW; j += 64) { mxs = fmaxf(mxs, ms[j]); mxt = fmaxf(mxt, mt[j]); }
+        mxs = abr::wave_max(mxs);
+        mxt = abr::wave_max(mxt);
+        float ses = 0.f, set = 0.f;
+        for (int j = lane; j < HW; j += 64) { ses += expf(ms[j] - mxs); set += expf(mt[j] - mxt); }
+        ses = abr::wave_sum(ses);
+        set = abr::wave_sum(set);
+        float afd = 0.f, pad = 0.f, S = 0.f;
+        for (int j = lane; j < HW; j += 64) {
+            const float as = (float)HW * (expf(ms[j] - mxs) / ses);
+            const float at = (float)HW * (expf(mt[j] - mxt) / set);
+            const float df = at - as;
+            const float sg = (df > 0.f) - (df < 0.f);
+            afd += as * d2[j];
+            pad += fabsf(df);
+            S += sg * at;
+            ms[j] = as;   // reuse LDS: A_s
+            mt[j] = at;   //            A_t
+            d2[j] = sg;   //            sign
+        }
+        afd = abr::wave_sum(afd);
+        pad = abr::wave_sum(pad);
+        S = abr::wave_sum(S);
+        float* co = coef + (size_t)n * 2 * HW;
+        for (int j = lane; j < HW; j += 64) {
+            co[j] = ms[j];                                   // A_s[hw]
+            co[HW + j] = mt[j] * (d2[j] - S / (float)HW);    // d(sum_i |A_t-A_s|)/d m_t[hw]
+        }
+        if (lane == 0) {
+            const float afd_n = afd / ((float)N * (float)C * (float)HW);
+            const float pad_n = pad / ((float)N * (float)HW);
+            atomicAdd(loss_out + 1, afd_n);
+            atomicAdd(loss_out + 2, pad_n);
+            atomicAdd(loss_out + 0, afd_n + gamma * pad_n);
+        }
+    }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void ard_bwd_kernel(const float* __restrict__ f_src, const float* __restrict__ f_tgt,
+                                                       const float* __restrict__ coef, int N, int C, int HW, int sHW, int sC,
+                                                       float gamma, float gscale, const float* __restrict__ gscale_dev,
+                                                       float* __restrict__ grad) {
+    const float g = gscale * (gscale_dev ? *gscale_dev : 1.f);
+    const float k_afd = -2.f * g / ((float)N * (float)C * (float)HW);
+    const float k_pad = 2.f * g * gamma / ((float)N * (float)HW * (float)C);
+    if (VEC4) {
+        const int cv = C / 4;
+        const int64_t total = (int64_t)N * HW * cv;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t row = i / cv;  // n*HW + hw
+            const int n = row / HW, hw = row % HW;
+            const float as = coef[(size_t)n * 2 * HW + hw], dm = coef[(size_t)n * 2 * HW + HW + hw];
+            const float4 s = reinterpret_cast<const float4*>(f_src)[i];
+            const float4 t = reinterpret_cast<const float4*>(f_tgt)[i];
+            const float ka = k_afd * as, kp = k_pad * dm;
+            float4 o;
+            o.x = ka * (s.x - t.x) + kp * t.x;
+            o.y = ka * (s.y - t.y) + kp * t.y;
+            o.z = ka * (s.z - t.z) + kp * t.z;
+            o.w = ka * (s.w - t.w) + kp * t.w;
+            reinterpret_cast<float4*>(grad)[i] = o;
+        }
+    } else {
+        const int64_t total = (int64_t)N * HW * C;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            // i enumerates memory order; recover (n, hw) from strides (sHW==1 => NCHW, sC==1 => NHWC)
+            const int64_t n = i / ((int64_t)HW * C), r = i % ((int64_t)HW * C);
+            const int hw = sC == 1 ? r / C : r % HW;
+            const float as = coef[(size_t)n * 2 * HW + hw], dm = coef[(size_t)n * 2 * HW + HW + hw];
+            const float s = f_src[i], t = f_tgt[i];
+            grad[i] = k_afd * as * (s - t) + k_pad * dm * t;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int abr_ard_forward(const float* f_src, const float* f_tgt, int N, int C, int HW, float gamma, int layout,
+                               float* coef, float* loss_out, void* stream) {
+    ABR_REQUIRE(N >= 0 && C > 0 && HW > 0 && HW <= kMaxHW, "ard_forward: bad shape (HW<=1024)");
+    ABR_REQUIRE(layout == ABR_NCHW || layout == ABR_NHWC, "ard_forward: bad layout");
+    ABR_REQUIRE(loss_out, "ard_forward: null loss_out");
+    hipStream_t st = abr::as_stream(stream);
+    if (hipMemsetAsync(loss_out, 0, sizeof(float) * 4, st) != hipSuccess) return ABR_E_LAUNCH;
+    if (N == 0) return ABR_OK;
+    ABR_REQUIRE(f_src && f_tgt && coef, "ard_forward: null pointer");
+    const size_t lds = sizeof(float) * (3 * (size_t)HW + 8);
+    if (layout == ABR_NHWC && C % 4 == 0)
+        ard_fwd_kernel<true><<<N, 256, lds, st>>>(f_src, f_tgt, N, C, HW, C, 1, gamma, coef, loss_out);
+    else if (layout == ABR_NHWC)
+        ard_fwd_kernel<false><<<N, 256, lds, st>>>(f_src, f_tgt, N, C, HW, C, 1, gamma, coef, loss_out);
+    else
+        ard_fwd_kernel<false><<<N, 256, lds, st>>>(f_src, f_tgt, N, C, HW, 1, HW, gamma, coef, loss_out);
+    ABR_CHECK_LAUNCH("ard_forward");
+    return ABR_OK;
+}
+
+extern "C" int abr_ard_backward(const float* f_src, const float* f_tgt, const float* coef, int N, int C, int HW,
+                                float gamma, int layout, float gscale, const float* gscale_dev, float* grad_tgt,
+                                void* stream) {
+    ABR_REQUIRE(N >= 0 && C > 0 && HW > 0 && HW <= kMaxHW, "ard_backward: bad shape");
+    ABR_REQUIRE(layout == ABR_NCHW || layout == ABR_NHWC, "ard_backward: bad layout");
+    if (N == 0) return ABR_OK;
+    ABR_REQUIRE(f_src && f_tgt && coef && grad_tgt, "ard_backward: null pointer");
+    hipStream_t st = abr::as_stream(stream);
+    const int64_t total = (int64_t)N * HW * C;
+    if (layout == ABR_NHWC && C % 4 == 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>((total / 4 + 255) / 256, 2048);
+        ard_bwd_kernel<true><<<grid, 256, 0, st>>>(f_src, f_tgt, coef, N, C, HW, C, 1, gamma, gscale, gscale_dev, grad_tgt);
+    } else {
+        const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+        const int sHW = layout == ABR_NHWC ? C : 1, sC = layout == ABR_NHWC ? 1 : HW;
+        ard_bwd_kernel<false><<<grid, 256, 0, st>>>(f_src, f_tgt, coef, N, C, HW, sHW, sC, gamma, gscale, gscale_dev,
+                                                    grad_tgt);
+    }
+    ABR_CHECK_LAUNCH("ard_backward");
+    return ABR_OK;
+}

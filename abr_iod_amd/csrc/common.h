@@ -1,0 +1,70 @@
+// Shared helpers for libabr_iod_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "abr_iod_hip.h"
+
+namespace abr {
+
+void set_error(const char* fmt, ...);
+
+#define ABR_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::abr::set_error(__VA_ARGS__);     \
+            return ABR_E_INVALID;              \
+        }                                      \
+    } while (0)
+
+#define ABR_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            ::abr::set_error("%s: launch failed: %s", name, hipGetErrorString(e__));  \
+            return ABR_E_LAUNCH;                                                      \
+        }                                                                             \
+    } while (0)
+
+constexpr int kWave = 64;
+constexpr int kNumXCD = 8;
+
+// Bijective XCD-aware remap (guide T1): hardware places block b on XCD b % 8; give every XCD a contiguous
+// chunk of the logical tile space so neighbouring tiles share one L2.  Speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk / kNumXCD, r = nblk % kNumXCD;
+    const unsigned xcd = bid % kNumXCD, pos = bid / kNumXCD;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + pos;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x == 64*NW.  `sm` must hold NW floats.  Result valid in every thread.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sm[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; i++) t += sm[i];
+    return t;
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace abr

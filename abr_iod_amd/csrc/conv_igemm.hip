@@ -1,0 +1,325 @@
+// Convolution forward / dgrad as implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, for the reference's hot path, cuDNN conv fwd + dgrad, FrozenBatchNorm2d, ReLU and the residual
+// add (modeling/backbone/resnet.py:327-346,363-368; layers/batch_norm.py:19-31; modeling/rpn/rpn.py:114-121;
+// roi_box_predictors.py:27-32 as a 1x1 conv on a 1x1 map).
+//
+//   out[m, n] = epilogue( sum_k A[m, k] * Wt[n, k] )     m = (b, ho, wo), n = cout, k = (r, s, cin)
+//
+// Layout: activations NHWC, weights OHWI -> BOTH operands are k-contiguous ("TN" GEMM): A rows are gathered
+// straight from the NHWC image (zero-filled halo), weight rows are read as stored.  No im2col buffer.
+// dgrad is the same kernel run on gy with the flipped/transposed weight copy from abr_conv_dgrad_weights;
+// the dgrad of a stride-2 1x1 conv stores its rows at (2ho, 2wo) of a zeroed tensor (out_sh/out_sw).
+//
+// Tiling (gfx950): 256 threads = 4 waves; block tile BM x BN x 32; each wave owns TM x TN accumulators of
+// 32x32 (16 VGPR each).  LDS tiles are [row][36] floats: the +4 pad makes the ds_read_b128 fragment reads
+// conflict-free (16-lane groups land on 16 distinct 16 B slots).  A lane reads 4 consecutive k with one
+// b128 and feeds them to 4 successive MFMAs; the lane-half h supplies k = 8u+4h+t for both operands, so the
+// products match (k order inside a tile is a free permutation).  Global->LDS is register-staged and split
+// (issue loads for tile t+1, run the 16*TM*TN MFMAs of tile t, then write LDS): one barrier per k-tile.
+// fp32 MFMA is bit-for-bit an fmaf chain, so results are exact-fp32 (no TF32/bf16 anywhere).
+// Bound: MFMA (157.3 TFLOP/s fp32 matrix peak); DESIGN.md has the per-layer flop counts.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDP = BK + 4;  // LDS row pitch in floats
+
+struct ConvP {
+    int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
+    int M, K;  // GEMM sizes
+    int out_H, out_W, out_sh, out_sw;
+    int relu, scatter;
+    int tiles_m, tiles_n;
+    const float* scale;
+    const float* bias;
+    const float* residual;
+    const float* mask;
+};
+
+// SMALL_C: Cin is not a multiple of 32 (the 3->4 padded stem): (r,s,c) is derived per 16 B slot.
+template <int BM, int BN, int WM, int WN, bool SMALL_C>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const float* __restrict__ x,
+                                                          const float* __restrict__ w, float* __restrict__ out) {
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int NA = BM / 32, NB = BN / 32;  // float4 staging loads per thread for A and B
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                     // [2][BM][LDP]
+    float* Bs = smem + 2 * BM * LDP;      // [2][BN][LDP]
+
+    const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- staging assignment: slot = tid + 256*i -> (row = slot/8, kq = slot%8)
+    const int kq = tid & 7;
+    const int srow = tid >> 3;  // 0..31 ; rows srow + 32*i
+    int a_hi0[NA], a_wi0[NA];
+    const float* a_base[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int m = m0 + srow + 32 * i;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int b = mm / (p.Ho * p.Wo), rem = mm % (p.Ho * p.Wo);
+        const int ho = rem / p.Wo, wo = rem % p.Wo;
+        a_hi0[i] = ho * p.stride - p.pad;
+        a_wi0[i] = wo * p.stride - p.pad;
+        a_base[i] = x + (size_t)b * p.H * p.W * p.Cin;
+    }
+    const float* b_ptr[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const int n = n0 + srow + 32 * i;
+        b_ok[i] = n < p.Cout;
+        b_ptr[i] = w + (size_t)(b_ok[i] ? n : 0) * p.K + kq * 4;
+    }
+
+    float4 ra[NA], rb[NB];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        if (!SMALL_C) {
+            const int rs = k0 / p.Cin, c0 = k0 % p.Cin;
+            const int r = rs / p.S, s = rs % p.S;
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+                const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
+                const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                ra[i] = ok ? *reinterpret_cast<const float4*>(a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + c0 + kq * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int k = k0 + kq * 4;
+            const int rs = k / p.Cin, c = k % p.Cin;
+            const int r = rs / p.S, s = rs % p.S;
+            const bool kin = k < p.K;
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+                const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
+                const bool ok = kin && a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                ra[i] = ok ? *reinterpret_cast<const float4*>(a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + c)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const bool kin = k0 + kq * 4 < p.K;
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+            rb[i] = (b_ok[i] && kin) ? *reinterpret_cast<const float4*>(b_ptr[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * LDP;
+        float* b = Bs + buf * BN * LDP;
+#pragma unroll
+        for (int i = 0; i < NA; i++) *reinterpret_cast<float4*>(a + (srow + 32 * i) * LDP + kq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; i++) *reinterpret_cast<float4*>(b + (srow + 32 * i) * LDP + kq * 4) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int a_row0 = wm * (TM * 32) + l31, b_row0 = wn * (TN * 32) + l31;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* a = As + cur * BM * LDP + a_row0 * LDP + lh * 4;
+        const float* b = Bs + cur * BN * LDP + b_row0 * LDP + lh * 4;
+#pragma unroll
+        for (int u = 0; u < BK / 8; u++) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDP + u * 8);
+#pragma unroll
+            for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDP + u * 8);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col(n) = lane&31, row(m) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float sc[TN], bi[TN];
+    bool n_ok[TN];
+    int ncol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        ncol[j] = n0 + wn * (TN * 32) + j * 32 + l31;
+        n_ok[j] = ncol[j] < p.Cout;
+        sc[j] = (p.scale && n_ok[j]) ? p.scale[ncol[j]] : 1.f;
+        bi[j] = (p.bias && n_ok[j]) ? p.bias[ncol[j]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= p.M) continue;
+            size_t row_off;
+            if (p.scatter) {
+                const int b = m / (p.Ho * p.Wo), rem = m % (p.Ho * p.Wo);
+                const int ho = rem / p.Wo, wo = rem % p.Wo;
+                row_off = (((size_t)b * p.out_H + (size_t)ho * p.out_sh) * p.out_W + (size_t)wo * p.out_sw) * p.Cout;
+            } else {
+                row_off = (size_t)m * p.Cout;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                if (!n_ok[j]) continue;
+                float v = acc[i][j][r] * sc[j] + bi[j];
+                if (p.residual) v += p.residual[row_off + ncol[j]];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.mask) v = p.mask[row_off + ncol[j]] > 0.f ? v : 0.f;
+                out[row_off + ncol[j]] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool SMALL_C>
+int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
+    ConvP q = p;
+    q.tiles_m = (p.M + BM - 1) / BM;
+    q.tiles_n = (p.Cout + BN - 1) / BN;
+    const size_t lds = sizeof(float) * 2 * (BM + BN) * LDP;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, SMALL_C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    kern<<<(unsigned)(q.tiles_m * q.tiles_n), 256, lds, st>>>(q, x, w, out);
+    return 0;
+}
+
+// (Cout, R*S, Cin) -> (Cin, R*S flipped, Cout), scaled by scale[cout]; 32x32 LDS transpose per (rs) plane.
+__global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                             int Cout, int RS, int Cin, float* __restrict__ wt) {
+    __shared__ float t[32][33];
+    const int rs = blockIdx.z;
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int co = co0 + i, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[((size_t)co * RS + rs) * Cin + ci] * (scale ? scale[co] : 1.f);
+        t[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int ci = ci0 + i, co = co0 + tx;
+        if (ci < Cin && co < Cout) wt[((size_t)ci * RS + (RS - 1 - rs)) * Cout + co] = t[tx][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ gy, int64_t M, int C, int rows_per_block,
+                                                         float* __restrict__ db) {
+    // block = 64 columns x 4 row-lanes; grid.x = column chunks, grid.y = row chunks
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    float acc = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + rl; r < r1; r += 4) acc += gy[r * C + c];
+    __shared__ float sm[4][64];
+    sm[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) atomicAdd(db + c, sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+}  // namespace
+
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int32_t info[3];
+        n = abr_device_info(info) == ABR_OK ? info[0] : 256;
+    }
+    return n;
+}
+
+extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const float* w, float* out, void* stream) {
+    ABR_REQUIRE(d && x && w && out, "conv_forward: null pointer");
+    ABR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->R > 0 && d->S > 0 && d->stride > 0,
+                "conv_forward: bad shape");
+    ABR_REQUIRE(d->Cin % 4 == 0, "conv_forward: Cin must be a multiple of 4 (pad the 3-channel image to 4)");
+    ABR_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->R) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->S) / d->stride + 1,
+                "conv_forward: Ho/Wo inconsistent with H,W,R,S,stride,pad");
+    ConvP p;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.R = d->R; p.S = d->S;
+    p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.M = d->B * d->Ho * d->Wo;
+    p.K = d->R * d->S * d->Cin;
+    p.out_H = d->out_H > 0 ? d->out_H : d->Ho;
+    p.out_W = d->out_W > 0 ? d->out_W : d->Wo;
+    p.out_sh = d->out_sh > 0 ? d->out_sh : 1;
+    p.out_sw = d->out_sw > 0 ? d->out_sw : 1;
+    p.scatter = !(p.out_H == p.Ho && p.out_W == p.Wo && p.out_sh == 1 && p.out_sw == 1);
+    ABR_REQUIRE((p.Ho - 1) * p.out_sh < p.out_H && (p.Wo - 1) * p.out_sw < p.out_W, "conv_forward: scatter out of range");
+    p.relu = d->relu;
+    p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.mask = d->mask;
+    p.tiles_m = p.tiles_n = 0;
+    hipStream_t st = abr::as_stream(stream);
+    const bool small_c = (d->Cin % BK) != 0;
+    // tile choice: biggest tile that still gives >= 2 workgroups per CU; narrow-N layers use BN=64
+    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
+    const int cus = num_cus();
+    if (small_c) {
+        launch<128, 64, 4, 1, true>(p, x, w, out, st);
+    } else if (p.Cout > 64 && t128 >= 2 * cus) {
+        launch<128, 128, 2, 2, false>(p, x, w, out, st);
+    } else if (t12864 >= 2 * cus || p.Cout <= 64) {
+        launch<128, 64, 4, 1, false>(p, x, w, out, st);
+    } else {
+        launch<64, 64, 2, 2, false>(p, x, w, out, st);
+    }
+    ABR_CHECK_LAUNCH("conv_forward");
+    return ABR_OK;
+}
+
+extern "C" int abr_conv_dgrad_weights(const float* w, const float* scale, int Cout, int R, int S, int Cin, float* wt,
+                                      void* stream) {
+    ABR_REQUIRE(w && wt && Cout > 0 && R > 0 && S > 0 && Cin > 0, "conv_dgrad_weights: bad args");
+    dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, R * S);
+    dgrad_weights_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(w, scale, Cout, R * S, Cin, wt);
+    ABR_CHECK_LAUNCH("conv_dgrad_weights");
+    return ABR_OK;
+}
+
+extern "C" int abr_bias_grad(const float* gy, int64_t M, int C, float* db, void* stream) {
+    ABR_REQUIRE(M >= 0 && C > 0 && db, "bias_grad: bad args");
+    if (M == 0) return ABR_OK;
+    ABR_REQUIRE(gy, "bias_grad: null pointer");
+    const int rows_per_block = 256;
+    dim3 grid((C + 63) / 64, (unsigned)((M + rows_per_block - 1) / rows_per_block));
+    bias_grad_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(gy, M, C, rows_per_block, db);
+    ABR_CHECK_LAUNCH("bias_grad");
+    return ABR_OK;
+}

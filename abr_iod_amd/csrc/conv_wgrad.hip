@@ -1,0 +1,182 @@
+// Convolution weight gradient on the fp32 matrix cores.
+//
+//   dW[n, k] += scale[n] * sum_m gy[m, n] * A[m, k]      n = cout, k = (r, s, cin), m = (b, ho, wo)
+//
+// Replaces cuDNN wgrad for the trainable convs of the reference (layer2/3, RPN head, layer4 head,
+// predictor FCs: modeling/backbone/resnet.py:261-323, modeling/rpn/rpn.py:83-85, roi_box_predictors.py:17-19).
+// `scale` is the FrozenBatchNorm2d scale that the forward epilogue applied after the conv
+// (layers/batch_norm.py:27-31), so d/dW of (conv*scale+bias) carries it per output channel.
+//
+// Shape of the problem on this path: the OUTPUT is small (<= 1024 x 9216) and the REDUCTION axis m is huge
+// (9.5k-37k pixels/RoI-cells), the opposite of forward.  So: a workgroup owns a 128(n) x 128(k) tile of dW
+// and a contiguous slice of m (split-M); partial tiles are combined with hardware fp32 atomics
+// (global_atomic_add_f32) straight into the gradient buffer, which also folds in the accumulation over the
+// two RoI passes of one step (512-RoI detection pass + 64-RoI distillation pass share the head weights).
+// Both operands arrive m-major (gy rows, NHWC pixels), i.e. the MFMA's reduction index is the SLOW axis in
+// memory: rows are staged as-is into LDS ([m][128], 512 B coalesced per row) and a lane picks its operand
+// with one ds_read_b64 = two adjacent n (or k) of row m; accumulator tile t then holds n = base + 2i + t.
+// That interleave is undone in the epilogue addressing, so no transpose is ever materialised.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TN_ = 128;  // dW tile rows  (cout)
+constexpr int TK_ = 128;  // dW tile cols  (r,s,cin)
+constexpr int MR = 32;    // m rows per stage
+
+struct WgP {
+    int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
+    int M, K;
+    int tiles_n, tiles_k, splits, mt_per_split;
+    int plain;  // 1x1, stride 1, pad 0: A row m is x + m*Cin
+    const float* scale;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const float* __restrict__ x,
+                                                          const float* __restrict__ gy, float* __restrict__ dw) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Gs = smem;                    // [2][MR][TN_]
+    float* As = smem + 2 * MR * TN_;     // [2][MR][TK_]
+
+    const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
+    const int split = bid % p.splits;
+    const int tile = bid / p.splits;
+    const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
+    const int n0 = tile_n * TN_, k0 = tile_k * TK_;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;  // wave tile: n in [wm*64, +64), k in [wn*64, +64)
+
+    // staging: slot = tid + 256*i -> row = tid/32 + 8*i, q = tid%32 (16 B column group)
+    const int q = tid & 31, r8 = tid >> 5;
+    const int gn = n0 + q * 4;
+    const bool g_ok = gn < p.Cout;  // Cout % 4 == 0
+    const int ak = k0 + q * 4;
+    const bool k_ok = ak < p.K;
+    int fr = 0, fs = 0, fc = 0;
+    if (k_ok) {
+        const int rs = ak / p.Cin;
+        fc = ak % p.Cin;
+        fr = rs / p.S;
+        fs = rs % p.S;
+    }
+    const int mt0 = split * p.mt_per_split;
+    const int mt1 = min(mt0 + p.mt_per_split, (p.M + MR - 1) / MR);
+
+    float4 rg[4], ra[4];
+    auto load_tile = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = mt * MR + r8 + 8 * i;
+            const bool m_ok = m < p.M;
+            rg[i] = (m_ok && g_ok) ? *reinterpret_cast<const float4*>(gy + (size_t)m * p.Cout + gn)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.plain) {
+                ra[i] = (m_ok && k_ok) ? *reinterpret_cast<const float4*>(x + (size_t)m * p.Cin + fc)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int mm = m_ok ? m : 0;
+                const int b = mm / (p.Ho * p.Wo), rem = mm % (p.Ho * p.Wo);
+                const int hi = (rem / p.Wo) * p.stride - p.pad + fr, wi = (rem % p.Wo) * p.stride - p.pad + fs;
+                const bool ok = m_ok && k_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                ra[i] = ok ? *reinterpret_cast<const float4*>(x + (((size_t)b * p.H + hi) * p.W + wi) * p.Cin + fc)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            *reinterpret_cast<float4*>(Gs + (buf * MR + r8 + 8 * i) * TN_ + q * 4) = rg[i];
+            *reinterpret_cast<float4*>(As + (buf * MR + r8 + 8 * i) * TK_ + q * 4) = ra[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (mt0 < mt1) {
+        load_tile(mt0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int mt = mt0; mt < mt1; mt++) {
+        const int cur = (mt - mt0) & 1;
+        if (mt + 1 < mt1) load_tile(mt + 1);
+        const float* g = Gs + cur * MR * TN_ + wm * 64 + 2 * l31;
+        const float* a = As + cur * MR * TK_ + wn * 64 + 2 * l31;
+#pragma unroll
+        for (int s = 0; s < MR / 2; s++) {
+            const float2 fg = *reinterpret_cast<const float2*>(g + (2 * s + lh) * TN_);
+            const float2 fa = *reinterpret_cast<const float2*>(a + (2 * s + lh) * TK_);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg.x, fa.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg.x, fa.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg.y, fa.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg.y, fa.y, acc[1][1], 0, 0, 0);
+        }
+        if (mt + 1 < mt1) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: tile (tm,tn) element (row i, col j) is dW[n0 + wm*64 + 2i + tm][k0 + wn*64 + 2j + tn]
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int n = n0 + wm * 64 + 2 * i + tm;
+            if (n >= p.Cout) continue;
+            const float sc = p.scale ? p.scale[n] : 1.f;
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) {
+                const int k = k0 + wn * 64 + 2 * l31 + tn;
+                if (k < p.K) unsafeAtomicAdd(dw + (size_t)n * p.K + k, acc[tm][tn][r] * sc);
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const float* gy, float* dw, void* stream) {
+    ABR_REQUIRE(d && x && gy && dw, "conv_wgrad: null pointer");
+    ABR_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "conv_wgrad: Cin and Cout must be multiples of 4");
+    ABR_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->R) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->S) / d->stride + 1,
+                "conv_wgrad: Ho/Wo inconsistent");
+    WgP p;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.R = d->R; p.S = d->S;
+    p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.M = d->B * d->Ho * d->Wo;
+    p.K = d->R * d->S * d->Cin;
+    p.plain = (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0);
+    p.scale = d->scale;
+    p.tiles_n = (p.Cout + TN_ - 1) / TN_;
+    p.tiles_k = (p.K + TK_ - 1) / TK_;
+    if (p.M == 0) return ABR_OK;
+    const int m_tiles = (p.M + MR - 1) / MR;
+    int32_t info[3];
+    const int cus = abr_device_info(info) == ABR_OK ? info[0] : 256;
+    const int tiles = p.tiles_n * p.tiles_k;
+    int splits = (3 * cus + tiles - 1) / tiles;
+    const int max_splits = (m_tiles + 7) / 8;  // at least 8 stages (256 rows) per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.splits = splits;
+    p.mt_per_split = (m_tiles + splits - 1) / splits;
+    const size_t lds = sizeof(float) * 2 * MR * (TN_ + TK_);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        attr_set = true;
+    }
+    conv_wgrad_kernel<<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
+    ABR_CHECK_LAUNCH("conv_wgrad");
+    return ABR_OK;
+}

@@ -1,0 +1,216 @@
+// Layout transforms, pooling, ReLU backward and the fused multi-tensor SGD step (all HBM-bound).
+#include "common.h"
+
+namespace {
+
+// [B,C,H,W] -> [B,H,W,Cpad] (extra channels zero).  Tiled through LDS so both sides are coalesced.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int C, int HW, int Cpad,
+                                                            float* __restrict__ out) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        t[i][tx] = (c < C && p < HW) ? x[((size_t)b * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        if (p < HW && c < Cpad) out[((size_t)b * HW + p) * Cpad + c] = t[tx][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, int C, int HW, float* __restrict__ out) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        t[i][tx] = (c < C && p < HW) ? x[((size_t)b * HW + p) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        if (p < HW && c < C) out[((size_t)b * C + c) * HW + p] = t[tx][i];
+    }
+}
+
+// max_pool2d(kernel 3, stride 2, padding 1) NHWC, 16 B per lane along C  (resnet.py:367)
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, int B, int H, int W, int C, int Ho, int Wo,
+                                                       float* __restrict__ out) {
+    const int cv = C / 4;
+    const int64_t total = (int64_t)B * Ho * Wo * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = i % cv;
+        const int64_t pix = i / cv;
+        const int wo = pix % Wo, ho = (pix / Wo) % Ho, b = pix / ((int64_t)Wo * Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            const int hi = ho * 2 - 1 + dy;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                const int wi = wo * 2 - 1 + dx;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 v = reinterpret_cast<const float4*>(x)[(((size_t)b * H + hi) * W + wi) * cv + c];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        reinterpret_cast<float4*>(out)[i] = m;
+    }
+}
+
+// x [N,HW,C] -> out [N,C] mean over HW
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, int64_t N, int HW, int C,
+                                                           float* __restrict__ out) {
+    const int cv = C / 4;
+    const int64_t total = N * cv;
+    const float inv = 1.f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / cv;
+        const int c = i % cv;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < HW; p++) {
+            const float4 v = reinterpret_cast<const float4*>(x)[(n * HW + p) * cv + c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+        reinterpret_cast<float4*>(out)[i] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ g, int64_t N, int HW, int C,
+                                                           float* __restrict__ gx) {
+    const int cv = C / 4;
+    const int64_t total = N * HW * cv;
+    const float inv = 1.f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = i % cv;
+        const int64_t n = i / ((int64_t)HW * cv);
+        float4 v = reinterpret_cast<const float4*>(g)[n * cv + c];
+        v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        reinterpret_cast<float4*>(gx)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, int64_t n4, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 gv = reinterpret_cast<float4*>(g)[i];
+        const float4 yv = reinterpret_cast<const float4*>(y)[i];
+        gv.x = yv.x > 0.f ? gv.x : 0.f; gv.y = yv.y > 0.f ? gv.y : 0.f;
+        gv.z = yv.z > 0.f ? gv.z : 0.f; gv.w = yv.w > 0.f ? gv.w : 0.f;
+        reinterpret_cast<float4*>(g)[i] = gv;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) g[i] = y[i] > 0.f ? g[i] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n4, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 av = reinterpret_cast<float4*>(a)[i];
+        const float4 bv = reinterpret_cast<const float4*>(b)[i];
+        av.x += bv.x; av.y += bv.y; av.z += bv.z; av.w += bv.w;
+        reinterpret_cast<float4*>(a)[i] = av;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) a[i] += b[i];
+}
+
+// Fused SGD(momentum) over ALL tensors in one launch.  Reference: one param group PER TENSOR
+// (solver/build.py:7-21) -> 52 x (wd add, momentum mul/add, update) tiny launches; here one streaming pass:
+// reads p,g,m and writes p,m = 5 x 4 B per element.  torch.optim.SGD semantics (dampening 0, no nesterov):
+//   d = g + wd*p ; m = first ? d : mu*m + d ; p -= lr*m.
+// seg_end is ascending; a thread finds its tensor by binary search over <= a few hundred segments.
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   int64_t total, const int64_t* __restrict__ seg_end,
+                                                   const float* __restrict__ lr, const float* __restrict__ wd, int n_seg,
+                                                   float mu, float gscale, int first) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_seg - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (i < seg_end[mid]) hi = mid; else lo = mid + 1;
+        }
+        const float pv = p[i];
+        const float d = g[i] * gscale + wd[lo] * pv;
+        const float mv = first ? d : mu * m[i] + d;
+        m[i] = mv;
+        p[i] = pv - lr[lo] * mv;
+    }
+}
+
+}  // namespace
+
+extern "C" int abr_nchw_to_nhwc_pad(const float* x, int B, int C, int H, int W, int Cpad, float* out, void* stream) {
+    ABR_REQUIRE(x && out && B > 0 && C > 0 && Cpad >= C, "nchw_to_nhwc_pad: bad args");
+    dim3 grid((H * W + 31) / 32, (Cpad + 31) / 32, B);
+    nchw_to_nhwc_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(x, C, H * W, Cpad, out);
+    ABR_CHECK_LAUNCH("nchw_to_nhwc_pad");
+    return ABR_OK;
+}
+extern "C" int abr_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* out, void* stream) {
+    return abr_nchw_to_nhwc_pad(x, B, C, H, W, C, out, stream);
+}
+extern "C" int abr_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* out, void* stream) {
+    ABR_REQUIRE(x && out && B > 0 && C > 0, "nhwc_to_nchw: bad args");
+    dim3 grid((H * W + 31) / 32, (C + 31) / 32, B);
+    nhwc_to_nchw_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(x, C, H * W, out);
+    ABR_CHECK_LAUNCH("nhwc_to_nchw");
+    return ABR_OK;
+}
+
+extern "C" int abr_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* out, void* stream) {
+    ABR_REQUIRE(x && out && C % 4 == 0, "maxpool3x3s2: bad args (C % 4 == 0)");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+    maxpool_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 16384), 256, 0, abr::as_stream(stream)>>>(x, B, H, W, C,
+                                                                                                                  Ho, Wo, out);
+    ABR_CHECK_LAUNCH("maxpool3x3s2");
+    return ABR_OK;
+}
+
+extern "C" int abr_avgpool_forward(const float* x, int N, int HW, int C, float* out, void* stream) {
+    ABR_REQUIRE(N >= 0 && HW > 0 && C % 4 == 0, "avgpool_forward: bad args");
+    if (N == 0) return ABR_OK;
+    const int64_t total = (int64_t)N * (C / 4);
+    avgpool_fwd_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 8192), 256, 0, abr::as_stream(stream)>>>(x, N, HW, C, out);
+    ABR_CHECK_LAUNCH("avgpool_forward");
+    return ABR_OK;
+}
+extern "C" int abr_avgpool_backward(const float* g, int N, int HW, int C, float* gx, void* stream) {
+    ABR_REQUIRE(N >= 0 && HW > 0 && C % 4 == 0, "avgpool_backward: bad args");
+    if (N == 0) return ABR_OK;
+    const int64_t total = (int64_t)N * HW * (C / 4);
+    avgpool_bwd_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 8192), 256, 0, abr::as_stream(stream)>>>(g, N, HW, C, gx);
+    ABR_CHECK_LAUNCH("avgpool_backward");
+    return ABR_OK;
+}
+
+extern "C" int abr_relu_backward(float* g, const float* y, int64_t n, void* stream) {
+    if (n == 0) return ABR_OK;
+    ABR_REQUIRE(g && y && n > 0, "relu_backward: bad args");
+    relu_bwd_kernel<<<(unsigned)std::min<int64_t>((n / 4 + 255) / 256 + 1, 8192), 256, 0, abr::as_stream(stream)>>>(g, y, n / 4, n);
+    ABR_CHECK_LAUNCH("relu_backward");
+    return ABR_OK;
+}
+extern "C" int abr_add_inplace(float* a, const float* b, int64_t n, void* stream) {
+    if (n == 0) return ABR_OK;
+    ABR_REQUIRE(a && b && n > 0, "add_inplace: bad args");
+    add_kernel<<<(unsigned)std::min<int64_t>((n / 4 + 255) / 256 + 1, 8192), 256, 0, abr::as_stream(stream)>>>(a, b, n / 4, n);
+    ABR_CHECK_LAUNCH("add_inplace");
+    return ABR_OK;
+}
+
+extern "C" int abr_sgd_momentum(float* p, const float* g, float* m, int64_t total, const int64_t* seg_end_dev,
+                                const float* lr_dev, const float* wd_dev, int n_seg, float momentum, float gscale,
+                                int first_step, void* stream) {
+    if (total == 0) return ABR_OK;
+    ABR_REQUIRE(p && g && m && seg_end_dev && lr_dev && wd_dev && n_seg > 0, "sgd_momentum: bad args");
+    sgd_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, abr::as_stream(stream)>>>(
+        p, g, m, total, seg_end_dev, lr_dev, wd_dev, n_seg, momentum, gscale, first_step);
+    ABR_CHECK_LAUNCH("sgd_momentum");
+    return ABR_OK;
+}

@@ -1,0 +1,366 @@
+// Detector + RoI-distillation losses: forward value and gradient in one launch each.
+// In the reference each of these is a chain of 5-15 small ATen kernels plus autograd; here the scalar and
+// the gradient (for a known upstream scale) come out of a single pass over the logits.
+#include <float.h>
+
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Sigmoid focal loss -- csrc/cuda/SigmoidFocalLoss_cuda.cu:20-101 (sub-expressions with `1.` literals are
+// evaluated in double there; kept so, it is elementwise and fp64 is cheap on CDNA4).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void focal_fwd(const float* __restrict__ logits, const int32_t* __restrict__ targets,
+                                                  int64_t total, int C, float gamma, float alpha,
+                                                  float* __restrict__ losses) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = i / C, d = i % C, t = targets[n];
+        const float c1 = (t == d + 1), c2 = (t >= 0) & (t != d + 1);
+        const float zn = (float)(1.0 - alpha), zp = alpha, x = logits[i];
+        const float p = (float)(1. / (1. + expf(-x)));
+        const float term1 = (float)(powf((float)(1. - p), gamma) * logf(fmaxf(p, FLT_MIN)));
+        const float term2 =
+            (float)(powf(p, gamma) * (-1. * x * (x >= 0) - logf((float)(1. + expf((float)(x - 2. * x * (x >= 0)))))));
+        float l = 0.f;
+        l += -c1 * term1 * zp;
+        l += -c2 * term2 * zn;
+        losses[i] = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void focal_bwd(const float* __restrict__ logits, const int32_t* __restrict__ targets,
+                                                  const float* __restrict__ d_losses, int64_t total, int C, float gamma,
+                                                  float alpha, float* __restrict__ d_logits) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = i / C, d = i % C, t = targets[n];
+        const float c1 = (t == d + 1), c2 = (t >= 0) & (t != d + 1);
+        const float zn = (float)(1.0 - alpha), zp = alpha, x = logits[i];
+        const float p = (float)(1. / (1. + expf(-x)));
+        const float term1 = (float)(powf((float)(1. - p), gamma) * (1. - p - (p * gamma * logf(fmaxf(p, FLT_MIN)))));
+        const float term2 = (float)(powf(p, gamma) *
+                                    ((-1. * x * (x >= 0) - logf((float)(1. + expf((float)(x - 2. * x * (x >= 0)))))) *
+                                         (1. - p) * gamma - p));
+        float g = 0.f;
+        g += -c1 * term1 * zp;
+        g += -c2 * term2 * zn;
+        d_logits[i] = g * d_losses[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// smooth L1 -- layers/smooth_l1_loss.py:6-17
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sl1(float d, float beta, float* g) {
+    const float a = fabsf(d);
+    if (a < beta) { *g = d / beta; return 0.5f * a * a / beta; }
+    *g = d > 0.f ? 1.f : -1.f;
+    return a - 0.5f * beta;
+}
+
+__global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t n,
+                                                         float beta, float scale, float* __restrict__ loss_out,
+                                                         float gscale, float* __restrict__ grad) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float g;
+        acc += sl1(x[i] - t[i], beta, &g);
+        if (grad) grad[i] = g * gscale * scale;
+    }
+    acc = abr::block_sum<4>(acc, sm);
+    if (threadIdx.x == 0) atomicAdd(loss_out, acc * scale);
+}
+
+// x row r=rows[i], columns col0[i]..col0[i]+3  vs  t row r (t is [*,4], indexed by the same r)
+__global__ __launch_bounds__(256) void smooth_l1_rows_kernel(const float* __restrict__ x, int x_cols,
+                                                              const float* __restrict__ t, const int64_t* __restrict__ rows,
+                                                              const int64_t* __restrict__ col0, int n_rows, float beta,
+                                                              float scale, float* __restrict__ loss_out, float gscale,
+                                                              float* __restrict__ grad) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * 4; i += gridDim.x * blockDim.x) {
+        const int64_t r = rows[i >> 2];
+        const int64_t c = (col0 ? col0[i >> 2] : 0) + (i & 3);
+        float g;
+        acc += sl1(x[r * x_cols + c] - t[r * 4 + (i & 3)], beta, &g);
+        if (grad) grad[r * x_cols + c] = g * gscale * scale;
+    }
+    acc = abr::block_sum<4>(acc, sm);
+    if (threadIdx.x == 0) atomicAdd(loss_out, acc * scale);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Classification loss of the box head -- modeling/roi_heads/box_head/loss.py:151-162
+// one thread per RoI row (K <= 128 classes, rows are 84 B at K=21)
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxK = 128;
+
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                          int n, int K, int inclusive, int n_old, const int* __restrict__ n_valid,
+                                                          float* __restrict__ loss_out, float gscale, float* __restrict__ dz) {
+    __shared__ float sm[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float li = 0.f;
+    if (i < n) {
+        const float* z = logits + (size_t)i * K;
+        const int64_t lab = labels[i];
+        float mx = z[0];
+        for (int c = 1; c < K; c++) mx = fmaxf(mx, z[c]);
+        float se = 0.f, se_old = 0.f;
+        for (int c = 0; c < K; c++) {
+            const float e = expf(z[c] - mx);
+            se += e;
+            if (c <= n_old) se_old += e;
+        }
+        const float lse = logf(se) + mx;
+        const float inv_n = 1.f / (float)(*n_valid);
+        if (lab >= 0) {
+            if (!inclusive) {
+                li = -(z[lab] - lse);
+            } else if (lab == 0) {
+                li = -((logf(se_old) + mx) - lse);      // :155 outputs[:,0] = lse(z[0..n_old]) - den
+            } else if (lab > n_old) {
+                li = -(z[lab] - lse);                   // :156
+            } else {
+                li = 0.f;                               // columns 1..n_old stay 0 (quirk 4)
+            }
+        }
+        if (dz) {
+            float* g = dz + (size_t)i * K;
+            const float s = gscale * inv_n;
+            for (int c = 0; c < K; c++) {
+                float v = 0.f;
+                if (lab >= 0) {
+                    const float p = expf(z[c] - lse);
+                    if (!inclusive) v = p - (c == lab);
+                    else if (lab == 0) v = p - (c <= n_old ? expf(z[c] - mx) / se_old : 0.f);
+                    else if (lab > n_old) v = p - (c == lab);
+                }
+                g[c] = v * s;
+            }
+        }
+        li *= inv_n;
+    }
+    li = abr::block_sum<4>(li, sm);
+    if (threadIdx.x == 0) atomicAdd(loss_out, li);
+}
+
+__global__ void count_valid_kernel(const int64_t* __restrict__ labels, int n, int* __restrict__ out) {
+    __shared__ float sm[4];
+    float c = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) c += labels[i] >= 0;
+    c = abr::block_sum<4>(c, sm);
+    if (threadIdx.x == 0) *out = max(1, (int)c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoI distillation -- distillation/distillation.py:164-240
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restrict__ z_s, const float* __restrict__ b_s,
+                                                           const float* __restrict__ z_t, const float* __restrict__ b_t, int n,
+                                                           int K_old, int K_all, int dist_id, float* __restrict__ loss_out,
+                                                           float gscale, float* __restrict__ d_zt, float* __restrict__ d_bt) {
+    __shared__ float sm[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float li = 0.f;
+    if (i < n) {
+        const float* zs = z_s + (size_t)i * K_old;
+        const float* zt = z_t + (size_t)i * K_all;
+        const float inv_n = 1.f / (float)n;
+        if (dist_id) {
+            float mt = zt[0], ms = zs[0];
+            for (int c = 1; c < K_all; c++) mt = fmaxf(mt, zt[c]);
+            for (int c = 1; c < K_old; c++) ms = fmaxf(ms, zs[c]);
+            float set = 0.f, sebg = 0.f, ses = 0.f;
+            for (int c = 0; c < K_all; c++) {
+                const float e = expf(zt[c] - mt);
+                set += e;
+                if (c == 0 || c >= K_old) sebg += e;
+            }
+            for (int c = 0; c < K_old; c++) ses += expf(zs[c] - ms);
+            const float den = logf(set) + mt;
+            const float out_bg = (logf(sebg) + mt) - den;                       // :196
+            const float lab0 = expf(zs[0] - ms) / ses;
+            float acc = lab0 * out_bg;
+            for (int c = 1; c < K_old; c++) acc += (expf(zs[c] - ms) / ses) * (zt[c] - den);   // :195,:198
+            li = -(acc / (float)K_old) * inv_n;                                 // :198-199
+            if (d_zt) {
+                float* g = d_zt + (size_t)i * K_all;
+                const float s = -gscale * inv_n / (float)K_old;
+                for (int c = 0; c < K_all; c++) {
+                    const float e = expf(zt[c] - mt);
+                    float v = -e / set;
+                    if (c == 0 || c >= K_old) v += lab0 * e / sebg;
+                    if (c >= 1 && c < K_old) v += expf(zs[c] - ms) / ses;
+                    g[c] = v * s;
+                }
+            }
+        } else {
+            float mean_s = 0.f, mean_t = 0.f;
+            for (int c = 0; c < K_old; c++) mean_s += zs[c];
+            for (int c = 0; c < K_all; c++) mean_t += zt[c];
+            mean_s /= (float)K_old;
+            mean_t /= (float)K_all;
+            float acc = 0.f, dsum = 0.f;
+            for (int c = 0; c < K_old; c++) {
+                const float d = (zt[c] - mean_t) - (zs[c] - mean_s);
+                acc += d * d;
+                dsum += d;
+            }
+            li = acc / (float)K_old * inv_n;                                    // :185-188
+            if (d_zt) {
+                float* g = d_zt + (size_t)i * K_all;
+                const float s = gscale * inv_n / (float)K_old;
+                for (int c = 0; c < K_all; c++) {
+                    float v = -2.f * dsum / (float)K_all;
+                    if (c < K_old) v += 2.f * ((zt[c] - mean_t) - (zs[c] - mean_s));
+                    g[c] = v * s;
+                }
+            }
+        }
+        // boxes: mean_n mean_k sum_4 (b_t[:,1:K_old] - b_s[:,1:])^2       :204-209
+        const float* bs = b_s + (size_t)i * K_old * 4;
+        const float* bt = b_t + (size_t)i * K_all * 4;
+        const int kk = K_old - 1;
+        float bacc = 0.f;
+        const float bsc = kk > 0 ? inv_n / (float)kk : 0.f;
+        for (int c = 4; c < K_old * 4; c++) {
+            const float d = bt[c] - bs[c];
+            bacc += d * d;
+        }
+        li += bacc * bsc;
+        if (d_bt) {
+            float* g = d_bt + (size_t)i * K_all * 4;
+            for (int c = 0; c < K_all * 4; c++)
+                g[c] = (c >= 4 && c < K_old * 4) ? 2.f * (bt[c] - bs[c]) * bsc * gscale : 0.f;
+        }
+    }
+    li = abr::block_sum<4>(li, sm);
+    if (threadIdx.x == 0) atomicAdd(loss_out, li);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BCE-with-logits over sampled anchors -- modeling/rpn/loss.py:145-146
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const int64_t* __restrict__ idx, int n_idx,
+                                                          float* __restrict__ loss_out, float gscale, float* __restrict__ grad) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    const float inv = 1.f / (float)n_idx;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_idx; i += gridDim.x * blockDim.x) {
+        const int64_t j = idx[i];
+        const float xv = x[j], yv = y[j];
+        acc += fmaxf(xv, 0.f) - xv * yv + log1pf(expf(-fabsf(xv)));
+        if (grad) grad[j] = (1.f / (1.f + expf(-xv)) - yv) * inv * gscale;
+    }
+    acc = abr::block_sum<4>(acc, sm);
+    if (threadIdx.x == 0) atomicAdd(loss_out, acc * inv);
+}
+
+}  // namespace
+
+extern "C" int abr_sigmoid_focal_forward(const float* logits, const int32_t* targets, int N, int C, float gamma,
+                                         float alpha, float* losses, void* stream) {
+    ABR_REQUIRE(N >= 0 && C > 0, "sigmoid_focal_forward: bad shape");
+    if (N == 0) return ABR_OK;
+    ABR_REQUIRE(logits && targets && losses, "sigmoid_focal_forward: null pointer");
+    const int64_t total = (int64_t)N * C;
+    focal_fwd<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, abr::as_stream(stream)>>>(
+        logits, targets, total, C, gamma, alpha, losses);
+    ABR_CHECK_LAUNCH("sigmoid_focal_forward");
+    return ABR_OK;
+}
+
+extern "C" int abr_sigmoid_focal_backward(const float* logits, const int32_t* targets, const float* d_losses, int N,
+                                          int C, float gamma, float alpha, float* d_logits, void* stream) {
+    ABR_REQUIRE(N >= 0 && C > 0, "sigmoid_focal_backward: bad shape");
+    if (N == 0) return ABR_OK;
+    ABR_REQUIRE(logits && targets && d_losses && d_logits, "sigmoid_focal_backward: null pointer");
+    const int64_t total = (int64_t)N * C;
+    focal_bwd<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, abr::as_stream(stream)>>>(
+        logits, targets, d_losses, total, C, gamma, alpha, d_logits);
+    ABR_CHECK_LAUNCH("sigmoid_focal_backward");
+    return ABR_OK;
+}
+
+static int zero_loss(float* loss_out, int nfloat, hipStream_t st, const char* who) {
+    if (hipMemsetAsync(loss_out, 0, sizeof(float) * nfloat, st) != hipSuccess) {
+        abr::set_error("%s: memset failed", who);
+        return ABR_E_LAUNCH;
+    }
+    return ABR_OK;
+}
+
+extern "C" int abr_smooth_l1(const float* x, const float* t, int64_t n, float beta, float scale, float* loss_out,
+                             float gscale, float* grad, void* stream) {
+    ABR_REQUIRE(n >= 0 && loss_out, "smooth_l1: bad args");
+    hipStream_t st = abr::as_stream(stream);
+    if (int e = zero_loss(loss_out, 1, st, "smooth_l1")) return e;
+    if (n == 0) return ABR_OK;
+    ABR_REQUIRE(x && t, "smooth_l1: null pointer");
+    smooth_l1_kernel<<<(unsigned)std::min<int64_t>((n + 255) / 256, 1024), 256, 0, st>>>(x, t, n, beta, scale, loss_out,
+                                                                                           gscale, grad);
+    ABR_CHECK_LAUNCH("smooth_l1");
+    return ABR_OK;
+}
+
+extern "C" int abr_smooth_l1_rows(const float* x, int x_cols, const float* t, const int64_t* rows, const int64_t* col0,
+                                  int n_rows, float beta, float scale, float* loss_out, float gscale, float* grad,
+                                  void* stream) {
+    ABR_REQUIRE(n_rows >= 0 && loss_out && x_cols >= 4, "smooth_l1_rows: bad args");
+    hipStream_t st = abr::as_stream(stream);
+    if (int e = zero_loss(loss_out, 1, st, "smooth_l1_rows")) return e;
+    if (n_rows == 0) return ABR_OK;
+    ABR_REQUIRE(x && t && rows, "smooth_l1_rows: null pointer");
+    smooth_l1_rows_kernel<<<abr::cdiv((int64_t)n_rows * 4, 256), 256, 0, st>>>(x, x_cols, t, rows, col0, n_rows, beta,
+                                                                                scale, loss_out, gscale, grad);
+    ABR_CHECK_LAUNCH("smooth_l1_rows");
+    return ABR_OK;
+}
+
+extern "C" int abr_softmax_ce(const float* logits, const int64_t* labels, int n, int K, int inclusive, int n_old,
+                              float* loss_out, float gscale, float* d_logits, void* stream) {
+    ABR_REQUIRE(n >= 0 && K > 0 && K <= kMaxK && loss_out, "softmax_ce: bad args (K<=128)");
+    ABR_REQUIRE(!inclusive || (n_old >= 0 && n_old < K), "softmax_ce: n_old out of range");
+    hipStream_t st = abr::as_stream(stream);
+    // loss_out[0] = loss ; loss_out[1] reinterpret as int scratch for the valid-row count
+    if (int e = zero_loss(loss_out, 2, st, "softmax_ce")) return e;
+    if (n == 0) return ABR_OK;
+    ABR_REQUIRE(logits && labels, "softmax_ce: null pointer");
+    int* cnt = reinterpret_cast<int*>(loss_out + 1);
+    count_valid_kernel<<<1, 256, 0, st>>>(labels, n, cnt);
+    softmax_ce_kernel<<<abr::cdiv(n, 256), 256, 0, st>>>(logits, labels, n, K, inclusive, n_old, cnt, loss_out, gscale,
+                                                          d_logits);
+    ABR_CHECK_LAUNCH("softmax_ce");
+    return ABR_OK;
+}
+
+extern "C" int abr_roi_distill(const float* z_s, const float* b_s, const float* z_t, const float* b_t, int n, int K_old,
+                               int K_all, int dist_id, float* loss_out, float gscale, float* d_zt, float* d_bt,
+                               void* stream) {
+    ABR_REQUIRE(n >= 0 && K_old > 0 && K_all >= K_old && K_all <= kMaxK && loss_out, "roi_distill: bad args");
+    ABR_REQUIRE(!dist_id || K_all > K_old, "roi_distill: dist='id' needs K_all > K_old (empty slice in the reference)");
+    hipStream_t st = abr::as_stream(stream);
+    if (int e = zero_loss(loss_out, 1, st, "roi_distill")) return e;
+    if (n == 0) return ABR_OK;
+    ABR_REQUIRE(z_s && b_s && z_t && b_t, "roi_distill: null pointer");
+    roi_distill_kernel<<<abr::cdiv(n, 256), 256, 0, st>>>(z_s, b_s, z_t, b_t, n, K_old, K_all, dist_id, loss_out, gscale,
+                                                           d_zt, d_bt);
+    ABR_CHECK_LAUNCH("roi_distill");
+    return ABR_OK;
+}
+
+extern "C" int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, int n_idx, float* loss_out,
+                                     float gscale, float* grad, void* stream) {
+    ABR_REQUIRE(n_idx >= 0 && loss_out, "bce_logits_gather: bad args");
+    hipStream_t st = abr::as_stream(stream);
+    if (int e = zero_loss(loss_out, 1, st, "bce_logits_gather")) return e;
+    if (n_idx == 0) return ABR_OK;
+    ABR_REQUIRE(x && y && idx, "bce_logits_gather: null pointer");
+    bce_gather_kernel<<<std::min(abr::cdiv(n_idx, 256), 256u), 256, 0, st>>>(x, y, idx, n_idx, loss_out, gscale, grad);
+    ABR_CHECK_LAUNCH("bce_logits_gather");
+    return ABR_OK;
+}

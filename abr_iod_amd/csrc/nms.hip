@@ -1,0 +1,148 @@
+// Greedy NMS entirely on device, batched over images.
+//
+// Reference semantics: csrc/cpu/nms_cpu.cpp:5-75 (`ovr >= thr` suppresses -- canonical here) and
+// csrc/cuda/nms.cu:23-131 (`>`; 64x64 bit-mask tiles, then an 18 MB blocking D2H copy and a serial
+// HOST sweep, nms.cu:99-123).  IoU arithmetic is kept in the reference's form inter/(a+b-inter) with
+// contraction off so the compare against thr is bit-identical (index-exact keep lists).
+//
+// MI355X design:
+//   pass 1  suppression bit-matrix: one wave64 per (row tile, column tile); a lane owns one row box and
+//           builds one 64-bit word against the 64 column boxes staged in LDS -> a wave writes one
+//           coalesced 512 B row of words.  Only tiles on/above the diagonal are computed.
+//   pass 2  the greedy sweep stays ON DEVICE: one 256-thread workgroup per image.  Per 64-box block the
+//           diagonal tile is resolved by wave 0 with lane broadcasts (no memory in the serial chain), then
+//           every thread ORs the rows of the newly kept boxes into its own word of the `removed` bitmap
+//           (loads are independent of the chain -> fully pipelined).  Stops once max_keep boxes are kept
+//           (post_nms_top_n), which on RPN proposals is long before the end of the list.
+#include "common.h"
+
+namespace {
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ bool suppresses(const float4 a, float area_a, const float4 b, float thr, int strict_gt) {
+    const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
+    const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+    const float w = fmaxf(0.f, xx2 - xx1 + 1), h = fmaxf(0.f, yy2 - yy1 + 1);
+    const float inter = w * h;
+    const float area_b = (b.z - b.x + 1) * (b.w - b.y + 1);
+    const float ovr = inter / (area_a + area_b - inter);
+    return strict_gt ? (ovr > thr) : (ovr >= thr);
+}
+
+// grid = (col tiles, row tiles, N); block = 64 (one wave)
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ counts,
+                                                       int n_max, int words, float thr, int strict_gt,
+                                                       uint64_t* __restrict__ mask) {
+    const int img = blockIdx.z, rt = blockIdx.y, ct = blockIdx.x;
+    if (ct < rt) return;  // lower triangle never read
+    const int n = counts[img];
+    if (rt * 64 >= n || ct * 64 >= n) return;
+    __shared__ float4 cb[64];
+    const float4* b = reinterpret_cast<const float4*>(boxes) + (size_t)img * n_max;
+    const int lane = threadIdx.x;
+    const int cj = ct * 64 + lane;
+    cb[lane] = cj < n ? b[cj] : make_float4(0, 0, -1, -1);
+    __syncthreads();
+    const int ri = rt * 64 + lane;
+    if (ri >= n) return;
+    const float4 a = b[ri];
+    const float area_a = (a.z - a.x + 1) * (a.w - a.y + 1);
+    uint64_t bits = 0;
+    const int jstart = (rt == ct) ? lane + 1 : 0;
+    const int jend = min(64, n - ct * 64);
+    for (int j = jstart; j < jend; j++)
+        if (suppresses(a, area_a, cb[j], thr, strict_gt)) bits |= 1ull << j;
+    mask[((size_t)img * n_max + ri) * words + ct] = bits;
+}
+
+// grid = N, block = 256.  removed bitmap lives in LDS (words <= 4096 -> n_max <= 262144).
+__global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t* __restrict__ mask, const int32_t* __restrict__ counts,
+                                                         int n_max, int words, int max_keep, int32_t* __restrict__ keep,
+                                                         int32_t* __restrict__ n_keep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* removed = reinterpret_cast<uint64_t*>(smem);         // [words]
+    uint64_t* s_kept = removed + words;                            // [1] kept bits of the current block
+    int* s_cnt = reinterpret_cast<int*>(s_kept + 1);               // [1]
+    const int img = blockIdx.x;
+    const int n = counts[img];
+    const uint64_t* m = mask + (size_t)img * n_max * words;
+    int32_t* kp = keep + (size_t)img * max_keep;
+    for (int w = threadIdx.x; w < words; w += blockDim.x) removed[w] = 0;
+    if (threadIdx.x == 0) *s_cnt = 0;
+    __syncthreads();
+    const int nblk = (n + 63) / 64;
+    for (int bi = 0; bi < nblk; bi++) {
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            const int i = bi * 64 + lane;
+            // diagonal word of row i (bits j>lane within this block); rows past n act as already removed
+            const uint64_t diag = i < n ? m[(size_t)i * words + bi] : 0ull;
+            uint64_t cur = removed[bi];
+            const int valid = min(64, n - bi * 64);
+            if (valid < 64) cur |= ~0ull << valid;
+            uint64_t kept = 0;
+            int cnt = *s_cnt;
+            for (int b = 0; b < valid; b++) {  // serial greedy chain, registers + lane broadcast only
+                if (!((cur >> b) & 1ull)) {
+                    if (cnt >= max_keep) break;
+                    kept |= 1ull << b;
+                    if (lane == 0) kp[cnt] = bi * 64 + b;
+                    cnt++;
+                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(diag & 0xffffffffu), b);
+                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), b);
+                    cur |= ((uint64_t)hi << 32) | lo;
+                }
+            }
+            if (lane == 0) { *s_kept = kept; *s_cnt = cnt; }
+        }
+        __syncthreads();
+        const uint64_t kept = *s_kept;
+        const int cnt = *s_cnt;
+        if (cnt >= max_keep) break;
+        // OR rows of the kept boxes into the words to the right of the diagonal
+        for (int w = bi + 1 + threadIdx.x; w < words; w += blockDim.x) {
+            uint64_t acc = 0, k = kept;
+            while (k) {
+                const int b = __builtin_ctzll(k);
+                k &= k - 1;
+                acc |= m[(size_t)(bi * 64 + b) * words + w];
+            }
+            removed[w] |= acc;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_keep[img] = *s_cnt;
+}
+
+}  // namespace
+
+extern "C" int64_t abr_nms_workspace_bytes(int N, int n_max) {
+    const int64_t words = (n_max + 63) / 64;
+    return (int64_t)N * n_max * words * 8;
+}
+
+extern "C" int abr_nms_sorted_batched(const float* boxes, const int32_t* counts, int N, int n_max, float thr,
+                                      int strict_gt, int max_keep, int32_t* keep, int32_t* n_keep, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
+    ABR_REQUIRE(N >= 0 && n_max >= 0 && max_keep >= 0, "nms: bad shape");
+    if (N == 0) return ABR_OK;
+    ABR_REQUIRE(counts && n_keep, "nms: null counts");
+    hipStream_t st = abr::as_stream(stream);
+    if (n_max == 0 || max_keep == 0) {
+        if (hipMemsetAsync(n_keep, 0, sizeof(int32_t) * N, st) != hipSuccess) return ABR_E_LAUNCH;
+        return ABR_OK;
+    }
+    ABR_REQUIRE(boxes && keep && workspace, "nms: null pointer");
+    ABR_REQUIRE(workspace_bytes >= abr_nms_workspace_bytes(N, n_max), "nms: workspace too small");
+    const int words = (n_max + 63) / 64;
+    ABR_REQUIRE(words <= 4096, "nms: n_max too large for the LDS bitmap (max 262144)");
+    // The mask rows are only partially written (upper triangle, rows < count): words left of the diagonal are
+    // never read, words right of it are always written for rows < n.  No memset needed.
+    dim3 grid(words, words, N);
+    nms_mask_kernel<<<grid, 64, 0, st>>>(boxes, counts, n_max, words, thr, strict_gt, (uint64_t*)workspace);
+    ABR_CHECK_LAUNCH("nms_mask");
+    const size_t lds = (size_t)words * 8 + 16;
+    nms_sweep_kernel<<<N, 256, lds, st>>>((const uint64_t*)workspace, counts, n_max, words, max_keep, keep, n_keep);
+    ABR_CHECK_LAUNCH("nms_sweep");
+    return ABR_OK;
+}

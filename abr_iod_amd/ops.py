@@ -1,0 +1,319 @@
+"""Functional host API over the C ABI in the library's NATIVE layout (NHWC activations, OHWI weights).
+
+Thin: shape bookkeeping + output allocation (torch = device-memory plumbing) + one C-ABI call each.
+The reference-shaped wrappers (autograd Functions, nn.Modules with the reference's names) live in
+abr_iod_amd/layers and abr_iod_amd/modeling and are built from these.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_f32 = torch.float32
+
+
+def _empty(shape, like, dtype=_f32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ----------------------------------------------------------------------------------------------- ROIAlign
+def roi_align_forward(feat, rois, spatial_scale, ph, pw, sampling_ratio, bin_step=1):
+    """feat [B,H,W,C], rois [K,5] -> [K, ceil(ph/step), ceil(pw/step), C]"""
+    L.require_cuda(feat, rois)
+    feat, rois = L.f32c(feat), L.f32c(rois)
+    B, H, W, Ch = feat.shape
+    K = rois.shape[0]
+    pho, pwo = -(-ph // bin_step), -(-pw // bin_step)
+    out = _empty((K, pho, pwo, Ch), feat)
+    L.check(L.lib().abr_roi_align_forward(L.ptr(feat), L.ptr(rois), K, B, Ch, H, W, float(spatial_scale), ph, pw,
+                                          sampling_ratio, bin_step, L.NHWC, L.ptr(out), L.stream()), "roi_align_forward")
+    return out
+
+
+def roi_align_backward(grad, rois, spatial_scale, ph, pw, sampling_ratio, B, H, W, Ch, bin_step=1, out=None):
+    """grad [K,pho,pwo,C] -> grad_feat [B,H,W,C]; accumulates into `out` when given."""
+    L.require_cuda(grad, rois)
+    grad, rois = L.f32c(grad), L.f32c(rois)
+    K = rois.shape[0]
+    acc = out is not None
+    if out is None:
+        out = _empty((B, H, W, Ch), grad)
+    L.check(L.lib().abr_roi_align_backward(L.ptr(grad), L.ptr(rois), K, B, Ch, H, W, float(spatial_scale), ph, pw,
+                                           sampling_ratio, bin_step, L.NHWC, int(acc), L.ptr(out), L.stream()),
+            "roi_align_backward")
+    return out
+
+
+def roi_align_taps(rois, H, W, spatial_scale, ph, pw, sampling_ratio, max_s):
+    rois = L.f32c(rois)
+    K = rois.shape[0]
+    idx = torch.empty((K, ph * pw, max_s, 4), dtype=torch.int32, device=rois.device)
+    grid = torch.empty((K, 2), dtype=torch.int32, device=rois.device)
+    L.check(L.lib().abr_roi_align_taps(L.ptr(rois), K, H, W, float(spatial_scale), ph, pw, sampling_ratio, max_s,
+                                       L.ptr(idx), L.ptr(grid), L.stream()), "roi_align_taps")
+    return idx, grid
+
+
+# ----------------------------------------------------------------------------------------------- NMS
+_nms_ws = {}
+
+
+def nms_sorted_batched(boxes, counts, thr, max_keep, strict_gt=False):
+    """boxes [N,n,4] sorted by descending score per image, counts [N] int32 -> keep [N,max_keep] int32, n_keep [N]"""
+    L.require_cuda(boxes, counts)
+    boxes = L.f32c(boxes)
+    N, n = boxes.shape[0], boxes.shape[1]
+    keep = torch.empty((N, max(max_keep, 1)), dtype=torch.int32, device=boxes.device)
+    n_keep = torch.empty((N,), dtype=torch.int32, device=boxes.device)
+    ws_bytes = L.lib().abr_nms_workspace_bytes(N, n)
+    key = (boxes.device, ws_bytes)
+    ws = _nms_ws.get(key)
+    if ws is None:
+        _nms_ws.clear()
+        ws = _nms_ws[key] = torch.empty((max(ws_bytes, 8),), dtype=torch.uint8, device=boxes.device)
+    L.check(L.lib().abr_nms_sorted_batched(L.ptr(boxes), L.ptr(counts), N, n, float(thr), int(strict_gt), max_keep,
+                                           L.ptr(keep), L.ptr(n_keep), L.ptr(ws), ws_bytes, L.stream()), "nms")
+    return keep, n_keep
+
+
+# ----------------------------------------------------------------------------------------------- losses
+def ard_forward(f_src, f_tgt, gamma, layout=L.NHWC):
+    """f_* [N,HW,C] (NHWC) -> (loss[4] = total, afd, pad, -), coef [N,2,HW])"""
+    L.require_cuda(f_src, f_tgt)
+    f_src, f_tgt = L.f32c(f_src), L.f32c(f_tgt)
+    if layout == L.NHWC:
+        N, HW, Ch = f_src.shape[0], f_src.shape[1:-1].numel(), f_src.shape[-1]
+    else:
+        N, Ch, HW = f_src.shape[0], f_src.shape[1], f_src.shape[2:].numel()
+    loss = _empty((4,), f_src)
+    coef = _empty((max(N, 1), 2, HW), f_src)
+    L.check(L.lib().abr_ard_forward(L.ptr(f_src), L.ptr(f_tgt), N, Ch, HW, float(gamma), layout, L.ptr(coef),
+                                    L.ptr(loss), L.stream()), "ard_forward")
+    return loss, coef
+
+
+def ard_backward(f_src, f_tgt, coef, gamma, gscale=1.0, gscale_dev=None, layout=L.NHWC):
+    f_src, f_tgt = L.f32c(f_src), L.f32c(f_tgt)
+    if layout == L.NHWC:
+        N, HW, Ch = f_src.shape[0], f_src.shape[1:-1].numel(), f_src.shape[-1]
+    else:
+        N, Ch, HW = f_src.shape[0], f_src.shape[1], f_src.shape[2:].numel()
+    grad = torch.empty_like(f_tgt)
+    L.check(L.lib().abr_ard_backward(L.ptr(f_src), L.ptr(f_tgt), L.ptr(coef), N, Ch, HW, float(gamma), layout,
+                                     float(gscale), L.ptr(gscale_dev), L.ptr(grad), L.stream()), "ard_backward")
+    return grad
+
+
+def smooth_l1(x, t, beta, scale=1.0, gscale=1.0, want_grad=False):
+    L.require_cuda(x, t)
+    x, t = L.f32c(x), L.f32c(t)
+    loss = _empty((4,), x)
+    grad = torch.empty_like(x) if want_grad else None
+    L.check(L.lib().abr_smooth_l1(L.ptr(x), L.ptr(t), x.numel(), float(beta), float(scale), L.ptr(loss), float(gscale),
+                                  L.ptr(grad), L.stream()), "smooth_l1")
+    return loss, grad
+
+
+def smooth_l1_rows(x, t, rows, col0, beta, scale=1.0, gscale=1.0, want_grad=False):
+    """sum over i of smoothL1(x[rows[i], col0[i]:col0[i]+4] - t[rows[i], :4]) * scale"""
+    L.require_cuda(x, t, rows)
+    x, t = L.f32c(x), L.f32c(t)
+    loss = _empty((4,), x)
+    grad = torch.zeros_like(x) if want_grad else None
+    L.check(L.lib().abr_smooth_l1_rows(L.ptr(x), x.shape[1], L.ptr(t), L.ptr(rows), L.ptr(col0), rows.numel(), float(beta),
+                                       float(scale), L.ptr(loss), float(gscale), L.ptr(grad), L.stream()), "smooth_l1_rows")
+    return loss, grad
+
+
+def softmax_ce(logits, labels, inclusive=False, n_old=0, gscale=1.0, want_grad=False):
+    L.require_cuda(logits, labels)
+    logits = L.f32c(logits)
+    labels = labels.contiguous()
+    loss = _empty((4,), logits)
+    grad = torch.empty_like(logits) if want_grad else None
+    L.check(L.lib().abr_softmax_ce(L.ptr(logits), L.ptr(labels), logits.shape[0], logits.shape[1], int(inclusive), n_old,
+                                   L.ptr(loss), float(gscale), L.ptr(grad), L.stream()), "softmax_ce")
+    return loss, grad
+
+
+def roi_distill(z_s, b_s, z_t, b_t, dist_id=True, gscale=1.0, want_grad=False):
+    L.require_cuda(z_s, b_s, z_t, b_t)
+    z_s, b_s, z_t, b_t = L.f32c(z_s), L.f32c(b_s), L.f32c(z_t), L.f32c(b_t)
+    loss = _empty((4,), z_t)
+    d_zt = torch.empty_like(z_t) if want_grad else None
+    d_bt = torch.empty_like(b_t) if want_grad else None
+    L.check(L.lib().abr_roi_distill(L.ptr(z_s), L.ptr(b_s), L.ptr(z_t), L.ptr(b_t), z_t.shape[0], z_s.shape[1], z_t.shape[1],
+                                    int(dist_id), L.ptr(loss), float(gscale), L.ptr(d_zt), L.ptr(d_bt), L.stream()),
+            "roi_distill")
+    return loss, d_zt, d_bt
+
+
+def bce_logits_gather(x, y, idx, gscale=1.0, want_grad=False):
+    L.require_cuda(x, y, idx)
+    x, y = L.f32c(x), L.f32c(y)
+    loss = _empty((4,), x)
+    grad = torch.zeros_like(x) if want_grad else None
+    L.check(L.lib().abr_bce_logits_gather(L.ptr(x), L.ptr(y), L.ptr(idx), idx.numel(), L.ptr(loss), float(gscale),
+                                          L.ptr(grad), L.stream()), "bce_logits_gather")
+    return loss, grad
+
+
+# ----------------------------------------------------------------------------------------------- conv
+def conv_desc(x_shape, w_shape, stride, pad, scale=None, bias=None, residual=None, mask=None, relu=False,
+              out_hw=None, out_stride=(1, 1)):
+    B, H, W, Cin = x_shape
+    Cout, R, S, Cin2 = w_shape
+    if Cin != Cin2:
+        raise RuntimeError(f"conv: input has {Cin} channels, weight expects {Cin2}")
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - S) // stride + 1
+    d = L.ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.R, d.S = B, H, W, Cin, Cout, R, S
+    d.stride, d.pad, d.Ho, d.Wo = stride, pad, Ho, Wo
+    d.scale, d.bias, d.residual, d.mask = L.ptr(scale), L.ptr(bias), L.ptr(residual), L.ptr(mask)
+    d.relu = int(relu)
+    if out_hw is None:
+        d.out_H, d.out_W, d.out_sh, d.out_sw = Ho, Wo, 1, 1
+    else:
+        d.out_H, d.out_W = out_hw
+        d.out_sh, d.out_sw = out_stride
+    return d
+
+
+def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, mask=None, relu=False,
+                 out=None, out_hw=None, out_stride=(1, 1)):
+    """x [B,H,W,Cin] NHWC, w [Cout,R,S,Cin] OHWI -> [B,Ho,Wo,Cout] (or scattered into `out` [B,out_H,out_W,Cout])"""
+    L.require_cuda(x, w)
+    x, w = L.f32c(x), L.f32c(w)
+    d = conv_desc(x.shape, w.shape, stride, pad, scale, bias, residual, mask, relu, out_hw, out_stride)
+    if out is None:
+        if out_hw is not None:
+            out = torch.zeros((d.B, d.out_H, d.out_W, d.Cout), dtype=_f32, device=x.device)
+        else:
+            out = _empty((d.B, d.Ho, d.Wo, d.Cout), x)
+    L.check(L.lib().abr_conv_forward(C.byref(d), L.ptr(x), L.ptr(w), L.ptr(out), L.stream()), "conv_forward")
+    return out
+
+
+def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None):
+    """dw [Cout,R,S,Cin] += scale * gy^T im2col(x) (fp32 atomics; caller zeroes dw once per step)"""
+    L.require_cuda(x, gy, dw)
+    x, gy = L.f32c(x), L.f32c(gy)
+    d = conv_desc(x.shape, dw.shape, stride, pad, scale=scale)
+    L.check(L.lib().abr_conv_wgrad(C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.stream()), "conv_wgrad")
+    return dw
+
+
+def conv_dgrad_weights(w, scale=None, out=None):
+    """w [Cout,R,S,Cin] -> [Cin,R,S,Cout] flipped, scaled by scale[Cout]"""
+    w = L.f32c(w)
+    Cout, R, S, Cin = w.shape
+    if out is None:
+        out = _empty((Cin, R, S, Cout), w)
+    L.check(L.lib().abr_conv_dgrad_weights(L.ptr(w), L.ptr(scale), Cout, R, S, Cin, L.ptr(out), L.stream()), "dgrad_weights")
+    return out
+
+
+def bias_grad(gy, db):
+    gy = L.f32c(gy)
+    Ch = gy.shape[-1]
+    L.check(L.lib().abr_bias_grad(L.ptr(gy), gy.numel() // Ch, Ch, L.ptr(db), L.stream()), "bias_grad")
+    return db
+
+
+# ----------------------------------------------------------------------------------------------- pointwise
+def nchw_to_nhwc(x, cpad=None):
+    x = L.f32c(x)
+    B, Ch, H, W = x.shape
+    cpad = cpad or Ch
+    out = _empty((B, H, W, cpad), x)
+    L.check(L.lib().abr_nchw_to_nhwc_pad(L.ptr(x), B, Ch, H, W, cpad, L.ptr(out), L.stream()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x):
+    x = L.f32c(x)
+    B, H, W, Ch = x.shape
+    out = _empty((B, Ch, H, W), x)
+    L.check(L.lib().abr_nhwc_to_nchw(L.ptr(x), B, Ch, H, W, L.ptr(out), L.stream()), "nhwc_to_nchw")
+    return out
+
+
+def maxpool3x3s2(x):
+    x = L.f32c(x)
+    B, H, W, Ch = x.shape
+    out = _empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Ch), x)
+    L.check(L.lib().abr_maxpool3x3s2(L.ptr(x), B, H, W, Ch, L.ptr(out), L.stream()), "maxpool")
+    return out
+
+
+def avgpool_forward(x):
+    """x [N,h,w,C] -> [N,C]"""
+    x = L.f32c(x)
+    N, Ch = x.shape[0], x.shape[-1]
+    HW = x.shape[1:-1].numel()
+    out = _empty((N, Ch), x)
+    L.check(L.lib().abr_avgpool_forward(L.ptr(x), N, HW, Ch, L.ptr(out), L.stream()), "avgpool_forward")
+    return out
+
+
+def avgpool_backward(g, shape):
+    g = L.f32c(g)
+    N, Ch = g.shape
+    gx = _empty(shape, g)
+    L.check(L.lib().abr_avgpool_backward(L.ptr(g), N, gx.numel() // (N * Ch) if N else 1, Ch, L.ptr(gx), L.stream()),
+            "avgpool_backward")
+    return gx
+
+
+def relu_backward_(g, y):
+    L.check(L.lib().abr_relu_backward(L.ptr(g), L.ptr(y), g.numel(), L.stream()), "relu_backward")
+    return g
+
+
+def add_(a, b):
+    L.check(L.lib().abr_add_inplace(L.ptr(a), L.ptr(b), a.numel(), L.stream()), "add_inplace")
+    return a
+
+
+# ----------------------------------------------------------------------------------------------- RPN glue
+def grid_anchors(cell, H, W, stride, img_h, img_w, straddle=0):
+    A = cell.shape[0]
+    out = torch.empty((H * W * A, 4), dtype=_f32, device=cell.device)
+    vis = torch.empty((H * W * A,), dtype=torch.uint8, device=cell.device)
+    L.check(L.lib().abr_grid_anchors(L.ptr(cell), A, H, W, stride, img_h, img_w, straddle, L.ptr(out), L.ptr(vis),
+                                     L.stream()), "grid_anchors")
+    return out, vis
+
+
+def rpn_decode_clip(reg, reg_col0, anchors, idx, img_hw, weights=(1.0, 1.0, 1.0, 1.0)):
+    """reg [N,n_anchor,stride] ; idx [N,k] int64 ; img_hw [N,2] int32 -> [N,k,4]"""
+    N, n_anchor, rs = reg.shape
+    k = idx.shape[1]
+    out = torch.empty((N, k, 4), dtype=_f32, device=reg.device)
+    L.check(L.lib().abr_rpn_decode_clip(L.ptr(reg), rs, reg_col0, L.ptr(anchors), L.ptr(idx), N, n_anchor, k,
+                                        L.ptr(img_hw), *[float(v) for v in weights], L.ptr(out), L.stream()), "rpn_decode_clip")
+    return out
+
+
+def match_encode(boxes, gt, gt_labels, vis, hi, lo, allow_low_quality, weights, rpn_labels):
+    """-> matched int64 [n], labels (fp32 RPN / int64 head) [n], reg_targets [n,4]"""
+    boxes, gt = L.f32c(boxes), L.f32c(gt)
+    n, G = boxes.shape[0], gt.shape[0]
+    dev = boxes.device
+    matched = torch.empty((n,), dtype=torch.int64, device=dev)
+    lab_f = torch.empty((n,), dtype=_f32, device=dev) if rpn_labels else None
+    lab_i = None if rpn_labels else torch.empty((n,), dtype=torch.int64, device=dev)
+    tgt = torch.empty((n, 4), dtype=_f32, device=dev)
+    ws = torch.empty((max(G, 1),), dtype=torch.int32, device=dev)
+    L.check(L.lib().abr_match_encode(L.ptr(boxes), n, L.ptr(gt), L.ptr(gt_labels), G, L.ptr(vis), float(hi), float(lo),
+                                     int(allow_low_quality), *[float(v) for v in weights], L.ptr(matched), L.ptr(lab_f),
+                                     L.ptr(lab_i), L.ptr(tgt), L.ptr(ws), ws.numel() * 4, L.stream()), "match_encode")
+    return matched, (lab_f if rpn_labels else lab_i), tgt
+
+
+# ----------------------------------------------------------------------------------------------- optimiser
+def sgd_momentum_(p, g, m, seg_end, lr, wd, momentum, gscale=1.0, first_step=False):
+    L.check(L.lib().abr_sgd_momentum(L.ptr(p), L.ptr(g), L.ptr(m), p.numel(), L.ptr(seg_end), L.ptr(lr), L.ptr(wd),
+                                     seg_end.numel(), float(momentum), float(gscale), int(first_step), L.stream()), "sgd")

@@ -1,0 +1,221 @@
+/*
+ * abr_iod_hip.h -- C ABI of libabr_iod_hip.so (hand-written HIP for gfx950 / MI355X).
+ *
+ * Drop-in boundary for the Faster R-CNN + ARD training hot path of YuyangSunshine/ABR_IOD.
+ * The reference crosses into native code through the pybind11 module `maskrcnn_benchmark._C`
+ * (maskrcnn_benchmark/csrc/vision.cpp:9-25); everything else on the path is ATen (cuDNN/cuBLAS/
+ * elementwise).  This library exports BOTH: section 1 mirrors `_C` one-to-one, sections 2-5 replace
+ * the ATen work the path does per step.  Citations are file:line under /root/reference/.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; no torch types anywhere
+ *   - outputs are caller-allocated (the Python host allocates them with torch so allocator / stream
+ *     semantics match the reference's at::empty, csrc/cuda/ROIAlign_cuda.cu:271,316)
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the call returns
+ *     without synchronising (reference: at::cuda::getCurrentCUDAStream(), ROIAlign_cuda.cu:273)
+ *   - return 0 on success, <0 on error (ABR_E_*); abr_last_error() gives the message (the reference
+ *     raises C++ exceptions -> Python RuntimeError; the Python host re-raises RuntimeError)
+ *   - empty inputs are legal and return 0 without launching (ROIAlign_cuda.cu:278-281, nms.h:15-16)
+ *   - layouts: ABR_NCHW is the reference's tensor layout (drop-in); ABR_NHWC is the library's native
+ *     layout (channel-contiguous => 4 KB coalesced rows at C=1024)
+ */
+#ifndef ABR_IOD_HIP_H
+#define ABR_IOD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABR_OK 0
+#define ABR_E_INVALID (-1) /* bad argument (AT_ASSERTM in the reference) */
+#define ABR_E_LAUNCH (-2)  /* hipGetLastError() != success after a launch (THCudaCheck) */
+#define ABR_E_WORKSPACE (-3)
+
+#define ABR_NCHW 0
+#define ABR_NHWC 1
+
+const char* abr_last_error(void);
+int abr_version(void);
+/* device properties the host side needs for grid sizing: out[0]=CU count, out[1]=LDS bytes/CU, out[2]=wave size */
+int abr_device_info(int32_t* out_host);
+
+/* =====================================================================================================
+ * 1. maskrcnn_benchmark._C  (csrc/vision.cpp:10-16)
+ * ===================================================================================================== */
+
+/* _C.roi_align_forward(input, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio)
+ *   csrc/ROIAlign.h:11-25 -> csrc/cuda/ROIAlign_cuda.cu:65-122,258-300 / csrc/cpu/ROIAlign_cpu.cpp:113-256
+ * feat [B,C,H,W] (NCHW) or [B,H,W,C] (NHWC); rois [K,5] = (batch_idx,x1,y1,x2,y2) fp32;
+ * out  [K,C,PH,PW] (NCHW) or [K,PHo,PWo,C] (NHWC) where PHo=ceil(PH/bin_step).
+ * bin_step: 1 = every bin (reference behaviour).  2 = only bins with even (ph,pw): what a following
+ *   stride-2 1x1 conv (ResNetHead.layer4.0, modeling/backbone/resnet.py:278) actually reads; NHWC only. */
+int abr_roi_align_forward(const float* feat, const float* rois, int K, int B, int C, int H, int W,
+                          float spatial_scale, int PH, int PW, int sampling_ratio, int bin_step,
+                          int layout, float* out, void* stream);
+
+/* _C.roi_align_backward(grad, rois, spatial_scale, ph, pw, B, C, H, W, sampling_ratio)
+ *   csrc/ROIAlign.h:27-45 -> csrc/cuda/ROIAlign_cuda.cu:178-254,304-346 (CPU: "Not implemented").
+ * grad_feat is zero-filled by the callee unless accumulate!=0 (reference: at::zeros, :316). */
+int abr_roi_align_backward(const float* grad, const float* rois, int K, int B, int C, int H, int W,
+                           float spatial_scale, int PH, int PW, int sampling_ratio, int bin_step,
+                           int layout, int accumulate, float* grad_feat, void* stream);
+
+/* Integer tap table of the forward kernel's OWN indexing code (parity instrument, not on the hot path):
+ * idx [K,PH*PW,max_s,4] int32 flat y*W+x (-1 = sample rejected, -2 = unused slot), grid [K,2]. */
+int abr_roi_align_taps(const float* rois, int K, int H, int W, float spatial_scale, int PH, int PW,
+                       int sampling_ratio, int max_s, int32_t* idx, int32_t* grid, void* stream);
+
+/* _C.nms(dets, scores, threshold)   csrc/nms.h:10-27 -> csrc/cpu/nms_cpu.cpp:5-75 / csrc/cuda/nms.cu:70-131
+ * Batched, boxes already sorted by descending score (the reference sorts first: nms_cpu.cpp:24, nms.cu:73).
+ *   boxes   [N, n_max, 4] xyxy fp32, image i uses its first counts[i] rows
+ *   strict_gt : 0 -> suppress when IoU >= thr (CPU rule, nms_cpu.cpp:60; the canonical one here)
+ *               1 -> suppress when IoU >  thr (CUDA rule, nms.cu:60)
+ *   keep    [N, max_keep] int32 : positions (in sorted order) of survivors, ascending; n_keep [N] int32
+ *   The greedy sweep runs ON DEVICE (no 18 MB D2H + host loop as nms.cu:99-123) and stops at max_keep.
+ *   workspace: abr_nms_workspace_bytes(N, n_max) bytes. */
+int64_t abr_nms_workspace_bytes(int N, int n_max);
+int abr_nms_sorted_batched(const float* boxes, const int32_t* counts, int N, int n_max, float thr,
+                           int strict_gt, int max_keep, int32_t* keep, int32_t* n_keep,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
+/* _C.sigmoid_focalloss_forward / _backward   csrc/SigmoidFocalLoss.h:10-41 -> csrc/cuda/SigmoidFocalLoss_cuda.cu:20-101
+ * logits [N,C] fp32, targets [N] int32 (0 = background, -1 = ignore, c>=1 = class c), losses/d_logits [N,C]. */
+int abr_sigmoid_focal_forward(const float* logits, const int32_t* targets, int N, int C, float gamma,
+                              float alpha, float* losses, void* stream);
+int abr_sigmoid_focal_backward(const float* logits, const int32_t* targets, const float* d_losses, int N,
+                               int C, float gamma, float alpha, float* d_logits, void* stream);
+
+/* =====================================================================================================
+ * 2. Distillation + detector losses (ATen elementwise/reduction chains in the reference)
+ *    Every loss kernel writes its scalar to loss_out[0] (device, loss_out must hold >= 4 floats) and, when grad pointers are non-NULL,
+ *    the gradient for upstream-gradient `gscale` in the same launch sequence.
+ * ===================================================================================================== */
+
+/* calculate_attentive_roi_feature_distillation(f_map_s=SOURCE, f_map_t=TARGET, gamma)
+ *   maskrcnn_benchmark/distillation/distillation.py:86-130, call site tools/train_incremental.py:115.
+ * f_src,f_tgt [N,HW,C] (NHWC) or [N,C,HW] (NCHW).
+ * coef [N,2,HW] fp32 scratch: a_src and dPad/dm_tgt per position, written by forward, read by backward.
+ * loss_out[0] = afd + gamma*pad ; loss_out[1] = afd ; loss_out[2] = pad. */
+int abr_ard_forward(const float* f_src, const float* f_tgt, int N, int C, int HW, float gamma, int layout,
+                    float* coef, float* loss_out, void* stream);
+/* grad_tgt = gscale * d(afd+gamma*pad)/d f_tgt ; gscale_dev (optional device scalar) multiplies gscale. */
+int abr_ard_backward(const float* f_src, const float* f_tgt, const float* coef, int N, int C, int HW,
+                     float gamma, int layout, float gscale, const float* gscale_dev, float* grad_tgt,
+                     void* stream);
+
+/* smooth_l1_loss(input, target, beta, size_average)   maskrcnn_benchmark/layers/smooth_l1_loss.py:6-17
+ * Optional row gather: when rows!=NULL only rows[i] (int64) of x/t take part and, per row, the 4 columns
+ * starting at col0[i] of x (box_head/loss.py:166-172 advanced indexing); x_cols = row length of x.
+ * loss_out[0] = sum * scale.  grad (optional, same shape as x, must be pre-zeroed when rows!=NULL). */
+int abr_smooth_l1(const float* x, const float* t, int64_t n, float beta, float scale, float* loss_out,
+                  float gscale, float* grad, void* stream);
+int abr_smooth_l1_rows(const float* x, int x_cols, const float* t, const int64_t* rows, const int64_t* col0,
+                       int n_rows, float beta, float scale, float* loss_out, float gscale, float* grad,
+                       void* stream);
+
+/* FastRCNNLossComputation classification term   modeling/roi_heads/box_head/loss.py:151-162
+ *   inclusive != 0 : "Inclusive Classification Loss" (dist_type=='id'), n_old = number of old classes
+ *   else           : F.cross_entropy.   labels int64 [n]; label<0 rows are ignored as F.nll_loss does (-100)
+ * loss_out[0] = mean over counted rows.  d_logits optional [n,K]. */
+int abr_softmax_ce(const float* logits, const int64_t* labels, int n, int K, int inclusive, int n_old,
+                   float* loss_out, float gscale, float* d_logits, void* stream);
+
+/* calculate_roi_distillation_losses(soften, target, dist)   distillation/distillation.py:164-240
+ *   dist_id!=0 -> unbiased cross-entropy + L2 boxes ; else mean-centred L2 + L2 boxes
+ * z_s [n,K_old], b_s [n,K_old,4], z_t [n,K_all], b_t [n,K_all,4]; d_zt/d_bt optional. */
+int abr_roi_distill(const float* z_s, const float* b_s, const float* z_t, const float* b_t, int n, int K_old,
+                    int K_all, int dist_id, float* loss_out, float gscale, float* d_zt, float* d_bt,
+                    void* stream);
+
+/* F.binary_cross_entropy_with_logits(x[idx], y[idx]).mean()   modeling/rpn/loss.py:145-146
+ * idx int64 [n_idx] into the flattened logits; grad optional, pre-zeroed, same shape as x. */
+int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, int n_idx, float* loss_out,
+                          float gscale, float* grad, void* stream);
+
+/* =====================================================================================================
+ * 3. Convolution as implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), NHWC / OHWI.
+ *    Replaces cuDNN fwd/dgrad/wgrad + FrozenBatchNorm2d + ReLU + residual add of
+ *    modeling/backbone/resnet.py:327-346,363-368, layers/batch_norm.py:19-31, modeling/rpn/rpn.py:114-121,
+ *    roi_box_predictors.py:27-32 (Linear = 1x1 conv on a 1x1 map).
+ * ===================================================================================================== */
+typedef struct {
+    int B, H, W, Cin;        /* input  [B,H,W,Cin]  (Cin % 4 == 0) */
+    int Cout, R, S;          /* weight [Cout,R,S,Cin] (OHWI)       */
+    int stride, pad;
+    int Ho, Wo;              /* output spatial size                 */
+    /* epilogue: y = acc*scale[c] + bias[c] (+ residual) ; relu ; y *= (mask>0) */
+    const float* scale;      /* [Cout] or NULL (=1)                 */
+    const float* bias;       /* [Cout] or NULL (=0)                 */
+    const float* residual;   /* same geometry as out, or NULL       */
+    const float* mask;       /* same geometry as out, or NULL: multiply by (mask>0) (ReLU backward) */
+    int relu;
+    /* output placement: row (b,ho,wo) is stored at pixel (b, ho*out_sh, wo*out_sw) of [B,out_H,out_W,Cout]
+       (out_sh=out_sw=1, out_H=Ho, out_W=Wo for an ordinary conv; 2 for the dgrad of a stride-2 1x1 conv) */
+    int out_H, out_W, out_sh, out_sw;
+} abr_conv_desc;
+
+int abr_conv_forward(const abr_conv_desc* d_host, const float* x, const float* w, float* out, void* stream);
+
+/* dW[Cout,R,S,Cin] (+)= sum_m gy[m,Cout]^T * im2col(x)[m,RSCin], columns scaled by d->scale (FrozenBN).
+ * Accumulates with fp32 atomics into dw (caller zeroes it once per step). */
+int abr_conv_wgrad(const abr_conv_desc* d_host, const float* x, const float* gy, float* dw, void* stream);
+
+/* w [Cout,R,S,Cin] -> wt [Cin,R,S,Cout] spatially flipped and scaled by scale[Cout]: the weight tensor
+ * that turns dgrad into abr_conv_forward(gy, wt). */
+int abr_conv_dgrad_weights(const float* w, const float* scale, int Cout, int R, int S, int Cin, float* wt,
+                           void* stream);
+/* db[c] += sum_m gy[m,c] (bias gradient of nn.Conv2d / nn.Linear) */
+int abr_bias_grad(const float* gy, int64_t M, int C, float* db, void* stream);
+
+/* =====================================================================================================
+ * 4. Pointwise / pooling / layout
+ * ===================================================================================================== */
+int abr_nchw_to_nhwc_pad(const float* x, int B, int C, int H, int W, int Cpad, float* out, void* stream);
+int abr_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* out, void* stream);
+int abr_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* out, void* stream);
+int abr_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* out, void* stream); /* resnet.py:367 */
+/* AdaptiveAvgPool2d(1)  roi_box_predictors.py:28 : x [N,HW,C] -> out [N,C] ; backward spreads g/HW */
+int abr_avgpool_forward(const float* x, int N, int HW, int C, float* out, void* stream);
+int abr_avgpool_backward(const float* g, int N, int HW, int C, float* gx, void* stream);
+/* g *= (y > 0) in place (ReLU backward) */
+int abr_relu_backward(float* g, const float* y, int64_t n, void* stream);
+int abr_add_inplace(float* a, const float* b, int64_t n, void* stream);
+
+/* =====================================================================================================
+ * 5. RPN / RoI-head glue (integer + fp32 index work; maskrcnn_benchmark/modeling/rpn/, matcher.py, box_coder.py)
+ * ===================================================================================================== */
+/* AnchorGenerator grid  anchor_generator.py:84-110 : out [H*W*A,4], vis [H*W*A] uint8 */
+int abr_grid_anchors(const float* cell, int A, int H, int W, int stride, int img_h, int img_w, int straddle,
+                     float* out, uint8_t* vis, void* stream);
+/* BoxCoder.decode + clip_to_image on gathered rows  (rpn/inference.py:96-112, box_coder.py:52-95, bounding_box.py:214-225)
+ * For image i and rank j<k: a = idx[i,j]; out[i,j,:] = clip(decode(reg[i,a,:], anchors[a,:])).
+ * reg [N,n_anchor,reg_stride] with the 4 deltas starting at column reg_col0. */
+int abr_rpn_decode_clip(const float* reg, int reg_stride, int reg_col0, const float* anchors,
+                        const int64_t* idx, int N, int n_anchor, int k, const int32_t* img_hw, float wx,
+                        float wy, float ww, float wh, float* out, void* stream);
+/* boxlist_iou + Matcher (+ RPN labels / box-head labels) + BoxCoder.encode in one pass per box.
+ *   boxes [n,4], gt [G,4], gt_labels [G] int64 (or NULL for RPN), vis [n] uint8 (or NULL)
+ *   matched [n] int64 (-1 / -2 / gt index), labels_out [n] (fp32 for RPN: 1/0/-1; int64 for head: class/0/-1),
+ *   reg_targets [n,4].   matcher.py:42-112, rpn/loss.py:66-102, box_head/loss.py:56-84 */
+int abr_match_encode(const float* boxes, int n, const float* gt, const int64_t* gt_labels, int G,
+                     const uint8_t* vis, float hi, float lo, int allow_low_quality, float wx, float wy,
+                     float ww, float wh, int64_t* matched, float* labels_f32, int64_t* labels_i64,
+                     float* reg_targets, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t abr_match_workspace_bytes(int n, int G);
+
+/* =====================================================================================================
+ * 6. Optimiser (solver/build.py:7-21, torch.optim.SGD semantics, one fused launch over all tensors)
+ *    p,g,m flat fp32 buffers of `total` elements; seg_end[i] = exclusive end offset of tensor i;
+ *    per-tensor lr[i], wd[i] (host arrays copied by the call).  m = mu*m + (g + wd*p); p -= lr*m.
+ *    gscale multiplies g first (1/world_size after an RCCL sum all-reduce).
+ * ===================================================================================================== */
+int abr_sgd_momentum(float* p, const float* g, float* m, int64_t total, const int64_t* seg_end_dev,
+                     const float* lr_dev, const float* wd_dev, int n_seg, float momentum, float gscale,
+                     int first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABR_IOD_HIP_H */

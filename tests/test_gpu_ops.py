@@ -1,0 +1,376 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the oracle and the reference-generated goldens.
+
+Integer / index outputs are compared bit-exact; floating point within the tolerance written at each assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev="cuda"):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def nhwc(x):  # numpy NCHW -> torch NHWC on device
+    return T(np.ascontiguousarray(np.transpose(x, (0, 2, 3, 1))))
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import ops
+    return ops
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import torch_ref
+    return torch_ref
+
+
+# ------------------------------------------------------------------------------------------ ROIAlign
+def test_roi_align_taps_bit_exact(gold, O):
+    """integer tap indices of the kernel's own indexing code == oracle's, on goldens and on 600x1000-shaped proposals"""
+    from abr_iod_amd import ops
+    g = gold("roi_align")
+    for sr in (0, 2):
+        idx, grid = ops.roi_align_taps(T(g["rois"]), 10, 14, 1 / 16, 7, 7, sr, 16)
+        ridx, rgrid = O.roi_align_taps(g["rois"], 10, 14, 1 / 16, 7, 7, sr, 16)
+        assert np.array_equal(grid.cpu().numpy(), rgrid)
+        assert np.array_equal(idx.cpu().numpy(), ridx)
+    rng = np.random.default_rng(0)
+    K = 4096
+    x1 = rng.uniform(-20, 980, K); y1 = rng.uniform(-20, 580, K)
+    w = np.exp(rng.uniform(np.log(2), np.log(900), K)); h = np.exp(rng.uniform(np.log(2), np.log(560), K))
+    rois = np.stack([rng.integers(0, 4, K), x1, y1, np.minimum(x1 + w, 1010), np.minimum(y1 + h, 610)], 1).astype(np.float32)
+    idx, grid = ops.roi_align_taps(T(rois), 38, 63, 0.0625, 7, 7, 0, 64)
+    ridx, rgrid = O.roi_align_taps(rois, 38, 63, 0.0625, 7, 7, 0, 64)
+    assert np.array_equal(grid.cpu().numpy(), rgrid)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+
+
+@pytest.mark.parametrize("name,hw", [("roi_align", (10, 14)), ("roi_align_c4", (38, 63))])
+def test_roi_align_forward_golden_bit_exact(gold, name, hw):
+    from abr_iod_amd import _C, ops
+    g = gold(name)
+    for sr in (0, 2):
+        want = g[f"out_sr{sr}"]
+        # drop-in NCHW entry point (maskrcnn_benchmark._C.roi_align_forward signature)
+        got = _C.roi_align_forward(T(g["feat"]), T(g["rois"]), 1 / 16, 7, 7, sr).cpu().numpy()
+        assert np.array_equal(got, want), f"NCHW sr={sr}: max abs diff {np.abs(got - want).max()}"
+        # native NHWC kernel
+        got = ops.roi_align_forward(nhwc(g["feat"]), T(g["rois"]), 1 / 16, 7, 7, sr).permute(0, 3, 1, 2).cpu().numpy()
+        assert np.array_equal(got, want), f"NHWC sr={sr}: max abs diff {np.abs(got - want).max()}"
+    if name == "roi_align":
+        got = _C.roi_align_forward(T(g["feat"]), T(g["rois"]), 0.0625, 3, 5, 0).cpu().numpy()
+        assert np.array_equal(got, g["out_sr0_3x5"])
+
+
+def test_roi_align_forward_bin_step_and_empty(gold):
+    from abr_iod_amd import _C, ops
+    g = gold("roi_align_c4")
+    full = ops.roi_align_forward(nhwc(g["feat"]), T(g["rois"]), 0.0625, 7, 7, 0)
+    even = ops.roi_align_forward(nhwc(g["feat"]), T(g["rois"]), 0.0625, 7, 7, 0, bin_step=2)
+    assert even.shape == (40, 4, 4, 24)
+    assert torch.equal(even, full[:, ::2, ::2, :].contiguous())
+    out = _C.roi_align_forward(T(g["feat"]), torch.zeros((0, 5), device="cuda"), 0.0625, 7, 7, 0)
+    assert out.shape == (0, 24, 7, 7)
+
+
+def test_roi_align_backward_vs_oracle(gold, O):
+    from abr_iod_amd import _C, ops
+    g = gold("roi_align_c4")
+    rng = np.random.default_rng(1)
+    for sr in (0, 2):
+        gy = rng.standard_normal((40, 24, 7, 7)).astype(np.float32)
+        want = O.roi_align_backward(gy, g["rois"], 0.0625, 7, 7, 2, 24, 38, 63, sr)
+        got = _C.roi_align_backward(T(gy), T(g["rois"]), 0.0625, 7, 7, 2, 24, 38, 63, sr).cpu().numpy()
+        # same per-tap products; only the fp32 summation order of the atomics differs
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+        got = ops.roi_align_backward(nhwc(gy), T(g["rois"]), 0.0625, 7, 7, sr, 2, 38, 63, 24).permute(0, 3, 1, 2).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    # bin_step=2 backward == full backward of a gradient that is zero on the odd bins
+    gy = rng.standard_normal((40, 24, 7, 7)).astype(np.float32)
+    gz = np.zeros_like(gy); gz[:, :, ::2, ::2] = gy[:, :, ::2, ::2]
+    want = O.roi_align_backward(gz, g["rois"], 0.0625, 7, 7, 2, 24, 38, 63, 0)
+    ge = nhwc(gy)[:, ::2, ::2, :].contiguous()
+    got = ops.roi_align_backward(ge, T(g["rois"]), 0.0625, 7, 7, 0, 2, 38, 63, 24, bin_step=2).permute(0, 3, 1, 2).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_roi_align_full_size_properties():
+    """BASELINE size (B=2, C=1024, 38x63, 1024 RoIs): constant map -> constant output; linearity; adjointness."""
+    from abr_iod_amd import ops
+    torch.manual_seed(0)
+    B, H, W, Ch, K = 2, 38, 63, 1024, 1024
+    x1 = torch.rand(K) * 900; y1 = torch.rand(K) * 500
+    rois = torch.stack([torch.randint(0, B, (K,)).float(), x1, y1, x1 + 16 + torch.rand(K) * 600, y1 + 16 + torch.rand(K) * 400], 1).cuda()
+    rois[:, 3].clamp_(max=999); rois[:, 4].clamp_(max=599)
+    ones = torch.full((B, H, W, Ch), 3.0, device="cuda")
+    out = ops.roi_align_forward(ones, rois, 0.0625, 7, 7, 0)
+    assert torch.allclose(out, torch.full_like(out, 3.0), rtol=0, atol=1e-5)  # weights of every sample sum to 1
+    a = torch.randn(B, H, W, Ch, device="cuda"); b = torch.randn(B, H, W, Ch, device="cuda")
+    ya, yb, yab = (ops.roi_align_forward(t, rois, 0.0625, 7, 7, 0) for t in (a, b, a + 2 * b))
+    assert torch.allclose(yab, ya + 2 * yb, rtol=1e-4, atol=1e-4)
+    gy = torch.randn_like(ya)
+    gx = ops.roi_align_backward(gy, rois, 0.0625, 7, 7, 0, B, H, W, Ch)
+    lhs = (ya.double() * gy.double()).sum().item(); rhs = (a.double() * gx.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
+# ------------------------------------------------------------------------------------------ NMS
+def test_nms_golden_index_exact(gold, O):
+    from abr_iod_amd import _C
+    g = gold("nms")
+    for thr, key in ((0.5, "keep_5"), (0.7, "keep_7")):
+        got = _C.nms(T(g["boxes"]), T(g["scores"]), thr).cpu().numpy()
+        assert got.dtype == np.int64 and np.array_equal(got, g[key])
+    # '>=' (CPU, canonical) vs '>' (CUDA) on the IoU == thr pair
+    assert 1 not in _C.nms(T(g["boxes"]), T(g["scores"]), 0.5).cpu().numpy()
+    assert 1 in _C.nms(T(g["boxes"]), T(g["scores"]), 0.5, strict_gt=True).cpu().numpy()
+    assert _C.nms(torch.zeros((0, 4), device="cuda"), torch.zeros((0,), device="cuda"), 0.5).numel() == 0
+
+
+def test_nms_large_vs_oracle(O):
+    """RPN-sized: 2 images x up to 6000 sorted proposals, batched, early stop at max_keep."""
+    from abr_iod_amd import ops
+    rng = np.random.default_rng(3)
+    N, n = 2, 6000
+    cx = rng.uniform(0, 1000, (N, n)); cy = rng.uniform(0, 600, (N, n))
+    w = np.exp(rng.uniform(np.log(16), np.log(500), (N, n))); h = np.exp(rng.uniform(np.log(16), np.log(400), (N, n)))
+    boxes = np.stack([np.clip(cx - w / 2, 0, 999), np.clip(cy - h / 2, 0, 599), np.clip(cx + w / 2, 0, 999), np.clip(cy + h / 2, 0, 599)], -1).astype(np.float32)
+    counts = np.array([6000, 4321], np.int32)
+    scores = -np.arange(n, dtype=np.float32)  # already sorted descending
+    for max_keep in (1000, 6000):
+        keep, nk = ops.nms_sorted_batched(T(boxes), T(counts), 0.7, max_keep)
+        keep, nk = keep.cpu().numpy(), nk.cpu().numpy()
+        for i in range(N):
+            want = O.nms(boxes[i, :counts[i]], scores[:counts[i]], 0.7)[:max_keep]
+            assert nk[i] == len(want)
+            assert np.array_equal(keep[i, :nk[i]], want)
+
+
+# ------------------------------------------------------------------------------------------ focal / smooth-L1
+def test_sigmoid_focal(gold, O):
+    from abr_iod_amd import _C
+    g = gold("sigmoid_focal")
+    lo = _C.sigmoid_focalloss_forward(T(g["logits"]), T(g["targets"]), 6, 2.0, 0.25).cpu().numpy()
+    np.testing.assert_allclose(lo, O.sigmoid_focal_forward(g["logits"], g["targets"], 2.0, 0.25), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(lo, g["loss"], rtol=2e-5, atol=1e-7)
+    d = _C.sigmoid_focalloss_backward(T(g["logits"]), T(g["targets"]), T(g["d_loss"]), 6, 2.0, 0.25).cpu().numpy()
+    np.testing.assert_allclose(d, O.sigmoid_focal_backward(g["logits"], g["targets"], g["d_loss"], 2.0, 0.25), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(d, g["d_logits"], rtol=2e-4, atol=2e-6)
+
+
+def test_smooth_l1(gold):
+    from abr_iod_amd import ops
+    g = gold("smooth_l1")
+    n = g["x"].size
+    for tag, beta, scale in (("b19_sum", 1 / 9, 1.0), ("b1_sum", 1.0, 1.0), ("b19_mean", 1 / 9, 1.0 / n)):
+        loss, grad = ops.smooth_l1(T(g["x"]), T(g["t"]), beta, scale=scale, want_grad=True)
+        np.testing.assert_allclose(loss[0].item(), g[f"{tag}_loss"], rtol=1e-6)
+        np.testing.assert_allclose(grad.cpu().numpy(), g[f"{tag}_grad"], rtol=1e-5, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------ box-head / distillation losses
+def test_box_head_losses(gold):
+    from abr_iod_amd import ops
+    g = gold("box_head_loss")
+    for (ko, ka) in ((16, 21), (11, 21), (11, 16)):
+        p = f"k{ko}_{ka}"
+        logits, reg, labels, rt = T(g[f"{p}_logits"]), T(g[f"{p}_reg"]), T(g[f"{p}_labels"]), T(g[f"{p}_rt"])
+        for dist in ("id", "l2"):
+            loss, dz = ops.softmax_ce(logits, labels, inclusive=(dist == "id"), n_old=ko - 1, want_grad=True)
+            np.testing.assert_allclose(loss[0].item(), g[f"{p}_{dist}_cls"], rtol=1e-5)          # 1e-4 budget
+            np.testing.assert_allclose(dz.cpu().numpy(), g[f"{p}_{dist}_dlogits"], rtol=1e-4, atol=1e-8)
+            pos = torch.nonzero(labels > 0).squeeze(1)
+            lb, dr = ops.smooth_l1_rows(reg, rt, pos, 4 * labels[pos], 1.0, scale=1.0 / labels.numel(), want_grad=True)
+            np.testing.assert_allclose(lb[0].item(), g[f"{p}_{dist}_box"], rtol=1e-5)
+            np.testing.assert_allclose(dr.cpu().numpy(), g[f"{p}_{dist}_dreg"], rtol=1e-5, atol=1e-9)
+
+
+def test_roi_distillation(gold):
+    from abr_iod_amd import ops
+    g = gold("roi_distill")
+    for (ko, ka) in ((16, 21), (11, 21), (11, 16), (21, 21)):
+        p = f"k{ko}_{ka}"
+        for dist in ("id", "l2"):
+            if f"{p}_{dist}_loss" not in g.files:
+                with pytest.raises(RuntimeError):  # K_all == K_old with dist='id': shape error in the reference too
+                    ops.roi_distill(T(g[f"{p}_zs"]), T(g[f"{p}_bs"]), T(g[f"{p}_zt"]), T(g[f"{p}_bt"]), dist_id=True)
+                continue
+            loss, dzt, dbt = ops.roi_distill(T(g[f"{p}_zs"]), T(g[f"{p}_bs"]), T(g[f"{p}_zt"]), T(g[f"{p}_bt"]),
+                                             dist_id=(dist == "id"), want_grad=True)
+            np.testing.assert_allclose(loss[0].item(), g[f"{p}_{dist}_loss"], rtol=1e-5)
+            np.testing.assert_allclose(dzt.cpu().numpy(), g[f"{p}_{dist}_dzt"], rtol=1e-4, atol=1e-8)
+            np.testing.assert_allclose(dbt.cpu().numpy(), g[f"{p}_{dist}_dbt"], rtol=1e-5, atol=1e-9)
+
+
+def test_ard(gold):
+    from abr_iod_amd import _lib, ops
+    g = gold("ard")
+    for tag in ("s", "m"):
+        fs, ft = g[f"{tag}_fs"], g[f"{tag}_ft"]
+        for gamma in (0, 1, 5):
+            loss, coef = ops.ard_forward(nhwc(fs), nhwc(ft), float(gamma))
+            np.testing.assert_allclose(loss[0].item(), g[f"{tag}_loss_g{gamma}"], rtol=1e-5)      # 1e-4 relative budget
+            np.testing.assert_allclose(coef[:, 0].cpu().numpy().reshape(g[f"{tag}_att_s"].shape), g[f"{tag}_att_s"], rtol=1e-5)
+            if f"{tag}_dft_g{gamma}" in g.files:
+                gr = ops.ard_backward(nhwc(fs), nhwc(ft), coef, float(gamma)).permute(0, 3, 1, 2).cpu().numpy()
+                want = g[f"{tag}_dft_g{gamma}"]
+                np.testing.assert_allclose(gr, want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
+        # reference tensor layout (NCHW) entry
+        loss, coef = ops.ard_forward(T(fs), T(ft), 1.0, layout=_lib.NCHW)
+        np.testing.assert_allclose(loss[0].item(), g[f"{tag}_loss_g1"], rtol=1e-5)
+        gr = ops.ard_backward(T(fs), T(ft), coef, 1.0, layout=_lib.NCHW).cpu().numpy()
+        np.testing.assert_allclose(gr, g[f"{tag}_dft_g1"], rtol=1e-4, atol=1e-5 * np.abs(g[f"{tag}_dft_g1"]).max())
+
+
+def test_ard_full_size_properties(R):
+    """[256,1024,7,7] (B=4): identical maps -> 0; loss vs torch-CPU oracle on a subsample-free run."""
+    from abr_iod_amd import ops
+    torch.manual_seed(0)
+    fs = torch.randn(256, 7, 7, 1024, device="cuda")
+    loss, _ = ops.ard_forward(fs, fs, 1.0)
+    assert loss[0].item() == 0.0
+    ft = fs + 0.3 * torch.randn_like(fs)
+    loss, coef = ops.ard_forward(fs, ft, 1.0)
+    want = R.ard_loss(fs[:32].permute(0, 3, 1, 2).cpu(), ft[:32].permute(0, 3, 1, 2).cpu(), 1.0).item()
+    l32, _ = ops.ard_forward(fs[:32].contiguous(), ft[:32].contiguous(), 1.0)
+    assert abs(l32[0].item() - want) < 1e-5 * abs(want)
+
+
+# ------------------------------------------------------------------------------------------ RPN glue
+def test_anchors_match_encode_decode(gold, O):
+    from abr_iod_amd import ops
+    g = gold("anchors")
+    cell = T(g["cell"].astype(np.float32))
+    for i in (0, 1):
+        a, v = ops.grid_anchors(cell, 38, 63, 16, int(g["image_sizes"][i][0]), int(g["image_sizes"][i][1]))
+        assert np.array_equal(a.cpu().numpy(), g[f"bbox{i}"]) and np.array_equal(v.cpu().numpy().astype(bool), g[f"vis{i}"].astype(bool))
+    g = gold("matcher")
+    for tag, hi, lo, lq in (("rpn", 0.7, 0.3, True), ("head", 0.5, 0.5, False)):
+        m, lab, tgt = ops.match_encode(T(g["prop"]), T(g["gt"]), None, None, hi, lo, lq, (1, 1, 1, 1), rpn_labels=True)
+        assert np.array_equal(m.cpu().numpy(), g[f"{tag}_matched"])
+    g = gold("rpn")
+    for i in (0, 1):
+        m, lab, tgt = ops.match_encode(T(g[f"anchors{i}"]), T(g[f"gt{i}"]), None, T(g[f"vis{i}"].astype(np.uint8)), 0.7, 0.3, True,
+                                       (1, 1, 1, 1), rpn_labels=True)
+        assert np.array_equal(m.cpu().numpy(), g["rpn_matched"][i])
+        assert np.array_equal(lab.cpu().numpy(), g["rpn_labels"][i])
+        np.testing.assert_allclose(tgt.cpu().numpy(), g["rpn_reg_targets"][i], rtol=1e-5, atol=1e-6)
+    g = gold("box_coder")
+    ex = T(g["ex"])
+    idx = torch.arange(64, device="cuda").view(1, 64)
+    hw = torch.tensor([[100000, 100000]], dtype=torch.int32, device="cuda")
+    for tag, w in (("rpn", (1, 1, 1, 1)), ("head", (10, 10, 5, 5))):
+        for c in range(3):
+            d = T(g[f"{tag}_deltas"]).view(1, 64, 12)
+            out = ops.rpn_decode_clip(d, 4 * c, ex, idx, hw, w)[0].cpu().numpy()
+            want = np.clip(g[f"{tag}_dec"][:, 4 * c:4 * c + 4], 0, 99999)
+            np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------ conv engine
+def _conv_ref(x, w, stride, pad, scale, bias, residual, relu):
+    y = torch.nn.functional.conv2d(x, w, stride=stride, padding=pad)
+    if scale is not None:
+        y = y * scale.view(1, -1, 1, 1)
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + residual
+    return torch.relu(y) if relu else y
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad   (shapes that exercise every tile config + edges)
+    (2, 64, 19, 23, 64, 1, 1, 0),      # BN=64 path
+    (2, 64, 19, 23, 256, 3, 1, 1),     # 3x3 halo
+    (1, 256, 38, 63, 512, 1, 2, 0),    # stride-2 1x1 (layer3.0 / downsample)
+    (2, 128, 16, 16, 76, 1, 1, 0),     # Cout not a multiple of 32 (fused RPN cls+bbox head)
+    (1, 4, 37, 45, 64, 7, 2, 3),       # padded stem, SMALL_C path
+    (1, 1024, 38, 63, 1024, 3, 1, 1),  # RPN 3x3 at full C4 size
+    (512, 512, 4, 4, 512, 3, 1, 1),    # layer4 conv2 on 512 RoIs
+    (8, 2048, 1, 1, 108, 1, 1, 0),     # predictor FC
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_vs_torch_cpu(case):
+    from abr_iod_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    torch.manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, H, W); w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout) + 0.5; bias = torch.randn(Cout) * 0.1
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = torch.randn(B, Cout, Ho, Wo)
+    want = _conv_ref(x, w, s, p, scale, bias, res, True)
+    got = ops.conv_forward(x.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), s, p,
+                           scale=scale.cuda(), bias=bias.cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda(), relu=True)
+    got = got.permute(0, 3, 1, 2).cpu()
+    # fp32 MFMA == fmaf chain; torch CPU (oneDNN) sums in another order: 1e-4 of the output scale (north_star tolerance)
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    plain = ops.conv_forward(x.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), s, p)
+    want = _conv_ref(x, w, s, p, None, None, None, False)
+    assert (plain.permute(0, 3, 1, 2).cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] % 4 == 0 and c[4] % 4 == 0])
+def test_conv_backward_vs_torch_autograd(case):
+    from abr_iod_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    if k == 7:
+        pytest.skip("stem is frozen (FREEZE_CONV_BODY_AT=2): no backward on the path")
+    torch.manual_seed(1 + hash(case) % 1000)
+    x = torch.randn(B, Cin, H, W, requires_grad=True); w = (torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5).requires_grad_(True)
+    scale = torch.rand(Cout) + 0.5
+    y = torch.nn.functional.conv2d(x, w, stride=s, padding=p) * scale.view(1, -1, 1, 1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xg = x.detach().permute(0, 2, 3, 1).contiguous().cuda(); wg = w.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    gyg = gy.permute(0, 2, 3, 1).contiguous().cuda(); sc = scale.cuda()
+    dw = torch.zeros_like(wg)
+    ops.conv_wgrad(xg, gyg, dw, s, p, scale=sc)
+    want = w.grad.permute(0, 2, 3, 1)
+    assert (dw.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    wt = ops.conv_dgrad_weights(wg, sc)
+    if s == 1:
+        dx = ops.conv_forward(gyg, wt, 1, k - 1 - p)
+    else:  # stride-2 1x1: rows land on the even pixels of a zeroed tensor
+        dx = ops.conv_forward(gyg, wt, 1, 0, out_hw=(H, W), out_stride=(s, s))
+    want = x.grad.permute(0, 2, 3, 1)
+    assert (dx.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+def test_pointwise_and_sgd():
+    from abr_iod_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 33, 47)
+    got = ops.nchw_to_nhwc(x.cuda(), cpad=4).cpu()
+    assert torch.equal(got[..., :3], x.permute(0, 2, 3, 1)) and torch.all(got[..., 3] == 0)
+    y = torch.randn(2, 64, 37, 45)
+    mp = ops.maxpool3x3s2(y.permute(0, 2, 3, 1).contiguous().cuda()).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(mp, torch.nn.functional.max_pool2d(y, 3, 2, 1))
+    z = torch.randn(16, 4, 4, 2048)
+    ap = ops.avgpool_forward(z.cuda()).cpu()
+    assert torch.allclose(ap, z.mean(dim=(1, 2)), rtol=1e-6, atol=1e-6)
+    back = ops.nhwc_to_nchw(ops.nchw_to_nhwc(y.cuda())).cpu()
+    assert torch.equal(back, y)
+    # fused multi-tensor SGD vs torch.optim.SGD with per-tensor groups (solver/build.py:7-21)
+    sizes = [1000, 64, 4096, 7]
+    ps = [torch.randn(s) for s in sizes]; gs = [torch.randn(s) for s in sizes]
+    lrs = [0.01, 0.02, 0.01, 0.02]; wds = [1e-4, 0.0, 1e-4, 0.0]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.SGD([{"params": [r], "lr": lr, "weight_decay": wd} for r, lr, wd in zip(ref, lrs, wds)], lr=0.01, momentum=0.9)
+    flat_p = torch.cat(ps).cuda(); flat_m = torch.zeros_like(flat_p)
+    seg = torch.tensor(np.cumsum(sizes), dtype=torch.int64, device="cuda")
+    lr_d = torch.tensor(lrs, device="cuda"); wd_d = torch.tensor(wds, device="cuda")
+    for step in range(3):
+        for r, g_ in zip(ref, gs):
+            r.grad = g_.clone() * (step + 1)
+        opt.step()
+        flat_g = torch.cat([g_ * (step + 1) for g_ in gs]).cuda()
+        ops.sgd_momentum_(flat_p, flat_g, flat_m, seg, lr_d, wd_d, 0.9, first_step=(step == 0))
+    assert torch.allclose(flat_p.cpu(), torch.cat([r.detach() for r in ref]), rtol=1e-6, atol=1e-7)
