@@ -28,7 +28,7 @@ def nms(dets, scores, threshold, strict_gt=None):
         raise RuntimeError("nms: dets and scores must be float32 (nms.cu:71 is float-only)")
     strict = NMS_STRICT_GT if strict_gt is None else strict_gt
     n = dets.shape[0]
-    order = torch.sort(scores, 0, descending=True, stable=True)[1]
+    order = torch.sort(scores, dim=0, descending=True, stable=True)[1]
     boxes = dets.index_select(0, order).contiguous()
     counts = torch.tensor([n], dtype=torch.int32, device=dets.device)
     keep = torch.empty((1, n), dtype=torch.int32, device=dets.device)

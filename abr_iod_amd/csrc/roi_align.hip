@@ -16,6 +16,8 @@
 //     neighbouring bins/RoIs re-read the same feature rows from that XCD's L2;
 //   * bin_step=2 computes only the even bins -- the only ones layer4's stride-2 1x1 conv reads.
 // Bound: HBM (output write / grad read) with L2-resident tap re-reads; see DESIGN.md.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -240,6 +242,131 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------
+// NHWC backward, separable per-RoI form (the one the hot path uses).
+//
+// The direct form above issues one atomic per (bin, sample, tap, channel): K*49*gh*gw*4*C of them -- at
+// K=2048, C=1024 that is ~3.7e9 atomics and the kernel is bound by the L2 atomic rate (25 ms measured).
+// Bilinear weights and the sample grid are both products of a y-part and an x-part, and so is the
+// reject test (y out of range OR x out of range), hence for one RoI
+//     dFeat[y][x][c] += sum_ph Wy[ph][y] * sum_pw Wx[pw][x] * g[ph][pw][c] / count
+// with Wy[ph][y] = sum of the y-weights that bin-row ph's samples put on feature row y (same for Wx).
+// A workgroup builds the two small tables in LDS with the SAME coordinate code as the forward (so the
+// integer taps are identical), then walks the RoI's pixel footprint once: per row it folds the <=7 bin
+// rows into 7 register vectors, per pixel it folds the bin columns and issues ONE vector atomic.
+// Atomics drop from 4*gh*gw*49 to ~(7*bh+1)*(7*bw+1) per RoI and channel (~9x fewer on RPN proposals).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kMaxPo = 8;  // pooled bins per axis handled by the separable kernel
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ void axis_tap(float start, float bin, int grid, int p, int i, int L, int* lo, int* hi,
+                                         float* wlo, float* whi, bool* ok) {
+    float v = start + p * bin + (float)(i + .5f) * bin / (float)grid;
+    if (v < -1.0f || v > (float)L) { *ok = false; return; }
+    *ok = true;
+    if (v <= 0) v = 0;
+    int l = (int)v, h;
+    if (l >= L - 1) { h = l = L - 1; v = (float)l; } else h = l + 1;
+    const float lw = v - l;
+    *lo = l; *hi = h; *wlo = 1.f - lw; *whi = lw;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void roi_align_bwd_nhwc_sep(const float* __restrict__ grad, const float* __restrict__ rois,
+                                                               int K, int C, int H, int W, float scale, int PH, int PW,
+                                                               int sr, int step, int PHo, int PWo, int tx, int cchunks,
+                                                               float* __restrict__ gfeat) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Wy = sm;                 // [PHo][H]
+    float* Wx = sm + PHo * H;       // [PWo][W]
+    int* rng = reinterpret_cast<int*>(Wx + PWo * W);  // ymin, ymax, xmin, xmax
+    const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
+    const int n = bid / cchunks, chunk = bid % cchunks;
+    const RoiGeom g = roi_geom(rois + 5 * (size_t)n, scale, PH, PW, sr);
+    const float inv_count = 1.f / (float)(g.gh * g.gw);
+
+    for (int i = threadIdx.x; i < PHo * H + PWo * W; i += 256) sm[i] = 0.f;
+    if (threadIdx.x == 0) { rng[0] = H; rng[1] = -1; rng[2] = W; rng[3] = -1; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < PHo * g.gh; t += 256) {
+        const int pi = t / g.gh, iy = t % g.gh;
+        int lo, hi; float wl, wh; bool ok;
+        axis_tap(g.y0, g.bh, g.gh, pi * step, iy, H, &lo, &hi, &wl, &wh, &ok);
+        if (ok) {
+            atomicAdd(&Wy[pi * H + lo], wl);
+            atomicAdd(&Wy[pi * H + hi], wh);
+            atomicMin(&rng[0], lo); atomicMax(&rng[1], hi);
+        }
+    }
+    for (int t = threadIdx.x; t < PWo * g.gw; t += 256) {
+        const int pi = t / g.gw, ix = t % g.gw;
+        int lo, hi; float wl, wh; bool ok;
+        axis_tap(g.x0, g.bw, g.gw, pi * step, ix, W, &lo, &hi, &wl, &wh, &ok);
+        if (ok) {
+            atomicAdd(&Wx[pi * W + lo], wl);
+            atomicAdd(&Wx[pi * W + hi], wh);
+            atomicMin(&rng[2], lo); atomicMax(&rng[3], hi);
+        }
+    }
+    __syncthreads();
+    const int ymin = rng[0], ymax = rng[1], xmin = rng[2], xmax = rng[3];
+    if (ymax < ymin || xmax < xmin) return;
+
+    using V = typename VecT<VEC>::type;
+    const int cvecs = C / VEC;
+    const int cl = threadIdx.x % tx, rl = threadIdx.x / tx, nrl = 256 / tx;
+    const int cv = chunk * tx + cl;
+    if (cv >= cvecs) return;
+    const float* gr = grad + (size_t)n * PHo * PWo * C + cv * VEC;
+    float* gb = gfeat + (size_t)g.b * H * W * C + cv * VEC;
+
+    for (int y = ymin + rl; y <= ymax; y += nrl) {
+        float T[kMaxPo][VEC];
+#pragma unroll
+        for (int j = 0; j < kMaxPo; j++)
+#pragma unroll
+            for (int i = 0; i < VEC; i++) T[j][i] = 0.f;
+        bool any = false;
+        for (int pi = 0; pi < PHo; pi++) {
+            const float wy = Wy[pi * H + y] * inv_count;
+            if (wy == 0.f) continue;
+            any = true;
+#pragma unroll
+            for (int j = 0; j < kMaxPo; j++) {
+                if (j < PWo) {
+                    const V v = *reinterpret_cast<const V*>(gr + ((size_t)pi * PWo + j) * C);
+                    const float* a = reinterpret_cast<const float*>(&v);
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) T[j][i] += wy * a[i];
+                }
+            }
+        }
+        if (!any) continue;
+        for (int x = xmin; x <= xmax; x++) {
+            float o[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; i++) o[i] = 0.f;
+            bool hit = false;
+#pragma unroll
+            for (int j = 0; j < kMaxPo; j++) {
+                if (j < PWo) {
+                    const float wx = Wx[j * W + x];
+                    if (wx != 0.f) {
+                        hit = true;
+#pragma unroll
+                        for (int i = 0; i < VEC; i++) o[i] += wx * T[j][i];
+                    }
+                }
+            }
+            if (hit) {
+                float* d = gb + ((size_t)y * W + x) * C;
+#pragma unroll
+                for (int i = 0; i < VEC; i++) unsafeAtomicAdd(d + i, o[i]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // NCHW compatibility kernels (the reference's own tensor layout; drop-in for `_C.roi_align_*`).
 // One thread per (n, c, ph, pw) like the reference; pw fastest so a wave reads neighbouring taps.
 // ---------------------------------------------------------------------------------------------------
@@ -374,7 +501,21 @@ extern "C" int abr_roi_align_backward(const float* grad, const float* rois, int 
         const int PHo = (PH + bin_step - 1) / bin_step, PWo = (PW + bin_step - 1) / bin_step;
         const int nbins = PHo * PWo;
         int tx, bpb;
-        if (C % 4 == 0) {
+        const size_t sep_lds = sizeof(float) * ((size_t)PHo * H + (size_t)PWo * W) + 16;
+        if (PHo <= kMaxPo && PWo <= kMaxPo && sep_lds <= 60 * 1024 && !getenv("ABR_ROIALIGN_BWD_DIRECT")) {
+            const int vec = (C % 4 == 0) ? 4 : 1;
+            const int cvecs = C / vec;
+            int t = 1;
+            while (t < cvecs && t < 256) t <<= 1;
+            if (t < 16) t = 16;
+            const int cchunks = (cvecs + t - 1) / t;
+            if (vec == 4)
+                roi_align_bwd_nhwc_sep<4><<<(unsigned)(K * cchunks), 256, sep_lds, st>>>(grad, rois, K, C, H, W, scale, PH, PW, sr,
+                                                                                        bin_step, PHo, PWo, t, cchunks, gfeat);
+            else
+                roi_align_bwd_nhwc_sep<1><<<(unsigned)(K * cchunks), 256, sep_lds, st>>>(grad, rois, K, C, H, W, scale, PH, PW, sr,
+                                                                                        bin_step, PHo, PWo, t, cchunks, gfeat);
+        } else if (C % 4 == 0) {
             pick_shape(C / 4, nbins, &tx, &bpb);
             const int bpr = (nbins + bpb - 1) / bpb;
             roi_align_bwd_nhwc<4><<<(unsigned)(K * bpr), 256, 0, st>>>(grad, rois, K, C, H, W, scale, PH, PW, sr,

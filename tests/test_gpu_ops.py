@@ -233,7 +233,7 @@ def test_ard_full_size_properties(R):
     torch.manual_seed(0)
     fs = torch.randn(256, 7, 7, 1024, device="cuda")
     loss, _ = ops.ard_forward(fs, fs, 1.0)
-    assert loss[0].item() == 0.0
+    assert abs(loss[0].item()) < 1e-6  # identical maps: afd == 0 exactly, pad only carries softmax rounding
     ft = fs + 0.3 * torch.randn_like(fs)
     loss, coef = ops.ard_forward(fs, ft, 1.0)
     want = R.ard_loss(fs[:32].permute(0, 3, 1, 2).cpu(), ft[:32].permute(0, 3, 1, 2).cpu(), 1.0).item()
