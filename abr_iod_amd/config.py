@@ -1,0 +1,178 @@
+"""Configuration: the keys the hot path reads, with the reference's defaults
+(maskrcnn_benchmark/config/defaults.py:21-503; per-key line numbers in SURVEY.md §5).  The node class offers the
+subset of the yacs CfgNode API the reference's drivers use (attribute access, clone, freeze/defrost,
+merge_from_file, merge_from_list), so `configs/voc/**.yaml` files load unchanged."""
+import ast
+import copy
+
+
+class CfgNode(dict):
+    def __init__(self, init=None):
+        super().__init__()
+        for k, v in (init or {}).items():
+            self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    def freeze(self):
+        pass
+
+    def defrost(self):
+        pass
+
+    @staticmethod
+    def _coerce(v):
+        if isinstance(v, str):
+            try:
+                return ast.literal_eval(v)
+            except Exception:
+                return v
+        if isinstance(v, list) and not any(isinstance(x, (dict, list)) for x in v):
+            return tuple(v)
+        return v
+
+    def _merge(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict):
+                if not isinstance(self.get(k), CfgNode):
+                    self[k] = CfgNode()
+                self[k]._merge(v)
+            else:
+                self[k] = self._coerce(v)
+
+    def merge_from_file(self, path):
+        import yaml
+        with open(path) as f:
+            self._merge(yaml.safe_load(f) or {})
+
+    def merge_from_list(self, lst):
+        for k, v in zip(lst[0::2], lst[1::2]):
+            node, parts = self, k.split(".")
+            for p in parts[:-1]:
+                node = node[p]
+            node[parts[-1]] = self._coerce(v)
+
+
+CN = CfgNode
+
+_C = CN()
+_C.MODEL = CN()
+_C.MODEL.DEVICE = "cuda"
+_C.MODEL.META_ARCHITECTURE = "GeneralizedRCNN"
+_C.MODEL.RPN_ONLY = False
+_C.MODEL.MASK_ON = False
+_C.MODEL.RETINANET_ON = False
+_C.MODEL.KEYPOINT_ON = False
+_C.MODEL.CLS_AGNOSTIC_BBOX_REG = False
+_C.MODEL.WEIGHT = ""
+_C.MODEL.SOURCE_WEIGHT = ""
+
+_C.INPUT = CN()
+_C.INPUT.MIN_SIZE_TRAIN = (800,)
+_C.INPUT.MAX_SIZE_TRAIN = 1333
+_C.INPUT.PIXEL_MEAN = [102.9801, 115.9465, 122.7717]
+_C.INPUT.PIXEL_STD = [1.0, 1.0, 1.0]
+_C.INPUT.TO_BGR255 = True
+
+_C.DATALOADER = CN()
+_C.DATALOADER.NUM_WORKERS = 4
+_C.DATALOADER.SIZE_DIVISIBILITY = 0
+
+_C.MODEL.BACKBONE = CN()
+_C.MODEL.BACKBONE.CONV_BODY = "R-50-C4"
+_C.MODEL.BACKBONE.FREEZE_CONV_BODY_AT = 2
+
+_C.MODEL.RESNETS = CN()
+_C.MODEL.RESNETS.NUM_GROUPS = 1
+_C.MODEL.RESNETS.WIDTH_PER_GROUP = 64
+_C.MODEL.RESNETS.STRIDE_IN_1X1 = True
+_C.MODEL.RESNETS.TRANS_FUNC = "BottleneckWithFixedBatchNorm"
+_C.MODEL.RESNETS.STEM_FUNC = "StemWithFixedBatchNorm"
+_C.MODEL.RESNETS.RES5_DILATION = 1
+_C.MODEL.RESNETS.BACKBONE_OUT_CHANNELS = 256 * 4
+_C.MODEL.RESNETS.RES2_OUT_CHANNELS = 256
+_C.MODEL.RESNETS.STEM_OUT_CHANNELS = 64
+
+_C.MODEL.RPN = CN()
+_C.MODEL.RPN.USE_FPN = False
+_C.MODEL.RPN.EXTERNAL_PROPOSAL = False
+_C.MODEL.RPN.ANCHOR_SIZES = (32, 64, 128, 256, 512)
+_C.MODEL.RPN.ANCHOR_STRIDE = (16,)
+_C.MODEL.RPN.ASPECT_RATIOS = (0.5, 1.0, 2.0)
+_C.MODEL.RPN.STRADDLE_THRESH = 0
+_C.MODEL.RPN.FG_IOU_THRESHOLD = 0.7
+_C.MODEL.RPN.BG_IOU_THRESHOLD = 0.3
+_C.MODEL.RPN.BATCH_SIZE_PER_IMAGE = 256
+_C.MODEL.RPN.POSITIVE_FRACTION = 0.5
+_C.MODEL.RPN.PRE_NMS_TOP_N_TRAIN = 12000
+_C.MODEL.RPN.PRE_NMS_TOP_N_TEST = 6000
+_C.MODEL.RPN.POST_NMS_TOP_N_TRAIN = 2000
+_C.MODEL.RPN.POST_NMS_TOP_N_TEST = 1000
+_C.MODEL.RPN.NMS_THRESH = 0.7
+_C.MODEL.RPN.MIN_SIZE = 0
+_C.MODEL.RPN.RPN_HEAD = "SingleConvRPNHead"
+_C.MODEL.RPN.CONV_FREEZE = False
+_C.MODEL.RPN.CLS_FREEZE = False
+_C.MODEL.RPN.BBS_FREEZE = False
+
+_C.MODEL.ROI_HEADS = CN()
+_C.MODEL.ROI_HEADS.USE_FPN = False
+_C.MODEL.ROI_HEADS.FG_IOU_THRESHOLD = 0.5
+_C.MODEL.ROI_HEADS.BG_IOU_THRESHOLD = 0.5
+_C.MODEL.ROI_HEADS.BBOX_REG_WEIGHTS = (10.0, 10.0, 5.0, 5.0)
+_C.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 512
+_C.MODEL.ROI_HEADS.POSITIVE_FRACTION = 0.25
+_C.MODEL.ROI_HEADS.SCORE_THRESH = 0.05
+_C.MODEL.ROI_HEADS.NMS = 0.5
+_C.MODEL.ROI_HEADS.DETECTIONS_PER_IMG = 100
+
+_C.MODEL.ROI_BOX_HEAD = CN()
+_C.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR = "ResNet50Conv5ROIFeatureExtractor"
+_C.MODEL.ROI_BOX_HEAD.PREDICTOR = "FastRCNNPredictor"
+_C.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION = 14
+_C.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO = 0
+_C.MODEL.ROI_BOX_HEAD.POOLER_SCALES = (1.0 / 16,)
+_C.MODEL.ROI_BOX_HEAD.NUM_CLASSES = 81
+_C.MODEL.ROI_BOX_HEAD.NAME_OLD_CLASSES = []
+_C.MODEL.ROI_BOX_HEAD.NAME_NEW_CLASSES = []
+_C.MODEL.ROI_BOX_HEAD.NAME_EXCLUDED_CLASSES = []
+
+_C.SOLVER = CN()
+_C.SOLVER.MAX_ITER = 40000
+_C.SOLVER.BASE_LR = 0.001
+_C.SOLVER.BIAS_LR_FACTOR = 2
+_C.SOLVER.MOMENTUM = 0.9
+_C.SOLVER.WEIGHT_DECAY = 0.0005
+_C.SOLVER.WEIGHT_DECAY_BIAS = 0
+_C.SOLVER.GAMMA = 0.1
+_C.SOLVER.STEPS = (30000,)
+_C.SOLVER.WARMUP_FACTOR = 1.0 / 3
+_C.SOLVER.WARMUP_ITERS = 500
+_C.SOLVER.WARMUP_METHOD = "linear"
+_C.SOLVER.CHECKPOINT_PERIOD = 2500
+_C.SOLVER.IMS_PER_BATCH = 16
+
+_C.DIST = CN()
+_C.DIST.TYPE = "l2"
+_C.DIST.FEAT = "no"
+_C.DIST.ALPHA = 0.0
+_C.DIST.BETA = 0.0
+_C.DIST.GAMMA = 1.0
+_C.DIST.RPN = False
+
+_C.INCREMENTAL = False
+_C.CLS_PER_STEP = -1
+_C.DTYPE = "float32"
+_C.OUTPUT_DIR = "."
+
+cfg = _C

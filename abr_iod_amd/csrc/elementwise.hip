@@ -119,6 +119,11 @@ __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const f
         for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) a[i] += b[i];
 }
 
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64_t n, float s, const float* __restrict__ s_dev) {
+    const float k = s * (s_dev ? *s_dev : 1.f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= k;
+}
+
 // Fused SGD(momentum) over ALL tensors in one launch.  Reference: one param group PER TENSOR
 // (solver/build.py:7-21) -> 52 x (wd add, momentum mul/add, update) tiny launches; here one streaming pass:
 // reads p,g,m and writes p,m = 5 x 4 B per element.  torch.optim.SGD semantics (dampening 0, no nesterov):
@@ -201,6 +206,14 @@ extern "C" int abr_add_inplace(float* a, const float* b, int64_t n, void* stream
     ABR_REQUIRE(a && b && n > 0, "add_inplace: bad args");
     add_kernel<<<(unsigned)std::min<int64_t>((n / 4 + 255) / 256 + 1, 8192), 256, 0, abr::as_stream(stream)>>>(a, b, n / 4, n);
     ABR_CHECK_LAUNCH("add_inplace");
+    return ABR_OK;
+}
+
+extern "C" int abr_scale_inplace(float* x, int64_t n, float s, const float* s_dev, void* stream) {
+    if (n == 0) return ABR_OK;
+    ABR_REQUIRE(x && n > 0, "scale_inplace: bad args");
+    scale_kernel<<<(unsigned)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, abr::as_stream(stream)>>>(x, n, s, s_dev);
+    ABR_CHECK_LAUNCH("scale_inplace");
     return ABR_OK;
 }
 

@@ -72,10 +72,11 @@ __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict_
     if (threadIdx.x == 0) atomicAdd(loss_out, acc * scale);
 }
 
-// x row r=rows[i], columns col0[i]..col0[i]+3  vs  t row r (t is [*,4], indexed by the same r)
+// x row rows[i], columns col0[i]..col0[i]+3  vs  t row trows[i] (t is [*,4]; trows==NULL -> same row as x)
 __global__ __launch_bounds__(256) void smooth_l1_rows_kernel(const float* __restrict__ x, int x_cols,
                                                               const float* __restrict__ t, const int64_t* __restrict__ rows,
-                                                              const int64_t* __restrict__ col0, int n_rows, float beta,
+                                                              const int64_t* __restrict__ col0, const int64_t* __restrict__ trows,
+                                                              int n_rows, float beta,
                                                               float scale, float* __restrict__ loss_out, float gscale,
                                                               float* __restrict__ grad) {
     __shared__ float sm[4];
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void smooth_l1_rows_kernel(const float* __rest
         const int64_t r = rows[i >> 2];
         const int64_t c = (col0 ? col0[i >> 2] : 0) + (i & 3);
         float g;
-        acc += sl1(x[r * x_cols + c] - t[r * 4 + (i & 3)], beta, &g);
+        const int64_t tr = trows ? trows[i >> 2] : r;
+        acc += sl1(x[r * x_cols + c] - t[tr * 4 + (i & 3)], beta, &g);
         if (grad) grad[r * x_cols + c] = g * gscale * scale;
     }
     acc = abr::block_sum<4>(acc, sm);
@@ -98,13 +100,13 @@ __global__ __launch_bounds__(256) void smooth_l1_rows_kernel(const float* __rest
 constexpr int kMaxK = 128;
 
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                          int n, int K, int inclusive, int n_old, const int* __restrict__ n_valid,
+                                                          int n, int K, int ldz, int ldg, int inclusive, int n_old, const int* __restrict__ n_valid,
                                                           float* __restrict__ loss_out, float gscale, float* __restrict__ dz) {
     __shared__ float sm[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float li = 0.f;
     if (i < n) {
-        const float* z = logits + (size_t)i * K;
+        const float* z = logits + (size_t)i * ldz;
         const int64_t lab = labels[i];
         float mx = z[0];
         for (int c = 1; c < K; c++) mx = fmaxf(mx, z[c]);
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
             }
         }
         if (dz) {
-            float* g = dz + (size_t)i * K;
+            float* g = dz + (size_t)i * ldg;
             const float s = gscale * inv_n;
             for (int c = 0; c < K; c++) {
                 float v = 0.f;
@@ -160,14 +162,15 @@ __global__ void count_valid_kernel(const int64_t* __restrict__ labels, int n, in
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restrict__ z_s, const float* __restrict__ b_s,
                                                            const float* __restrict__ z_t, const float* __restrict__ b_t, int n,
+                                                           int ld_zs, int ld_bs, int ld_zt, int ld_bt, int ld_dzt, int ld_dbt,
                                                            int K_old, int K_all, int dist_id, float* __restrict__ loss_out,
                                                            float gscale, float* __restrict__ d_zt, float* __restrict__ d_bt) {
     __shared__ float sm[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float li = 0.f;
     if (i < n) {
-        const float* zs = z_s + (size_t)i * K_old;
-        const float* zt = z_t + (size_t)i * K_all;
+        const float* zs = z_s + (size_t)i * ld_zs;
+        const float* zt = z_t + (size_t)i * ld_zt;
         const float inv_n = 1.f / (float)n;
         if (dist_id) {
             float mt = zt[0], ms = zs[0];
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restric
             for (int c = 1; c < K_old; c++) acc += (expf(zs[c] - ms) / ses) * (zt[c] - den);   // :195,:198
             li = -(acc / (float)K_old) * inv_n;                                 // :198-199
             if (d_zt) {
-                float* g = d_zt + (size_t)i * K_all;
+                float* g = d_zt + (size_t)i * ld_dzt;
                 const float s = -gscale * inv_n / (float)K_old;
                 for (int c = 0; c < K_all; c++) {
                     const float e = expf(zt[c] - mt);
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restric
             }
             li = acc / (float)K_old * inv_n;                                    // :185-188
             if (d_zt) {
-                float* g = d_zt + (size_t)i * K_all;
+                float* g = d_zt + (size_t)i * ld_dzt;
                 const float s = gscale * inv_n / (float)K_old;
                 for (int c = 0; c < K_all; c++) {
                     float v = -2.f * dsum / (float)K_all;
@@ -221,8 +224,8 @@ __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restric
             }
         }
         // boxes: mean_n mean_k sum_4 (b_t[:,1:K_old] - b_s[:,1:])^2       :204-209
-        const float* bs = b_s + (size_t)i * K_old * 4;
-        const float* bt = b_t + (size_t)i * K_all * 4;
+        const float* bs = b_s + (size_t)i * ld_bs;
+        const float* bt = b_t + (size_t)i * ld_bt;
         const int kk = K_old - 1;
         float bacc = 0.f;
         const float bsc = kk > 0 ? inv_n / (float)kk : 0.f;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restric
         }
         li += bacc * bsc;
         if (d_bt) {
-            float* g = d_bt + (size_t)i * K_all * 4;
+            float* g = d_bt + (size_t)i * ld_dbt;
             for (int c = 0; c < K_all * 4; c++)
                 g[c] = (c >= 4 && c < K_old * 4) ? 2.f * (bt[c] - bs[c]) * bsc * gscale : 0.f;
         }
@@ -245,14 +248,14 @@ __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restric
 // BCE-with-logits over sampled anchors -- modeling/rpn/loss.py:145-146
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bce_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                          const int64_t* __restrict__ idx, int n_idx,
+                                                          const int64_t* __restrict__ idx, const int64_t* __restrict__ yidx, int n_idx,
                                                           float* __restrict__ loss_out, float gscale, float* __restrict__ grad) {
     __shared__ float sm[4];
     float acc = 0.f;
     const float inv = 1.f / (float)n_idx;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_idx; i += gridDim.x * blockDim.x) {
         const int64_t j = idx[i];
-        const float xv = x[j], yv = y[j];
+        const float xv = x[j], yv = y[yidx ? yidx[i] : j];
         acc += fmaxf(xv, 0.f) - xv * yv + log1pf(expf(-fabsf(xv)));
         if (grad) grad[j] = (1.f / (1.f + expf(-xv)) - yv) * inv * gscale;
     }
@@ -308,21 +311,23 @@ extern "C" int abr_smooth_l1(const float* x, const float* t, int64_t n, float be
 }
 
 extern "C" int abr_smooth_l1_rows(const float* x, int x_cols, const float* t, const int64_t* rows, const int64_t* col0,
-                                  int n_rows, float beta, float scale, float* loss_out, float gscale, float* grad,
+                                  const int64_t* trows, int n_rows, float beta, float scale, float* loss_out, float gscale, float* grad,
                                   void* stream) {
     ABR_REQUIRE(n_rows >= 0 && loss_out && x_cols >= 4, "smooth_l1_rows: bad args");
     hipStream_t st = abr::as_stream(stream);
     if (int e = zero_loss(loss_out, 1, st, "smooth_l1_rows")) return e;
     if (n_rows == 0) return ABR_OK;
     ABR_REQUIRE(x && t && rows, "smooth_l1_rows: null pointer");
-    smooth_l1_rows_kernel<<<abr::cdiv((int64_t)n_rows * 4, 256), 256, 0, st>>>(x, x_cols, t, rows, col0, n_rows, beta,
-                                                                                scale, loss_out, gscale, grad);
+    smooth_l1_rows_kernel<<<abr::cdiv((int64_t)n_rows * 4, 256), 256, 0, st>>>(x, x_cols, t, rows, col0, trows, n_rows,
+                                                                                beta, scale, loss_out, gscale, grad);
     ABR_CHECK_LAUNCH("smooth_l1_rows");
     return ABR_OK;
 }
 
-extern "C" int abr_softmax_ce(const float* logits, const int64_t* labels, int n, int K, int inclusive, int n_old,
-                              float* loss_out, float gscale, float* d_logits, void* stream) {
+extern "C" int abr_softmax_ce(const float* logits, int ld_logits, const int64_t* labels, int n, int K, int inclusive, int n_old,
+                              float* loss_out, float gscale, float* d_logits, int ld_dlogits, void* stream) {
+    if (ld_logits <= 0) ld_logits = K;
+    if (ld_dlogits <= 0) ld_dlogits = K;
     ABR_REQUIRE(n >= 0 && K > 0 && K <= kMaxK && loss_out, "softmax_ce: bad args (K<=128)");
     ABR_REQUIRE(!inclusive || (n_old >= 0 && n_old < K), "softmax_ce: n_old out of range");
     hipStream_t st = abr::as_stream(stream);
@@ -332,35 +337,40 @@ extern "C" int abr_softmax_ce(const float* logits, const int64_t* labels, int n,
     ABR_REQUIRE(logits && labels, "softmax_ce: null pointer");
     int* cnt = reinterpret_cast<int*>(loss_out + 1);
     count_valid_kernel<<<1, 256, 0, st>>>(labels, n, cnt);
-    softmax_ce_kernel<<<abr::cdiv(n, 256), 256, 0, st>>>(logits, labels, n, K, inclusive, n_old, cnt, loss_out, gscale,
+    softmax_ce_kernel<<<abr::cdiv(n, 256), 256, 0, st>>>(logits, labels, n, K, ld_logits, ld_dlogits, inclusive, n_old, cnt, loss_out, gscale,
                                                           d_logits);
     ABR_CHECK_LAUNCH("softmax_ce");
     return ABR_OK;
 }
 
 extern "C" int abr_roi_distill(const float* z_s, const float* b_s, const float* z_t, const float* b_t, int n, int K_old,
-                               int K_all, int dist_id, float* loss_out, float gscale, float* d_zt, float* d_bt,
-                               void* stream) {
+                               int K_all, const int32_t* ld_host, int dist_id, float* loss_out, float gscale, float* d_zt,
+                               float* d_bt, void* stream) {
+    int ld[6] = {K_old, K_old * 4, K_all, K_all * 4, K_all, K_all * 4};
+    if (ld_host)
+        for (int i = 0; i < 6; i++)
+            if (ld_host[i] > 0) ld[i] = ld_host[i];
     ABR_REQUIRE(n >= 0 && K_old > 0 && K_all >= K_old && K_all <= kMaxK && loss_out, "roi_distill: bad args");
     ABR_REQUIRE(!dist_id || K_all > K_old, "roi_distill: dist='id' needs K_all > K_old (empty slice in the reference)");
     hipStream_t st = abr::as_stream(stream);
     if (int e = zero_loss(loss_out, 1, st, "roi_distill")) return e;
     if (n == 0) return ABR_OK;
     ABR_REQUIRE(z_s && b_s && z_t && b_t, "roi_distill: null pointer");
-    roi_distill_kernel<<<abr::cdiv(n, 256), 256, 0, st>>>(z_s, b_s, z_t, b_t, n, K_old, K_all, dist_id, loss_out, gscale,
+    roi_distill_kernel<<<abr::cdiv(n, 256), 256, 0, st>>>(z_s, b_s, z_t, b_t, n, ld[0], ld[1], ld[2], ld[3], ld[4], ld[5], K_old, K_all, dist_id, loss_out,
+                                                           gscale,
                                                            d_zt, d_bt);
     ABR_CHECK_LAUNCH("roi_distill");
     return ABR_OK;
 }
 
-extern "C" int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, int n_idx, float* loss_out,
+extern "C" int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, const int64_t* yidx, int n_idx, float* loss_out,
                                      float gscale, float* grad, void* stream) {
     ABR_REQUIRE(n_idx >= 0 && loss_out, "bce_logits_gather: bad args");
     hipStream_t st = abr::as_stream(stream);
     if (int e = zero_loss(loss_out, 1, st, "bce_logits_gather")) return e;
     if (n_idx == 0) return ABR_OK;
     ABR_REQUIRE(x && y && idx, "bce_logits_gather: null pointer");
-    bce_gather_kernel<<<std::min(abr::cdiv(n_idx, 256), 256u), 256, 0, st>>>(x, y, idx, n_idx, loss_out, gscale, grad);
+    bce_gather_kernel<<<std::min(abr::cdiv(n_idx, 256), 256u), 256, 0, st>>>(x, y, idx, yidx, n_idx, loss_out, gscale, grad);
     ABR_CHECK_LAUNCH("bce_logits_gather");
     return ABR_OK;
 }

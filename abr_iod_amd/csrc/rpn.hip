@@ -20,7 +20,7 @@ __global__ void grid_anchors_kernel(const float* __restrict__ cell, int A, int H
 }
 
 #pragma clang fp contract(off)
-__global__ void decode_clip_kernel(const float* __restrict__ reg, int reg_stride, int reg_col0,
+__global__ void decode_clip_kernel(const float* __restrict__ reg, int reg_stride, int reg_col0, int A,
                                    const float* __restrict__ anchors, const int64_t* __restrict__ idx, int N, int n_anchor,
                                    int k, const int32_t* __restrict__ img_hw, float wx, float wy, float ww, float wh,
                                    float* __restrict__ out) {
@@ -29,7 +29,8 @@ __global__ void decode_clip_kernel(const float* __restrict__ reg, int reg_stride
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         const int i = t / k;
         const int64_t a = idx[t];
-        const float* d = reg + ((size_t)i * n_anchor + a) * reg_stride + reg_col0;
+        // anchor a = location*A + a': its 4 deltas sit in row `location` of reg at columns reg_col0 + 4a' (NHWC head output)
+        const float* d = reg + ((size_t)i * (n_anchor / A) + a / A) * reg_stride + reg_col0 + 4 * (a % A);
         const float4 b = reinterpret_cast<const float4*>(anchors)[a];
         const float w = b.z - b.x + 1, h = b.w - b.y + 1;               // box_coder.py:66-69
         const float cx = b.x + 0.5f * w, cy = b.y + 0.5f * h;
@@ -37,12 +38,14 @@ __global__ void decode_clip_kernel(const float* __restrict__ reg, int reg_stride
         const float dw = fminf(d[2] / ww, clip), dh = fminf(d[3] / wh, clip);
         const float pcx = dx * w + cx, pcy = dy * h + cy;
         const float pw = expf(dw) * w, ph = expf(dh) * h;
-        const float W1 = (float)(img_hw[2 * i + 1] - 1), H1 = (float)(img_hw[2 * i] - 1);
-        float4 o;
-        o.x = fminf(fmaxf(pcx - 0.5f * pw, 0.f), W1);                   // bounding_box.py:214-225 clip_to_image
-        o.y = fminf(fmaxf(pcy - 0.5f * ph, 0.f), H1);
-        o.z = fminf(fmaxf(pcx + 0.5f * pw - 1, 0.f), W1);
-        o.w = fminf(fmaxf(pcy + 0.5f * ph - 1, 0.f), H1);
+        float4 o = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw - 1, pcy + 0.5f * ph - 1);
+        if (img_hw) {                                                   // bounding_box.py:214-225 clip_to_image
+            const float W1 = (float)(img_hw[2 * i + 1] - 1), H1 = (float)(img_hw[2 * i] - 1);
+            o.x = fminf(fmaxf(o.x, 0.f), W1);
+            o.y = fminf(fmaxf(o.y, 0.f), H1);
+            o.z = fminf(fmaxf(o.z, 0.f), W1);
+            o.w = fminf(fmaxf(o.w, 0.f), H1);
+        }
         reinterpret_cast<float4*>(out)[t] = o;
     }
 }
@@ -119,7 +122,31 @@ __global__ void match_encode_kernel(const float* __restrict__ boxes, int n, cons
     }
 }
 
+// BoxCoder.encode row-wise (box_coder.py:22-50): out[i] = encode(gt[i], ex[i])
+#pragma clang fp contract(off)
+__global__ void box_encode_kernel(const float* __restrict__ gt, const float* __restrict__ ex, int n, float wx, float wy,
+                                  float ww, float wh, float* __restrict__ out) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const float4 r = reinterpret_cast<const float4*>(gt)[j], b = reinterpret_cast<const float4*>(ex)[j];
+        const float ew = b.z - b.x + 1, eh = b.w - b.y + 1;
+        const float ecx = b.x + 0.5f * ew, ecy = b.y + 0.5f * eh;
+        const float gw = r.z - r.x + 1, gh = r.w - r.y + 1;
+        const float gcx = r.x + 0.5f * gw, gcy = r.y + 0.5f * gh;
+        reinterpret_cast<float4*>(out)[j] = make_float4(wx * (gcx - ecx) / ew, wy * (gcy - ecy) / eh, ww * logf(gw / ew), wh * logf(gh / eh));
+    }
+}
+
 }  // namespace
+
+extern "C" int abr_box_encode(const float* gt, const float* ex, int n, float wx, float wy, float ww, float wh, float* out,
+                              void* stream) {
+    ABR_REQUIRE(n >= 0, "box_encode: bad n");
+    if (n == 0) return ABR_OK;
+    ABR_REQUIRE(gt && ex && out, "box_encode: null pointer");
+    box_encode_kernel<<<abr::cdiv(n, 256), 256, 0, abr::as_stream(stream)>>>(gt, ex, n, wx, wy, ww, wh, out);
+    ABR_CHECK_LAUNCH("box_encode");
+    return ABR_OK;
+}
 
 extern "C" int abr_grid_anchors(const float* cell, int A, int H, int W, int stride, int img_h, int img_w, int straddle,
                                 float* out, uint8_t* vis, void* stream) {
@@ -130,14 +157,14 @@ extern "C" int abr_grid_anchors(const float* cell, int A, int H, int W, int stri
     return ABR_OK;
 }
 
-extern "C" int abr_rpn_decode_clip(const float* reg, int reg_stride, int reg_col0, const float* anchors, const int64_t* idx,
+extern "C" int abr_rpn_decode_clip(const float* reg, int reg_stride, int reg_col0, int A, const float* anchors, const int64_t* idx,
                                    int N, int n_anchor, int k, const int32_t* img_hw, float wx, float wy, float ww, float wh,
                                    float* out, void* stream) {
-    ABR_REQUIRE(N >= 0 && k >= 0 && reg_stride >= 4, "rpn_decode_clip: bad args");
+    ABR_REQUIRE(N >= 0 && k >= 0 && reg_stride >= 4 && A >= 1 && n_anchor % A == 0, "rpn_decode_clip: bad args");
     if (N == 0 || k == 0) return ABR_OK;
-    ABR_REQUIRE(reg && anchors && idx && img_hw && out, "rpn_decode_clip: null pointer");
+    ABR_REQUIRE(reg && anchors && idx && out, "rpn_decode_clip: null pointer");
     decode_clip_kernel<<<abr::cdiv((int64_t)N * k, 256), 256, 0, abr::as_stream(stream)>>>(
-        reg, reg_stride, reg_col0, anchors, idx, N, n_anchor, k, img_hw, wx, wy, ww, wh, out);
+        reg, reg_stride, reg_col0, A, anchors, idx, N, n_anchor, k, img_hw, wx, wy, ww, wh, out);
     ABR_CHECK_LAUNCH("rpn_decode_clip");
     return ABR_OK;
 }

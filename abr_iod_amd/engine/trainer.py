@@ -1,0 +1,118 @@
+"""Incremental trainer loop.
+
+Mirror of tools/train_incremental.py:55-181 (`do_train`) and maskrcnn_benchmark/engine/trainer.py:15-37 (`reduce_loss_dict`).
+`train_step` is the body of one loop iteration (train_incremental.py:77-147) factored out so that the benchmark and the
+smoke test run exactly the code the loop runs.
+
+Work the reference does whose results are never used is skipped, with identical outputs:
+  * with DIST.ALPHA == 0 and DIST.FEAT != 'ard' (the finetune configs) the source pass and the second RoI pass feed nothing;
+  * `model_source.roi_heads.box.loss_evaluator.subsample(soften_proposal, targets)` (train_incremental.py:86) is dead: its result
+    is overwritten with None at :102.  It is still executed when `faithful_rng=True` because it consumes device RNG.
+Data parallelism: one process per GPU; gradients are summed over ranks by ONE RCCL all-reduce of the flat gradient buffer inside
+optimizer.step() (DistributedDataParallel in the reference, train_incremental.py:231-235).
+"""
+import datetime
+import logging
+import time
+
+import torch
+import torch.distributed as dist
+
+from ..distillation.distillation import calculate_attentive_roi_feature_distillation, calculate_roi_distillation_losses
+from ..utils.comm import get_world_size
+
+
+def reduce_loss_dict(loss_dict):
+    """engine/trainer.py:15-37: sum the loss scalars to rank 0 and average there (logging only)."""
+    world_size = get_world_size()
+    if world_size < 2:
+        return loss_dict
+    with torch.no_grad():
+        names = sorted(loss_dict.keys())
+        all_losses = torch.stack([loss_dict[k] for k in names], dim=0)
+        dist.reduce(all_losses, dst=0)
+        if dist.get_rank() == 0:
+            all_losses /= world_size
+        return {k: v for k, v in zip(names, all_losses)}
+
+
+def train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg, faithful_rng=False, log=None):
+    """One iteration of tools/train_incremental.py:77-147.  Returns (loss_dict_target incl. 'distillation_loss', total loss)."""
+    dist_type = cfg.DIST.TYPE
+    use_id = cfg.DIST.ALPHA > 0
+    use_ard = cfg.DIST.FEAT == "ard"
+    need_source = use_id or use_ard or cfg.DIST.RPN or cfg.DIST.FEAT == "std"
+
+    soften_result = soften_proposal = roi_align_features_source = rpn_output_source = None
+    if need_source:
+        with torch.no_grad():                                                                              # :82-86
+            soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
+                model_source.generate_soften_proposal(images)
+            if faithful_rng:
+                model_source.roi_heads.box.loss_evaluator.subsample(soften_proposal, targets)
+
+    loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results = \
+        model_target(images, targets, rpn_output_source=rpn_output_source)                                 # :89-90
+    faster_rcnn_losses = sum(loss for loss in loss_dict_target.values())                                   # :91
+
+    distillation_losses = torch.zeros((), device=faster_rcnn_losses.device)
+    if need_source:
+        target_result, _, roi_align_features_target = model_target.forward(images, targets, features=feature_target,
+                                                                           proposals=soften_proposal)      # :93-95
+        if use_id:                                                                                         # :101-103
+            distillation_losses = cfg.DIST.ALPHA * calculate_roi_distillation_losses(soften_result, target_result, dist=dist_type,
+                                                                                     soften_proposal=None)
+        if use_ard:                                                                                        # :113-116
+            feature_distillation_losses = calculate_attentive_roi_feature_distillation(roi_align_features_source,
+                                                                                       roi_align_features_target, gamma=cfg.DIST.GAMMA)
+            distillation_losses = distillation_losses + cfg.DIST.BETA * feature_distillation_losses
+        elif cfg.DIST.FEAT == "std" or cfg.DIST.RPN:
+            raise NotImplementedError("DIST.FEAT='std' / DIST.RPN are ablation-only and hard-code 'cuda' in the reference; next-tier")
+
+    loss_dict_target = dict(loss_dict_target)
+    loss_dict_target["distillation_loss"] = distillation_losses.clone().detach()                           # :124-126
+    losses = faster_rcnn_losses + distillation_losses                                                      # :128
+
+    optimizer.zero_grad()                                                                                  # :142
+    losses.backward()                                                                                      # :144-145 (amp O0 = identity)
+    optimizer.step()                                                                                       # :146 (+ RCCL all-reduce)
+    scheduler.step()                                                                                       # :147
+    return loss_dict_target, losses
+
+
+def do_train(model_source, model_target, data_loader, optimizer, scheduler, checkpointer_target, device, checkpoint_period,
+             arguments_target, summary_writer, cfg):
+    """Same signature as tools/train_incremental.py:55-56.  data_loader yields (images, targets, _, idx)."""
+    logger = logging.getLogger("abr_iod_amd.trainer")
+    logger.info("Start training")
+    max_iter = len(data_loader)
+    start_iter = arguments_target["iteration"]
+    model_target.train()
+    model_source.eval()
+    start_training_time = time.time()
+    end = time.time()
+    for iteration, (images, targets, _, idx) in enumerate(data_loader, start_iter):
+        data_time = time.time() - end
+        iteration = iteration + 1
+        arguments_target["iteration"] = iteration
+        images = images.to(device)
+        targets = [t.to(device) for t in targets]
+        loss_dict_target, losses = train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg)
+        loss_dict_reduced = reduce_loss_dict(loss_dict_target)
+        batch_time = time.time() - end
+        end = time.time()
+        if iteration % 100 == 0 or iteration == max_iter:
+            losses_reduced = sum(loss for loss in loss_dict_reduced.values())
+            eta = str(datetime.timedelta(seconds=int(batch_time * (max_iter - iteration))))
+            logger.info("eta: {}  iter: {}  loss: {:.4f}  {}  time: {:.4f}  data: {:.4f}  lr: {:.6f}".format(
+                eta, iteration, float(losses_reduced), "  ".join("{}: {:.4f}".format(k, float(v)) for k, v in loss_dict_reduced.items()),
+                batch_time, data_time, optimizer.param_groups[0]["lr"]))
+            if summary_writer is not None:
+                summary_writer.add_scalar("train_loss_raw", float(losses_reduced), iteration)
+        if checkpointer_target is not None:
+            if iteration % checkpoint_period == 0:
+                checkpointer_target.save("model_last", **arguments_target)
+            if iteration == max_iter:
+                checkpointer_target.save("model_final", **arguments_target)
+    total = time.time() - start_training_time
+    logger.info("Total training time: {} ({:.4f} s / it)".format(str(datetime.timedelta(seconds=total)), total / max(max_iter, 1)))

@@ -1,0 +1,266 @@
+"""ResNet-50 C4 body and C5 head on the HIP conv engine.
+
+Mirror of maskrcnn_benchmark/modeling/backbone/resnet.py for the one variant every configs/voc YAML uses
+(CONV_BODY "R-50-C4", BottleneckWithFixedBatchNorm, StemWithFixedBatchNorm, STRIDE_IN_1X1=True, no DCN, groups=1):
+    ResNet (:81-155)       stem + layer1..layer3, FREEZE_CONV_BODY_AT semantics of _freeze_backbone (:134-143)
+    ResNetHead (:158-207)  layer4, used by ResNet50Conv5ROIFeatureExtractor
+    Bottleneck (:242-346), BaseStem (:349-368)
+Module / parameter / buffer NAMES are the reference's (state_dict keys match; conv weights are stored OHWI
+instead of OIHW, converted at the checkpoint boundary).
+
+Execution model: every conv is ONE launch of the implicit-GEMM MFMA kernel with FrozenBN scale/bias, the residual
+add and the ReLU fused in its epilogue.  A whole stage (3-6 bottlenecks) is a single autograd node whose backward is
+hand-scheduled: dgrad is the same kernel on a flipped/transposed weight copy with the ReLU mask of the producer
+fused in the epilogue, wgrad accumulates atomically into the flat gradient buffer.  Activations are NHWC.
+"""
+from collections import namedtuple
+
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from ... import ops
+from ...layers import FrozenBatchNorm2d
+from ...layers._layout import as_nhwc, from_nhwc
+
+StageSpec = namedtuple("StageSpec", ["index", "block_count", "return_features"])
+ResNet50StagesTo4 = tuple(StageSpec(index=i, block_count=c, return_features=r) for (i, c, r) in ((1, 3, False), (2, 4, False), (3, 6, True)))
+ResNet50StagesTo5 = tuple(StageSpec(index=i, block_count=c, return_features=r) for (i, c, r) in ((1, 3, False), (2, 4, False), (3, 6, False), (4, 3, True)))
+
+# bumped by the optimiser after every step: cached dgrad weight copies are rebuilt lazily when stale
+_PARAM_VERSION = [0]
+
+
+def bump_param_version():
+    _PARAM_VERSION[0] += 1
+
+
+class Conv2d(nn.Module):
+    """nn.Conv2d stand-in (layers/misc.py:30-43) holding an OHWI weight [Cout,R,S,Cin]; `cin_pad` zero-pads input
+    channels (the 3-channel stem runs with Cin=4 so that every gather is a 16 B load)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, cin_pad=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding = stride, padding
+        cin = cin_pad or in_channels
+        self.weight = nn.Parameter(torch.zeros(out_channels, kernel_size, kernel_size, cin))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self._wt = None
+        self._wt_version = -1
+
+    def kaiming_uniform_(self, a=1):
+        """nn.init.kaiming_uniform_(w, a=1) of the reference (resnet.py:270,315,325,361), fan_in = Cin*R*S of the REAL channels."""
+        fan_in = self.in_channels * self.kernel_size * self.kernel_size
+        bound = (6.0 / ((1 + a * a) * fan_in)) ** 0.5
+        with torch.no_grad():
+            self.weight.zero_()
+            self.weight[..., : self.in_channels].uniform_(-bound, bound)
+
+    def load_oihw(self, w):
+        """copy a reference-layout [Cout,Cin,R,S] tensor in"""
+        with torch.no_grad():
+            self.weight.zero_()
+            self.weight[..., : w.shape[1]].copy_(w.permute(0, 2, 3, 1))
+        self._wt_version = -1
+
+    def oihw(self):
+        return self.weight.detach()[..., : self.in_channels].permute(0, 3, 1, 2).contiguous()
+
+    def dgrad_weight(self, scale=None):
+        """[Cin,R,S,Cout] flipped copy with the FrozenBN scale folded in; rebuilt only after an optimiser step."""
+        if self._wt is None or self._wt_version != _PARAM_VERSION[0] or self._wt.device != self.weight.device:
+            self._wt = ops.conv_dgrad_weights(self.weight.detach(), scale, out=self._wt if self._wt is not None and self._wt.device == self.weight.device else None)
+            self._wt_version = _PARAM_VERSION[0]
+        return self._wt
+
+
+def _grad_buf(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class Bottleneck(nn.Module):
+    """resnet.py:242-346 (BottleneckWithFixedBatchNorm :371-395): 1x1(stride) -> 3x3 -> 1x1 (+identity / 1x1(stride) downsample) -> ReLU."""
+
+    def __init__(self, in_channels, bottleneck_channels, out_channels, stride):
+        super().__init__()
+        self.downsample = None
+        if in_channels != out_channels:
+            self.downsample = nn.Sequential(Conv2d(in_channels, out_channels, 1, stride=stride, bias=False), FrozenBatchNorm2d(out_channels))
+            self.downsample[0].kaiming_uniform_()
+        self.conv1 = Conv2d(in_channels, bottleneck_channels, 1, stride=stride, bias=False)  # STRIDE_IN_1X1
+        self.bn1 = FrozenBatchNorm2d(bottleneck_channels)
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, 3, stride=1, padding=1, bias=False)
+        self.bn2 = FrozenBatchNorm2d(bottleneck_channels)
+        self.conv3 = Conv2d(bottleneck_channels, out_channels, 1, bias=False)
+        self.bn3 = FrozenBatchNorm2d(out_channels)
+        for l in (self.conv1, self.conv2, self.conv3):
+            l.kaiming_uniform_()
+        self.stride = stride
+
+    # x, returns NHWC tensors.  `stride` may be overridden to 1 when the caller already sub-sampled (bin_step=2 ROIAlign)
+    def fwd(self, x, save, stride=None):
+        s = self.stride if stride is None else stride
+        s1, b1 = self.bn1.scale_bias()
+        s2, b2 = self.bn2.scale_bias()
+        s3, b3 = self.bn3.scale_bias()
+        o1 = ops.conv_forward(x, self.conv1.weight, s, 0, scale=s1, bias=b1, relu=True)
+        o2 = ops.conv_forward(o1, self.conv2.weight, 1, 1, scale=s2, bias=b2, relu=True)
+        if self.downsample is not None:
+            sd, bd = self.downsample[1].scale_bias()
+            idt = ops.conv_forward(x, self.downsample[0].weight, s, 0, scale=sd, bias=bd)
+        else:
+            idt = x
+        out = ops.conv_forward(o2, self.conv3.weight, 1, 0, scale=s3, bias=b3, residual=idt, relu=True)
+        return out, ((x, o1, o2, out, s) if save else None)
+
+    def bwd(self, saved, gout, need_dx, g_owned):
+        """gout = dL/d(out) (not yet masked by out's ReLU).  Writes weight grads into .grad; returns dL/dx or None."""
+        x, o1, o2, out, s = saved
+        s1, _ = self.bn1.scale_bias()
+        s2, _ = self.bn2.scale_bias()
+        s3, _ = self.bn3.scale_bias()
+        g = gout if g_owned else gout.clone()
+        ops.relu_backward_(g, out)                                             # through the block's final ReLU
+        ops.conv_wgrad(o2, g, _grad_buf(self.conv3.weight), 1, 0, scale=s3)
+        g2 = ops.conv_forward(g, self.conv3.dgrad_weight(s3), 1, 0, mask=o2)    # dgrad + ReLU mask of o2
+        ops.conv_wgrad(o1, g2, _grad_buf(self.conv2.weight), 1, 1, scale=s2)
+        g1 = ops.conv_forward(g2, self.conv2.dgrad_weight(s2), 1, 1, mask=o1)   # 3x3 dgrad: pad = 3-1-1
+        ops.conv_wgrad(x, g1, _grad_buf(self.conv1.weight), s, 0, scale=s1)
+        ds = self.downsample
+        if ds is not None:
+            sd, _ = ds[1].scale_bias()
+            ops.conv_wgrad(x, g, _grad_buf(ds[0].weight), s, 0, scale=sd)
+        if not need_dx:
+            return None
+        if s == 1:
+            if ds is not None:
+                gx = ops.conv_forward(g, ds[0].dgrad_weight(sd), 1, 0)
+                return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=gx, out=gx)
+            return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=g)
+        # stride-2 1x1 convs: gradient rows land on the even pixels of a zeroed tensor
+        B, H, W, _ = x.shape
+        gx = ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, out_hw=(H, W), out_stride=(s, s))
+        if ds is not None:
+            ops.conv_forward(g, ds[0].dgrad_weight(sd), 1, 0, residual=gx, out=gx, out_hw=(H, W), out_stride=(s, s))
+        return gx
+
+
+class _StageFn(Function):
+    """A run of bottlenecks as one autograd node.  Weight gradients are accumulated straight into p.grad
+    (views of the flat gradient buffer) by the wgrad kernel, so backward returns None for them."""
+
+    @staticmethod
+    def forward(ctx, x, blocks, first_stride, need_dx, *params):
+        ctx.blocks, ctx.need_dx = blocks, need_dx
+        ctx.saved = []
+        save = True  # run_stage only takes this path when a gradient is wanted (grad mode is off INSIDE Function.forward)
+        h = as_nhwc(x)
+        for i, blk in enumerate(blocks):
+            h, s = blk.fwd(h, save, stride=first_stride if i == 0 else None)
+            ctx.saved.append(s)
+        return from_nhwc(h)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = as_nhwc(gout)
+        owned = False
+        n = len(ctx.blocks)
+        for i in range(n - 1, -1, -1):
+            need = ctx.need_dx or i > 0
+            g = ctx.blocks[i].bwd(ctx.saved[i], g, need, owned)
+            ctx.saved[i] = None
+            owned = True
+        return (from_nhwc(g) if g is not None else None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+def run_stage(x, blocks, first_stride=None, need_dx=True):
+    """x logical [B,C,H,W] -> logical output; differentiable when any block parameter requires grad."""
+    params = [p for b in blocks for p in b.parameters()]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return _StageFn.apply(x, blocks, first_stride, need_dx and x.requires_grad, *params)
+    h = as_nhwc(x)
+    for i, blk in enumerate(blocks):
+        h, _ = blk.fwd(h, False, stride=first_stride if i == 0 else None)
+    return from_nhwc(h)
+
+
+def _make_stage(in_channels, bottleneck_channels, out_channels, block_count, first_stride):
+    blocks, stride = [], first_stride
+    for _ in range(block_count):
+        blocks.append(Bottleneck(in_channels, bottleneck_channels, out_channels, stride))
+        stride, in_channels = 1, out_channels
+    return nn.Sequential(*blocks)
+
+
+class StemWithFixedBatchNorm(nn.Module):
+    """BaseStem (resnet.py:349-368): conv7x7 s2 p3 (3->64) -> FrozenBN -> ReLU -> maxpool 3x3 s2 p1."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        out_channels = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
+        self.conv1 = Conv2d(3, out_channels, 7, stride=2, padding=3, bias=False, cin_pad=4)
+        self.bn1 = FrozenBatchNorm2d(out_channels)
+        self.conv1.kaiming_uniform_()
+
+    def forward(self, x):
+        """x: [B,3,H,W] plain NCHW image batch -> logical [B,64,H/4,W/4]"""
+        xh = ops.nchw_to_nhwc(x.contiguous(), cpad=4) if x.shape[1] == 3 else as_nhwc(x)
+        s, b = self.bn1.scale_bias()
+        y = ops.conv_forward(xh, self.conv1.weight, 2, 3, scale=s, bias=b, relu=True)
+        return from_nhwc(ops.maxpool3x3s2(y))
+
+
+class ResNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        assert cfg.MODEL.BACKBONE.CONV_BODY == "R-50-C4", "only the R-50-C4 body is on the hot path (every configs/voc YAML)"
+        assert cfg.MODEL.RESNETS.STRIDE_IN_1X1 and cfg.MODEL.RESNETS.NUM_GROUPS == 1
+        self.stem = StemWithFixedBatchNorm(cfg)
+        width = cfg.MODEL.RESNETS.NUM_GROUPS * cfg.MODEL.RESNETS.WIDTH_PER_GROUP
+        in_channels = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
+        out2 = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS
+        self.stages, self.return_features = [], {}
+        for spec in ResNet50StagesTo4:
+            name = "layer" + str(spec.index)
+            f = 2 ** (spec.index - 1)
+            self.add_module(name, _make_stage(in_channels, width * f, out2 * f, spec.block_count, int(spec.index > 1) + 1))
+            in_channels = out2 * f
+            self.stages.append(name)
+            self.return_features[name] = spec.return_features
+        self._freeze_backbone(cfg.MODEL.BACKBONE.FREEZE_CONV_BODY_AT)
+
+    def _freeze_backbone(self, freeze_at):
+        for stage_index in range(max(freeze_at, 0)):
+            m = self.stem if stage_index == 0 else getattr(self, "layer" + str(stage_index))
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def forward(self, x):
+        outputs, backbone_features = [], []
+        x = self.stem(x)
+        for name in self.stages:
+            x = run_stage(x, list(getattr(self, name)))
+            if self.return_features[name]:
+                outputs.append(x)
+            backbone_features.append(x)
+        return outputs, backbone_features
+
+
+class ResNetHead(nn.Module):
+    """layer4 on pooled RoI features (resnet.py:158-207).  `first_stride=1` is used when ROIAlign already produced only
+    the even bins (bin_step=2): a stride-2 1x1 conv over a 7x7 map reads exactly bins (0,2,4,6)^2."""
+
+    def __init__(self, stage_index=4, block_count=3, width_per_group=64, res2_out_channels=256, stride_init=None):
+        super().__init__()
+        f = 2 ** (stage_index - 1)
+        out_channels = res2_out_channels * f
+        stride = stride_init or (int(stage_index > 1) + 1)
+        self.layer4 = _make_stage(out_channels // 2, width_per_group * f, out_channels, block_count, stride)
+        self.stages = ["layer4"]
+        self.out_channels = out_channels
+
+    def forward(self, x, first_stride=None):
+        return run_stage(x, list(self.layer4), first_stride=first_stride)

@@ -1,0 +1,110 @@
+"""GeneralizedRCNN (mirror of maskrcnn_benchmark/modeling/detector/generalized_rcnn.py:22-175):
+backbone -> rpn -> roi_heads orchestration with the reference's three entry points, argument lists and return tuples:
+
+    forward(images, targets=None, rpn_output_source=None, features=None, proposals=None)                       (:50-95)
+        training, full pass  -> (losses, features, backbone_features, anchors, rpn_output, proposals,
+                                 roi_align_features, soften_results)                                            (:93)
+        features+proposals   -> ((target_scores, target_bboxes), mask_logits, roi_align_features)               (:66-68)
+    generate_soften_proposal(images, targets=None)
+                             -> ((soften_scores, soften_bboxes), mask_logits, all_selected_proposals, features,
+                                 backbone_features, anchors, rpn_output, roi_align_features)                    (:121-167)
+    generate_feature_logits_by_targets(images, targets=None)
+                             -> ((target_scores, target_bboxes), mask_logits, features, backbone_features,
+                                 roi_align_features)                                                            (:169-175)
+"""
+import random
+
+import torch
+from torch import nn
+
+from ...structures.bounding_box import BoxList
+from ...structures.image_list import to_image_list
+from ..backbone.backbone import build_backbone
+from ..roi_heads.roi_heads import build_roi_heads
+from ..rpn.rpn import build_rpn
+from .._flat import flatten_parameters
+
+
+class GeneralizedRCNN(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.backbone = build_backbone(cfg)
+        self.incremental = cfg.INCREMENTAL
+        self.n_old_cl = len(cfg.MODEL.ROI_BOX_HEAD.NAME_OLD_CLASSES)
+        self.n_new_cl = len(cfg.MODEL.ROI_BOX_HEAD.NAME_NEW_CLASSES)
+        assert not cfg.MODEL.RPN.EXTERNAL_PROPOSAL, "external (EdgeBoxes) proposals are outside the hot path"
+        self.rpn = build_rpn(cfg, self.backbone.out_channels)
+        self.roi_heads = build_roi_heads(cfg, self.backbone.out_channels)
+        self.flat = None
+
+    # --- storage: one flat fp32 buffer for parameters, one for gradients (RCCL all-reduce + fused SGD work on them)
+    def flatten_parameters(self):
+        self.flat = flatten_parameters(self)
+        return self.flat
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if self.flat is not None and next(self.parameters()).device != self.flat.params.device:
+            self.flat = flatten_parameters(self)
+        return out
+
+    def forward(self, images, targets=None, rpn_output_source=None, features=None, proposals=None):
+        if self.training and targets is None:
+            raise ValueError("In training mode, targets should be passed")
+        if features is not None and proposals is not None:
+            target_scores, target_bboxes, mask_logits, roi_align_features = self.roi_heads.calculate_soften_label(features, proposals)
+            return (target_scores, target_bboxes), mask_logits, roi_align_features
+        images = to_image_list(images)
+        features, backbone_features = self.backbone(images.tensors)
+        (proposals, proposal_losses), anchors, rpn_output = self.rpn(images, features, targets, rpn_output_source)
+        if not self.training:
+            raise NotImplementedError("test-time detection (PostProcessor) is next-tier (SURVEY.md §8f F4)")
+        x, result, soften_results, detector_losses, roi_align_features = self.roi_heads(features, proposals, targets)
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        return losses, features, backbone_features, anchors, rpn_output, result, roi_align_features, soften_results
+
+    def generate_soften_proposal(self, images, targets=None, selected_indices=None):
+        """Source-model pass (model.eval(), under no_grad in the trainer): top-128 by objectness, python `random.sample`
+        picks 64 (:140-149).  `selected_indices` (list of index lists) injects that choice for parity tests."""
+        images = to_image_list(images)
+        features, backbone_features = self.backbone(images.tensors)
+        (all_proposals, _), anchors, rpn_output = self.rpn(images, features, targets)
+        all_selected = []
+        for k, props in enumerate(all_proposals):
+            order = props.get_field("objectness").sort(descending=True)[1]
+            props = props[order]
+            n = len(props)
+            if selected_indices is not None:
+                sel = list(selected_indices[k])
+            elif n < 64:
+                sel = random.sample(range(0, n, 1), n)
+            elif n < 128:
+                sel = random.sample(range(0, n, 1), 64)
+            else:
+                sel = random.sample(range(0, 128, 1), 64)
+            idx = torch.tensor(sel, dtype=torch.int64, device=props.bbox.device)
+            chosen = BoxList(props.bbox.index_select(0, idx).view(-1, 4), props.size, props.mode)
+            chosen.add_field("objectness", props.get_field("objectness").index_select(0, idx).view(-1))
+            all_selected.append(chosen)
+        soften_scores, soften_bboxes, mask_logits, roi_align_features = self.roi_heads.calculate_soften_label(features, all_selected)
+        return (soften_scores, soften_bboxes), mask_logits, all_selected, features, backbone_features, anchors, rpn_output, roi_align_features
+
+    def generate_feature_logits_by_targets(self, images, targets=None):
+        images = to_image_list(images)
+        features, backbone_features = self.backbone(images.tensors)
+        target_scores, target_bboxes, mask_logits, roi_align_features = self.roi_heads.calculate_soften_label(features, targets)
+        return (target_scores, target_bboxes), mask_logits, features, backbone_features, roi_align_features
+
+
+def build_detection_model(cfg):
+    """modeling/detector/detectors.py: META_ARCHITECTURE 'GeneralizedRCNN'.  The model is created on cfg.MODEL.DEVICE and its
+    parameters are re-homed into flat buffers (see modeling/_flat.py)."""
+    assert cfg.MODEL.META_ARCHITECTURE == "GeneralizedRCNN"
+    model = GeneralizedRCNN(cfg)
+    dev = torch.device(cfg.MODEL.DEVICE)
+    if dev.type == "cuda":
+        model.to(dev)
+        model.flatten_parameters()
+    return model

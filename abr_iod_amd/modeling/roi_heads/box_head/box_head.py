@@ -1,0 +1,301 @@
+"""RoI box head on the HIP library.
+
+Mirrors (C4 / ResNet50Conv5 variant, the only one configs/voc uses):
+    Pooler                              maskrcnn_benchmark/modeling/poolers.py:45-105 (single level -> ROIAlign)
+    ResNet50Conv5ROIFeatureExtractor    modeling/roi_heads/box_head/roi_box_feature_extractors.py:14-55
+    FastRCNNPredictor                   modeling/roi_heads/box_head/roi_box_predictors.py:8-33
+    FastRCNNLossComputation             modeling/roi_heads/box_head/loss.py:15-181
+    ROIBoxHead                          modeling/roi_heads/box_head/box_head.py:12-87
+
+MI355X-first differences (results identical):
+  * layer4's first 1x1 convs have stride 2 over the 7x7 pooled map, i.e. they read bins (0,2,4,6)^2 only.  When the
+    caller does not consume the pooled features themselves (the 512-RoI detection pass: train_incremental.py:89 binds
+    them to `_`) ROIAlign computes just those 16 bins (bin_step=2) and layer4 runs stride-1 on the 4x4 map: 3x less
+    ROIAlign traffic, forward and backward.  The 64-RoI distillation passes need all 49 bins for ARD and get them.
+  * avgpool + cls_score + bbox_pred is one pooled vector and ONE GEMM with K_all + 4*K_all (+pad) output columns.
+  * IoU/Matcher/labels/encode are one kernel per image; both loss terms and their gradients are one kernel each.
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from .... import ops
+from ....layers import ROIAlign
+from ....layers._layout import as_nhwc, from_nhwc
+from ....structures.bounding_box import BoxList
+from ...backbone.resnet import Conv2d, ResNetHead, _grad_buf, _PARAM_VERSION
+from ...balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+from ...box_coder import BoxCoder
+from ...matcher import Matcher
+
+
+# ------------------------------------------------------------------------------------------------ pooler
+def convert_to_roi_format(boxes):
+    """poolers.py:73-86: [K,5] = (batch index, x1, y1, x2, y2)"""
+    concat = torch.cat([b.bbox for b in boxes], dim=0)
+    ids = torch.cat([torch.full((len(b), 1), i, dtype=concat.dtype, device=concat.device) for i, b in enumerate(boxes)], dim=0)
+    return torch.cat([ids, concat], dim=1)
+
+
+class Pooler(nn.Module):
+    def __init__(self, output_size, scales, sampling_ratio):
+        super().__init__()
+        assert len(scales) == 1, "single-level pooling only (C4); FPN level mapping is out of scope"
+        self.poolers = nn.ModuleList([ROIAlign(output_size, spatial_scale=scales[0], sampling_ratio=sampling_ratio)])
+        self.output_size = output_size
+
+    def forward(self, x, boxes, bin_step=1):
+        return self.poolers[0](x[0], convert_to_roi_format(boxes), bin_step)
+
+
+class ResNet50Conv5ROIFeatureExtractor(nn.Module):
+    def __init__(self, config, in_channels):
+        super().__init__()
+        res = config.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        self.pooler = Pooler((res, res), config.MODEL.ROI_BOX_HEAD.POOLER_SCALES, config.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO)
+        self.head = ResNetHead(stage_index=4, block_count=3, width_per_group=config.MODEL.RESNETS.WIDTH_PER_GROUP,
+                               res2_out_channels=config.MODEL.RESNETS.RES2_OUT_CHANNELS)
+        self.out_channels = self.head.out_channels
+        self.resolution = res
+
+    def forward(self, x, proposals, need_roi_features=True):
+        """-> (head features logical [K,2048,4,4], roi_align_features).  need_roi_features=False lets ROIAlign skip the bins
+        layer4 never reads; roi_align_features is then the [K,1024,4,4] even-bin sub-grid instead of [K,1024,7,7]."""
+        sparse = (not need_roi_features) and self.resolution % 2 == 1 and list(self.head.layer4)[0].stride == 2
+        roi_align_features = self.pooler(x, proposals, bin_step=2 if sparse else 1)
+        x = self.head(roi_align_features, first_stride=1 if sparse else None)
+        return x, roi_align_features
+
+
+# ------------------------------------------------------------------------------------------------ predictor
+class _PredictorFn(Function):
+    @staticmethod
+    def forward(ctx, x, pred, *params):
+        xh = as_nhwc(x)                                   # [K,4,4,2048]
+        pooled = ops.avgpool_forward(xh)                  # AdaptiveAvgPool2d(1), roi_box_predictors.py:28
+        K_ = pooled.shape[0]
+        y = ops.conv_forward(pooled.view(K_, 1, 1, -1), pred.fused_weight, 1, 0, bias=pred.fused_bias).view(K_, -1)
+        ctx.pred, ctx.saved, ctx.xshape = pred, pooled, tuple(xh.shape)
+        ctx.need_dx = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        pred, pooled = ctx.pred, ctx.saved
+        K_ = pooled.shape[0]
+        g = gy.contiguous().view(K_, 1, 1, -1)
+        ops.conv_wgrad(pooled.view(K_, 1, 1, -1), g, pred.fused_weight_grad, 1, 0)
+        ops.bias_grad(g, pred.fused_bias_grad)
+        gx = None
+        if ctx.need_dx:
+            gp = ops.conv_forward(g, pred.fused_dgrad_weight(), 1, 0).view(K_, -1)
+            gx = from_nhwc(ops.avgpool_backward(gp, ctx.xshape))
+        ctx.saved = None
+        return (gx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class _Linear(nn.Module):
+    """nn.Linear stand-in: weight [out,in], bias [out] (reference names cls_score / bbox_pred)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(out_features, in_features))
+        self.bias = nn.Parameter(torch.zeros(out_features))
+
+
+class FastRCNNPredictor(nn.Module):
+    def __init__(self, config, in_channels):
+        super().__init__()
+        num_inputs = in_channels
+        num_classes = config.MODEL.ROI_BOX_HEAD.NUM_CLASSES
+        self.num_classes = num_classes
+        self.num_bbox_reg_classes = 2 if config.MODEL.CLS_AGNOSTIC_BBOX_REG else num_classes
+        self.cls_score = _Linear(num_inputs, num_classes)
+        self.bbox_pred = _Linear(num_inputs, self.num_bbox_reg_classes * 4)
+        nn.init.normal_(self.cls_score.weight, mean=0, std=0.01)     # roi_box_predictors.py:21-25
+        nn.init.normal_(self.bbox_pred.weight, mean=0, std=0.001)
+        self.n_out = num_classes + self.num_bbox_reg_classes * 4
+        self.n_out_pad = (self.n_out + 3) // 4 * 4
+        self._fuse()
+
+    def _fuse(self):
+        K, R4, dev = self.num_classes, self.num_bbox_reg_classes * 4, self.cls_score.weight.device
+        C_ = self.cls_score.weight.shape[1]
+        fw = torch.zeros(self.n_out_pad, C_, device=dev)
+        fb = torch.zeros(self.n_out_pad, device=dev)
+        with torch.no_grad():
+            fw[:K].copy_(self.cls_score.weight)
+            fw[K:K + R4].copy_(self.bbox_pred.weight)
+            fb[:K].copy_(self.cls_score.bias)
+            fb[K:K + R4].copy_(self.bbox_pred.bias)
+        self._set_fused(fw, fb, torch.zeros_like(fw), torch.zeros_like(fb))
+
+    def _set_fused(self, fw, fb, gw, gb):
+        K, R4 = self.num_classes, self.num_bbox_reg_classes * 4
+        self._fw2d, self._gw2d = fw, gw
+        self.fused_weight = fw.view(self.n_out_pad, 1, 1, -1)
+        self.fused_bias = fb
+        self.fused_weight_grad, self.fused_bias_grad = gw.view(self.n_out_pad, 1, 1, -1), gb
+        for mod, lo, hi in ((self.cls_score, 0, K), (self.bbox_pred, K, K + R4)):
+            mod.weight.data, mod.bias.data = fw[lo:hi], fb[lo:hi]
+            mod.weight.grad, mod.bias.grad = gw[lo:hi], gb[lo:hi]
+        self._wt, self._wt_version = None, -1
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._fuse()
+        return out
+
+    def flat_groups(self):
+        return [("weight", [self.cls_score.weight, self.bbox_pred.weight], self.n_out_pad - self.n_out),
+                ("bias", [self.cls_score.bias, self.bbox_pred.bias], self.n_out_pad - self.n_out)]
+
+    def rehome(self, which, view, grad_view):
+        """called by flatten_parameters: adopt flat-buffer storage for the fused weight / bias"""
+        if which == "weight":
+            self._set_fused(view.view(self.n_out_pad, -1), self.fused_bias, grad_view.view(self.n_out_pad, -1), self.fused_bias_grad)
+        else:
+            self._set_fused(self._fw2d, view, self._gw2d, grad_view)
+
+    def fused_dgrad_weight(self):
+        if self._wt is None or self._wt_version != _PARAM_VERSION[0]:
+            self._wt = ops.conv_dgrad_weights(self.fused_weight, None, out=self._wt)
+            self._wt_version = _PARAM_VERSION[0]
+        return self._wt
+
+    def forward_fused(self, x):
+        params = list(self.parameters())
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            return _PredictorFn.apply(x, self, *params)
+        pooled = ops.avgpool_forward(as_nhwc(x))
+        K_ = pooled.shape[0]
+        return ops.conv_forward(pooled.view(K_, 1, 1, -1), self.fused_weight, 1, 0, bias=self.fused_bias).view(K_, -1)
+
+    def forward(self, x):
+        """-> (cls_logit [K,K_all], bbox_pred [K,4*K_all]) as column slices of the fused output"""
+        y = self.forward_fused(x)
+        K = self.num_classes
+        return y[:, :K], y[:, K:K + self.num_bbox_reg_classes * 4]
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class _BoxHeadLossFn(Function):
+    """classification (plain CE or the inclusive loss of dist_type=='id') + class-specific smooth-L1(beta=1)/N, both reading
+    the fused predictor output and writing ONE fused gradient buffer (box_head/loss.py:151-179)."""
+
+    @staticmethod
+    def forward(ctx, fused, K, labels, regression_targets, inclusive, n_old, cls_agnostic):
+        n = fused.shape[0]
+        want = fused.requires_grad
+        grad = torch.zeros_like(fused) if want else None
+        lc, _ = ops.softmax_ce(fused[:, :K], labels, inclusive, n_old, want_grad=want, grad_out=grad[:, :K] if want else None)
+        pos = torch.nonzero(labels > 0).squeeze(1)                                   # :166
+        col0 = K + (4 * labels[pos] if not cls_agnostic else torch.full_like(pos, 4))  # :168-171
+        lb, gb = ops.smooth_l1_rows(fused, regression_targets, pos, col0, 1.0, scale=1.0 / max(n, 1), want_grad=want)
+        if want:
+            ops.add_(grad, gb)
+        ctx.save_for_backward(grad)
+        ctx.K = K
+        ctx.g_cls_cols = K
+        return lc[0], lb[0]
+
+    @staticmethod
+    def backward(ctx, g_lc, g_lb):
+        (grad,) = ctx.saved_tensors
+        # the two losses enter the total with the same weight in every caller; honour distinct upstream scales anyway
+        K = ctx.K
+        gc = grad[:, :K].contiguous()
+        ops.scale_(gc, 1.0, g_lc.contiguous())
+        gr = grad[:, K:].contiguous()
+        ops.scale_(gr, 1.0, g_lb.contiguous())
+        return torch.cat((gc, gr), 1), None, None, None, None, None, None
+
+
+class FastRCNNLossComputation(object):
+    def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, cls_agnostic_bbox_reg=False, dist_type=None, old_classes=()):
+        self.proposal_matcher, self.fg_bg_sampler, self.box_coder = proposal_matcher, fg_bg_sampler, box_coder
+        self.cls_agnostic_bbox_reg = cls_agnostic_bbox_reg
+        self.dist_type = dist_type
+        self.n_old_cl = len(old_classes)
+
+    def prepare_targets(self, proposals, targets):
+        """box_head/loss.py:56-84: labels int64 (class / 0 background / -1 ignore) + encoded regression targets"""
+        labels, regression_targets = [], []
+        for p, t in zip(proposals, targets):
+            _, lab, tgt = self.proposal_matcher.match_boxes(t.bbox, p.bbox, t.get_field("labels").to(torch.int64), None,
+                                                            self.box_coder.weights, rpn_labels=False)
+            labels.append(lab)
+            regression_targets.append(tgt)
+        return labels, regression_targets
+
+    def subsample(self, proposals, targets, sampled_inds=None):
+        """:86-120.  Keeps state (self._proposals).  `sampled_inds` (list of index tensors) injects the sampler's choice."""
+        labels, regression_targets = self.prepare_targets(proposals, targets)
+        proposals = list(proposals)
+        for i, (lab, tgt, p) in enumerate(zip(labels, regression_targets, proposals)):
+            p.add_field("labels", lab)
+            p.add_field("regression_targets", tgt)
+            if sampled_inds is not None:
+                inds = sampled_inds[i]
+            else:
+                pos, neg = self.fg_bg_sampler.sample_indices(lab)
+                inds = torch.cat((pos, neg)).sort()[0]       # nonzero(pos_mask | neg_mask): ascending (:114)
+            proposals[i] = p[inds]
+        self._proposals = proposals
+        return proposals
+
+    def __call__(self, class_logits, box_regression, fused=None):
+        if not hasattr(self, "_proposals"):
+            raise RuntimeError("subsample needs to be called before")
+        proposals = self._proposals
+        labels = torch.cat([p.get_field("labels") for p in proposals], dim=0)
+        regression_targets = torch.cat([p.get_field("regression_targets") for p in proposals], dim=0)
+        if fused is None:
+            fused = torch.cat((torch.cat(class_logits, 0), torch.cat(box_regression, 0)), 1)
+            K = class_logits[0].shape[1]
+        else:
+            K = class_logits
+        return _BoxHeadLossFn.apply(fused, K, labels, regression_targets, self.dist_type == "id", self.n_old_cl, self.cls_agnostic_bbox_reg)
+
+
+def make_roi_box_loss_evaluator(cfg):
+    matcher = Matcher(cfg.MODEL.ROI_HEADS.FG_IOU_THRESHOLD, cfg.MODEL.ROI_HEADS.BG_IOU_THRESHOLD, allow_low_quality_matches=False)
+    box_coder = BoxCoder(weights=cfg.MODEL.ROI_HEADS.BBOX_REG_WEIGHTS)
+    sampler = BalancedPositiveNegativeSampler(cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE, cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION)
+    return FastRCNNLossComputation(matcher, sampler, box_coder, cfg.MODEL.CLS_AGNOSTIC_BBOX_REG, cfg.DIST.TYPE,
+                                   cfg.MODEL.ROI_BOX_HEAD.NAME_OLD_CLASSES)
+
+
+# ------------------------------------------------------------------------------------------------ head
+class ROIBoxHead(nn.Module):
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        self.feature_extractor = ResNet50Conv5ROIFeatureExtractor(cfg, in_channels)
+        self.predictor = FastRCNNPredictor(cfg, self.feature_extractor.out_channels)
+        self.loss_evaluator = make_roi_box_loss_evaluator(cfg)
+        self.post_processor = None  # eval-only PostProcessor: next-tier
+        self.need_roi_features_in_training = False
+
+    def forward(self, features, proposals, targets=None):
+        """training: -> (x, proposals, (class_logits, box_regression[K,K_all,4]), loss dict, roi_align_features)  (box_head.py:24-58)"""
+        if not self.training:
+            raise NotImplementedError("test-time PostProcessor is next-tier (SURVEY.md §8f F4); the hot path is training")
+        with torch.no_grad():
+            proposals = self.loss_evaluator.subsample(proposals, targets)
+        x, roi_align_features = self.feature_extractor(features, proposals, need_roi_features=self.need_roi_features_in_training)
+        fused = self.predictor.forward_fused(x)
+        K = self.predictor.num_classes
+        loss_classifier, loss_box_reg = self.loss_evaluator(K, None, fused=fused)
+        class_logits, box_regression = fused[:, :K], fused[:, K:K + 4 * self.predictor.num_bbox_reg_classes]
+        return (x, proposals, (class_logits, box_regression.reshape(-1, K, 4)),
+                dict(loss_classifier=loss_classifier, loss_box_reg=loss_box_reg), roi_align_features)
+
+    def calculate_soften_label(self, features, proposals, targets=None):
+        """box_head.py:60-78 -> (soften_scores [K,Kc], soften_bboxes [K,Kc,4], x, roi_align_features [K,1024,7,7])"""
+        x, roi_align_features = self.feature_extractor(features, proposals, need_roi_features=True)
+        class_logits, box_regression = self.predictor(x)
+        return class_logits, box_regression.reshape(-1, class_logits.shape[1], 4), x, roi_align_features
+
+
+def build_roi_box_head(cfg, in_channels):
+    return ROIBoxHead(cfg, in_channels)

@@ -1,0 +1,382 @@
+"""Region Proposal Network on the HIP library.
+
+Mirrors, for the single-level C4 case every configs/voc YAML uses:
+    AnchorGenerator          maskrcnn_benchmark/modeling/rpn/anchor_generator.py:34-123, 215-284
+    RPNHead                  modeling/rpn/rpn.py:70-121  (conv3x3+ReLU, cls_logits 1x1, bbox_pred 1x1)
+    RPNPostProcessor         modeling/rpn/inference.py:14-147
+    RPNLossComputation       modeling/rpn/loss.py:21-148
+    RPNModule / build_rpn    modeling/rpn/rpn.py:124-230
+
+MI355X-first differences (results identical):
+  * cls_logits and bbox_pred are ONE 1x1 conv with 15+60(+1 pad)=76 output channels over the shared 3x3 feature: the
+    1024-channel tensor `t` is read once.  The NHWC output [N,H,W,76] already IS the reference's
+    permute_and_flatten order (location-major, anchor-minor; rpn/utils.py:10-14), so no permute kernels exist.
+  * proposals for all images are decoded / clipped / NMS-ed in batched launches; the greedy NMS sweep stays on device.
+  * anchors are cached per (H, W, image size) instead of being rebuilt with numpy every step.
+  * IoU + Matcher + labels + BoxCoder.encode for 35 910 anchors is one kernel per image.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from ... import ops
+from ...layers._layout import as_nhwc, from_nhwc
+from ...structures.bounding_box import BoxList
+from ...structures.image_list import ImageList
+from ..backbone.resnet import Conv2d, _grad_buf
+from ..balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+from ..box_coder import BoxCoder
+from ..matcher import Matcher
+
+
+# ------------------------------------------------------------------------------------------------ anchors
+def generate_anchors(stride=16, sizes=(32, 64, 128, 256, 512), aspect_ratios=(0.5, 1, 2)):
+    """Cell anchors (anchor_generator.py:215-284): float64, numpy round (half-to-even) on the ratio enumeration."""
+    base = float(stride)
+    xc = yc = 0.5 * (base - 1)
+    area = base * base
+    out = []
+    for r in aspect_ratios:
+        ws = np.round(np.sqrt(area / r))
+        hs = np.round(ws * r)
+        x1, y1, x2, y2 = xc - 0.5 * (ws - 1), yc - 0.5 * (hs - 1), xc + 0.5 * (ws - 1), yc + 0.5 * (hs - 1)
+        w0, h0 = x2 - x1 + 1, y2 - y1 + 1
+        cx, cy = x1 + 0.5 * (w0 - 1), y1 + 0.5 * (h0 - 1)
+        for s in sizes:
+            sc = float(s) / stride
+            w, h = w0 * sc, h0 * sc
+            out.append([cx - 0.5 * (w - 1), cy - 0.5 * (h - 1), cx + 0.5 * (w - 1), cy + 0.5 * (h - 1)])
+    return torch.tensor(np.array(out, dtype=np.float64)).float()
+
+
+class AnchorGenerator(nn.Module):
+    def __init__(self, sizes=(128, 256, 512), aspect_ratios=(0.5, 1.0, 2.0), anchor_strides=(8, 16, 32), straddle_thresh=0):
+        super().__init__()
+        assert len(anchor_strides) == 1, "single feature level (C4) only: FPN is out of scope (no voc config uses it)"
+        self.strides = anchor_strides
+        self.straddle_thresh = straddle_thresh
+        self.register_buffer("cell_anchors", generate_anchors(anchor_strides[0], sizes, aspect_ratios))
+        self._cache = {}
+
+    def num_anchors_per_location(self):
+        return [self.cell_anchors.shape[0]]
+
+    def grid(self, H, W, image_hw):
+        """([H*W*A,4] anchors, [H*W*A] uint8 visibility) for one image size; cached on device."""
+        key = (H, W, int(image_hw[0]), int(image_hw[1]), self.cell_anchors.device)
+        hit = self._cache.get(key)
+        if hit is None:
+            hit = ops.grid_anchors(self.cell_anchors, H, W, self.strides[0], int(image_hw[0]), int(image_hw[1]), self.straddle_thresh)
+            self._cache[key] = hit
+        return hit
+
+    def forward(self, image_list, feature_maps):
+        H, W = feature_maps[0].shape[-2:]
+        anchors = []
+        for (ih, iw) in image_list.image_sizes:
+            a, vis = self.grid(H, W, (ih, iw))
+            bl = BoxList(a, (iw, ih), mode="xyxy")
+            bl.add_field("visibility", vis.bool())
+            anchors.append([bl])
+        return anchors
+
+
+def make_anchor_generator(cfg):
+    return AnchorGenerator(cfg.MODEL.RPN.ANCHOR_SIZES, cfg.MODEL.RPN.ASPECT_RATIOS, cfg.MODEL.RPN.ANCHOR_STRIDE, cfg.MODEL.RPN.STRADDLE_THRESH)
+
+
+# ------------------------------------------------------------------------------------------------ head
+class _RPNHeadFn(Function):
+    """t = relu(conv3x3(x)+b) ; y = conv1x1_fused(t)+b  as one autograd node with a hand-scheduled backward."""
+
+    @staticmethod
+    def forward(ctx, x, head, *params):
+        xh = as_nhwc(x)
+        t = ops.conv_forward(xh, head.conv.weight, 1, 1, bias=head.conv.bias, relu=True)
+        y = ops.conv_forward(t, head.fused_weight, 1, 0, bias=head.fused_bias)
+        ctx.head, ctx.saved = head, (xh, t)
+        ctx.need_dx = x.requires_grad
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        head = ctx.head
+        xh, t = ctx.saved
+        g = as_nhwc(gy)
+        if not g.is_contiguous():
+            g = g.contiguous()
+        ops.conv_wgrad(t, g, head.fused_weight_grad, 1, 0)
+        ops.bias_grad(g, head.fused_bias_grad)
+        gt = ops.conv_forward(g, head.fused_dgrad_weight(), 1, 0, mask=t)
+        ops.conv_wgrad(xh, gt, _grad_buf(head.conv.weight), 1, 1)
+        ops.bias_grad(gt, _grad_buf(head.conv.bias))
+        gx = from_nhwc(ops.conv_forward(gt, head.conv.dgrad_weight(), 1, 1)) if ctx.need_dx else None
+        ctx.saved = None
+        return (gx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class RPNHead(nn.Module):
+    """rpn.py:70-121.  `cls_logits` / `bbox_pred` keep their reference names and shapes; their storage is two
+    row-slices of one fused [76,1,1,C] buffer (rows 0..14, 15..74, row 75 = zero pad so that Cout % 4 == 0)."""
+
+    def __init__(self, cfg, in_channels, num_anchors):
+        super().__init__()
+        self.num_anchors = num_anchors
+        self.conv = Conv2d(in_channels, in_channels, 3, stride=1, padding=1)
+        self.cls_logits = Conv2d(in_channels, num_anchors, 1)
+        self.bbox_pred = Conv2d(in_channels, num_anchors * 4, 1)
+        for l in (self.conv, self.cls_logits, self.bbox_pred):  # rpn.py:87-89
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+        if cfg.MODEL.RPN.CONV_FREEZE:
+            for p in self.conv.parameters():
+                p.requires_grad = False
+        if cfg.MODEL.RPN.CLS_FREEZE:
+            for p in self.cls_logits.parameters():
+                p.requires_grad = False
+        if cfg.MODEL.RPN.BBS_FREEZE:
+            for p in self.bbox_pred.parameters():
+                p.requires_grad = False
+        self.n_out = num_anchors * 5
+        self.n_out_pad = (self.n_out + 3) // 4 * 4
+        self._fuse()
+
+    def _fuse(self):
+        """(re)build the fused storage and re-point the two reference-named parameters into it"""
+        A, C_, dev = self.num_anchors, self.conv.in_channels, self.cls_logits.weight.device
+        fw = torch.zeros(self.n_out_pad, 1, 1, C_, device=dev)
+        fb = torch.zeros(self.n_out_pad, device=dev)
+        with torch.no_grad():
+            fw[:A].copy_(self.cls_logits.weight)
+            fw[A:5 * A].copy_(self.bbox_pred.weight)
+            fb[:A].copy_(self.cls_logits.bias)
+            fb[A:5 * A].copy_(self.bbox_pred.bias)
+        self._set_fused(fw, fb, torch.zeros_like(fw), torch.zeros_like(fb))
+
+    def _set_fused(self, fw, fb, gw, gb):
+        A = self.num_anchors
+        self.fused_weight, self.fused_bias = fw, fb
+        self.fused_weight_grad, self.fused_bias_grad = gw, gb
+        for mod, lo, hi in ((self.cls_logits, 0, A), (self.bbox_pred, A, 5 * A)):
+            mod.weight.data, mod.bias.data = fw[lo:hi], fb[lo:hi]
+            mod.weight.grad, mod.bias.grad = gw[lo:hi], gb[lo:hi]
+        self._wt, self._wt_version = None, -1
+
+    def rehome(self, which, view, grad_view):
+        """called by flatten_parameters: adopt flat-buffer storage for the fused weight / bias"""
+        if which == "weight":
+            shp = self.fused_weight.shape
+            self._set_fused(view.view(shp), self.fused_bias, grad_view.view(shp), self.fused_bias_grad)
+        else:
+            self._set_fused(self.fused_weight, view, self.fused_weight_grad, grad_view)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._fuse()
+        return out
+
+    def flat_groups(self):
+        """tensors that must stay contiguous when the model's parameters are re-homed into one flat buffer"""
+        return [("weight", [self.cls_logits.weight, self.bbox_pred.weight], self.n_out_pad - self.n_out),
+                ("bias", [self.cls_logits.bias, self.bbox_pred.bias], self.n_out_pad - self.n_out)]
+
+    def fused_dgrad_weight(self):
+        from ..backbone.resnet import _PARAM_VERSION
+        if self._wt is None or self._wt_version != _PARAM_VERSION[0]:
+            self._wt = ops.conv_dgrad_weights(self.fused_weight, None, out=self._wt)
+            self._wt_version = _PARAM_VERSION[0]
+        return self._wt
+
+    def forward_fused(self, x):
+        """x logical [N,C,H,W] -> logical [N,76,H,W] whose NHWC memory is [N,H,W,(15 obj | 60 reg | pad)]"""
+        params = list(self.parameters())
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            return _RPNHeadFn.apply(x, self, *params)
+        xh = as_nhwc(x)
+        t = ops.conv_forward(xh, self.conv.weight, 1, 1, bias=self.conv.bias, relu=True)
+        return from_nhwc(ops.conv_forward(t, self.fused_weight, 1, 0, bias=self.fused_bias))
+
+    def forward(self, x):
+        logits, bbox_reg = [], []
+        for feature in x:
+            y = self.forward_fused(feature)
+            logits.append(y[:, : self.num_anchors])
+            bbox_reg.append(y[:, self.num_anchors: 5 * self.num_anchors])
+        return logits, bbox_reg
+
+
+# ------------------------------------------------------------------------------------------------ proposals
+class RPNPostProcessor(nn.Module):
+    """inference.py:14-147: sigmoid -> top-k (sorted) -> decode -> clip -> remove small -> NMS -> first post_nms (+GT in training)."""
+
+    def __init__(self, pre_nms_top_n, post_nms_top_n, nms_thresh, min_size, box_coder=None, fpn_post_nms_top_n=None,
+                 fpn_post_nms_per_batch=True):
+        super().__init__()
+        self.pre_nms_top_n, self.post_nms_top_n = pre_nms_top_n, post_nms_top_n
+        self.nms_thresh, self.min_size = nms_thresh, min_size
+        self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+
+    def add_gt_proposals(self, proposals, targets):
+        out = []
+        for p, t in zip(proposals, targets):
+            gt = BoxList(t.bbox, t.size, t.mode)
+            gt.add_field("objectness", torch.ones(len(gt), device=t.bbox.device))
+            b = BoxList(torch.cat((p.bbox, gt.bbox), 0), p.size, p.mode)
+            b.add_field("objectness", torch.cat((p.get_field("objectness"), gt.get_field("objectness")), 0))
+            out.append(b)
+        return out
+
+    def forward_fused(self, anchors, fused, num_anchors, targets=None):
+        """fused: logical [N,5A(+pad),H,W] head output.  anchors: list (per image) of [BoxList] as AnchorGenerator returns."""
+        y = as_nhwc(fused)
+        N, H, W, Cf = y.shape
+        A = num_anchors
+        n_anchor = H * W * A
+        yf = y.reshape(N, H * W, Cf)
+        objectness = yf[:, :, :A].reshape(N, n_anchor).sigmoid()                         # inference.py:87-88
+        k = min(self.pre_nms_top_n, n_anchor)
+        scores, topk_idx = objectness.topk(k, dim=1, sorted=True)                        # :95-96
+        same = all(a[0].bbox.data_ptr() == anchors[0][0].bbox.data_ptr() for a in anchors)
+        img_hw = torch.tensor([[a[0].size[1], a[0].size[0]] for a in anchors], dtype=torch.int32, device=y.device)
+        assert same, "per-image anchor grids of one batch share (H,W): they differ only in the visibility field"
+        props = ops.rpn_decode_clip(yf, A, anchors[0][0].bbox, topk_idx, img_hw, self.box_coder.weights, A=A)  # :101-112
+        counts = torch.full((N,), k, dtype=torch.int32, device=y.device)
+        if self.min_size > 0:  # remove_small_boxes (boxlist_ops.py:34-48): with MIN_SIZE=0 (every voc config) nothing is dropped
+            raise NotImplementedError("RPN.MIN_SIZE > 0 is not used by any configs/voc YAML")
+        keep, n_keep = ops.nms_sorted_batched(props, counts, self.nms_thresh, self.post_nms_top_n)     # :113-116
+        nk = n_keep.tolist()  # the only host sync of the proposal path (the reference syncs inside every nms call)
+        result = []
+        for i in range(N):
+            ki = keep[i, : nk[i]].long()
+            b = BoxList(props[i].index_select(0, ki), anchors[i][0].size, mode="xyxy")
+            b.add_field("objectness", scores[i].index_select(0, ki))
+            result.append(b)
+        if self.training and targets is not None:
+            result = self.add_gt_proposals(result, targets)                               # :144-145
+        return result
+
+    def forward(self, anchors, objectness, box_regression, targets=None):
+        """reference signature (lists of logical [N,A,H,W] / [N,4A,H,W]); re-fuses the two tensors (compat path)."""
+        fused = torch.cat((objectness[0], box_regression[0]), 1)
+        return self.forward_fused(anchors, fused, objectness[0].shape[1], targets)
+
+
+def make_rpn_postprocessor(config, rpn_box_coder, is_train):
+    pre = config.MODEL.RPN.PRE_NMS_TOP_N_TRAIN if is_train else config.MODEL.RPN.PRE_NMS_TOP_N_TEST
+    post = config.MODEL.RPN.POST_NMS_TOP_N_TRAIN if is_train else config.MODEL.RPN.POST_NMS_TOP_N_TEST
+    return RPNPostProcessor(pre, post, config.MODEL.RPN.NMS_THRESH, config.MODEL.RPN.MIN_SIZE, rpn_box_coder)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class _RPNLossFn(Function):
+    """BCE-with-logits over the sampled anchors + smooth-L1(beta=1/9) over the sampled positives / #sampled
+    (rpn/loss.py:136,145-146), reading objectness and deltas straight out of the fused NHWC head output."""
+
+    @staticmethod
+    def forward(ctx, fused, A, labels, reg_targets, pos_idx, samp_idx):
+        y = as_nhwc(fused)
+        N, H, W, Cf = y.shape
+        y2 = y.reshape(N * H * W, Cf)
+        n_samp = samp_idx.numel()
+        # anchor j of the flattened batch lives in row j // A; objectness at column j % A, deltas at A + 4*(j % A)
+        obj_flat_idx = (samp_idx // A) * Cf + samp_idx % A
+        want = fused.requires_grad
+        lo, g_obj = ops.bce_logits_gather(y2, labels, obj_flat_idx, want_grad=want, yidx=samp_idx)
+        lb, g_reg = ops.smooth_l1_rows(y2, reg_targets, pos_idx // A, A + 4 * (pos_idx % A), 1.0 / 9, scale=1.0 / max(n_samp, 1),
+                                       want_grad=want, trows=pos_idx)
+        ctx.shape = (N, H, W, Cf)
+        ctx.save_for_backward(g_obj, g_reg)
+        return lo[0], lb[0]
+
+    @staticmethod
+    def backward(ctx, g_lo, g_lb):
+        g_obj, g_reg = ctx.saved_tensors
+        ops.scale_(g_obj, 1.0, g_lo.contiguous())
+        ops.scale_(g_reg, 1.0, g_lb.contiguous())
+        ops.add_(g_obj, g_reg)  # disjoint columns of the same [N*H*W, Cf] buffer
+        return from_nhwc(g_obj.view(ctx.shape)), None, None, None, None, None
+
+
+class RPNLossComputation(object):
+    def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, generate_labels_func=None):
+        self.proposal_matcher, self.fg_bg_sampler, self.box_coder = proposal_matcher, fg_bg_sampler, box_coder
+        self.discard_cases = ["not_visibility", "between_thresholds"]
+
+    def prepare_targets(self, anchors, targets):
+        """rpn/loss.py:66-102 per image -> labels fp32 {1,0,-1}, regression targets, matched idxs"""
+        labels, regression_targets, matched = [], [], []
+        for a, t in zip(anchors, targets):
+            vis = a.get_field("visibility")
+            m, lab, tgt = self.proposal_matcher.match_boxes(t.bbox, a.bbox, None, vis.to(torch.uint8) if vis.dtype != torch.uint8 else vis,
+                                                            self.box_coder.weights, rpn_labels=True)
+            labels.append(lab)
+            regression_targets.append(tgt)
+            matched.append(m)
+        return labels, regression_targets, matched
+
+    def sample(self, labels):
+        """global (batch-flattened) indices of the sampled positives and of all sampled anchors (pos first, :119-123)"""
+        n = labels[0].numel()
+        pos, neg = [], []
+        for i, lab in enumerate(labels):
+            p, q = self.fg_bg_sampler.sample_indices(lab)
+            pos.append(p.sort()[0] + i * n)   # nonzero() of a mask yields ascending indices in the reference
+            neg.append(q.sort()[0] + i * n)
+        pos, neg = torch.cat(pos), torch.cat(neg)
+        return pos, torch.cat([pos, neg])
+
+    def __call__(self, anchors, objectness, box_regression, targets, rpn_output_source=None, fused=None, sampled=None):
+        """Returns (objectness_loss, box_loss).  `rpn_output_source` is accepted and ignored as in the reference (:129-143).
+        `sampled=(pos_idx, samp_idx)` injects the sampler's choice (parity tests)."""
+        anchors = [a[0] if isinstance(a, (list, tuple)) else a for a in anchors]
+        labels, regression_targets, _ = self.prepare_targets(anchors, targets)
+        pos_idx, samp_idx = sampled if sampled is not None else self.sample(labels)
+        self.last_sampled, self.last_targets = (pos_idx, samp_idx), (labels, regression_targets)  # introspection for parity tests
+        if fused is None:
+            fused = torch.cat((objectness[0], box_regression[0]), 1)
+            A = objectness[0].shape[1]
+        else:
+            A = anchors[0].bbox.shape[0] // (fused.shape[-1] * fused.shape[-2])
+        return _RPNLossFn.apply(fused, A, torch.cat(labels), torch.cat(regression_targets), pos_idx, samp_idx)
+
+
+def make_rpn_loss_evaluator(cfg, box_coder):
+    matcher = Matcher(cfg.MODEL.RPN.FG_IOU_THRESHOLD, cfg.MODEL.RPN.BG_IOU_THRESHOLD, allow_low_quality_matches=True)
+    sampler = BalancedPositiveNegativeSampler(cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE, cfg.MODEL.RPN.POSITIVE_FRACTION)
+    return RPNLossComputation(matcher, sampler, box_coder)
+
+
+# ------------------------------------------------------------------------------------------------ module
+class RPNModule(nn.Module):
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        self.cfg = cfg.clone()
+        self.anchor_generator = make_anchor_generator(cfg)
+        self.head = RPNHead(cfg, in_channels, self.anchor_generator.num_anchors_per_location()[0])
+        rpn_box_coder = BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+        self.box_selector_train = make_rpn_postprocessor(cfg, rpn_box_coder, is_train=True)
+        self.box_selector_test = make_rpn_postprocessor(cfg, rpn_box_coder, is_train=False)
+        self.loss_evaluator = make_rpn_loss_evaluator(cfg, rpn_box_coder)
+
+    def forward(self, images, features, targets=None, rpn_output_source=None):
+        """-> ((boxes, losses), anchors, rpn_output) exactly as rpn.py:161-183."""
+        fused = self.head.forward_fused(features[0])
+        A = self.head.num_anchors
+        anchors = self.anchor_generator(images, features)
+        rpn_output = ([fused[:, :A]], [fused[:, A:5 * A]])
+        if self.training:
+            with torch.no_grad():
+                self.box_selector_train.train()
+                boxes = self.box_selector_train.forward_fused(anchors, fused.detach(), A, targets)
+            loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, None, None, targets, rpn_output_source, fused=fused)
+            return (boxes, {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}), anchors, rpn_output
+        self.box_selector_test.eval()
+        boxes = self.box_selector_test.forward_fused(anchors, fused, A)
+        return (boxes, {}), anchors, rpn_output
+
+
+def build_rpn(cfg, in_channels):
+    return RPNModule(cfg, in_channels)

@@ -115,46 +115,70 @@ def smooth_l1(x, t, beta, scale=1.0, gscale=1.0, want_grad=False):
     return loss, grad
 
 
-def smooth_l1_rows(x, t, rows, col0, beta, scale=1.0, gscale=1.0, want_grad=False):
-    """sum over i of smoothL1(x[rows[i], col0[i]:col0[i]+4] - t[rows[i], :4]) * scale"""
+def smooth_l1_rows(x, t, rows, col0, beta, scale=1.0, gscale=1.0, want_grad=False, trows=None):
+    """sum over i of smoothL1(x[rows[i], col0[i]:col0[i]+4] - t[trows[i] (default rows[i]), :4]) * scale"""
     L.require_cuda(x, t, rows)
     x, t = L.f32c(x), L.f32c(t)
     loss = _empty((4,), x)
     grad = torch.zeros_like(x) if want_grad else None
-    L.check(L.lib().abr_smooth_l1_rows(L.ptr(x), x.shape[1], L.ptr(t), L.ptr(rows), L.ptr(col0), rows.numel(), float(beta),
+    L.check(L.lib().abr_smooth_l1_rows(L.ptr(x), x.shape[1], L.ptr(t), L.ptr(rows), L.ptr(col0), L.ptr(trows), rows.numel(), float(beta),
                                        float(scale), L.ptr(loss), float(gscale), L.ptr(grad), L.stream()), "smooth_l1_rows")
     return loss, grad
 
 
-def softmax_ce(logits, labels, inclusive=False, n_old=0, gscale=1.0, want_grad=False):
+def _rows2d(t):
+    """2-D fp32 tensor whose rows are contiguous (column slices of a fused buffer are fine) -> (tensor, row pitch)"""
+    if t.dtype != _f32:
+        raise RuntimeError(f"expected float32, got {t.dtype}")
+    if t.dim() != 2 or t.stride(1) != 1:
+        t = t.reshape(t.shape[0], -1).contiguous()
+    return t, t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+def softmax_ce(logits, labels, inclusive=False, n_old=0, gscale=1.0, want_grad=False, grad_out=None):
+    """grad_out: optional [n,>=K]-pitched view to receive d_logits (e.g. a column slice of the fused grad buffer)"""
     L.require_cuda(logits, labels)
-    logits = L.f32c(logits)
+    logits, ldz = _rows2d(logits)
     labels = labels.contiguous()
     loss = _empty((4,), logits)
-    grad = torch.empty_like(logits) if want_grad else None
-    L.check(L.lib().abr_softmax_ce(L.ptr(logits), L.ptr(labels), logits.shape[0], logits.shape[1], int(inclusive), n_old,
-                                   L.ptr(loss), float(gscale), L.ptr(grad), L.stream()), "softmax_ce")
+    grad = None
+    if want_grad:
+        grad = grad_out if grad_out is not None else torch.empty((logits.shape[0], logits.shape[1]), dtype=_f32, device=logits.device)
+    ldg = grad.stride(0) if grad is not None and grad.shape[0] > 1 else logits.shape[1]
+    L.check(L.lib().abr_softmax_ce(L.ptr(logits), ldz, L.ptr(labels), logits.shape[0], logits.shape[1], int(inclusive), n_old,
+                                   L.ptr(loss), float(gscale), L.ptr(grad), ldg, L.stream()), "softmax_ce")
     return loss, grad
 
 
-def roi_distill(z_s, b_s, z_t, b_t, dist_id=True, gscale=1.0, want_grad=False):
+def roi_distill(z_s, b_s, z_t, b_t, dist_id=True, gscale=1.0, want_grad=False, d_zt=None, d_bt=None):
+    """z_s [n,K_old], b_s [n,K_old,4], z_t [n,K_all], b_t [n,K_all,4]; any of them may be a column slice of a fused
+    [n,ld] buffer (rows contiguous).  d_zt / d_bt: optional pre-made (possibly sliced) gradient destinations."""
     L.require_cuda(z_s, b_s, z_t, b_t)
-    z_s, b_s, z_t, b_t = L.f32c(z_s), L.f32c(b_s), L.f32c(z_t), L.f32c(b_t)
+    n, K_old, K_all = z_t.shape[0], z_s.shape[1], z_t.shape[1]
+    z_s, l0 = _rows2d(z_s)
+    b_s, l1 = _rows2d(b_s.reshape(n, K_old * 4) if b_s.dim() == 3 else b_s)
+    z_t, l2 = _rows2d(z_t)
+    b_t, l3 = _rows2d(b_t.reshape(n, K_all * 4) if b_t.dim() == 3 else b_t)
     loss = _empty((4,), z_t)
-    d_zt = torch.empty_like(z_t) if want_grad else None
-    d_bt = torch.empty_like(b_t) if want_grad else None
-    L.check(L.lib().abr_roi_distill(L.ptr(z_s), L.ptr(b_s), L.ptr(z_t), L.ptr(b_t), z_t.shape[0], z_s.shape[1], z_t.shape[1],
-                                    int(dist_id), L.ptr(loss), float(gscale), L.ptr(d_zt), L.ptr(d_bt), L.stream()),
-            "roi_distill")
+    if want_grad:
+        d_zt = d_zt if d_zt is not None else torch.empty((n, K_all), dtype=_f32, device=z_t.device)
+        d_bt = d_bt if d_bt is not None else torch.empty((n, K_all * 4), dtype=_f32, device=z_t.device)
+    else:
+        d_zt = d_bt = None
+    l4 = d_zt.stride(0) if d_zt is not None and n > 1 else K_all
+    l5 = d_bt.stride(0) if d_bt is not None and n > 1 else K_all * 4
+    ld = (C.c_int32 * 6)(l0, l1, l2, l3, l4, l5)
+    L.check(L.lib().abr_roi_distill(L.ptr(z_s), L.ptr(b_s), L.ptr(z_t), L.ptr(b_t), n, K_old, K_all, C.cast(ld, C.c_void_p),
+                                    int(dist_id), L.ptr(loss), float(gscale), L.ptr(d_zt), L.ptr(d_bt), L.stream()), "roi_distill")
     return loss, d_zt, d_bt
 
 
-def bce_logits_gather(x, y, idx, gscale=1.0, want_grad=False):
+def bce_logits_gather(x, y, idx, gscale=1.0, want_grad=False, yidx=None):
     L.require_cuda(x, y, idx)
     x, y = L.f32c(x), L.f32c(y)
     loss = _empty((4,), x)
     grad = torch.zeros_like(x) if want_grad else None
-    L.check(L.lib().abr_bce_logits_gather(L.ptr(x), L.ptr(y), L.ptr(idx), idx.numel(), L.ptr(loss), float(gscale),
+    L.check(L.lib().abr_bce_logits_gather(L.ptr(x), L.ptr(y), L.ptr(idx), L.ptr(yidx), idx.numel(), L.ptr(loss), float(gscale),
                                           L.ptr(grad), L.stream()), "bce_logits_gather")
     return loss, grad
 
@@ -277,6 +301,14 @@ def add_(a, b):
     return a
 
 
+def scale_(x, s=1.0, s_dev=None):
+    """x *= s * s_dev[0] (s_dev: device scalar, e.g. the upstream gradient of a loss) -- no host sync"""
+    if x is None:
+        return None
+    L.check(L.lib().abr_scale_inplace(L.ptr(x), x.numel(), float(s), L.ptr(s_dev), L.stream()), "scale_inplace")
+    return x
+
+
 # ----------------------------------------------------------------------------------------------- RPN glue
 def grid_anchors(cell, H, W, stride, img_h, img_w, straddle=0):
     A = cell.shape[0]
@@ -287,13 +319,22 @@ def grid_anchors(cell, H, W, stride, img_h, img_w, straddle=0):
     return out, vis
 
 
-def rpn_decode_clip(reg, reg_col0, anchors, idx, img_hw, weights=(1.0, 1.0, 1.0, 1.0)):
-    """reg [N,n_anchor,stride] ; idx [N,k] int64 ; img_hw [N,2] int32 -> [N,k,4]"""
-    N, n_anchor, rs = reg.shape
+def box_encode_rows(gt, ex, weights, out=None):
+    gt, ex = L.f32c(gt), L.f32c(ex)
+    if out is None:
+        out = torch.empty_like(ex)
+    L.check(L.lib().abr_box_encode(L.ptr(gt), L.ptr(ex), ex.shape[0], *[float(v) for v in weights], L.ptr(out), L.stream()), "box_encode")
+    return out
+
+
+def rpn_decode_clip(reg, reg_col0, anchors, idx, img_hw, weights=(1.0, 1.0, 1.0, 1.0), A=1, clip=True):
+    """reg [N,n_anchor/A,stride] ; idx [N,k] int64 anchor ids ; img_hw [N,2] int32 -> [N,k,4]"""
+    N, nloc, rs = reg.shape
+    n_anchor = nloc * A
     k = idx.shape[1]
     out = torch.empty((N, k, 4), dtype=_f32, device=reg.device)
-    L.check(L.lib().abr_rpn_decode_clip(L.ptr(reg), rs, reg_col0, L.ptr(anchors), L.ptr(idx), N, n_anchor, k,
-                                        L.ptr(img_hw), *[float(v) for v in weights], L.ptr(out), L.stream()), "rpn_decode_clip")
+    L.check(L.lib().abr_rpn_decode_clip(L.ptr(reg), rs, reg_col0, A, L.ptr(anchors), L.ptr(idx), N, n_anchor, k,
+                                        L.ptr(img_hw) if clip else None, *[float(v) for v in weights], L.ptr(out), L.stream()), "rpn_decode_clip")
     return out
 
 

@@ -1,0 +1,39 @@
+"""WarmupMultiStepLR (mirror of maskrcnn_benchmark/solver/lr_scheduler.py:10-52):
+lr = initial_lr * warmup(iter) * gamma ** (number of milestones <= iter)."""
+from bisect import bisect_right
+
+
+class WarmupMultiStepLR(object):
+    def __init__(self, optimizer, milestones, gamma=0.1, warmup_factor=1.0 / 3, warmup_iters=500, warmup_method="linear",
+                 last_epoch=-1):
+        if list(milestones) != sorted(milestones):
+            raise ValueError("Milestones should be a list of increasing integers. Got {}".format(milestones))
+        if warmup_method not in ("constant", "linear"):
+            raise ValueError("Only 'constant' or 'linear' warmup_method accepted, got {}".format(warmup_method))
+        self.optimizer, self.milestones, self.gamma = optimizer, list(milestones), gamma
+        self.warmup_factor, self.warmup_iters, self.warmup_method = warmup_factor, warmup_iters, warmup_method
+        self.base_lrs = [g["initial_lr"] for g in optimizer.param_groups]
+        self.last_epoch = last_epoch
+        self.step()
+
+    def get_lr(self):
+        warmup_factor = 1
+        if self.last_epoch < self.warmup_iters:
+            if self.warmup_method == "constant":
+                warmup_factor = self.warmup_factor
+            else:
+                alpha = float(self.last_epoch) / self.warmup_iters
+                warmup_factor = self.warmup_factor * (1 - alpha) + alpha
+        k = self.gamma ** bisect_right(self.milestones, self.last_epoch)
+        return [base_lr * warmup_factor * k for base_lr in self.base_lrs]
+
+    def step(self):
+        self.last_epoch += 1
+        for g, lr in zip(self.optimizer.param_groups, self.get_lr()):
+            g["lr"] = lr
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = sd["last_epoch"]

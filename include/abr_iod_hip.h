@@ -112,27 +112,30 @@ int abr_ard_backward(const float* f_src, const float* f_tgt, const float* coef, 
 int abr_smooth_l1(const float* x, const float* t, int64_t n, float beta, float scale, float* loss_out,
                   float gscale, float* grad, void* stream);
 int abr_smooth_l1_rows(const float* x, int x_cols, const float* t, const int64_t* rows, const int64_t* col0,
-                       int n_rows, float beta, float scale, float* loss_out, float gscale, float* grad,
-                       void* stream);
+                       const int64_t* trows /* rows of t, NULL = rows */, int n_rows, float beta, float scale,
+                       float* loss_out, float gscale, float* grad, void* stream);
 
 /* FastRCNNLossComputation classification term   modeling/roi_heads/box_head/loss.py:151-162
  *   inclusive != 0 : "Inclusive Classification Loss" (dist_type=='id'), n_old = number of old classes
  *   else           : F.cross_entropy.   labels int64 [n]; label<0 rows are ignored as F.nll_loss does (-100)
  * loss_out[0] = mean over counted rows.  d_logits optional [n,K]. */
-int abr_softmax_ce(const float* logits, const int64_t* labels, int n, int K, int inclusive, int n_old,
-                   float* loss_out, float gscale, float* d_logits, void* stream);
+int abr_softmax_ce(const float* logits, int ld_logits /* row pitch, <=0: K */, const int64_t* labels, int n, int K,
+                   int inclusive, int n_old, float* loss_out, float gscale, float* d_logits, int ld_dlogits,
+                   void* stream);
 
 /* calculate_roi_distillation_losses(soften, target, dist)   distillation/distillation.py:164-240
  *   dist_id!=0 -> unbiased cross-entropy + L2 boxes ; else mean-centred L2 + L2 boxes
  * z_s [n,K_old], b_s [n,K_old,4], z_t [n,K_all], b_t [n,K_all,4]; d_zt/d_bt optional. */
+/* ld_host: optional 6 row pitches (z_s, b_s, z_t, b_t, d_zt, d_bt) in floats, <=0 = dense; lets the scores / boxes
+ * be column slices of the fused predictor output. */
 int abr_roi_distill(const float* z_s, const float* b_s, const float* z_t, const float* b_t, int n, int K_old,
-                    int K_all, int dist_id, float* loss_out, float gscale, float* d_zt, float* d_bt,
-                    void* stream);
+                    int K_all, const int32_t* ld_host, int dist_id, float* loss_out, float gscale, float* d_zt,
+                    float* d_bt, void* stream);
 
 /* F.binary_cross_entropy_with_logits(x[idx], y[idx]).mean()   modeling/rpn/loss.py:145-146
  * idx int64 [n_idx] into the flattened logits; grad optional, pre-zeroed, same shape as x. */
-int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, int n_idx, float* loss_out,
-                          float gscale, float* grad, void* stream);
+int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, const int64_t* yidx /* NULL = idx */,
+                          int n_idx, float* loss_out, float gscale, float* grad, void* stream);
 
 /* =====================================================================================================
  * 3. Convolution as implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), NHWC / OHWI.
@@ -182,6 +185,8 @@ int abr_avgpool_backward(const float* g, int N, int HW, int C, float* gx, void* 
 /* g *= (y > 0) in place (ReLU backward) */
 int abr_relu_backward(float* g, const float* y, int64_t n, void* stream);
 int abr_add_inplace(float* a, const float* b, int64_t n, void* stream);
+/* x *= s * (s_dev ? *s_dev : 1): applies an upstream (device-resident) loss gradient without a host sync */
+int abr_scale_inplace(float* x, int64_t n, float s, const float* s_dev, void* stream);
 
 /* =====================================================================================================
  * 5. RPN / RoI-head glue (integer + fp32 index work; maskrcnn_benchmark/modeling/rpn/, matcher.py, box_coder.py)
@@ -191,10 +196,14 @@ int abr_grid_anchors(const float* cell, int A, int H, int W, int stride, int img
                      float* out, uint8_t* vis, void* stream);
 /* BoxCoder.decode + clip_to_image on gathered rows  (rpn/inference.py:96-112, box_coder.py:52-95, bounding_box.py:214-225)
  * For image i and rank j<k: a = idx[i,j]; out[i,j,:] = clip(decode(reg[i,a,:], anchors[a,:])).
- * reg [N,n_anchor,reg_stride] with the 4 deltas starting at column reg_col0. */
-int abr_rpn_decode_clip(const float* reg, int reg_stride, int reg_col0, const float* anchors,
+ * reg [N,n_anchor/A,reg_stride]: anchor a = loc*A + a' reads columns reg_col0 + 4a' .. +3 of row loc
+ * (A=1: one row per anchor; A=15, reg_stride=76, reg_col0=15: the fused NHWC RPN head output). */
+int abr_rpn_decode_clip(const float* reg, int reg_stride, int reg_col0, int A, const float* anchors,
                         const int64_t* idx, int N, int n_anchor, int k, const int32_t* img_hw, float wx,
                         float wy, float ww, float wh, float* out, void* stream);
+/* BoxCoder.encode row-wise (box_coder.py:22-50): out[i] = encode(gt[i], ex[i]); img_hw==NULL above = decode without clip */
+int abr_box_encode(const float* gt, const float* ex, int n, float wx, float wy, float ww, float wh, float* out,
+                   void* stream);
 /* boxlist_iou + Matcher (+ RPN labels / box-head labels) + BoxCoder.encode in one pass per box.
  *   boxes [n,4], gt [G,4], gt_labels [G] int64 (or NULL for RPN), vis [n] uint8 (or NULL)
  *   matched [n] int64 (-1 / -2 / gt index), labels_out [n] (fp32 for RPN: 1/0/-1; int64 for head: class/0/-1),

@@ -1,0 +1,176 @@
+"""End-to-end parity of one incremental training step (ARD + inclusive distillation on):
+the HIP path vs the torch-CPU oracle model (oracle/model_ref.py) on IDENTICAL weights, inputs and sampled indices.
+
+What is compared
+  * integer / index outputs: anchors' labels & matches are covered in test_gpu_ops; here the proposals the GPU path selected
+    are fed to the oracle (sampling is device RNG and cannot be reproduced -- SURVEY.md §7 'Hard parts')
+  * every loss of the step: loss_classifier, loss_box_reg, loss_objectness, loss_rpn_box_reg, ID distillation, ARD
+    -> within 1e-4 (relative where the magnitude is >> 1), the north_star tolerance
+  * the gradient of the total loss w.r.t. every trainable tensor (autograd on the oracle) -> 1e-3 of the tensor's max |g|
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=1e-4):
+    return abs(a - b) <= tol * max(1.0, abs(b))
+
+
+@pytest.fixture(scope="module")
+def step_state():
+    import random
+
+    from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
+    from abr_iod_amd.utils.checkpoint import reference_state_dict
+
+    overrides = ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 600, "MODEL.RPN.POST_NMS_TOP_N_TRAIN", 100, "MODEL.RPN.PRE_NMS_TOP_N_TEST", 300,
+                 "MODEL.RPN.POST_NMS_TOP_N_TEST", 150, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 48, "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 64]
+    cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, overrides=overrides)
+    torch.manual_seed(0)
+    random.seed(0)
+    ms, mt = build_models(cfg_s, cfg_t, seed=0)
+    # full (7x7) pooled features in the detection pass too, so shapes match the reference tuple
+    images, targets = synthetic_batch(2, 160, 224, seed=3, max_boxes=3)
+    # keep GT inside the small image
+    for t in targets:
+        t.bbox[:, 0::2].clamp_(max=223); t.bbox[:, 1::2].clamp_(max=159)
+        t.bbox[:, 2] = torch.max(t.bbox[:, 2], t.bbox[:, 0] + 8).clamp(max=223); t.bbox[:, 3] = torch.max(t.bbox[:, 3], t.bbox[:, 1] + 8).clamp(max=159)
+    return dict(cfg_s=cfg_s, cfg_t=cfg_t, ms=ms, mt=mt, images=images, targets=targets,
+                sd_s=reference_state_dict(ms), sd_t=reference_state_dict(mt))
+
+
+def test_train_step_losses_and_grads_vs_oracle(step_state):
+    from abr_iod_amd.distillation.distillation import calculate_attentive_roi_feature_distillation, calculate_roi_distillation_losses
+    from abr_iod_amd.modeling.roi_heads.box_head.box_head import convert_to_roi_format
+    from oracle import torch_ref as R
+    from oracle.model_ref import RefModel
+
+    S = step_state
+    ms, mt, images, targets, cfg = S["ms"], S["mt"], S["images"], S["targets"], S["cfg_t"]
+    mt.flat.zero_grad()
+    # ---------------- GPU path (the trainer's sequence, train_incremental.py:82-128)
+    with torch.no_grad():
+        soften_result, _, soften_proposal, feat_s, _, _, _, raf_s = ms.generate_soften_proposal(images)
+    loss_dict, feat_t, _, anchors, rpn_out, props, raf_det, _ = mt(images, targets)
+    target_result, _, raf_t = mt.forward(images, targets, features=feat_t, proposals=soften_proposal)
+    l_id = calculate_roi_distillation_losses(soften_result, target_result, dist="id")
+    l_ard = calculate_attentive_roi_feature_distillation(raf_s, raf_t, gamma=cfg.DIST.GAMMA)
+    total = sum(loss_dict.values()) + cfg.DIST.ALPHA * l_id + cfg.DIST.BETA * l_ard
+    total.backward()
+    torch.cuda.synchronize()
+    gpu = {k: float(v) for k, v in loss_dict.items()}
+    gpu["id"], gpu["ard"] = float(l_id), float(l_ard)
+
+    # ---------------- oracle on the same weights, same proposals / samples
+    ref_s, ref_t = RefModel(S["sd_s"], trainable_prefixes=()), RefModel(S["sd_t"])
+    img = images.cpu()
+    with torch.no_grad():
+        fs = ref_s.backbone(img)
+    np.testing.assert_allclose(feat_s[0].cpu().numpy(), fs.numpy(), rtol=0, atol=1e-4 * float(fs.abs().max()))
+    ft = ref_t.backbone(img)
+    np.testing.assert_allclose(feat_t[0].detach().cpu().numpy(), ft.detach().numpy(), rtol=0, atol=1e-4 * float(ft.abs().max()))
+    obj, reg = ref_t.rpn_head(ft)
+    np.testing.assert_allclose(rpn_out[0][0].detach().cpu().numpy(), obj.detach().numpy(), rtol=0, atol=1e-4 * float(obj.abs().max()))
+    ev = mt.rpn.loss_evaluator
+    labels, reg_t = ev.last_targets
+    pos_idx, samp_idx = ev.last_sampled
+    n = labels[0].numel()
+    posm = torch.zeros(2 * n, dtype=torch.bool); posm[pos_idx.cpu()] = True
+    negm = torch.zeros(2 * n, dtype=torch.bool); negm[samp_idx.cpu()] = True; negm &= ~posm
+    # labels / targets themselves against the C oracle (index-exact)
+    for i in range(2):
+        lab, tgt, _ = R.rpn_prepare_targets(anchors[i][0].bbox.cpu().numpy(), anchors[i][0].get_field("visibility").cpu().numpy().astype(bool),
+                                            targets[i].bbox.cpu().numpy())
+        assert np.array_equal(lab, labels[i].cpu().numpy())
+        np.testing.assert_allclose(tgt, reg_t[i].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    lo, lb = R.rpn_loss(obj, reg, torch.stack([l.cpu() for l in labels]), torch.stack([t.cpu() for t in reg_t]), posm.view(2, n), negm.view(2, n))
+    # detection pass on the GPU-sampled proposals
+    det_props = mt.roi_heads.box.loss_evaluator._proposals
+    rois = convert_to_roi_format(det_props).cpu()
+    labels_h = torch.cat([p.get_field("labels") for p in det_props]).cpu()
+    rt_h = torch.cat([p.get_field("regression_targets") for p in det_props]).cpu()
+    _, logits, boxreg = ref_t.box_head(ft, rois)
+    lc, lbox = R.box_head_loss(logits, boxreg, labels_h, rt_h, "id", 15)
+    # distillation pass on the source's 64 proposals
+    rois64 = convert_to_roi_format(soften_proposal).cpu()
+    with torch.no_grad():
+        pooled_s, zs, bs = ref_s.box_head(fs, rois64)
+    pooled_t, zt, bt = ref_t.box_head(ft, rois64)
+    l_id_r = R.roi_distillation_loss(zs, bs.view(-1, 16, 4), zt, bt.view(-1, 21, 4), "id")
+    l_ard_r = R.ard_loss(pooled_s, pooled_t, cfg.DIST.GAMMA)
+    total_r = lc + lbox + lo + lb + cfg.DIST.ALPHA * l_id_r + cfg.DIST.BETA * l_ard_r
+    total_r.backward()
+    ref = dict(loss_classifier=float(lc), loss_box_reg=float(lbox), loss_objectness=float(lo), loss_rpn_box_reg=float(lb),
+               id=float(l_id_r), ard=float(l_ard_r))
+    print("GPU   ", gpu)
+    print("oracle", ref)
+    for k in ref:
+        assert _close(gpu[k], ref[k]), f"{k}: gpu {gpu[k]} vs oracle {ref[k]}"
+
+    # ---------------- gradients of every trainable tensor
+    from abr_iod_amd.utils.checkpoint import reference_state_dict
+    from abr_iod_amd.modeling.backbone.resnet import Conv2d
+    convs = {id(m.weight): m for m in mt.modules() if isinstance(m, Conv2d)}
+    rgrads = ref_t.grads()
+    worst = 0.0
+    checked = 0
+    for name, p in mt.named_parameters():
+        if not p.requires_grad:
+            continue
+        g = p.grad
+        if id(p) in convs:
+            g = g[..., : convs[id(p)].in_channels].permute(0, 3, 1, 2)
+        g = g.detach().cpu()
+        r = rgrads[name]
+        scale = float(r.abs().max())
+        err = float((g - r).abs().max())
+        worst = max(worst, err / max(scale, 1e-12))
+        assert err <= 1e-3 * max(scale, 1e-8), f"grad {name}: max err {err} vs scale {scale}"
+        checked += 1
+    assert checked == 52, checked  # the reference's 52 trainable tensors
+    print("worst relative gradient error", worst)
+
+
+def test_sparse_pool_equals_full_pool(step_state):
+    """bin_step=2 ROIAlign + stride-1 layer4 (the fast detection-pass path) == full 7x7 pooling + stride-2 layer4."""
+    S = step_state
+    mt, images, targets = S["mt"], S["images"], S["targets"]
+    from abr_iod_amd.structures.image_list import to_image_list
+    with torch.no_grad():
+        feats, _ = mt.backbone(to_image_list(images).tensors)
+        props = S["mt"].roi_heads.box.loss_evaluator._proposals
+        fx = mt.roi_heads.box.feature_extractor
+        x_full, raf_full = fx(feats, props, need_roi_features=True)
+        x_sparse, raf_sparse = fx(feats, props, need_roi_features=False)
+    assert raf_full.shape[-2:] == (7, 7) and raf_sparse.shape[-2:] == (4, 4)
+    assert torch.equal(raf_sparse, raf_full[:, :, ::2, ::2])
+    assert torch.equal(x_full, x_sparse)
+
+
+def test_sgd_step_matches_torch_sgd(step_state):
+    """FusedSGD on the flat buffers == torch.optim.SGD with the reference's per-tensor groups (solver/build.py:7-21)."""
+    from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer
+    S = step_state
+    mt, cfg = S["mt"], S["cfg_t"]
+    opt = make_optimizer(cfg, mt)
+    sch = make_lr_scheduler(cfg, opt)
+    named = [(n, p) for n, p in mt.named_parameters() if p.requires_grad]
+    before = {n: p.detach().clone() for n, p in named}
+    grads = {n: p.grad.detach().clone() for n, p in named}
+    ref_p = [before[n].clone().requires_grad_(True) for n, _ in named]
+    groups = []
+    for (n, _), r in zip(named, ref_p):
+        lr, wd = cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY
+        if "bias" in n:
+            lr, wd = cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR, cfg.SOLVER.WEIGHT_DECAY_BIAS
+        groups.append({"params": [r], "lr": lr * opt.param_groups[0]["lr"] / opt.param_groups[0]["initial_lr"], "weight_decay": wd})
+    topt = torch.optim.SGD(groups, lr=cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM)
+    for (n, _), r in zip(named, ref_p):
+        r.grad = grads[n].clone()
+    topt.step()
+    opt.step()
+    for (n, p), r in zip(named, ref_p):
+        assert torch.allclose(p.detach(), r.detach(), rtol=1e-6, atol=1e-7), n
