@@ -19,6 +19,10 @@ namespace {
 
 constexpr int kMaxHW = 1024;
 
+__device__ __forceinline__ float sumsq4(float acc, const float4 v) {
+    return fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, fmaf(v.x, v.x, acc))));
+}
+
 // element (n, hw, c) at base + hw*sHW + c*sC
 template <bool VEC4>
 __global__ __launch_bounds__(256) void ard_fwd_kernel(const float* __restrict__ f_src, const float* __restrict__ f_tgt,
@@ -39,17 +43,19 @@ __global__ __launch_bounds__(256) void ard_fwd_kernel(const float* __restrict__ 
             const float4* rt = reinterpret_cast<const float4*>(pt + (size_t)hw * sHW);
             for (int c = lane; c < C / 4; c += 64) {
                 const float4 s = rs[c], t = rt[c];
-                a += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
-                b += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
-                const float e0 = s.x - t.x, e1 = s.y - t.y, e2 = s.z - t.z, e3 = s.w - t.w;
-                d += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+                // identical explicit fma chains for both maps: when F_s == F_t bitwise, m_s == m_t bitwise, hence
+                // A_t - A_s == 0 exactly and sign(0) = 0 as in torch's L1Loss backward (the first incremental step
+                // starts with target == source)
+                a = sumsq4(a, s);
+                b = sumsq4(b, t);
+                d = sumsq4(d, make_float4(s.x - t.x, s.y - t.y, s.z - t.z, s.w - t.w));
             }
         } else {
             for (int c = lane; c < C; c += 64) {
                 const float s = ps[(size_t)hw * sHW + (size_t)c * sC], t = pt[(size_t)hw * sHW + (size_t)c * sC];
-                a += s * s;
-                b += t * t;
-                d += (s - t) * (s - t);
+                a = fmaf(s, s, a);
+                b = fmaf(t, t, b);
+                d = fmaf(s - t, s - t, d);
             }
         }
         a = abr::wave_sum(a);

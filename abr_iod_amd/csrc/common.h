@@ -64,6 +64,13 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
     return t;
 }
 
+// Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Off by default.
+enum ProfId { PROF_IGEMM_128x128 = 0, PROF_IGEMM_128x64, PROF_IGEMM_64x64, PROF_IGEMM_SMALLC, PROF_WGRAD, PROF_ROIALIGN_FWD,
+              PROF_ROIALIGN_BWD, PROF_COUNT };
+bool prof_enabled();
+int prof_start(hipStream_t st, int id, double work);  // returns record index (or -1)
+void prof_stop(hipStream_t st, int rec);
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 

@@ -1,6 +1,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace abr {
@@ -11,7 +13,51 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
 }
+
+struct ProfRec { hipEvent_t a, b; double work; int id; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+bool prof_enabled() { return g_prof; }
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+int prof_start(hipStream_t st, int id, double work) {
+    if (!g_prof) return -1;
+    ProfRec r{get_event(), get_event(), work, id};
+    (void)hipEventRecord(r.a, st);
+    g_recs.push_back(r);
+    return (int)g_recs.size() - 1;
+}
+void prof_stop(hipStream_t st, int rec) {
+    if (rec >= 0) (void)hipEventRecord(g_recs[rec].b, st);
+}
 }  // namespace abr
+
+extern "C" int abr_prof_begin(void) {
+    abr::g_prof = true;
+    return ABR_OK;
+}
+// out[id*3 + {0,1,2}] = {launch count, total milliseconds, total work (flops or bytes)} ; stops profiling
+extern "C" int abr_prof_end(double* out, int n_ids) {
+    abr::g_prof = false;
+    for (int i = 0; i < n_ids * 3; i++) out[i] = 0.0;
+    for (auto& r : abr::g_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.id < n_ids) {
+            out[r.id * 3 + 0] += 1.0;
+            out[r.id * 3 + 1] += ms;
+            out[r.id * 3 + 2] += r.work;
+        }
+        abr::g_pool.push_back(r.a);
+        abr::g_pool.push_back(r.b);
+    }
+    abr::g_recs.clear();
+    return ABR_OK;
+}
 
 extern "C" const char* abr_last_error(void) { return abr::g_err; }
 extern "C" int abr_version(void) { return 100; }

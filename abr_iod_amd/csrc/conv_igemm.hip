@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
 }
 
 template <int BM, int BN, int WM, int WN, bool SMALL_C>
-int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
+int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st, int prof_id) {
     ConvP q = p;
     q.tiles_m = (p.M + BM - 1) / BM;
     q.tiles_n = (p.Cout + BN - 1) / BN;
@@ -213,7 +213,9 @@ int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    const int rec = abr::prof_start(st, prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
     kern<<<(unsigned)(q.tiles_m * q.tiles_n), 256, lds, st>>>(q, x, w, out);
+    abr::prof_stop(st, rec);
     return 0;
 }
 
@@ -292,13 +294,13 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
     const int cus = num_cus();
     if (small_c) {
-        launch<128, 64, 4, 1, true>(p, x, w, out, st);
+        launch<128, 64, 4, 1, true>(p, x, w, out, st, abr::PROF_IGEMM_SMALLC);
     } else if (p.Cout > 64 && t128 >= 2 * cus) {
-        launch<128, 128, 2, 2, false>(p, x, w, out, st);
+        launch<128, 128, 2, 2, false>(p, x, w, out, st, abr::PROF_IGEMM_128x128);
     } else if (t12864 >= 2 * cus || p.Cout <= 64) {
-        launch<128, 64, 4, 1, false>(p, x, w, out, st);
+        launch<128, 64, 4, 1, false>(p, x, w, out, st, abr::PROF_IGEMM_128x64);
     } else {
-        launch<64, 64, 2, 2, false>(p, x, w, out, st);
+        launch<64, 64, 2, 2, false>(p, x, w, out, st, abr::PROF_IGEMM_64x64);
     }
     ABR_CHECK_LAUNCH("conv_forward");
     return ABR_OK;

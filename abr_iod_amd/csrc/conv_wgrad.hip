@@ -176,7 +176,9 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
                             (int)lds);
         attr_set = true;
     }
+    const int rec = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
     conv_wgrad_kernel<<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
+    abr::prof_stop(abr::as_stream(stream), rec);
     ABR_CHECK_LAUNCH("conv_wgrad");
     return ABR_OK;
 }

@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Benchmark of the north-star hot path: one incremental training step of R50-C4 Faster R-CNN with Attentive RoI
+Distillation + inclusive distillation (BASELINE.json configs[2]: task 15-5, --feat ard --dist_type id, batch 4 per GPU,
+synthetic 600x1000 images, fp32), data-parallel over N MI355X with one RCCL all-reduce of the flat gradient per step.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task description) plus the `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMG_ARD = 1304.0   # algorithmic conv/linear FLOPs of one ARD training image
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PROF_NAMES = ["conv_igemm_kernel<128,128>", "conv_igemm_kernel<128,64>", "conv_igemm_kernel<64,64>", "conv_igemm_kernel<128,64,small_c>",
+              "conv_wgrad_kernel"]
+
+
+def cpu_baseline(model_target, images, targets, n_old):
+    """Reference CPU path (forward + 4 losses; it has no CPU backward) on a bounded sample, on this box's host cores."""
+    import torch
+    from abr_iod_amd.utils.checkpoint import reference_state_dict
+    from oracle.step_ref import cpu_forward_loss  # the oracle is the checker / baseline only
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = reference_state_dict(model_target)
+    img = images[:1].cpu()
+    gtb = [targets[0].bbox.cpu().numpy()]
+    gtl = [targets[0].get_field("labels").cpu().numpy()]
+    tm = {}
+    cpu_forward_loss(sd, img, gtb, gtl, n_old, timings=tm)
+    return {"value": round(1.0 / tm["total"], 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "1 synthetic 600x1000 image, target-model forward + 4 detector losses only (the reference has no CPU "
+                      "backward: csrc/ROIAlign.h:44), torch-CPU convs + oracle.c ROIAlign/NMS single-threaded as the reference",
+            "seconds": {k: round(v, 3) for k, v in tm.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")  # "nccl" IS RCCL on ROCm
+
+    from abr_iod_amd import _lib
+    from abr_iod_amd.engine import train_step
+    from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
+    from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer
+
+    B = a.batch_per_gpu
+    cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, ims_per_batch=B * world)
+    model_source, model_target = build_models(cfg_s, cfg_t, seed=0)       # same seed on every rank = broadcast weights
+    optimizer = make_optimizer(cfg_t, model_target)
+    scheduler = make_lr_scheduler(cfg_t, optimizer)
+    images, targets = synthetic_batch(B, 600, 1000, seed=42 + rank)        # each rank its own shard of the global batch
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t)
+
+    time_kernels = (rank == 0) and not a.no_kernel_timing
+    barrier()
+    if time_kernels:
+        _lib.check(_lib.lib().abr_prof_begin(), "prof_begin")
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(a.steps):
+        last = train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if time_kernels:
+        buf = (ctypes.c_double * (3 * len(PROF_NAMES)))()
+        _lib.check(_lib.lib().abr_prof_end(ctypes.cast(buf, ctypes.c_void_p), len(PROF_NAMES)), "prof_end")
+        prof = [(PROF_NAMES[i], buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(len(PROF_NAMES))]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_imgs = B * world * a.steps
+        value = total_imgs / elapsed
+        loss_dict, total = last
+        out = {
+            "metric": "training images/sec (R50-C4 Faster R-CNN + ARD)", "value": round(value, 3), "unit": "img/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: task 15-5 ABR step, --feat ard --dist_type id (alpha .5, beta 1, gamma 1), "
+                                   "R50-C4, 600x1000, 512 RoIs/img + 64 distillation RoIs/img, source+target models, SGD step",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "gflop_per_img_algorithmic": GFLOP_PER_IMG_ARD},
+            "final_losses": {k: round(float(v), 5) for k, v in loss_dict.items()},
+            "conv_roofline_frac_whole_step": round(value / world * GFLOP_PER_IMG_ARD / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+        }
+        if prof:
+            dom = max(prof, key=lambda r: r[2])
+            name, n, ms, flops = dom
+            achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
+                               "avg_gflop_per_launch": round(flops / max(n, 1) / 1e9, 3),
+                               "all_conv_kernels": {r[0]: {"launches": int(r[1]), "ms": round(r[2], 3),
+                                                           "tflops": round(r[3] / (r[2] * 1e-3) / 1e12, 2) if r[2] > 0 else 0.0} for r in prof}}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model_target, images, targets, len(cfg_t.MODEL.ROI_BOX_HEAD.NAME_OLD_CLASSES))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

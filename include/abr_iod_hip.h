@@ -41,6 +41,12 @@ int abr_version(void);
 /* device properties the host side needs for grid sizing: out[0]=CU count, out[1]=LDS bytes/CU, out[2]=wave size */
 int abr_device_info(int32_t* out_host);
 
+/* Per-launch timing of the conv kernels with HIP events on the launch stream (bench.py's roofline leg; off by default).
+ * abr_prof_end: out[id*3+{0,1,2}] = {launches, total ms, total flops} for id = 0 igemm 128x128, 1 igemm 128x64,
+ * 2 igemm 64x64, 3 igemm small-C (stem), 4 wgrad; synchronises on the recorded events and stops profiling. */
+int abr_prof_begin(void);
+int abr_prof_end(double* out_host, int n_ids);
+
 /* =====================================================================================================
  * 1. maskrcnn_benchmark._C  (csrc/vision.cpp:10-16)
  * ===================================================================================================== */

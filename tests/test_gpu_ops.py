@@ -204,7 +204,7 @@ def test_roi_distillation(gold):
                                              dist_id=(dist == "id"), want_grad=True)
             np.testing.assert_allclose(loss[0].item(), g[f"{p}_{dist}_loss"], rtol=1e-5)
             np.testing.assert_allclose(dzt.cpu().numpy(), g[f"{p}_{dist}_dzt"], rtol=1e-4, atol=1e-8)
-            np.testing.assert_allclose(dbt.cpu().numpy(), g[f"{p}_{dist}_dbt"], rtol=1e-5, atol=1e-9)
+            np.testing.assert_allclose(dbt.cpu().numpy().reshape(g[f"{p}_{dist}_dbt"].shape), g[f"{p}_{dist}_dbt"], rtol=1e-5, atol=1e-9)
 
 
 def test_ard(gold):
@@ -233,7 +233,7 @@ def test_ard_full_size_properties(R):
     torch.manual_seed(0)
     fs = torch.randn(256, 7, 7, 1024, device="cuda")
     loss, _ = ops.ard_forward(fs, fs, 1.0)
-    assert abs(loss[0].item()) < 1e-6  # identical maps: afd == 0 exactly, pad only carries softmax rounding
+    assert loss[0].item() == 0.0  # identical maps: both attention maps are bitwise equal -> afd == pad == 0 exactly
     ft = fs + 0.3 * torch.randn_like(fs)
     loss, coef = ops.ard_forward(fs, ft, 1.0)
     want = R.ard_loss(fs[:32].permute(0, 3, 1, 2).cpu(), ft[:32].permute(0, 3, 1, 2).cpu(), 1.0).item()
