@@ -30,7 +30,7 @@ def cpu_baseline(model_target, images, targets, n_old):
     from abr_iod_amd.utils.checkpoint import reference_state_dict
     from oracle.step_ref import cpu_forward_loss  # the oracle is the checker / baseline only
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)  # oneDNN convs on this path stop scaling (and regress badly) beyond a few dozen threads
     torch.set_num_threads(cores)
     sd = reference_state_dict(model_target)
     img = images[:1].cpu()

@@ -1,0 +1,100 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange used by FusedSGD/bench.py -- ONE sum all-reduce of the flat gradient
+buffer + 1/world scaling folded into the update -- equals single-process training on the concatenated batch, and
+reduce_loss_dict matches the reference's semantics (engine/trainer.py:15-37).  The HIP SGD kernel itself is GPU-only, so the
+update rule is restated here in torch on the same flat layout; the GPU kernel is checked against torch.optim.SGD in
+tests/test_gpu_e2e.py and tests/test_gpu_ops.py."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from abr_iod_amd.engine.trainer import reduce_loss_dict
+    from abr_iod_amd.modeling._flat import flatten_parameters
+    from abr_iod_amd.utils.comm import get_rank, get_world_size
+
+    assert get_world_size() == world and get_rank() == rank
+    torch.manual_seed(0)  # same init on every rank (what loading the same checkpoint does)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    flat = flatten_parameters(model)
+    assert flat.n_trainable >= sum(p.numel() for p in model.parameters())
+    for p in model.parameters():  # parameters and grads are views of the flat buffers
+        assert p.data_ptr() >= flat.params.data_ptr() and p.grad.data_ptr() >= flat.grads.data_ptr()
+    g = torch.Generator().manual_seed(123)
+    x_all, y_all = torch.randn(8, 8, generator=g), torch.randn(8, 3, generator=g)
+    shard = slice(rank * 4, rank * 4 + 4)  # DistributedSampler: contiguous rank slice (data/samplers/distributed.py:42-60)
+    lr, wd, mu = 0.1, 1e-4, 0.9
+    mom = torch.zeros_like(flat.grads)
+    losses = []
+    for step in range(3):
+        flat.zero_grad()
+        loss = ((model(x_all[shard]) - y_all[shard]) ** 2).mean()
+        grads = torch.autograd.grad(loss, list(model.parameters()))
+        for p, gr in zip(model.parameters(), grads):
+            p.grad.add_(gr)                       # what the wgrad kernels do: accumulate into the flat views
+        dist.all_reduce(flat.grads, op=dist.ReduceOp.SUM)      # FusedSGD.all_reduce_grads
+        d = flat.grads / world + wd * flat.params[: flat.n_trainable]
+        mom = d if step == 0 else mu * mom + d
+        flat.params[: flat.n_trainable].sub_(lr * mom)
+        losses.append(loss.detach())
+    red = reduce_loss_dict({"b": losses[-1].clone(), "a": losses[0].clone()})
+    if rank == 0:
+        out.put((flat.params.clone(), {k: float(v) for k, v in red.items()}, [float(l) for l in losses]))
+    else:
+        out.put((None, None, [float(l) for l in losses]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_flat_allreduce_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    params0, red, _ = next(g for g in got if g[0] is not None)
+    per_rank_losses = [g[2] for g in got]
+
+    # single process on the concatenated batch with torch.optim.SGD
+    sys.path.insert(0, ROOT)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    g = torch.Generator().manual_seed(123)
+    x_all, y_all = torch.randn(8, 8, generator=g), torch.randn(8, 3, generator=g)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    for step in range(3):
+        opt.zero_grad()
+        # per-rank losses are means over 4 samples; DDP averages gradients -> equals the mean over all 8
+        (((model(x_all) - y_all) ** 2).mean()).backward()
+        opt.step()
+    ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    from abr_iod_amd.modeling._flat import flatten_parameters
+    flat = flatten_parameters(model)  # same layout as in the workers
+    assert torch.allclose(params0, flat.params, rtol=1e-5, atol=1e-6)
+    # reduce_loss_dict: rank 0 holds the mean over ranks, keys sorted (engine/trainer.py:27-36)
+    assert abs(red["a"] - sum(l[0] for l in per_rank_losses) / world) < 1e-6
+    assert abs(red["b"] - sum(l[-1] for l in per_rank_losses) / world) < 1e-6
