@@ -28,17 +28,106 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDP = BK + 4;  // LDS row pitch in floats
 
+constexpr int EPAD = 4;  // epilogue LDS pitch = wave-tile columns + 4 floats (keeps 16 B alignment)
+
+// n / d for 0 <= n < 2^31 with a precomputed multiplier (the kernels divide by Ho*Wo, Wo, Cin, S on every tile / row;
+// a generic 32-bit division is ~40 VALU instructions, this is 3).
+struct FastDiv {
+    unsigned mul, shr, d;
+    __host__ void init(unsigned div) {
+        d = div;
+        shr = 0;
+        while ((1u << shr) < div) shr++;
+        mul = (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << shr) - div)) / div + 1);
+    }
+    __device__ __forceinline__ unsigned div(unsigned n) const { return (__umulhi(n, mul) + n) >> shr; }
+    __device__ __forceinline__ void divmod(unsigned n, unsigned& q, unsigned& r) const { q = div(n); r = n - q * d; }
+};
+
 struct ConvP {
     int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
     int M, K;  // GEMM sizes
     int out_H, out_W, out_sh, out_sw;
     int relu, scatter;
     int tiles_m, tiles_n;
+    FastDiv d_howo, d_wo, d_cin, d_s;
     const float* scale;
     const float* bias;
     const float* residual;
     const float* mask;
 };
+
+
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][TN], float* ep, int m_base, int n_base, int lane,
+                                              float* __restrict__ out) {
+    constexpr int WR = TM * 32, WC = TN * 32, EP = WC + EPAD;
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EP + j * 32 + l31] = acc[i][j][r];
+    constexpr int LPR = WC / 4;    // lanes per row (16 B each)
+    constexpr int RPI = 64 / LPR;  // rows per iteration of the wave
+    const int c4 = (lane % LPR) * 4;
+    const int ncol = n_base + c4;
+    const bool vec_ok = (p.Cout % 4 == 0) && (ncol + 3 < p.Cout);
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ncol < p.Cout) {
+        float* s_ = reinterpret_cast<float*>(&sc4);
+        float* b_ = reinterpret_cast<float*>(&bi4);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (ncol + e < p.Cout) {
+                if (p.scale) s_[e] = p.scale[ncol + e];
+                if (p.bias) b_[e] = p.bias[ncol + e];
+            }
+    }
+#pragma unroll 4
+    for (int it = 0; it < WR / RPI; it++) {
+        const int row = it * RPI + lane / LPR;
+        const int m = m_base + row;
+        if (m >= p.M || ncol >= p.Cout) continue;
+        size_t row_off;
+        if (p.scatter) {
+            unsigned b, rem, ho, wo;
+            p.d_howo.divmod((unsigned)m, b, rem);
+            p.d_wo.divmod(rem, ho, wo);
+            row_off = (((size_t)b * p.out_H + (size_t)ho * p.out_sh) * p.out_W + (size_t)wo * p.out_sw) * p.Cout;
+        } else {
+            row_off = (size_t)m * p.Cout;
+        }
+        float4 v = *reinterpret_cast<const float4*>(ep + row * EP + c4);
+        v.x = v.x * sc4.x + bi4.x; v.y = v.y * sc4.y + bi4.y; v.z = v.z * sc4.z + bi4.z; v.w = v.w * sc4.w + bi4.w;
+        float* o = out + row_off + ncol;
+        if (vec_ok) {
+            if (p.residual) {
+                const float4 rr = *reinterpret_cast<const float4*>(p.residual + row_off + ncol);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.mask) {
+                const float4 mm = *reinterpret_cast<const float4*>(p.mask + row_off + ncol);
+                v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f; v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(o) = v;
+        } else {
+            const float* vv = reinterpret_cast<const float*>(&v);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (ncol + e >= p.Cout) break;
+                float t = vv[e];
+                if (p.residual) t += p.residual[row_off + ncol + e];
+                if (p.relu) t = fmaxf(t, 0.f);
+                if (p.mask) t = p.mask[row_off + ncol + e] > 0.f ? t : 0.f;
+                o[e] = t;
+            }
+        }
+    }
+}
 
 // SMALL_C: Cin is not a multiple of 32 (the 3->4 padded stem): (r,s,c) is derived per 16 B slot.
 template <int BM, int BN, int WM, int WN, bool SMALL_C>
@@ -67,10 +156,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
         const int m = m0 + srow + 32 * i;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
-        const int b = mm / (p.Ho * p.Wo), rem = mm % (p.Ho * p.Wo);
-        const int ho = rem / p.Wo, wo = rem % p.Wo;
-        a_hi0[i] = ho * p.stride - p.pad;
-        a_wi0[i] = wo * p.stride - p.pad;
+        unsigned b, rem, ho, wo;
+        p.d_howo.divmod((unsigned)mm, b, rem);
+        p.d_wo.divmod(rem, ho, wo);
+        a_hi0[i] = (int)ho * p.stride - p.pad;
+        a_wi0[i] = (int)wo * p.stride - p.pad;
         a_base[i] = x + (size_t)b * p.H * p.W * p.Cin;
     }
     const float* b_ptr[NB];
@@ -86,23 +176,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
         if (!SMALL_C) {
-            const int rs = k0 / p.Cin, c0 = k0 % p.Cin;
-            const int r = rs / p.S, s = rs % p.S;
+            unsigned rs, c0, r, s;
+            p.d_cin.divmod((unsigned)k0, rs, c0);
+            p.d_s.divmod(rs, r, s);
 #pragma unroll
             for (int i = 0; i < NA; i++) {
-                const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
+                const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
                 const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 ra[i] = ok ? *reinterpret_cast<const float4*>(a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + c0 + kq * 4)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
             const int k = k0 + kq * 4;
-            const int rs = k / p.Cin, c = k % p.Cin;
-            const int r = rs / p.S, s = rs % p.S;
+            unsigned rs, c, r, s;
+            p.d_cin.divmod((unsigned)k, rs, c);
+            p.d_s.divmod(rs, r, s);
             const bool kin = k < p.K;
 #pragma unroll
             for (int i = 0; i < NA; i++) {
-                const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
+                const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
                 const bool ok = kin && a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 ra[i] = ok ? *reinterpret_cast<const float4*>(a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + c)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -163,42 +255,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col(n) = lane&31, row(m) = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float sc[TN], bi[TN];
-    bool n_ok[TN];
-    int ncol[TN];
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        ncol[j] = n0 + wn * (TN * 32) + j * 32 + l31;
-        n_ok[j] = ncol[j] < p.Cout;
-        sc[j] = (p.scale && n_ok[j]) ? p.scale[ncol[j]] : 1.f;
-        bi[j] = (p.bias && n_ok[j]) ? p.bias[ncol[j]] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m >= p.M) continue;
-            size_t row_off;
-            if (p.scatter) {
-                const int b = m / (p.Ho * p.Wo), rem = m % (p.Ho * p.Wo);
-                const int ho = rem / p.Wo, wo = rem % p.Wo;
-                row_off = (((size_t)b * p.out_H + (size_t)ho * p.out_sh) * p.out_W + (size_t)wo * p.out_sw) * p.Cout;
-            } else {
-                row_off = (size_t)m * p.Cout;
-            }
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                if (!n_ok[j]) continue;
-                float v = acc[i][j][r] * sc[j] + bi[j];
-                if (p.residual) v += p.residual[row_off + ncol[j]];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.mask) v = p.mask[row_off + ncol[j]] > 0.f ? v : 0.f;
-                out[row_off + ncol[j]] = v;
-            }
-        }
-    }
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col(n) = lane&31, row(m) = (r&3) + 8*(r>>2) + 4*(lane>>5): a lane holds ONE
+    // column of 16 rows, so storing straight from the accumulators is 64 scalar stores of 128 B segments per wave (measured:
+    // ~0.9 TB/s effective, 20-25 % of the kernel at K <= 1024).  Instead each wave transposes its TM*32 x TN*32 tile through its
+    // own slice of the (now idle) operand LDS and streams whole rows: 16 B per lane, 128-256 B contiguous per row, with the
+    // residual / mask read the same way.  Waves only touch their own slice, so no workgroup barrier is needed here.
+    epilogue_rows<TM, TN>(p, acc, smem + wave * (TM * 32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
 }
 
 template <int BM, int BN, int WM, int WN, bool SMALL_C>
@@ -287,6 +349,7 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     p.relu = d->relu;
     p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.mask = d->mask;
     p.tiles_m = p.tiles_n = 0;
+    p.d_howo.init((unsigned)(p.Ho * p.Wo)); p.d_wo.init((unsigned)p.Wo); p.d_cin.init((unsigned)p.Cin); p.d_s.init((unsigned)p.S);
     hipStream_t st = abr::as_stream(stream);
     const bool small_c = (d->Cin % BK) != 0;
     // tile choice: biggest tile that still gives >= 2 workgroups per CU; narrow-N layers use BN=64

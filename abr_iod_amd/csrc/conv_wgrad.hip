@@ -16,6 +16,8 @@
 // memory: rows are staged as-is into LDS ([m][128], 512 B coalesced per row) and a lane picks its operand
 // with one ds_read_b64 = two adjacent n (or k) of row m; accumulator tile t then holds n = base + 2i + t.
 // That interleave is undone in the epilogue addressing, so no transpose is ever materialised.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -26,11 +28,28 @@ constexpr int TN_ = 128;  // dW tile rows  (cout)
 constexpr int TK_ = 128;  // dW tile cols  (r,s,cin)
 constexpr int MR = 32;    // m rows per stage
 
+// n / d for 0 <= n < 2^31 with a precomputed multiplier (a generic 32-bit division is ~40 VALU instructions, this is 3; the
+// 3x3 path needs two per staged row per stage)
+struct FastDiv {
+    unsigned mul, shr, d;
+    __host__ void init(unsigned div) {
+        d = div;
+        shr = 0;
+        while ((1u << shr) < div) shr++;
+        mul = (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << shr) - div)) / div + 1);
+    }
+    __device__ __forceinline__ void divmod(unsigned n, unsigned& q, unsigned& r) const {
+        q = (__umulhi(n, mul) + n) >> shr;
+        r = n - q * d;
+    }
+};
+
 struct WgP {
     int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
     int M, K;
     int tiles_n, tiles_k, splits, mt_per_split;
     int plain;  // 1x1, stride 1, pad 0: A row m is x + m*Cin
+    FastDiv d_howo, d_wo;
     const float* scale;
 };
 
@@ -77,8 +96,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
                                        : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 const int mm = m_ok ? m : 0;
-                const int b = mm / (p.Ho * p.Wo), rem = mm % (p.Ho * p.Wo);
-                const int hi = (rem / p.Wo) * p.stride - p.pad + fr, wi = (rem % p.Wo) * p.stride - p.pad + fs;
+                unsigned b, rem, ho, wo;
+                p.d_howo.divmod((unsigned)mm, b, rem);
+                p.d_wo.divmod(rem, ho, wo);
+                const int hi = (int)ho * p.stride - p.pad + fr, wi = (int)wo * p.stride - p.pad + fs;
                 const bool ok = m_ok && k_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 ra[i] = ok ? *reinterpret_cast<const float4*>(x + (((size_t)b * p.H + hi) * p.W + wi) * p.Cin + fc)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -156,6 +177,7 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     p.K = d->R * d->S * d->Cin;
     p.plain = (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0);
     p.scale = d->scale;
+    p.d_howo.init((unsigned)(d->Ho * d->Wo)); p.d_wo.init((unsigned)d->Wo);
     p.tiles_n = (p.Cout + TN_ - 1) / TN_;
     p.tiles_k = (p.K + TK_ - 1) / TK_;
     if (p.M == 0) return ABR_OK;
@@ -163,10 +185,21 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     int32_t info[3];
     const int cus = abr_device_info(info) == ABR_OK ? info[0] : 256;
     const int tiles = p.tiles_n * p.tiles_k;
-    int splits = (3 * cus + tiles - 1) / tiles;
-    const int max_splits = (m_tiles + 7) / 8;  // at least 8 stages (256 rows) per workgroup
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
+    // split-M so that the grid fills the chip evenly: among the candidates pick the one with the best load balance
+    // (workgroups / (ceil(workgroups / CUs) * CUs)), preferring fewer splits (less atomic traffic) on ties; every
+    // workgroup keeps at least 8 stages (256 rows) of work.
+    const int max_splits = std::max(1, (m_tiles + 7) / 8);
+    int splits = 1;
+    double best = -1.0;
+    for (int sp = 1; sp <= max_splits; sp++) {
+        const long wgs = (long)tiles * sp;
+        if (wgs > 8L * cus && sp > 1) break;
+        const long rounds = (wgs + cus - 1) / cus;
+        double eff = (double)wgs / (double)(rounds * cus);
+        if (wgs < cus) eff *= 0.5;                 // not even one workgroup per CU
+        eff -= 0.0002 * sp;                        // tie-break: fewer partial sums
+        if (eff > best) { best = eff; splits = sp; }
+    }
     p.splits = splits;
     p.mt_per_split = (m_tiles + splits - 1) / splits;
     const size_t lds = sizeof(float) * 2 * MR * (TN_ + TK_);
