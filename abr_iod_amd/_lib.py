@@ -37,6 +37,8 @@ _SIGS = {
     "abr_prof_end": (_i, [_vp, _i]),
     "abr_roi_align_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp]),
     "abr_roi_align_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "abr_roi_align_backward_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "abr_roi_align_backward_gather": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "abr_roi_align_taps": (_i, [_vp, _i, _i, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     "abr_nms_workspace_bytes": (_i64, [_i, _i]),
     "abr_nms_sorted_batched": (_i, [_vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _i64, _vp]),

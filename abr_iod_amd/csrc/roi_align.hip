@@ -367,6 +367,135 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc_sep(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
+// NHWC backward, atomic-free GATHER form (what the training step uses).
+//
+// The scatter forms above are bound by the L2 atomic rate (3.1 ms per step at B=4).  The same separable identity lets every
+// feature pixel GATHER its gradient instead:
+//     dFeat[b][y][x][:] = sum over RoIs r of image b:  sum_ph Wy_r[ph][y] * sum_pw Wx_r[pw][x] * g_r[ph][pw][:]
+// Pass 1 (one small workgroup per RoI) writes the RoI's weight tables Wy_r [PHo][H], Wx_r [PWo][Wp] (1/count folded into
+// Wy) and its footprint rectangle, using the forward's coordinate code -> identical integer taps.
+// Pass 2: a workgroup owns one feature row y and XT=8 consecutive pixels for all channels (16 B per lane); it walks the RoI
+// list with wave-uniform (scalar) range tests, and for an overlapping RoI folds the <=2 active bin rows into PWo register
+// vectors and then the bin columns into the 8 pixel accumulators.  Every dFeat element is written exactly once, coalesced,
+// in a fixed summation order (deterministic; no zero-fill pass, `accumulate` is a read-add-write).
+// ---------------------------------------------------------------------------------------------------
+struct RoiRect { int b, ymin, ymax, xmin, xmax, pad0, pad1, pad2; };
+
+__global__ __launch_bounds__(64) void roi_bwd_tables_kernel(const float* __restrict__ rois, int K, int H, int W, int Wp,
+                                                             float scale, int PH, int PW, int sr, int step, int PHo, int PWo,
+                                                             float* __restrict__ Wy, float* __restrict__ Wx,
+                                                             RoiRect* __restrict__ rect) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sy = sm;             // [PHo][H]
+    float* sx = sm + PHo * H;   // [PWo][Wp]
+    int* rng = reinterpret_cast<int*>(sx + PWo * Wp);
+    const int n = blockIdx.x;
+    const RoiGeom g = roi_geom(rois + 5 * (size_t)n, scale, PH, PW, sr);
+    const float inv_count = 1.f / (float)(g.gh * g.gw);
+    for (int i = threadIdx.x; i < PHo * H + PWo * Wp; i += 64) sm[i] = 0.f;
+    if (threadIdx.x == 0) { rng[0] = H; rng[1] = -1; rng[2] = W; rng[3] = -1; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < PHo * g.gh; t += 64) {
+        const int pi = t / g.gh, iy = t % g.gh;
+        int lo, hi; float wl, wh; bool ok;
+        axis_tap(g.y0, g.bh, g.gh, pi * step, iy, H, &lo, &hi, &wl, &wh, &ok);
+        if (ok) {
+            atomicAdd(&sy[pi * H + lo], wl);
+            atomicAdd(&sy[pi * H + hi], wh);
+            atomicMin(&rng[0], lo); atomicMax(&rng[1], hi);
+        }
+    }
+    for (int t = threadIdx.x; t < PWo * g.gw; t += 64) {
+        const int pi = t / g.gw, ix = t % g.gw;
+        int lo, hi; float wl, wh; bool ok;
+        axis_tap(g.x0, g.bw, g.gw, pi * step, ix, W, &lo, &hi, &wl, &wh, &ok);
+        if (ok) {
+            atomicAdd(&sx[pi * Wp + lo], wl);
+            atomicAdd(&sx[pi * Wp + hi], wh);
+            atomicMin(&rng[2], lo); atomicMax(&rng[3], hi);
+        }
+    }
+    __syncthreads();
+    float* oy = Wy + (size_t)n * PHo * H;
+    float* ox = Wx + (size_t)n * PWo * Wp;
+    for (int i = threadIdx.x; i < PHo * H; i += 64) oy[i] = sy[i] * inv_count;
+    for (int i = threadIdx.x; i < PWo * Wp; i += 64) ox[i] = sx[i];
+    if (threadIdx.x == 0) {
+        RoiRect r;
+        r.b = g.b; r.ymin = rng[0]; r.ymax = rng[1]; r.xmin = rng[2]; r.xmax = rng[3]; r.pad0 = r.pad1 = r.pad2 = 0;
+        rect[n] = r;
+    }
+}
+
+constexpr int kXT = 8;  // pixels per workgroup along x
+
+template <int PO>  // PO = compile-time bound on PHo and PWo (4 for bin_step=2 on 7x7, 8 otherwise)
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* __restrict__ grad, int K, int C, int H, int W, int Wp,
+                                                                    int PHo, int PWo, const float* __restrict__ Wy,
+                                                                    const float* __restrict__ Wx, const RoiRect* __restrict__ rect,
+                                                                    int cchunks, int accumulate, float* __restrict__ gfeat) {
+    const int xt = blockIdx.x / cchunks, chunk = blockIdx.x % cchunks;
+    const int y = blockIdx.y, b = blockIdx.z;
+    const int x0 = xt * kXT;
+    const int cv = chunk * 256 + threadIdx.x;
+    const bool c_ok = cv < C / 4;
+    float4 acc[kXT];
+#pragma unroll
+    for (int i = 0; i < kXT; i++) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < K; r++) {
+        const RoiRect rc = rect[r];  // wave-uniform: scalar loads
+        if (rc.b != b || y < rc.ymin || y > rc.ymax || rc.xmax < x0 || rc.xmin >= x0 + kXT) continue;
+        const float* wyr = Wy + (size_t)r * PHo * H + y;
+        const float* g = grad + (size_t)r * PHo * PWo * C + cv * 4;
+        float4 T[PO];
+#pragma unroll
+        for (int j = 0; j < PO; j++) T[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool any = false;
+#pragma unroll
+        for (int pi = 0; pi < PO; pi++) {
+            if (pi < PHo) {
+                const float wy = wyr[pi * H];
+                if (wy != 0.f) {
+                    any = true;
+                    if (c_ok) {
+#pragma unroll
+                        for (int j = 0; j < PO; j++)
+                            if (j < PWo) {
+                                const float4 v = *reinterpret_cast<const float4*>(g + ((size_t)pi * PWo + j) * C);
+                                T[j].x += wy * v.x; T[j].y += wy * v.y; T[j].z += wy * v.z; T[j].w += wy * v.w;
+                            }
+                    }
+                }
+            }
+        }
+        if (!any) continue;
+        const float* wxr = Wx + (size_t)r * PWo * Wp + x0;
+#pragma unroll
+        for (int j = 0; j < PO; j++) {
+            if (j < PWo) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wxr + j * Wp);       // 8 consecutive pixels, 32 B aligned
+                const float4 w1 = *reinterpret_cast<const float4*>(wxr + j * Wp + 4);
+                const float wv[kXT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int i = 0; i < kXT; i++) {
+                    acc[i].x += wv[i] * T[j].x; acc[i].y += wv[i] * T[j].y; acc[i].z += wv[i] * T[j].z; acc[i].w += wv[i] * T[j].w;
+                }
+            }
+        }
+    }
+    if (!c_ok) return;
+#pragma unroll
+    for (int i = 0; i < kXT; i++) {
+        const int x = x0 + i;
+        if (x >= W) break;
+        float4* d = reinterpret_cast<float4*>(gfeat + (((size_t)b * H + y) * W + x) * C) + cv;
+        float4 v = acc[i];
+        if (accumulate) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *d = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // NCHW compatibility kernels (the reference's own tensor layout; drop-in for `_C.roi_align_*`).
 // One thread per (n, c, ph, pw) like the reference; pw fastest so a wave reads neighbouring taps.
 // ---------------------------------------------------------------------------------------------------
@@ -528,6 +657,47 @@ extern "C" int abr_roi_align_backward(const float* grad, const float* rois, int 
         }
     }
     ABR_CHECK_LAUNCH("roi_align_backward");
+    return ABR_OK;
+}
+
+static inline int round8(int w) { return (w + 7) / 8 * 8; }
+
+extern "C" int64_t abr_roi_align_backward_ws_bytes(int K, int H, int W, int PH, int PW, int bin_step) {
+    const int PHo = (PH + bin_step - 1) / bin_step, PWo = (PW + bin_step - 1) / bin_step;
+    return (int64_t)K * ((int64_t)PHo * H + (int64_t)PWo * round8(W)) * 4 + (int64_t)K * sizeof(RoiRect) + 256;
+}
+
+extern "C" int abr_roi_align_backward_gather(const float* grad, const float* rois, int K, int B, int C, int H, int W, float scale,
+                                             int PH, int PW, int sr, int bin_step, int accumulate, float* gfeat, void* workspace,
+                                             int64_t ws_bytes, void* stream) {
+    ABR_REQUIRE(K >= 0 && B > 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && bin_step >= 1, "roi_align_backward_gather: bad shape");
+    ABR_REQUIRE(C % 4 == 0, "roi_align_backward_gather: C must be a multiple of 4");
+    ABR_REQUIRE(gfeat, "roi_align_backward_gather: null output");
+    const int PHo = (PH + bin_step - 1) / bin_step, PWo = (PW + bin_step - 1) / bin_step;
+    ABR_REQUIRE(PHo <= 8 && PWo <= 8, "roi_align_backward_gather: at most 8 bins per axis");
+    hipStream_t st = abr::as_stream(stream);
+    if (K == 0) {
+        if (!accumulate && hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * C * H * W, st) != hipSuccess) return ABR_E_LAUNCH;
+        return ABR_OK;
+    }
+    ABR_REQUIRE(grad && rois && workspace, "roi_align_backward_gather: null pointer");
+    ABR_REQUIRE(ws_bytes >= abr_roi_align_backward_ws_bytes(K, H, W, PH, PW, bin_step), "roi_align_backward_gather: workspace too small");
+    const int Wp = round8(W);
+    float* Wy = (float*)workspace;
+    float* Wx = Wy + (size_t)K * PHo * H;
+    RoiRect* rect = (RoiRect*)(((uintptr_t)(Wx + (size_t)K * PWo * Wp) + 63) & ~(uintptr_t)63);
+    const size_t lds = sizeof(float) * ((size_t)PHo * H + (size_t)PWo * Wp) + 16;
+    ABR_REQUIRE(lds <= 60 * 1024, "roi_align_backward_gather: feature map too large for the table builder");
+    roi_bwd_tables_kernel<<<K, 64, lds, st>>>(rois, K, H, W, Wp, scale, PH, PW, sr, bin_step, PHo, PWo, Wy, Wx, rect);
+    const int cchunks = (C / 4 + 255) / 256;
+    dim3 grid((unsigned)(((W + kXT - 1) / kXT) * cchunks), (unsigned)H, (unsigned)B);
+    const int rec = abr::prof_start(st, abr::PROF_ROIALIGN_BWD, 0.0);
+    if (PHo <= 4 && PWo <= 4)
+        roi_align_bwd_gather_kernel<4><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, cchunks, accumulate, gfeat);
+    else
+        roi_align_bwd_gather_kernel<8><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, cchunks, accumulate, gfeat);
+    abr::prof_stop(st, rec);
+    ABR_CHECK_LAUNCH("roi_align_backward_gather");
     return ABR_OK;
 }
 

@@ -31,14 +31,28 @@ def roi_align_forward(feat, rois, spatial_scale, ph, pw, sampling_ratio, bin_ste
     return out
 
 
-def roi_align_backward(grad, rois, spatial_scale, ph, pw, sampling_ratio, B, H, W, Ch, bin_step=1, out=None):
-    """grad [K,pho,pwo,C] -> grad_feat [B,H,W,C]; accumulates into `out` when given."""
+_roi_bwd_ws = {}
+
+
+def roi_align_backward(grad, rois, spatial_scale, ph, pw, sampling_ratio, B, H, W, Ch, bin_step=1, out=None, method="gather"):
+    """grad [K,pho,pwo,C] -> grad_feat [B,H,W,C]; accumulates into `out` when given.
+    method 'gather' = atomic-free two-kernel form (default), 'scatter' = per-RoI atomics (abr_roi_align_backward)."""
     L.require_cuda(grad, rois)
     grad, rois = L.f32c(grad), L.f32c(rois)
     K = rois.shape[0]
     acc = out is not None
     if out is None:
         out = _empty((B, H, W, Ch), grad)
+    if method == "gather" and Ch % 4 == 0 and -(-ph // bin_step) <= 8 and -(-pw // bin_step) <= 8:
+        nbytes = L.lib().abr_roi_align_backward_ws_bytes(K, H, W, ph, pw, bin_step)
+        key = (grad.device,)
+        ws = _roi_bwd_ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = _roi_bwd_ws[key] = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=grad.device)
+        L.check(L.lib().abr_roi_align_backward_gather(L.ptr(grad), L.ptr(rois), K, B, Ch, H, W, float(spatial_scale), ph, pw,
+                                                      sampling_ratio, bin_step, int(acc), L.ptr(out), L.ptr(ws), ws.numel(),
+                                                      L.stream()), "roi_align_backward_gather")
+        return out
     L.check(L.lib().abr_roi_align_backward(L.ptr(grad), L.ptr(rois), K, B, Ch, H, W, float(spatial_scale), ph, pw,
                                            sampling_ratio, bin_step, L.NHWC, int(acc), L.ptr(out), L.stream()),
             "roi_align_backward")

@@ -68,6 +68,14 @@ int abr_roi_align_backward(const float* grad, const float* rois, int K, int B, i
                            float spatial_scale, int PH, int PW, int sampling_ratio, int bin_step,
                            int layout, int accumulate, float* grad_feat, void* stream);
 
+/* Same result as abr_roi_align_backward(layout=ABR_NHWC) without atomics: every feature pixel gathers from the RoIs that
+ * cover it (two kernels: per-RoI separable weight tables, then one coalesced write per dFeat element, deterministic order).
+ * workspace: abr_roi_align_backward_ws_bytes(...) bytes.  This is the form the training step uses. */
+int64_t abr_roi_align_backward_ws_bytes(int K, int H, int W, int PH, int PW, int bin_step);
+int abr_roi_align_backward_gather(const float* grad, const float* rois, int K, int B, int C, int H, int W,
+                                  float spatial_scale, int PH, int PW, int sampling_ratio, int bin_step, int accumulate,
+                                  float* grad_feat, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Integer tap table of the forward kernel's OWN indexing code (parity instrument, not on the hot path):
  * idx [K,PH*PW,max_s,4] int32 flat y*W+x (-1 = sample rejected, -2 = unused slot), grid [K,2]. */
 int abr_roi_align_taps(const float* rois, int K, int H, int W, float spatial_scale, int PH, int PW,

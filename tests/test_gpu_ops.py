@@ -88,8 +88,14 @@ def test_roi_align_backward_vs_oracle(gold, O):
         got = _C.roi_align_backward(T(gy), T(g["rois"]), 0.0625, 7, 7, 2, 24, 38, 63, sr).cpu().numpy()
         # same per-tap products; only the fp32 summation order of the atomics differs
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
-        got = ops.roi_align_backward(nhwc(gy), T(g["rois"]), 0.0625, 7, 7, sr, 2, 38, 63, 24).permute(0, 3, 1, 2).cpu().numpy()
-        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+        for method in ("gather", "scatter"):  # atomic-free gather (training default) and per-RoI atomic scatter
+            got = ops.roi_align_backward(nhwc(gy), T(g["rois"]), 0.0625, 7, 7, sr, 2, 38, 63, 24, method=method).permute(0, 3, 1, 2).cpu().numpy()
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+        a1 = ops.roi_align_backward(nhwc(gy), T(g["rois"]), 0.0625, 7, 7, sr, 2, 38, 63, 24)
+        a2 = ops.roi_align_backward(nhwc(gy), T(g["rois"]), 0.0625, 7, 7, sr, 2, 38, 63, 24)
+        assert torch.equal(a1, a2)  # the gather form is deterministic (fixed summation order)
+        acc = ops.roi_align_backward(nhwc(gy), T(g["rois"]), 0.0625, 7, 7, sr, 2, 38, 63, 24, out=a1.clone())
+        assert torch.allclose(acc, 2 * a1, rtol=1e-6, atol=1e-6)
     # bin_step=2 backward == full backward of a gradient that is zero on the odd bins
     gy = rng.standard_normal((40, 24, 7, 7)).astype(np.float32)
     gz = np.zeros_like(gy); gz[:, :, ::2, ::2] = gy[:, :, ::2, ::2]
