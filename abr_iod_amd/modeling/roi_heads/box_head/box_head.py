@@ -231,6 +231,8 @@ class FastRCNNLossComputation(object):
     def subsample(self, proposals, targets, sampled_inds=None):
         """:86-120.  Keeps state (self._proposals).  `sampled_inds` (list of index tensors) injects the sampler's choice."""
         labels, regression_targets = self.prepare_targets(proposals, targets)
+        if sampled_inds is None:
+            sampled_inds = getattr(self, "inject_sampled_inds", None)  # parity tests pin the sampler's draw here
         proposals = list(proposals)
         for i, (lab, tgt, p) in enumerate(zip(labels, regression_targets, proposals)):
             p.add_field("labels", lab)

@@ -333,6 +333,8 @@ class RPNLossComputation(object):
         `sampled=(pos_idx, samp_idx)` injects the sampler's choice (parity tests)."""
         anchors = [a[0] if isinstance(a, (list, tuple)) else a for a in anchors]
         labels, regression_targets, _ = self.prepare_targets(anchors, targets)
+        if sampled is None:
+            sampled = getattr(self, "inject_sampled", None)  # parity tests pin the sampler's draw here
         pos_idx, samp_idx = sampled if sampled is not None else self.sample(labels)
         self.last_sampled, self.last_targets = (pos_idx, samp_idx), (labels, regression_targets)  # introspection for parity tests
         if fused is None:
