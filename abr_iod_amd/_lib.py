@@ -47,10 +47,10 @@ _SIGS = {
     "abr_ard_forward": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "abr_ard_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp]),
     "abr_smooth_l1": (_i, [_vp, _vp, _i64, _f, _f, _vp, _f, _vp, _vp]),
-    "abr_smooth_l1_rows": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _f, _vp, _vp]),
+    "abr_smooth_l1_rows": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _f, _vp, _vp]),
     "abr_softmax_ce": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _f, _vp, _i, _vp]),
     "abr_roi_distill": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _f, _vp, _vp, _vp]),
-    "abr_bce_logits_gather": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp]),
+    "abr_bce_logits_gather": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp]),
     "abr_conv_forward": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "abr_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "abr_conv_dgrad_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -69,6 +69,7 @@ _SIGS = {
     "abr_box_encode": (_i, [_vp, _vp, _i, _f, _f, _f, _f, _vp, _vp]),
     "abr_match_workspace_bytes": (_i64, [_i, _i]),
     "abr_match_encode": (_i, [_vp, _i, _vp, _vp, _i, _vp, _f, _f, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "abr_sample_pos_neg": (_i, [_vp, _i, _i, _i, _i64, _i, _i, C.c_uint64, _i, _i64, _vp, _vp, _vp, _vp]),
     "abr_sgd_momentum": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _f, _i, _vp]),
 }
 

@@ -77,12 +77,15 @@ __global__ __launch_bounds__(256) void smooth_l1_rows_kernel(const float* __rest
                                                               const float* __restrict__ t, const int64_t* __restrict__ rows,
                                                               const int64_t* __restrict__ col0, const int64_t* __restrict__ trows,
                                                               int n_rows, float beta,
-                                                              float scale, float* __restrict__ loss_out, float gscale,
+                                                              float scale, const float* __restrict__ denom_dev,
+                                                              float* __restrict__ loss_out, float gscale,
                                                               float* __restrict__ grad) {
     __shared__ float sm[4];
     float acc = 0.f;
+    if (denom_dev) scale = scale / fmaxf(*denom_dev, 1.f);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * 4; i += gridDim.x * blockDim.x) {
         const int64_t r = rows[i >> 2];
+        if (r < 0) continue;  // -1 padding of a fixed-size index list
         const int64_t c = (col0 ? col0[i >> 2] : 0) + (i & 3);
         float g;
         const int64_t tr = trows ? trows[i >> 2] : r;
@@ -249,12 +252,14 @@ __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bce_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           const int64_t* __restrict__ idx, const int64_t* __restrict__ yidx, int n_idx,
-                                                          float* __restrict__ loss_out, float gscale, float* __restrict__ grad) {
+                                                          const float* __restrict__ denom_dev, float* __restrict__ loss_out,
+                                                          float gscale, float* __restrict__ grad) {
     __shared__ float sm[4];
     float acc = 0.f;
-    const float inv = 1.f / (float)n_idx;
+    const float inv = 1.f / (denom_dev ? fmaxf(*denom_dev, 1.f) : (float)n_idx);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_idx; i += gridDim.x * blockDim.x) {
         const int64_t j = idx[i];
+        if (j < 0) continue;  // -1 padding of a fixed-size index list
         const float xv = x[j], yv = y[yidx ? yidx[i] : j];
         acc += fmaxf(xv, 0.f) - xv * yv + log1pf(expf(-fabsf(xv)));
         if (grad) grad[j] = (1.f / (1.f + expf(-xv)) - yv) * inv * gscale;
@@ -311,15 +316,15 @@ extern "C" int abr_smooth_l1(const float* x, const float* t, int64_t n, float be
 }
 
 extern "C" int abr_smooth_l1_rows(const float* x, int x_cols, const float* t, const int64_t* rows, const int64_t* col0,
-                                  const int64_t* trows, int n_rows, float beta, float scale, float* loss_out, float gscale, float* grad,
-                                  void* stream) {
+                                  const int64_t* trows, int n_rows, float beta, float scale, const float* denom_dev, float* loss_out,
+                                  float gscale, float* grad, void* stream) {
     ABR_REQUIRE(n_rows >= 0 && loss_out && x_cols >= 4, "smooth_l1_rows: bad args");
     hipStream_t st = abr::as_stream(stream);
     if (int e = zero_loss(loss_out, 1, st, "smooth_l1_rows")) return e;
     if (n_rows == 0) return ABR_OK;
     ABR_REQUIRE(x && t && rows, "smooth_l1_rows: null pointer");
     smooth_l1_rows_kernel<<<abr::cdiv((int64_t)n_rows * 4, 256), 256, 0, st>>>(x, x_cols, t, rows, col0, trows, n_rows,
-                                                                                beta, scale, loss_out, gscale, grad);
+                                                                                beta, scale, denom_dev, loss_out, gscale, grad);
     ABR_CHECK_LAUNCH("smooth_l1_rows");
     return ABR_OK;
 }
@@ -363,14 +368,15 @@ extern "C" int abr_roi_distill(const float* z_s, const float* b_s, const float* 
     return ABR_OK;
 }
 
-extern "C" int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, const int64_t* yidx, int n_idx, float* loss_out,
+extern "C" int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, const int64_t* yidx, int n_idx,
+                                     const float* denom_dev, float* loss_out,
                                      float gscale, float* grad, void* stream) {
     ABR_REQUIRE(n_idx >= 0 && loss_out, "bce_logits_gather: bad args");
     hipStream_t st = abr::as_stream(stream);
     if (int e = zero_loss(loss_out, 1, st, "bce_logits_gather")) return e;
     if (n_idx == 0) return ABR_OK;
     ABR_REQUIRE(x && y && idx, "bce_logits_gather: null pointer");
-    bce_gather_kernel<<<std::min(abr::cdiv(n_idx, 256), 256u), 256, 0, st>>>(x, y, idx, yidx, n_idx, loss_out, gscale, grad);
+    bce_gather_kernel<<<std::min(abr::cdiv(n_idx, 256), 256u), 256, 0, st>>>(x, y, idx, yidx, n_idx, denom_dev, loss_out, gscale, grad);
     ABR_CHECK_LAUNCH("bce_logits_gather");
     return ABR_OK;
 }

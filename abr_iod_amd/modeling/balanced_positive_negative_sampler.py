@@ -3,6 +3,8 @@ Random choice uses the device RNG exactly as the reference (torch.randperm per i
 arithmetic, and cannot be reproduced across devices -> parity tests inject the sampled indices instead."""
 import torch
 
+from .. import ops
+
 
 class BalancedPositiveNegativeSampler(object):
     def __init__(self, batch_size_per_image, positive_fraction):
@@ -17,6 +19,12 @@ class BalancedPositiveNegativeSampler(object):
         pos = positive[torch.randperm(positive.numel(), device=positive.device)[:num_pos]]
         neg = negative[torch.randperm(negative.numel(), device=negative.device)[:num_neg]]
         return pos, neg
+
+    def sample_padded(self, labels2d, index_offset_per_image=0):
+        """Fused device path (one kernel for all rows of labels2d [N,n], no host sync):
+        -> pos_idx [N,num_pos_max], neg_idx [N,batch] (ascending, -1 padded, + i*index_offset_per_image), counts [N,2] int32."""
+        return ops.sample_pos_neg(labels2d, self.batch_size_per_image, int(self.batch_size_per_image * self.positive_fraction),
+                                  index_offset_per_image)
 
     def __call__(self, matched_idxs, objectness=None):
         pos_idx, neg_idx = [], []

@@ -189,8 +189,10 @@ class _BoxHeadLossFn(Function):
         want = fused.requires_grad
         grad = torch.zeros_like(fused) if want else None
         lc, _ = ops.softmax_ce(fused[:, :K], labels, inclusive, n_old, want_grad=want, grad_out=grad[:, :K] if want else None)
-        pos = torch.nonzero(labels > 0).squeeze(1)                                   # :166
-        col0 = K + (4 * labels[pos] if not cls_agnostic else torch.full_like(pos, 4))  # :168-171
+        # rows with label > 0 (:166) as a fixed-size list: non-positive rows become -1 and are skipped by the kernel (no nonzero() sync)
+        ar = torch.arange(n, device=labels.device)
+        pos = torch.where(labels > 0, ar, torch.full_like(ar, -1))
+        col0 = K + (4 * labels.clamp(min=0) if not cls_agnostic else torch.full_like(ar, 4))  # :168-171
         lb, gb = ops.smooth_l1_rows(fused, regression_targets, pos, col0, 1.0, scale=1.0 / max(n, 1), want_grad=want)
         if want:
             ops.add_(grad, gb)
@@ -234,15 +236,15 @@ class FastRCNNLossComputation(object):
         if sampled_inds is None:
             sampled_inds = getattr(self, "inject_sampled_inds", None)  # parity tests pin the sampler's draw here
         proposals = list(proposals)
+        if sampled_inds is None:
+            # fused sampler: one launch per image (ragged proposal counts), all counts fetched with ONE host sync
+            drawn = [self.fg_bg_sampler.sample_padded(lab) for lab in labels]
+            cnt = torch.cat([d[2] for d in drawn]).tolist()
+            sampled_inds = [torch.cat((d[0][0, :c[0]], d[1][0, :c[1]])).sort()[0] for d, c in zip(drawn, cnt)]  # ascending (:114)
         for i, (lab, tgt, p) in enumerate(zip(labels, regression_targets, proposals)):
             p.add_field("labels", lab)
             p.add_field("regression_targets", tgt)
-            if sampled_inds is not None:
-                inds = sampled_inds[i]
-            else:
-                pos, neg = self.fg_bg_sampler.sample_indices(lab)
-                inds = torch.cat((pos, neg)).sort()[0]       # nonzero(pos_mask | neg_mask): ascending (:114)
-            proposals[i] = p[inds]
+            proposals[i] = p[sampled_inds[i]]
         self._proposals = proposals
         return proposals
 

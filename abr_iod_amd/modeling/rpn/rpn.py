@@ -276,17 +276,22 @@ class _RPNLossFn(Function):
     (rpn/loss.py:136,145-146), reading objectness and deltas straight out of the fused NHWC head output."""
 
     @staticmethod
-    def forward(ctx, fused, A, labels, reg_targets, pos_idx, samp_idx):
+    def forward(ctx, fused, A, labels, reg_targets, pos_idx, samp_idx, denom=None):
         y = as_nhwc(fused)
         N, H, W, Cf = y.shape
         y2 = y.reshape(N * H * W, Cf)
+        # index lists may be fixed-size and -1 padded (fused sampler): negative entries stay negative below and are skipped
+        # by the kernels; `denom` is then the device-resident number of sampled anchors
         n_samp = samp_idx.numel()
         # anchor j of the flattened batch lives in row j // A; objectness at column j % A, deltas at A + 4*(j % A)
-        obj_flat_idx = (samp_idx // A) * Cf + samp_idx % A
+        row = torch.div(samp_idx, A, rounding_mode="floor")
+        obj_flat_idx = row * Cf + (samp_idx - row * A)
+        prow = torch.div(pos_idx, A, rounding_mode="floor")
         want = fused.requires_grad
-        lo, g_obj = ops.bce_logits_gather(y2, labels, obj_flat_idx, want_grad=want, yidx=samp_idx)
-        lb, g_reg = ops.smooth_l1_rows(y2, reg_targets, pos_idx // A, A + 4 * (pos_idx % A), 1.0 / 9, scale=1.0 / max(n_samp, 1),
-                                       want_grad=want, trows=pos_idx)
+        lo, g_obj = ops.bce_logits_gather(y2, labels, obj_flat_idx, want_grad=want, yidx=samp_idx, denom_dev=denom)
+        lb, g_reg = ops.smooth_l1_rows(y2, reg_targets, prow, A + 4 * (pos_idx - prow * A), 1.0 / 9,
+                                       scale=1.0 if denom is not None else 1.0 / max(n_samp, 1), want_grad=want, trows=pos_idx,
+                                       denom_dev=denom)
         ctx.shape = (N, H, W, Cf)
         ctx.save_for_backward(g_obj, g_reg)
         return lo[0], lb[0]
@@ -297,7 +302,7 @@ class _RPNLossFn(Function):
         ops.scale_(g_obj, 1.0, g_lo.contiguous())
         ops.scale_(g_reg, 1.0, g_lb.contiguous())
         ops.add_(g_obj, g_reg)  # disjoint columns of the same [N*H*W, Cf] buffer
-        return from_nhwc(g_obj.view(ctx.shape)), None, None, None, None, None
+        return from_nhwc(g_obj.view(ctx.shape)), None, None, None, None, None, None
 
 
 class RPNLossComputation(object):
@@ -318,15 +323,14 @@ class RPNLossComputation(object):
         return labels, regression_targets, matched
 
     def sample(self, labels):
-        """global (batch-flattened) indices of the sampled positives and of all sampled anchors (pos first, :119-123)"""
-        n = labels[0].numel()
-        pos, neg = [], []
-        for i, lab in enumerate(labels):
-            p, q = self.fg_bg_sampler.sample_indices(lab)
-            pos.append(p.sort()[0] + i * n)   # nonzero() of a mask yields ascending indices in the reference
-            neg.append(q.sort()[0] + i * n)
-        pos, neg = torch.cat(pos), torch.cat(neg)
-        return pos, torch.cat([pos, neg])
+        """One fused sampler launch for the whole batch, nothing leaves the device.  Returns batch-flattened index lists of
+        FIXED length (-1 padded): positives [N*128], all sampled (positives then negatives) [N*128 + N*256], and the device
+        scalar #sampled that normalises both losses (rpn/loss.py:119-123,136,146)."""
+        lab2d = torch.stack(labels)
+        n = lab2d.shape[1]
+        pos, neg, counts = self.fg_bg_sampler.sample_padded(lab2d, index_offset_per_image=n)
+        pos = pos.reshape(-1)
+        return pos, torch.cat([pos, neg.reshape(-1)]), counts.sum().to(torch.float32).reshape(1)
 
     def __call__(self, anchors, objectness, box_regression, targets, rpn_output_source=None, fused=None, sampled=None):
         """Returns (objectness_loss, box_loss).  `rpn_output_source` is accepted and ignored as in the reference (:129-143).
@@ -335,14 +339,18 @@ class RPNLossComputation(object):
         labels, regression_targets, _ = self.prepare_targets(anchors, targets)
         if sampled is None:
             sampled = getattr(self, "inject_sampled", None)  # parity tests pin the sampler's draw here
-        pos_idx, samp_idx = sampled if sampled is not None else self.sample(labels)
+        denom = None
+        if sampled is not None:
+            pos_idx, samp_idx = sampled
+        else:
+            pos_idx, samp_idx, denom = self.sample(labels)
         self.last_sampled, self.last_targets = (pos_idx, samp_idx), (labels, regression_targets)  # introspection for parity tests
         if fused is None:
             fused = torch.cat((objectness[0], box_regression[0]), 1)
             A = objectness[0].shape[1]
         else:
             A = anchors[0].bbox.shape[0] // (fused.shape[-1] * fused.shape[-2])
-        return _RPNLossFn.apply(fused, A, torch.cat(labels), torch.cat(regression_targets), pos_idx, samp_idx)
+        return _RPNLossFn.apply(fused, A, torch.cat(labels), torch.cat(regression_targets), pos_idx, samp_idx, denom)
 
 
 def make_rpn_loss_evaluator(cfg, box_coder):

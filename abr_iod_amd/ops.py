@@ -129,14 +129,14 @@ def smooth_l1(x, t, beta, scale=1.0, gscale=1.0, want_grad=False):
     return loss, grad
 
 
-def smooth_l1_rows(x, t, rows, col0, beta, scale=1.0, gscale=1.0, want_grad=False, trows=None):
+def smooth_l1_rows(x, t, rows, col0, beta, scale=1.0, gscale=1.0, want_grad=False, trows=None, denom_dev=None):
     """sum over i of smoothL1(x[rows[i], col0[i]:col0[i]+4] - t[trows[i] (default rows[i]), :4]) * scale"""
     L.require_cuda(x, t, rows)
     x, t = L.f32c(x), L.f32c(t)
     loss = _empty((4,), x)
     grad = torch.zeros_like(x) if want_grad else None
     L.check(L.lib().abr_smooth_l1_rows(L.ptr(x), x.shape[1], L.ptr(t), L.ptr(rows), L.ptr(col0), L.ptr(trows), rows.numel(), float(beta),
-                                       float(scale), L.ptr(loss), float(gscale), L.ptr(grad), L.stream()), "smooth_l1_rows")
+                                       float(scale), L.ptr(denom_dev), L.ptr(loss), float(gscale), L.ptr(grad), L.stream()), "smooth_l1_rows")
     return loss, grad
 
 
@@ -187,12 +187,12 @@ def roi_distill(z_s, b_s, z_t, b_t, dist_id=True, gscale=1.0, want_grad=False, d
     return loss, d_zt, d_bt
 
 
-def bce_logits_gather(x, y, idx, gscale=1.0, want_grad=False, yidx=None):
+def bce_logits_gather(x, y, idx, gscale=1.0, want_grad=False, yidx=None, denom_dev=None):
     L.require_cuda(x, y, idx)
     x, y = L.f32c(x), L.f32c(y)
     loss = _empty((4,), x)
     grad = torch.zeros_like(x) if want_grad else None
-    L.check(L.lib().abr_bce_logits_gather(L.ptr(x), L.ptr(y), L.ptr(idx), L.ptr(yidx), idx.numel(), L.ptr(loss), float(gscale),
+    L.check(L.lib().abr_bce_logits_gather(L.ptr(x), L.ptr(y), L.ptr(idx), L.ptr(yidx), idx.numel(), L.ptr(denom_dev), L.ptr(loss), float(gscale),
                                           L.ptr(grad), L.stream()), "bce_logits_gather")
     return loss, grad
 
@@ -366,6 +366,30 @@ def match_encode(boxes, gt, gt_labels, vis, hi, lo, allow_low_quality, weights, 
                                      int(allow_low_quality), *[float(v) for v in weights], L.ptr(matched), L.ptr(lab_f),
                                      L.ptr(lab_i), L.ptr(tgt), L.ptr(ws), ws.numel() * 4, L.stream()), "match_encode")
     return matched, (lab_f if rpn_labels else lab_i), tgt
+
+
+_sample_calls = [0]
+
+
+def sample_pos_neg(labels, batch_size, max_pos, index_offset_per_image=0, seed=None):
+    """labels [N,n] (fp32 or int64, rows contiguous) -> pos_idx [N,max_pos] int64, neg_idx [N,batch_size] int64 (-1 padded,
+    ascending), counts [N,2] int32 -- all on device, no sync."""
+    if labels.dim() == 1:
+        labels = labels.view(1, -1)
+    N, n = labels.shape
+    dev = labels.device
+    pos = torch.empty((N, max(max_pos, 1)), dtype=torch.int64, device=dev)
+    neg = torch.empty((N, batch_size), dtype=torch.int64, device=dev)
+    counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
+    if seed is None:
+        _sample_calls[0] += 1
+        seed = (torch.initial_seed() * 0x9E3779B1 + _sample_calls[0] * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+    is64 = labels.dtype == torch.int64
+    if not is64 and labels.dtype != _f32:
+        raise RuntimeError("sample_pos_neg: labels must be float32 or int64")
+    L.check(L.lib().abr_sample_pos_neg(L.ptr(labels), int(is64), N, n, labels.stride(0), batch_size, max_pos, seed, 0,
+                                       index_offset_per_image, L.ptr(pos), L.ptr(neg), L.ptr(counts), L.stream()), "sample_pos_neg")
+    return pos, neg, counts
 
 
 # ----------------------------------------------------------------------------------------------- optimiser

@@ -127,6 +127,7 @@ int abr_smooth_l1(const float* x, const float* t, int64_t n, float beta, float s
                   float gscale, float* grad, void* stream);
 int abr_smooth_l1_rows(const float* x, int x_cols, const float* t, const int64_t* rows, const int64_t* col0,
                        const int64_t* trows /* rows of t, NULL = rows */, int n_rows, float beta, float scale,
+                       const float* denom_dev /* optional device scalar: scale /= max(*denom_dev,1); rows < 0 are skipped */,
                        float* loss_out, float gscale, float* grad, void* stream);
 
 /* FastRCNNLossComputation classification term   modeling/roi_heads/box_head/loss.py:151-162
@@ -149,7 +150,9 @@ int abr_roi_distill(const float* z_s, const float* b_s, const float* z_t, const 
 /* F.binary_cross_entropy_with_logits(x[idx], y[idx]).mean()   modeling/rpn/loss.py:145-146
  * idx int64 [n_idx] into the flattened logits; grad optional, pre-zeroed, same shape as x. */
 int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, const int64_t* yidx /* NULL = idx */,
-                          int n_idx, float* loss_out, float gscale, float* grad, void* stream);
+                          int n_idx, const float* denom_dev /* optional device scalar replacing n_idx as the mean's
+                          denominator; idx < 0 entries are skipped (fixed-size, -1 padded index lists) */,
+                          float* loss_out, float gscale, float* grad, void* stream);
 
 /* =====================================================================================================
  * 3. Convolution as implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), NHWC / OHWI.
@@ -227,6 +230,15 @@ int abr_match_encode(const float* boxes, int n, const float* gt, const int64_t* 
                      float ww, float wh, int64_t* matched, float* labels_f32, int64_t* labels_i64,
                      float* reg_targets, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t abr_match_workspace_bytes(int n, int G);
+
+/* BalancedPositiveNegativeSampler (balanced_positive_negative_sampler.py:19-77) for N images in one launch, no host sync:
+ * labels [N, n] (row pitch `stride`; fp32 for the RPN, int64 for the box head): >=1 positive, ==0 negative, else ignored.
+ * Draws min(#pos, max_pos) positives and min(#neg, batch_size - that) negatives uniformly at random (counter-based keys from
+ * `seed`, image first_image+i, index) and writes them ASCENDING: pos_idx [N, max_pos], neg_idx [N, batch_size], padded
+ * with -1; every index has i*index_offset_per_image added (batch-flattened indices); counts [N,2] = (#pos, #neg) taken. */
+int abr_sample_pos_neg(const void* labels, int labels_are_int64, int N, int n, int64_t stride, int batch_size,
+                       int max_pos, uint64_t seed, int first_image, int64_t index_offset_per_image,
+                       int64_t* pos_idx, int64_t* neg_idx, int32_t* counts, void* stream);
 
 /* =====================================================================================================
  * 6. Optimiser (solver/build.py:7-21, torch.optim.SGD semantics, one fused launch over all tensors)

@@ -84,8 +84,10 @@ def test_train_step_losses_and_grads_vs_oracle(step_state):
     labels, reg_t = ev.last_targets
     pos_idx, samp_idx = ev.last_sampled
     n = labels[0].numel()
-    posm = torch.zeros(2 * n, dtype=torch.bool); posm[pos_idx.cpu()] = True
-    negm = torch.zeros(2 * n, dtype=torch.bool); negm[samp_idx.cpu()] = True; negm &= ~posm
+    pos_idx, samp_idx = pos_idx.cpu(), samp_idx.cpu()
+    pos_idx, samp_idx = pos_idx[pos_idx >= 0], samp_idx[samp_idx >= 0]  # the fused sampler pads its fixed-size lists with -1
+    posm = torch.zeros(2 * n, dtype=torch.bool); posm[pos_idx] = True
+    negm = torch.zeros(2 * n, dtype=torch.bool); negm[samp_idx] = True; negm &= ~posm
     # labels / targets themselves against the C oracle (index-exact)
     for i in range(2):
         lab, tgt, _ = R.rpn_prepare_targets(anchors[i][0].bbox.cpu().numpy(), anchors[i][0].get_field("visibility").cpu().numpy().astype(bool),

@@ -380,3 +380,40 @@ def test_pointwise_and_sgd():
         flat_g = torch.cat([g_ * (step + 1) for g_ in gs]).cuda()
         ops.sgd_momentum_(flat_p, flat_g, flat_m, seg, lr_d, wd_d, 0.9, first_step=(step == 0))
     assert torch.allclose(flat_p.cpu(), torch.cat([r.detach() for r in ref]), rtol=1e-6, atol=1e-7)
+
+
+def test_fused_sampler():
+    """abr_sample_pos_neg == BalancedPositiveNegativeSampler semantics: counts, membership, ascending unique indices, -1 padding,
+    and a uniform draw (every candidate is chosen with the same frequency)."""
+    from abr_iod_amd import ops
+    torch.manual_seed(0)
+    N, n = 3, 5000
+    labels = torch.zeros(N, n)
+    labels[0, torch.randperm(n)[:40]] = 1           # fewer positives than the cap
+    labels[1, torch.randperm(n)[:700]] = 1          # more positives than the cap
+    labels[2, :] = -1; labels[2, 100:130] = 1; labels[2, 200:260] = 0   # not enough negatives either
+    labels[0, torch.randperm(n)[:500]] = -1
+    lab = labels.cuda()
+    pos, neg, counts = ops.sample_pos_neg(lab, 256, 128, index_offset_per_image=n, seed=1234)
+    c = counts.cpu().numpy()
+    want = [(min(int((labels[i] >= 1).sum()), 128),) for i in range(N)]
+    for i in range(N):
+        npos = want[i][0]; nneg = min(int((labels[i] == 0).sum()), 256 - npos)
+        assert tuple(c[i]) == (npos, nneg)
+        p = pos[i].cpu(); q = neg[i].cpu()
+        assert (p[npos:] == -1).all() and (q[nneg:] == -1).all()
+        p, q = p[:npos] - i * n, q[:nneg] - i * n
+        assert (p[1:] > p[:-1]).all() and (q[1:] > q[:-1]).all()            # ascending, unique
+        assert (labels[i][p] >= 1).all() and (labels[i][q] == 0).all()
+    # int64 labels (box head), single image
+    li = torch.randint(-1, 4, (3000,)).cuda()
+    p, q, c = ops.sample_pos_neg(li, 512, 128, seed=7)
+    assert int(c[0, 0]) == 128 and int(c[0, 1]) == 384 and (li[p[0]] >= 1).all() and (li[q[0, :384]] == 0).all() and (q[0, 384:] == -1).all()
+    # uniformity: 700 positives, 128 drawn, 600 independent draws -> each chosen ~ 600*128/700 = 109.7 times (sigma ~ 9.5)
+    hits = torch.zeros(n)
+    for s in range(600):
+        p, _, _ = ops.sample_pos_neg(lab[1:2], 256, 128, seed=1000 + s)
+        hits[p[0].cpu() - 0] += 1
+    h = hits[labels[1] >= 1]
+    assert abs(h.mean().item() - 600 * 128 / 700) < 1e-3 and h.std().item() < 13 and h.min() > 60 and h.max() < 160
+    assert hits[labels[1] < 1].sum() == 0
