@@ -69,8 +69,10 @@ class AnchorGenerator(nn.Module):
         key = (H, W, int(image_hw[0]), int(image_hw[1]), self.cell_anchors.device)
         hit = self._cache.get(key)
         if hit is None:
-            hit = ops.grid_anchors(self.cell_anchors, H, W, self.strides[0], int(image_hw[0]), int(image_hw[1]), self.straddle_thresh)
-            self._cache[key] = hit
+            a, vis = ops.grid_anchors(self.cell_anchors, H, W, self.strides[0], int(image_hw[0]), int(image_hw[1]), self.straddle_thresh)
+            # the boxes depend on (H, W) only, the visibility also on the image size: share ONE box tensor per grid
+            a = self._cache.setdefault((H, W, self.cell_anchors.device), a)
+            hit = self._cache[key] = (a, vis)
         return hit
 
     def forward(self, image_list, feature_maps):

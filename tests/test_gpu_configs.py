@@ -1,0 +1,71 @@
+"""GPU: the other BASELINE.json configurations and edge cases run through the same step:
+finetune (no distillation; the source model is never run), task 10-10 with the L2 distillation, task 10-5 (K_old=11, K_all=16),
+a ragged batch (images of different sizes, zero-padded as to_image_list does), and the reference's error behaviour."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 600, "MODEL.RPN.POST_NMS_TOP_N_TRAIN", 200, "MODEL.RPN.PRE_NMS_TOP_N_TEST", 300,
+         "MODEL.RPN.POST_NMS_TOP_N_TEST", 150, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 64, "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 64]
+
+
+def _run(task, dist_type, feat, alpha, beta, steps=2, sizes=((192, 256), (192, 256)), label_range=(16, 21)):
+    from abr_iod_amd.engine import train_step
+    from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
+    from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer
+    from abr_iod_amd.structures.bounding_box import BoxList
+    cfg_s, cfg_t = make_cfgs(task, dist_type=dist_type, feat=feat, alpha=alpha, beta=beta, overrides=SMALL)
+    need_source = alpha > 0 or feat == "ard"
+    ms, mt = build_models(cfg_s, cfg_t, seed=0, need_source=need_source)
+    opt = make_optimizer(cfg_t, mt); sch = make_lr_scheduler(cfg_t, opt)
+    imgs, tgts = [], []
+    for i, (h, w) in enumerate(sizes):
+        im, tg = synthetic_batch(1, h, w, seed=10 + i, label_range=label_range, max_boxes=2)
+        t = tg[0]
+        t.bbox[:, 0::2].clamp_(max=w - 1); t.bbox[:, 1::2].clamp_(max=h - 1)
+        t.bbox[:, 2] = torch.max(t.bbox[:, 2], t.bbox[:, 0] + 8).clamp(max=w - 1); t.bbox[:, 3] = torch.max(t.bbox[:, 3], t.bbox[:, 1] + 8).clamp(max=h - 1)
+        imgs.append(im[0]); tgts.append(BoxList(t.bbox, (w, h), "xyxy")); tgts[-1].add_field("labels", t.get_field("labels"))
+    from abr_iod_amd.structures.image_list import to_image_list
+    images = to_image_list(imgs)
+    out = []
+    for _ in range(steps):
+        ld, total = train_step(ms, mt, images, tgts, opt, sch, cfg_t)
+        out.append({k: float(v) for k, v in ld.items()})
+    torch.cuda.synchronize()
+    for d in out:
+        assert all(v == v and abs(v) < 1e3 for v in d.values()), d
+    return out, ms, mt
+
+
+def test_finetune_without_distillation_skips_source():
+    out, ms, mt = _run("15-5", "l2", "no", 0.0, 0.0)
+    assert ms is None and out[0]["distillation_loss"] == 0.0
+    assert set(out[0]) == {"loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg", "distillation_loss"}
+
+
+def test_task_10_10_l2_distillation_and_ard():
+    out, _, mt = _run("10-10", "l2", "ard", 0.1, 0.5, label_range=(11, 21))
+    assert mt.roi_heads.box.predictor.num_classes == 21 and out[0]["distillation_loss"] > 0
+
+
+def test_task_10_5_id_distillation_ragged_batch():
+    out, ms, mt = _run("10-5", "id", "ard", 0.5, 1.0, sizes=((160, 256), (192, 224)), label_range=(11, 16))
+    assert ms.roi_heads.box.predictor.num_classes == 11 and mt.roi_heads.box.predictor.num_classes == 16
+
+
+def test_reference_error_behaviour():
+    from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
+    from abr_iod_amd.structures.bounding_box import BoxList
+    cfg_s, cfg_t = make_cfgs("15-5", overrides=SMALL)
+    _, mt = build_models(cfg_s, cfg_t, seed=0, need_source=False)
+    images, targets = synthetic_batch(1, 160, 224, max_boxes=1)
+    with pytest.raises(ValueError):  # generalized_rcnn.py:63-64
+        mt(images, None)
+    empty = BoxList(torch.zeros((0, 4), device="cuda"), (224, 160)); empty.add_field("labels", torch.zeros((0,), dtype=torch.int64, device="cuda"))
+    with pytest.raises((ValueError, RuntimeError)):  # matcher.py:53-57: no ground-truth boxes
+        mt(images, [empty])
+    from abr_iod_amd.distillation.distillation import calculate_roi_distillation_losses
+    z = torch.randn(4, 21, device="cuda"); b = torch.randn(4, 21, 4, device="cuda")
+    with pytest.raises(RuntimeError):  # K_all == K_old with dist='id': empty slice -> shape error in the reference as well
+        calculate_roi_distillation_losses((z, b), (z.clone().requires_grad_(True), b.clone()), dist="id")
