@@ -9,11 +9,11 @@
 //   pass 1  suppression bit-matrix: one wave64 per (row tile, column tile); a lane owns one row box and
 //           builds one 64-bit word against the 64 column boxes staged in LDS -> a wave writes one
 //           coalesced 512 B row of words.  Only tiles on/above the diagonal are computed.
-//   pass 2  the greedy sweep stays ON DEVICE: one 256-thread workgroup per image.  Per 64-box block the
-//           diagonal tile is resolved by wave 0 with lane broadcasts (no memory in the serial chain), then
-//           every thread ORs the rows of the newly kept boxes into its own word of the `removed` bitmap
-//           (loads are independent of the chain -> fully pipelined).  Stops once max_keep boxes are kept
-//           (post_nms_top_n), which on RPN proposals is long before the end of the list.
+//   pass 2  the greedy sweep stays ON DEVICE: one 256-thread workgroup per image.  Per 64-box block the word of
+//           already-suppressed boxes is the OR of mask[i][block] over the boxes i kept so far (one independent
+//           8 B load per kept box, spread over the workgroup), then wave 0 resolves the diagonal tile with lane
+//           broadcasts (no memory in the serial chain).  Stops once max_keep boxes are kept (post_nms_top_n),
+//           which on RPN proposals is long before the end of the list.
 #include "common.h"
 
 namespace {
@@ -55,59 +55,58 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     mask[((size_t)img * n_max + ri) * words + ct] = bits;
 }
 
-// grid = N, block = 256.  removed bitmap lives in LDS (words <= 4096 -> n_max <= 262144).
+// grid = N, block = 256.  The kept list lives in LDS (max_keep ints).
+// Column formulation: when the sweep reaches 64-box block bi, the boxes of that block already suppressed are
+//   removed(bi) = OR over every box i kept so far of mask[i][bi]
+// -- one 8-byte load per kept box, independent of each other, spread over the 256 threads and OR-reduced (<= max_keep/256
+// loads per thread).  Only then does wave 0 run the 64-step greedy chain on the diagonal word with lane broadcasts.
+// (The earlier row formulation OR-ed each kept row into all later words: ~188x more loads; 0.85 ms -> see DESIGN.md.)
 __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t* __restrict__ mask, const int32_t* __restrict__ counts,
                                                          int n_max, int words, int max_keep, int32_t* __restrict__ keep,
                                                          int32_t* __restrict__ n_keep) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* removed = reinterpret_cast<uint64_t*>(smem);         // [words]
-    uint64_t* s_kept = removed + words;                            // [1] kept bits of the current block
-    int* s_cnt = reinterpret_cast<int*>(s_kept + 1);               // [1]
+    int* kept = reinterpret_cast<int*>(smem);                                  // [max_keep]
+    uint64_t* s_red = reinterpret_cast<uint64_t*>(smem + (((size_t)max_keep * 4 + 15) & ~(size_t)15));  // [4] + [1]
+    int* s_cnt = reinterpret_cast<int*>(s_red + 5);
     const int img = blockIdx.x;
     const int n = counts[img];
     const uint64_t* m = mask + (size_t)img * n_max * words;
     int32_t* kp = keep + (size_t)img * max_keep;
-    for (int w = threadIdx.x; w < words; w += blockDim.x) removed[w] = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) *s_cnt = 0;
     __syncthreads();
     const int nblk = (n + 63) / 64;
     for (int bi = 0; bi < nblk; bi++) {
-        if (threadIdx.x < 64) {
-            const int lane = threadIdx.x;
+        const int cnt = *s_cnt;
+        if (cnt >= max_keep) break;
+        uint64_t acc = 0;
+        for (int k = threadIdx.x; k < cnt; k += 256) acc |= m[(size_t)kept[k] * words + bi];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)(acc & 0xffffffffu), o, 64);
+            const unsigned hi = __shfl_xor((unsigned)(acc >> 32), o, 64);
+            acc |= ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 0) s_red[wave] = acc;
+        __syncthreads();
+        if (wave == 0) {
+            uint64_t cur = s_red[0] | s_red[1] | s_red[2] | s_red[3];
             const int i = bi * 64 + lane;
-            // diagonal word of row i (bits j>lane within this block); rows past n act as already removed
-            const uint64_t diag = i < n ? m[(size_t)i * words + bi] : 0ull;
-            uint64_t cur = removed[bi];
+            const uint64_t diag = i < n ? m[(size_t)i * words + bi] : 0ull;  // bits j > lane of this block
             const int valid = min(64, n - bi * 64);
             if (valid < 64) cur |= ~0ull << valid;
-            uint64_t kept = 0;
-            int cnt = *s_cnt;
-            for (int b = 0; b < valid; b++) {  // serial greedy chain, registers + lane broadcast only
+            int c = cnt;
+            for (int b = 0; b < valid; b++) {  // serial greedy chain: registers + lane broadcasts only
                 if (!((cur >> b) & 1ull)) {
-                    if (cnt >= max_keep) break;
-                    kept |= 1ull << b;
-                    if (lane == 0) kp[cnt] = bi * 64 + b;
-                    cnt++;
+                    if (c >= max_keep) break;
+                    if (lane == 0) { kept[c] = bi * 64 + b; kp[c] = bi * 64 + b; }
+                    c++;
                     const unsigned lo = __builtin_amdgcn_readlane((unsigned)(diag & 0xffffffffu), b);
                     const unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), b);
                     cur |= ((uint64_t)hi << 32) | lo;
                 }
             }
-            if (lane == 0) { *s_kept = kept; *s_cnt = cnt; }
-        }
-        __syncthreads();
-        const uint64_t kept = *s_kept;
-        const int cnt = *s_cnt;
-        if (cnt >= max_keep) break;
-        // OR rows of the kept boxes into the words to the right of the diagonal
-        for (int w = bi + 1 + threadIdx.x; w < words; w += blockDim.x) {
-            uint64_t acc = 0, k = kept;
-            while (k) {
-                const int b = __builtin_ctzll(k);
-                k &= k - 1;
-                acc |= m[(size_t)(bi * 64 + b) * words + w];
-            }
-            removed[w] |= acc;
+            if (lane == 0) *s_cnt = c;
         }
         __syncthreads();
     }
@@ -135,13 +134,15 @@ extern "C" int abr_nms_sorted_batched(const float* boxes, const int32_t* counts,
     ABR_REQUIRE(boxes && keep && workspace, "nms: null pointer");
     ABR_REQUIRE(workspace_bytes >= abr_nms_workspace_bytes(N, n_max), "nms: workspace too small");
     const int words = (n_max + 63) / 64;
-    ABR_REQUIRE(words <= 4096, "nms: n_max too large for the LDS bitmap (max 262144)");
     // The mask rows are only partially written (upper triangle, rows < count): words left of the diagonal are
     // never read, words right of it are always written for rows < n.  No memset needed.
     dim3 grid(words, words, N);
     nms_mask_kernel<<<grid, 64, 0, st>>>(boxes, counts, n_max, words, thr, strict_gt, (uint64_t*)workspace);
     ABR_CHECK_LAUNCH("nms_mask");
-    const size_t lds = (size_t)words * 8 + 16;
+    const size_t lds = (((size_t)max_keep * 4 + 15) & ~(size_t)15) + 5 * 8 + 16;
+    ABR_REQUIRE(lds <= 150 * 1024, "nms: max_keep too large for the LDS keep list");
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     nms_sweep_kernel<<<N, 256, lds, st>>>((const uint64_t*)workspace, counts, n_max, words, max_keep, keep, n_keep);
     ABR_CHECK_LAUNCH("nms_sweep");
     return ABR_OK;

@@ -122,11 +122,20 @@ def main():
             "conv_roofline_frac_whole_step": round(value / world * GFLOP_PER_IMG_ARD / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
         }
         if prof:
+            traffic, traffic_src = None, None
+            pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
             dom = max(prof, key=lambda r: r[2])
+            if os.path.exists(pmc_file):  # HBM bytes/launch from separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.sh)
+                pk = json.load(open(pmc_file))["kernels"]
+                key = {"conv_igemm_kernel<128,128>": "conv_igemm_kernel<128, 128, 2, 2, false>", "conv_wgrad_kernel": "conv_wgrad_kernel",
+                       "conv_igemm_kernel<64,64>": "conv_igemm_kernel<64, 64, 2, 2, false>",
+                       "conv_igemm_kernel<128,64>": "conv_igemm_kernel<128, 64, 4, 1, false>"}.get(dom[0])
+                if key in pk:
+                    traffic, traffic_src = pk[key]["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
             name, n, ms, flops = dom
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                                "avg_gflop_per_launch": round(flops / max(n, 1) / 1e9, 3),
                                "all_conv_kernels": {r[0]: {"launches": int(r[1]), "ms": round(r[2], 3),
