@@ -65,6 +65,7 @@ _SIGS = {
     "abr_add_inplace": (_i, [_vp, _vp, _i64, _vp]),
     "abr_scale_inplace": (_i, [_vp, _i64, _f, _vp, _vp]),
     "abr_grid_anchors": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "abr_topk_sigmoid": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "abr_rpn_decode_clip": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _f, _f, _f, _f, _vp, _vp]),
     "abr_box_encode": (_i, [_vp, _vp, _i, _f, _f, _f, _f, _vp, _vp]),
     "abr_match_workspace_bytes": (_i64, [_i, _i]),

@@ -238,9 +238,11 @@ class RPNPostProcessor(nn.Module):
         A = num_anchors
         n_anchor = H * W * A
         yf = y.reshape(N, H * W, Cf)
-        objectness = yf[:, :, :A].reshape(N, n_anchor).sigmoid()                         # inference.py:87-88
         k = min(self.pre_nms_top_n, n_anchor)
-        scores, topk_idx = objectness.topk(k, dim=1, sorted=True)                        # :95-96
+        if k <= 15360:   # one fused kernel per batch: sigmoid + radix select + in-LDS bitonic sort (inference.py:87-96)
+            scores, topk_idx = ops.topk_sigmoid(yf, A, k)
+        else:            # beyond the in-LDS sort capacity (no voc config gets here: PRE_NMS_TOP_N is 12000 / 6000)
+            scores, topk_idx = yf[:, :, :A].reshape(N, n_anchor).sigmoid().topk(k, dim=1, sorted=True)
         same = all(a[0].bbox.data_ptr() == anchors[0][0].bbox.data_ptr() for a in anchors)
         img_hw = torch.tensor([[a[0].size[1], a[0].size[0]] for a in anchors], dtype=torch.int32, device=y.device)
         assert same, "per-image anchor grids of one batch share (H,W): they differ only in the visibility field"

@@ -333,6 +333,17 @@ def grid_anchors(cell, H, W, stride, img_h, img_w, straddle=0):
     return out, vis
 
 
+def topk_sigmoid(y, A, k):
+    """y [N, nloc, ld] fp32 contiguous (columns 0..A-1 of every row are logits of anchors loc*A+a) -> (scores [N,k], idx [N,k] int64):
+    the k largest sigmoid(logit) per image, sorted descending, ties by ascending anchor index."""
+    y = L.f32c(y)
+    N, nloc, ld = y.shape
+    scores = torch.empty((N, k), dtype=_f32, device=y.device)
+    idx = torch.empty((N, k), dtype=torch.int64, device=y.device)
+    L.check(L.lib().abr_topk_sigmoid(L.ptr(y), nloc * ld, N, nloc * A, A, ld, k, L.ptr(scores), L.ptr(idx), L.stream()), "topk_sigmoid")
+    return scores, idx
+
+
 def box_encode_rows(gt, ex, weights, out=None):
     gt, ex = L.f32c(gt), L.f32c(ex)
     if out is None:

@@ -211,6 +211,11 @@ int abr_scale_inplace(float* x, int64_t n, float s, const float* s_dev, void* st
 /* AnchorGenerator grid  anchor_generator.py:84-110 : out [H*W*A,4], vis [H*W*A] uint8 */
 int abr_grid_anchors(const float* cell, int A, int H, int W, int stride, int img_h, int img_w, int straddle,
                      float* out, uint8_t* vis, void* stream);
+/* sigmoid + top-k (sorted, descending; ties by ascending index) of the RPN objectness, per image, in one launch
+ * (rpn/inference.py:87-96).  Anchor j of image i is logits[i*img_stride + (j/A)*ld + j%A] (A=15, ld=76 on the fused NHWC head
+ * output; A=1, ld=1 for a plain [N,n] matrix).  scores [N,k] fp32, idx [N,k] int64.  k <= 15360. */
+int abr_topk_sigmoid(const float* logits, int64_t img_stride, int N, int n, int A, int ld, int k, float* scores,
+                     int64_t* idx, void* stream);
 /* BoxCoder.decode + clip_to_image on gathered rows  (rpn/inference.py:96-112, box_coder.py:52-95, bounding_box.py:214-225)
  * For image i and rank j<k: a = idx[i,j]; out[i,j,:] = clip(decode(reg[i,a,:], anchors[a,:])).
  * reg [N,n_anchor/A,reg_stride]: anchor a = loc*A + a' reads columns reg_col0 + 4a' .. +3 of row loc

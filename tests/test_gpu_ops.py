@@ -417,3 +417,25 @@ def test_fused_sampler():
     h = hits[labels[1] >= 1]
     assert abs(h.mean().item() - 600 * 128 / 700) < 1e-3 and h.std().item() < 13 and h.min() > 60 and h.max() < 160
     assert hits[labels[1] < 1].sum() == 0
+
+
+def test_topk_sigmoid_matches_torch():
+    """fused sigmoid + sorted top-k == torch.sigmoid(...).topk(sorted=True) (values exact up to 1 ulp of expf, order identical
+    wherever scores differ; ties resolved by ascending index)."""
+    from abr_iod_amd import ops
+    torch.manual_seed(0)
+    N, H, W, A, ld = 3, 38, 63, 15, 76
+    y = torch.randn(N, H * W, ld, device="cuda") * 3
+    y[0, :50, :A] = 25.0   # a saturated tie group (sigmoid == 1.0f)
+    for k in (12000, 6000, 100):
+        sc, idx = ops.topk_sigmoid(y, A, k)
+        ref_s, ref_i = torch.sigmoid(y[:, :, :A].reshape(N, -1)).topk(k, dim=1, sorted=True)
+        assert torch.allclose(sc, ref_s, rtol=2e-7, atol=0)
+        assert (sc[:, 1:] <= sc[:, :-1]).all()
+        g = torch.sigmoid(y[:, :, :A].reshape(N, -1)).gather(1, idx)          # idx really points at those scores
+        assert torch.allclose(g, sc, rtol=2e-7, atol=0)
+        assert all(len(set(idx[i].tolist())) == k for i in range(N))           # no duplicates
+        strict = ref_s[:, 1:] < ref_s[:, :-1]                                  # where the order is unambiguous it is identical
+        same = (idx == ref_i)
+        assert same[:, 1:-1][strict[:, :-1] & strict[:, 1:]].float().mean() > 0.999
+    assert idx[0, :50].tolist() == sorted(idx[0, :50].tolist())               # tie group: ascending index
