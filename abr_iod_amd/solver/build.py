@@ -19,6 +19,7 @@ class FusedSGD(object):
     def __init__(self, model, base_lr, momentum, weight_decay, bias_lr_factor, weight_decay_bias):
         if getattr(model, "flat", None) is None:
             model.flatten_parameters()
+        self.model = model
         self.flat = model.flat
         self.momentum = momentum
         self.param_groups = []
@@ -56,14 +57,64 @@ class FusedSGD(object):
         self._steps += 1
         bump_param_version()  # cached dgrad weight copies are stale now
 
+    def _reference_params(self):
+        """(name, parameter, offset into the flat buffer, Conv2d module or None) for every trainable tensor, in the
+        reference optimiser's order = named_parameters() order of the requires_grad tensors (solver/build.py:9-18)."""
+        from ..modeling.backbone.resnet import Conv2d
+        convs = {id(m.weight): m for m in self.model.modules() if isinstance(m, Conv2d)}
+        base = self.flat.params.data_ptr()
+        for name, p in self.model.named_parameters():
+            if p.requires_grad:
+                yield name, p, (p.data_ptr() - base) // 4, convs.get(id(p))
+
+    def _group_of(self, off):
+        for g in self.param_groups:
+            if g["range"][0] <= off < g["range"][1]:
+                return g
+        raise KeyError(off)
+
     def state_dict(self):
-        return {"momentum_buffer": self.momentum_buffer, "steps": self._steps, "param_groups": [dict(g) for g in self.param_groups]}
+        """torch.optim.SGD.state_dict() layout -- what the reference's Checkpointer stores under "optimizer"
+        (utils/checkpoint.py:41-43): one param group per tensor, momentum buffers in the reference's OIHW layout."""
+        groups, state = [], {}
+        for i, (name, p, off, conv) in enumerate(self._reference_params()):
+            g = self._group_of(off)
+            groups.append({"lr": g["lr"], "momentum": self.momentum, "dampening": 0, "weight_decay": g["weight_decay"],
+                           "nesterov": False, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                           "initial_lr": g["initial_lr"], "params": [i]})
+            if self._steps > 0:
+                m = self.momentum_buffer[off:off + p.numel()].view(p.shape)
+                if conv is not None:
+                    m = m[..., : conv.in_channels].permute(0, 3, 1, 2)
+                state[i] = {"momentum_buffer": m.contiguous().clone()}
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.momentum_buffer.copy_(sd["momentum_buffer"])
-        self._steps = sd["steps"]
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        ref = list(self._reference_params())
+        if len(sd["param_groups"]) != len(ref):
+            raise ValueError("loaded state dict has {} parameter groups, the optimizer has {}".format(len(sd["param_groups"]), len(ref)))
+        self.momentum_buffer.zero_()
+        any_state = False
+        for i, ((name, p, off, conv), g_in) in enumerate(zip(ref, sd["param_groups"])):
+            g = self._group_of(off)
+            for k in ("lr", "weight_decay", "initial_lr"):
+                if k in g_in:
+                    g[k] = g_in[k]
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is None or st.get("momentum_buffer") is None:
+                continue
+            v = st["momentum_buffer"].to(self.momentum_buffer.device)
+            m = self.momentum_buffer[off:off + p.numel()].view(p.shape)
+            if conv is not None:
+                v = v.permute(0, 2, 3, 1)
+                m = m[..., : conv.in_channels]
+            if v.shape != m.shape:
+                raise ValueError("momentum buffer of {} has shape {}, expected {}".format(name, tuple(v.shape), tuple(m.shape)))
+            m.copy_(v)
+            any_state = True
+        self._steps = 1 if any_state else 0
+        self._wd.copy_(torch.tensor([g["weight_decay"] for g in self.param_groups], dtype=torch.float32))
+        self._lr_host = None
 
 
 def make_optimizer(cfg, model):

@@ -33,7 +33,10 @@ class WarmupMultiStepLR(object):
             g["lr"] = lr
 
     def state_dict(self):
-        return {"last_epoch": self.last_epoch}
+        """torch's _LRScheduler.state_dict(): every attribute but the optimizer (what the reference checkpoints hold)."""
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
 
     def load_state_dict(self, sd):
-        self.last_epoch = sd["last_epoch"]
+        for k in ("milestones", "gamma", "warmup_factor", "warmup_iters", "warmup_method", "base_lrs", "last_epoch"):
+            if k in sd:
+                setattr(self, k, list(sd[k]) if k in ("milestones", "base_lrs") else sd[k])
