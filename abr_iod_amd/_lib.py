@@ -66,6 +66,9 @@ _SIGS = {
     "abr_scale_inplace": (_i, [_vp, _i64, _f, _vp, _vp]),
     "abr_grid_anchors": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "abr_topk_sigmoid": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "abr_det_softmax_decode": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
+    "abr_det_select_workspace_bytes": (_i64, [_i, _i, _i]),
+    "abr_det_select": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "abr_rpn_decode_clip": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _f, _f, _f, _f, _vp, _vp]),
     "abr_box_encode": (_i, [_vp, _vp, _i, _f, _f, _f, _f, _vp, _vp]),
     "abr_match_workspace_bytes": (_i64, [_i, _i]),

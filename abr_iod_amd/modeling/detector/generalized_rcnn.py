@@ -57,8 +57,9 @@ class GeneralizedRCNN(nn.Module):
         images = to_image_list(images)
         features, backbone_features = self.backbone(images.tensors)
         (proposals, proposal_losses), anchors, rpn_output = self.rpn(images, features, targets, rpn_output_source)
-        if not self.training:
-            raise NotImplementedError("test-time detection (PostProcessor) is next-tier (SURVEY.md §8f F4)")
+        if not self.training:  # generalized_rcnn.py:76-78 -> (detections, features, background detections)
+            x, result, results_background, _ = self.roi_heads(features, proposals, targets)
+            return result, features, results_background
         x, result, soften_results, detector_losses, roi_align_features = self.roi_heads(features, proposals, targets)
         losses = {}
         losses.update(detector_losses)

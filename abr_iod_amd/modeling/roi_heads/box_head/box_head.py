@@ -271,19 +271,28 @@ def make_roi_box_loss_evaluator(cfg):
 
 
 # ------------------------------------------------------------------------------------------------ head
+from .inference import make_roi_box_post_processor  # noqa: E402
+
+
 class ROIBoxHead(nn.Module):
     def __init__(self, cfg, in_channels):
         super().__init__()
         self.feature_extractor = ResNet50Conv5ROIFeatureExtractor(cfg, in_channels)
         self.predictor = FastRCNNPredictor(cfg, self.feature_extractor.out_channels)
         self.loss_evaluator = make_roi_box_loss_evaluator(cfg)
-        self.post_processor = None  # eval-only PostProcessor: next-tier
+        self.post_processor = make_roi_box_post_processor(cfg)
         self.need_roi_features_in_training = False
 
     def forward(self, features, proposals, targets=None):
-        """training: -> (x, proposals, (class_logits, box_regression[K,K_all,4]), loss dict, roi_align_features)  (box_head.py:24-58)"""
+        """training: -> (x, proposals, (class_logits, box_regression[K,K_all,4]), loss dict, roi_align_features)
+        eval: -> (x, detections, results_background)  (box_head.py:24-58)"""
         if not self.training:
-            raise NotImplementedError("test-time PostProcessor is next-tier (SURVEY.md §8f F4); the hot path is training")
+            x, _ = self.feature_extractor(features, proposals, need_roi_features=False)
+            fused = self.predictor.forward_fused(x)
+            K = self.predictor.num_classes
+            result, results_background = self.post_processor(
+                (fused[:, :K], fused[:, K:K + 4 * self.predictor.num_bbox_reg_classes]), proposals)
+            return x, result, results_background
         with torch.no_grad():
             proposals = self.loss_evaluator.subsample(proposals, targets)
         x, roi_align_features = self.feature_extractor(features, proposals, need_roi_features=self.need_roi_features_in_training)

@@ -11,8 +11,12 @@ class CombinedROIHeads(torch.nn.ModuleDict):
         self.cfg = cfg.clone()
 
     def forward(self, features, proposals, targets=None):
-        """training -> (x, detections, soften_results, losses, roi_align_features)  (roi_heads.py:23-63)"""
+        """training -> (x, detections, soften_results, losses, roi_align_features); eval -> (x, detections, results_background, [])
+        (roi_heads.py:23-63)"""
         losses = {}
+        if not self.training:
+            x, detections, results_background = self.box(features, proposals, targets)
+            return x, detections, results_background, []
         x, detections, soft_res, loss_box, roi_align_features = self.box(features, proposals, targets)
         losses.update(loss_box)
         return x, detections, soft_res, losses, roi_align_features

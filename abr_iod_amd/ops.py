@@ -407,3 +407,45 @@ def sample_pos_neg(labels, batch_size, max_pos, index_offset_per_image=0, seed=N
 def sgd_momentum_(p, g, m, seg_end, lr, wd, momentum, gscale=1.0, first_step=False):
     L.check(L.lib().abr_sgd_momentum(L.ptr(p), L.ptr(g), L.ptr(m), p.numel(), L.ptr(seg_end), L.ptr(lr), L.ptr(wd),
                                      seg_end.numel(), float(momentum), float(gscale), int(first_step), L.stream()), "sgd")
+
+
+# ----------------------------------------------------------------------------------------------- test-time detections (F4)
+def det_softmax_decode(logits, deltas, rois, C, img_hw, weights, cls_agnostic=False):
+    """logits [K,>=C] / deltas [K,4C] (row-strided views of the fused predictor output are fine), rois [K,5], img_hw [N,2] int32
+    -> prob [K,C], boxes [K,C,4]   (roi_heads/box_head/inference.py:55-70)"""
+    L.require_cuda(logits, deltas, rois, img_hw)
+    K = logits.shape[0]
+    if logits.stride(-1) != 1 or logits.dtype != _f32:
+        logits = L.f32c(logits)
+    if deltas.stride(-1) != 1 or deltas.dtype != _f32:
+        deltas = L.f32c(deltas)
+    rois = L.f32c(rois)
+    prob = torch.empty((K, C), dtype=_f32, device=logits.device)
+    boxes = torch.empty((K, C, 4), dtype=_f32, device=logits.device)
+    ld_l = logits.stride(0) if K > 1 else max(logits.shape[1], C)
+    ld_d = deltas.stride(0) if K > 1 else max(deltas.shape[1], 4)
+    agn = deltas.shape[1] - 4 if cls_agnostic else -1
+    L.check(L.lib().abr_det_softmax_decode(L.ptr(logits), ld_l, L.ptr(deltas), ld_d, 0, agn, L.ptr(rois), K, C, L.ptr(img_hw),
+                                           *[float(w) for w in weights], L.ptr(prob), L.ptr(boxes), L.stream()), "det_softmax_decode")
+    return prob, boxes
+
+
+def det_select(prob, boxes, row_off, N, C, r_max, score_thresh, nms_thresh, detections_per_img, background=True):
+    """filter_results for the batch (inference.py:106-151) -> out_boxes [N,cap,4], out_scores [N,cap], out_labels [N,cap] int64,
+    out_count [N] int32, bg_boxes [N,r_max,4], bg_scores [N,r_max], bg_count [N]"""
+    L.require_cuda(prob, boxes, row_off)
+    dev = prob.device
+    cap = (C - 1) * r_max
+    ob = torch.empty((N, cap, 4), dtype=_f32, device=dev)
+    os_ = torch.empty((N, cap), dtype=_f32, device=dev)
+    ol = torch.empty((N, cap), dtype=torch.int64, device=dev)
+    oc = torch.empty((N,), dtype=torch.int32, device=dev)
+    bb = torch.empty((N, r_max, 4), dtype=_f32, device=dev) if background else None
+    bs = torch.empty((N, r_max), dtype=_f32, device=dev) if background else None
+    bc = torch.empty((N,), dtype=torch.int32, device=dev) if background else None
+    ws_bytes = L.lib().abr_det_select_workspace_bytes(N, C, r_max)
+    ws = torch.empty((max(ws_bytes, 8),), dtype=torch.uint8, device=dev)
+    L.check(L.lib().abr_det_select(L.ptr(L.f32c(prob)), L.ptr(L.f32c(boxes)), L.ptr(row_off), N, C, r_max, float(score_thresh),
+                                   float(nms_thresh), int(detections_per_img), cap, L.ptr(ob), L.ptr(os_), L.ptr(ol), L.ptr(oc),
+                                   L.ptr(bb), L.ptr(bs), L.ptr(bc), L.ptr(ws), ws_bytes, L.stream()), "det_select")
+    return ob, os_, ol, oc, bb, bs, bc

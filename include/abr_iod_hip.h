@@ -216,6 +216,24 @@ int abr_grid_anchors(const float* cell, int A, int H, int W, int stride, int img
  * output; A=1, ld=1 for a plain [N,n] matrix).  scores [N,k] fp32, idx [N,k] int64.  k <= 15360. */
 int abr_topk_sigmoid(const float* logits, int64_t img_stride, int N, int n, int A, int ld, int k, float* scores,
                      int64_t* idx, void* stream);
+/* Test-time PostProcessor, stage 1 (roi_heads/box_head/inference.py:55-70, box_coder.py:52-95, bounding_box.py:214-225):
+ * prob = softmax(logits[:, :C]); boxes[r,j] = clip_to_image(decode(deltas[r, delta_col0 + 4j .. +3], rois[r,1:5])).
+ * rois [K,5] = (image index, x1,y1,x2,y2); img_hw [N,2] int32 (h,w).  agnostic_col >= 0 (CLS_AGNOSTIC_BBOX_REG): every class
+ * reads the 4 columns at delta_col0 + agnostic_col instead.  prob [K,C], boxes [K,C,4]. */
+int abr_det_softmax_decode(const float* logits, int ld_logits, const float* deltas, int ld_deltas, int delta_col0,
+                           int agnostic_col, const float* rois, int K, int C, const int32_t* img_hw, float wx, float wy,
+                           float ww, float wh, float* prob, float* boxes, void* stream);
+/* Test-time PostProcessor, stage 2 = filter_results (inference.py:106-151) for the whole batch: per image and class
+ * score > score_thresh, sort, NMS (`>=` as the CPU _C.nms), classes 1..C-1 concatenated, and when more than
+ * detections_per_img (> 0) remain only those with score >= the detections_per_img-th largest (ties kept, order kept).
+ * row_offsets [N+1] int32 (device): rows of image i in prob/boxes; r_max >= every image's row count (<= 16384).
+ * out_* [N,cap,...] (cap = (C-1)*r_max holds every case), out_labels int64, out_count [N] int32.
+ * bg_* [N,r_max,...] / bg_count [N]: class 0's NMS survivors (the reference's `results_background`); NULL to skip. */
+int64_t abr_det_select_workspace_bytes(int N, int C, int r_max);
+int abr_det_select(const float* prob, const float* boxes, const int32_t* row_offsets, int N, int C, int r_max,
+                   float score_thresh, float nms_thresh, int detections_per_img, int cap, float* out_boxes,
+                   float* out_scores, int64_t* out_labels, int32_t* out_count, float* bg_boxes, float* bg_scores,
+                   int32_t* bg_count, void* workspace, int64_t workspace_bytes, void* stream);
 /* BoxCoder.decode + clip_to_image on gathered rows  (rpn/inference.py:96-112, box_coder.py:52-95, bounding_box.py:214-225)
  * For image i and rank j<k: a = idx[i,j]; out[i,j,:] = clip(decode(reg[i,a,:], anchors[a,:])).
  * reg [N,n_anchor/A,reg_stride]: anchor a = loc*A + a' reads columns reg_col0 + 4a' .. +3 of row loc

@@ -139,6 +139,65 @@ def rpn_post_process(objectness, box_regression, anchors, image_sizes, pre_nms_t
     return out
 
 
+# ------------------------------------------------------------------ F4  test-time PostProcessor
+def det_softmax_decode(class_logits, box_regression, proposals, image_sizes_wh, weights=(10.0, 10.0, 5.0, 5.0),
+                       cls_agnostic=False):
+    """roi_heads/box_head/inference.py:55-70,84-105: softmax, per-class BoxCoder.decode, clip_to_image.
+    class_logits [K,C], box_regression [K,4C] torch; proposals list of [n_i,4] numpy; image_sizes_wh (w,h) per image.
+    -> prob [K,C], boxes [K,C,4] numpy."""
+    prob = F.softmax(class_logits, -1).numpy()
+    K, C = prob.shape
+    reg = box_regression.numpy()
+    if cls_agnostic:
+        reg = np.tile(reg[:, -4:], (1, C))
+    cat = np.concatenate(proposals, 0).astype(np.float32)
+    boxes = np.empty((K, C, 4), np.float32)
+    for j in range(C):
+        boxes[:, j] = cops.box_decode(reg[:, 4 * j:4 * j + 4], cat, weights)
+    r0 = 0
+    for p, (w, h) in zip(proposals, image_sizes_wh):
+        b = boxes[r0:r0 + len(p)]
+        b[..., 0] = np.clip(b[..., 0], 0, w - 1); b[..., 1] = np.clip(b[..., 1], 0, h - 1)
+        b[..., 2] = np.clip(b[..., 2], 0, w - 1); b[..., 3] = np.clip(b[..., 3], 0, h - 1)
+        r0 += len(p)
+    return prob, boxes
+
+
+def det_filter_results(prob, boxes, score_thresh=0.05, nms_thresh=0.5, detections_per_img=100):
+    """filter_results (inference.py:106-151) for ONE image: prob [n,C], boxes [n,C,4] numpy ->
+    (boxes, scores, labels) of classes 1..C-1 and (boxes, scores) of the background class 0.
+    Equal scores are ordered by ascending proposal index (the sort the reference leaves unspecified)."""
+    n, C = prob.shape
+    rb, rs, rl = [], [], []
+    bg = None
+    for j in range(C):
+        inds = np.nonzero(prob[:, j] > score_thresh)[0]
+        sj, bj = prob[inds, j], boxes[inds, j]
+        keep = cops.nms(bj, sj, nms_thresh)
+        if j > 0:
+            rb.append(bj[keep]); rs.append(sj[keep]); rl.append(np.full(len(keep), j, np.int64))
+        else:
+            bg = (bj[keep], sj[keep])
+    rb, rs, rl = np.concatenate(rb, 0), np.concatenate(rs, 0), np.concatenate(rl, 0)
+    if len(rs) > detections_per_img > 0:
+        thresh = np.sort(rs)[len(rs) - detections_per_img]      # kthvalue(n - D + 1)
+        keep = np.nonzero(rs >= thresh)[0]
+        rb, rs, rl = rb[keep], rs[keep], rl[keep]
+    return (rb, rs, rl), bg
+
+
+def post_process(class_logits, box_regression, proposals, image_sizes_wh, score_thresh=0.05, nms_thresh=0.5,
+                 detections_per_img=100, weights=(10.0, 10.0, 5.0, 5.0)):
+    """PostProcessor.forward (inference.py:43-82): -> list of (boxes, scores, labels), background of the LAST image."""
+    prob, boxes = det_softmax_decode(class_logits, box_regression, proposals, image_sizes_wh, weights)
+    out, bg, r0 = [], None, 0
+    for p in proposals:
+        res, bg = det_filter_results(prob[r0:r0 + len(p)], boxes[r0:r0 + len(p)], score_thresh, nms_thresh, detections_per_img)
+        out.append(res)
+        r0 += len(p)
+    return out, bg
+
+
 # ------------------------------------------------------------------ A2/A3/A12/A13  conv blocks
 def frozen_bn(x, w, b, rm, rv):
     """layers/batch_norm.py:19-31 : scale = w * rsqrt(var) (NO eps), bias = b - mean*scale."""

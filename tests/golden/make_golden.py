@@ -282,8 +282,35 @@ def gold_rpn():
     save("rpn", **out)
 
 
+def gold_post_processor():
+    """F4: test-time PostProcessor (roi_heads/box_head/inference.py:43-151), ragged proposal counts, > 100 candidates."""
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.inference import PostProcessor
+    g = torch.Generator().manual_seed(21)
+    C = 21
+    sizes = [(224, 160), (200, 150)]  # BoxList.size = (w, h)
+    counts = [120, 90]
+    props = []
+    for (w, h), n in zip(sizes, counts):
+        b = BoxList(rand_boxes(g, n, w, h, 16.0, 110.0), (w, h), mode="xyxy")
+        props.append(b)
+    K = sum(counts)
+    logits = torch.randn(K, C, generator=g) * 2.0
+    reg = torch.randn(K, 4 * C, generator=g) * 0.5
+    out = {"logits": logits, "box_regression": reg, "counts": np.array(counts), "sizes_wh": np.array(sizes),
+           "boxes0": props[0].bbox, "boxes1": props[1].bbox}
+    for tag, (thr, nms_t, det) in {"std": (0.05, 0.5, 100), "tight": (0.2, 0.3, 7), "all": (0.05, 0.5, 0)}.items():
+        pp = PostProcessor(thr, nms_t, det, BoxCoder(weights=(10., 10., 5., 5.)), False)
+        res, bg = pp((logits, reg), props)
+        for i, r in enumerate(res):
+            out[f"{tag}_boxes{i}"] = r.bbox; out[f"{tag}_scores{i}"] = r.get_field("scores")
+            out[f"{tag}_labels{i}"] = r.get_field("labels")
+        out[f"{tag}_bg_boxes"] = bg.bbox; out[f"{tag}_bg_scores"] = bg.get_field("scores")
+        print(tag, [len(r) for r in res], len(bg))
+    save("post_processor", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     gold_anchors(); gold_box_coder(); gold_matcher(); gold_nms(); gold_roi_align()
-    gold_elementwise(); gold_box_head_loss(); gold_roi_distill(); gold_ard(); gold_rpn()
+    gold_elementwise(); gold_box_head_loss(); gold_roi_distill(); gold_ard(); gold_rpn(); gold_post_processor()
     print("done")

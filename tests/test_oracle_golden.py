@@ -172,3 +172,18 @@ def test_rpn_targets_loss_and_proposals(gold):
             assert b.shape == g[f"{tag}_boxes{i}"].shape
             np.testing.assert_allclose(b, g[f"{tag}_boxes{i}"], rtol=1e-5, atol=2e-4)
             np.testing.assert_allclose(s, g[f"{tag}_scores{i}"], rtol=1e-6)
+
+
+def test_post_processor_against_reference(gold):
+    """F4: the oracle's PostProcessor restatement reproduces the reference's detections (boxes, scores, labels, order) on a
+    ragged 2-image batch for three (score_thresh, nms, detections_per_img) settings."""
+    g = gold("post_processor")
+    props = [g["boxes0"], g["boxes1"]]
+    for tag, (thr, nms_t, det) in {"std": (0.05, 0.5, 100), "tight": (0.2, 0.3, 7), "all": (0.05, 0.5, 0)}.items():
+        res, bg = R.post_process(T(g["logits"]), T(g["box_regression"]), props, g["sizes_wh"], thr, nms_t, det)
+        for i, (b, s, l) in enumerate(res):
+            assert np.array_equal(l, g[f"{tag}_labels{i}"]), tag
+            np.testing.assert_allclose(s, g[f"{tag}_scores{i}"], rtol=1e-6)
+            np.testing.assert_allclose(b, g[f"{tag}_boxes{i}"], rtol=1e-5, atol=2e-4)
+        np.testing.assert_allclose(bg[1], g[f"{tag}_bg_scores"], rtol=1e-6)
+        np.testing.assert_allclose(bg[0], g[f"{tag}_bg_boxes"], rtol=1e-5, atol=2e-4)
