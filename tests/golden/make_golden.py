@@ -309,8 +309,48 @@ def gold_post_processor():
     save("post_processor", **out)
 
 
+def gold_voc_eval():
+    """F4: VOC mAP on random detections vs random GT (data/datasets/evaluation/voc/voc_eval.py:57-228): 40 images,
+    classes 1..20, difficult flags, duplicate detections of one GT, equal scores, images without detections / without GT."""
+    import importlib.util  # the package __init__ chain needs torchvision (absent here); the file itself only needs structures/
+    spec = importlib.util.spec_from_file_location(
+        "ref_voc_eval", "/root/reference/maskrcnn_benchmark/data/datasets/evaluation/voc/voc_eval.py")
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    eval_detection_voc = mod.eval_detection_voc
+    rs = np.random.RandomState(13)
+    out = {"n_images": 40}
+    preds, gts = [], []
+    for i in range(40):
+        W, H = int(rs.randint(200, 500)), int(rs.randint(200, 400))
+        ng = int(rs.randint(0, 5)) if i % 9 else 0
+        x1, y1 = rs.rand(ng) * (W - 60), rs.rand(ng) * (H - 60)
+        gb = np.stack([x1, y1, x1 + 20 + rs.rand(ng) * 100, y1 + 20 + rs.rand(ng) * 100], 1).astype(np.float32).reshape(-1, 4)
+        gl = rs.randint(1, 21, ng).astype(np.int64)
+        gd = (rs.rand(ng) < 0.2).astype(np.uint8)
+        nd = int(rs.randint(0, 30)) if i % 7 else 0
+        db, dl, ds = [], [], []
+        for _ in range(nd):
+            if ng and rs.rand() < 0.6:   # jittered copy of a GT, right or wrong label
+                k = rs.randint(ng)
+                db.append(gb[k] + rs.randn(4) * 8); dl.append(gl[k] if rs.rand() < 0.8 else rs.randint(1, 21))
+            else:
+                a, b = rs.rand() * (W - 60), rs.rand() * (H - 60)
+                db.append([a, b, a + 20 + rs.rand() * 100, b + 20 + rs.rand() * 100]); dl.append(rs.randint(1, 21))
+            ds.append(np.round(rs.rand(), 2))  # 2 decimals -> equal scores occur
+        db = np.array(db, np.float32).reshape(-1, 4); dl = np.array(dl, np.int64); ds = np.array(ds, np.float32)
+        p = BoxList(torch.from_numpy(db), (W, H)); p.add_field("labels", torch.from_numpy(dl)); p.add_field("scores", torch.from_numpy(ds))
+        t = BoxList(torch.from_numpy(gb), (W, H)); t.add_field("labels", torch.from_numpy(gl)); t.add_field("difficult", torch.from_numpy(gd))
+        preds.append(p); gts.append(t)
+        out.update({f"size{i}": np.array([W, H]), f"gb{i}": gb, f"gl{i}": gl, f"gd{i}": gd, f"db{i}": db, f"dl{i}": dl, f"ds{i}": ds})
+    for tag, m07 in (("area", False), ("voc07", True)):
+        r = eval_detection_voc(preds, gts, iou_thresh=0.5, use_07_metric=m07)
+        out[f"ap_{tag}"] = r["ap"]; out[f"map_{tag}"] = r["map"]
+        print(tag, r["map"], np.round(r["ap"], 3))
+    save("voc_eval", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     gold_anchors(); gold_box_coder(); gold_matcher(); gold_nms(); gold_roi_align()
-    gold_elementwise(); gold_box_head_loss(); gold_roi_distill(); gold_ard(); gold_rpn(); gold_post_processor()
+    gold_elementwise(); gold_box_head_loss(); gold_roi_distill(); gold_ard(); gold_rpn(); gold_post_processor(); gold_voc_eval()
     print("done")

@@ -98,3 +98,38 @@ def test_flat_allreduce_matches_single_process():
     # reduce_loss_dict: rank 0 holds the mean over ranks, keys sorted (engine/trainer.py:27-36)
     assert abs(red["a"] - sum(l[0] for l in per_rank_losses) / world) < 1e-6
     assert abs(red["b"] - sum(l[-1] for l in per_rank_losses) / world) < 1e-6
+
+
+def _eval_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from abr_iod_amd.engine.inference import _accumulate_predictions_from_multiple_gpus
+    from abr_iod_amd.structures.bounding_box import BoxList
+    mine = {}
+    for i in range(rank, 6, world):  # each rank evaluated every world-th image
+        b = BoxList(torch.full((i + 1, 4), float(i)), (100 + i, 50), mode="xyxy")
+        b.add_field("scores", torch.arange(i + 1, dtype=torch.float32))
+        mine[i] = b
+    merged = _accumulate_predictions_from_multiple_gpus(mine)
+    out.put((rank, None if merged is None else [(len(p), p.size, float(p.bbox[0, 0]), p.get_field("scores").tolist()) for p in merged]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_eval_predictions_merge_across_ranks():
+    """Sharded evaluation (one process per GPU): rank 0 ends up with every image's detections ordered by image id, the other
+    ranks with None (engine/inference.py:143-160)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[1] is None
+    assert got[0] == [(i + 1, (100 + i, 50), float(i), [float(v) for v in range(i + 1)]) for i in range(6)]

@@ -119,3 +119,50 @@ def test_eval_forward_end_to_end():
         np.testing.assert_allclose(r.get_field("scores").cpu().numpy(), s, rtol=1e-5)
         np.testing.assert_allclose(r.bbox.cpu().numpy(), b, rtol=1e-5, atol=2e-4)
     np.testing.assert_allclose(bg.get_field("scores").cpu().numpy(), ref_bg[1], rtol=1e-5)
+
+
+def test_inference_loop_to_map(tmp_path):
+    """engine.inference.inference(): eval forward over a loader -> per-image BoxLists on the host -> VOC mAP dict."""
+    from abr_iod_amd.engine.inference import inference
+    from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
+    tiny = ["MODEL.RESNETS.STEM_OUT_CHANNELS", 16, "MODEL.RESNETS.RES2_OUT_CHANNELS", 32, "MODEL.RESNETS.WIDTH_PER_GROUP", 8,
+            "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 128, "MODEL.RPN.PRE_NMS_TOP_N_TEST", 300, "MODEL.RPN.POST_NMS_TOP_N_TEST", 150]
+    cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, overrides=tiny)
+    _, mt = build_models(cfg_s, cfg_t, seed=0, need_source=False)
+
+    class DS(object):
+        def __init__(self):
+            self.items = []
+            for b in range(3):
+                images, targets = synthetic_batch(2, 160, 224, seed=10 + b, label_range=(1, 21))
+                for t in targets:
+                    t = t.to("cpu")
+                    t.add_field("difficult", torch.zeros(len(t), dtype=torch.uint8))
+                    self.items.append(t)
+                self.batches = getattr(self, "batches", []) + [(images, targets, (2 * b, 2 * b + 1))]
+
+        def __len__(self):
+            return len(self.items)
+
+        def get_img_info(self, i):
+            return {"width": 448, "height": 320}  # "original" images are 2x the network input
+
+        def get_groundtruth(self, i):
+            return self.items[i].resize((448, 320))
+
+        def map_class_id_to_class_name(self, i):
+            return str(i)
+
+    ds = DS()
+
+    class Loader(object):
+        dataset = ds
+
+        def __iter__(self):
+            return iter(ds.batches)
+
+    r = inference(mt, Loader(), "synthetic_voc", output_folder=str(tmp_path), save_predictions=True)
+    assert set(r.keys()) == {"ap", "map"} and len(r["ap"]) <= 21
+    preds = torch.load(str(tmp_path / "predictions.pth"), weights_only=False)
+    assert len(preds) == 6 and all(p.bbox.device.type == "cpu" and p.has_field("scores") and p.has_field("labels") for p in preds)
+    assert (tmp_path / "result.txt").exists()
