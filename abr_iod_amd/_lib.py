@@ -34,6 +34,7 @@ _SIGS = {
     "abr_version": (_i, []),
     "abr_device_info": (_i, [_vp]),
     "abr_prof_begin": (_i, []),
+    "abr_prof_mark_overlap": (_i, [_i]),
     "abr_prof_end": (_i, [_vp, _i]),
     "abr_roi_align_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp]),
     "abr_roi_align_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -14,8 +14,9 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-struct ProfRec { hipEvent_t a, b; double work; int id; };
+struct ProfRec { hipEvent_t a, b; double work; int id; bool overlapped; };
 static bool g_prof = false;
+static bool g_overlap = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 bool prof_enabled() { return g_prof; }
@@ -27,7 +28,7 @@ static hipEvent_t get_event() {
 }
 int prof_start(hipStream_t st, int id, double work) {
     if (!g_prof) return -1;
-    ProfRec r{get_event(), get_event(), work, id};
+    ProfRec r{get_event(), get_event(), work, id, g_overlap};
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
     return (int)g_recs.size() - 1;
@@ -41,16 +42,21 @@ extern "C" int abr_prof_begin(void) {
     abr::g_prof = true;
     return ABR_OK;
 }
-// out[id*3 + {0,1,2}] = {launch count, total milliseconds, total work (flops or bytes)} ; stops profiling
+extern "C" int abr_prof_mark_overlap(int on) {
+    abr::g_overlap = on != 0;
+    return ABR_OK;
+}
+// out[id*6 + {0,1,2}] = {launch count, total milliseconds, total work (flops or bytes)} of exclusive launches, +3: overlapped ones
 extern "C" int abr_prof_end(double* out, int n_ids) {
     abr::g_prof = false;
-    for (int i = 0; i < n_ids * 3; i++) out[i] = 0.0;
+    for (int i = 0; i < n_ids * 6; i++) out[i] = 0.0;
     for (auto& r : abr::g_recs) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.id < n_ids) {
-            out[r.id * 3 + 0] += 1.0;
-            out[r.id * 3 + 1] += ms;
-            out[r.id * 3 + 2] += r.work;
+            double* o = out + r.id * 6 + (r.overlapped ? 3 : 0);
+            o[0] += 1.0;
+            o[1] += ms;
+            o[2] += r.work;
         }
         abr::g_pool.push_back(r.a);
         abr::g_pool.push_back(r.b);

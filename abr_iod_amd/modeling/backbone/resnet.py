@@ -124,15 +124,15 @@ class Bottleneck(nn.Module):
         s3, _ = self.bn3.scale_bias()
         g = gout if g_owned else gout.clone()
         ops.relu_backward_(g, out)                                             # through the block's final ReLU
-        ops.conv_wgrad(o2, g, _grad_buf(self.conv3.weight), 1, 0, scale=s3)
+        ops.conv_wgrad_async(o2, g, _grad_buf(self.conv3.weight), 1, 0, scale=s3)
         g2 = ops.conv_forward(g, self.conv3.dgrad_weight(s3), 1, 0, mask=o2)    # dgrad + ReLU mask of o2
-        ops.conv_wgrad(o1, g2, _grad_buf(self.conv2.weight), 1, 1, scale=s2)
+        ops.conv_wgrad_async(o1, g2, _grad_buf(self.conv2.weight), 1, 1, scale=s2)
         g1 = ops.conv_forward(g2, self.conv2.dgrad_weight(s2), 1, 1, mask=o1)   # 3x3 dgrad: pad = 3-1-1
-        ops.conv_wgrad(x, g1, _grad_buf(self.conv1.weight), s, 0, scale=s1)
+        ops.conv_wgrad_async(x, g1, _grad_buf(self.conv1.weight), s, 0, scale=s1)
         ds = self.downsample
         if ds is not None:
             sd, _ = ds[1].scale_bias()
-            ops.conv_wgrad(x, g, _grad_buf(ds[0].weight), s, 0, scale=sd)
+            ops.conv_wgrad_async(x, g, _grad_buf(ds[0].weight), s, 0, scale=sd)
         if not need_dx:
             return None
         if s == 1:

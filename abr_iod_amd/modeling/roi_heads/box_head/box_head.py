@@ -84,7 +84,7 @@ class _PredictorFn(Function):
         pred, pooled = ctx.pred, ctx.saved
         K_ = pooled.shape[0]
         g = gy.contiguous().view(K_, 1, 1, -1)
-        ops.conv_wgrad(pooled.view(K_, 1, 1, -1), g, pred.fused_weight_grad, 1, 0)
+        ops.conv_wgrad_async(pooled.view(K_, 1, 1, -1), g, pred.fused_weight_grad, 1, 0)
         ops.bias_grad(g, pred.fused_bias_grad)
         gx = None
         if ctx.need_dx:

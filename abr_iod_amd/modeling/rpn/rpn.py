@@ -110,10 +110,10 @@ class _RPNHeadFn(Function):
         g = as_nhwc(gy)
         if not g.is_contiguous():
             g = g.contiguous()
-        ops.conv_wgrad(t, g, head.fused_weight_grad, 1, 0)
+        ops.conv_wgrad_async(t, g, head.fused_weight_grad, 1, 0)
         ops.bias_grad(g, head.fused_bias_grad)
         gt = ops.conv_forward(g, head.fused_dgrad_weight(), 1, 0, mask=t)
-        ops.conv_wgrad(xh, gt, _grad_buf(head.conv.weight), 1, 1)
+        ops.conv_wgrad_async(xh, gt, _grad_buf(head.conv.weight), 1, 1)
         ops.bias_grad(gt, _grad_buf(head.conv.bias))
         gx = from_nhwc(ops.conv_forward(gt, head.conv.dgrad_weight(), 1, 1)) if ctx.need_dx else None
         ctx.saved = None

@@ -5,6 +5,7 @@ The reference-shaped wrappers (autograd Functions, nn.Modules with the reference
 abr_iod_amd/layers and abr_iod_amd/modeling and are built from these.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -81,10 +82,9 @@ def nms_sorted_batched(boxes, counts, thr, max_keep, strict_gt=False):
     keep = torch.empty((N, max(max_keep, 1)), dtype=torch.int32, device=boxes.device)
     n_keep = torch.empty((N,), dtype=torch.int32, device=boxes.device)
     ws_bytes = L.lib().abr_nms_workspace_bytes(N, n)
-    key = (boxes.device, ws_bytes)
+    key = (boxes.device, L.stream())  # one workspace per stream: the source and target models may run on different streams
     ws = _nms_ws.get(key)
-    if ws is None:
-        _nms_ws.clear()
+    if ws is None or ws.numel() < ws_bytes:
         ws = _nms_ws[key] = torch.empty((max(ws_bytes, 8),), dtype=torch.uint8, device=boxes.device)
     L.check(L.lib().abr_nms_sorted_batched(L.ptr(boxes), L.ptr(counts), N, n, float(thr), int(strict_gt), max_keep,
                                            L.ptr(keep), L.ptr(n_keep), L.ptr(ws), ws_bytes, L.stream()), "nms")
@@ -240,6 +240,57 @@ def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None):
     x, gy = L.f32c(x), L.f32c(gy)
     d = conv_desc(x.shape, dw.shape, stride, pad, scale=scale)
     L.check(L.lib().abr_conv_wgrad(C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.stream()), "conv_wgrad")
+    return dw
+
+
+# Weight gradients do not feed anything else in backward (they accumulate atomically into the flat gradient buffer), so they
+# run on a SIDE HIP stream next to the dgrad chain: their workgroups fill the tail rounds of the main stream's kernels (and
+# vice versa) instead of each kernel draining the chip alone.  ABR_WGRAD_STREAM=0 keeps everything on one stream.
+WGRAD_SIDE_STREAM = os.environ.get("ABR_WGRAD_STREAM", "1") != "0"
+_side_streams = {}
+_join_pending = [False]
+
+
+def side_stream(key):
+    """key = device index (the wgrad stream) or (device index, tag)"""
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(device=key[0] if isinstance(key, tuple) else key)
+    return s
+
+
+def mark_overlap(on):
+    """Tell the per-launch profiler (abr_prof_*) that main-stream launches now share the device with another stream."""
+    L.lib().abr_prof_mark_overlap(1 if on else 0)
+
+
+def join_side_stream():
+    """Make the current stream wait for everything queued on the side stream (queued automatically as an end-of-backward
+    callback by conv_wgrad_async; FusedSGD.step calls it again before touching the gradients)."""
+    if _join_pending[0]:
+        L.lib().abr_prof_mark_overlap(0)
+    _join_pending[0] = False
+    if torch.cuda.is_available():
+        s = _side_streams.get(torch.cuda.current_device())
+        if s is not None:
+            torch.cuda.current_stream().wait_stream(s)
+
+
+def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None):
+    """conv_wgrad on the side stream.  Only for use inside an autograd backward (the join is an engine callback)."""
+    if not WGRAD_SIDE_STREAM:
+        return conv_wgrad(x, gy, dw, stride, pad, scale)
+    cur = torch.cuda.current_stream()
+    side = side_stream(x.device.index)
+    if not _join_pending[0]:
+        _join_pending[0] = True
+        L.lib().abr_prof_mark_overlap(1)  # from here to the join, main-stream launches share the device with the side stream
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+    side.wait_stream(cur)  # x, gy (and the zeroed gradient buffer) are produced on the current stream
+    with torch.cuda.stream(side):
+        conv_wgrad(x, gy, dw, stride, pad, scale)
+    x.record_stream(side)  # the caching allocator must not recycle them for the main stream while the side kernel reads
+    gy.record_stream(side)
     return dw
 
 

@@ -46,6 +46,7 @@ class FusedSGD(object):
             dist.all_reduce(self.flat.grads, op=dist.ReduceOp.SUM)
 
     def step(self):
+        ops.join_side_stream()  # weight gradients queued on the side stream (no-op when already joined after backward)
         self.all_reduce_grads()
         lrs = [g["lr"] for g in self.param_groups]
         if lrs != self._lr_host:  # only re-upload when the scheduler changed something

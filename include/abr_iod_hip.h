@@ -42,9 +42,13 @@ int abr_version(void);
 int abr_device_info(int32_t* out_host);
 
 /* Per-launch timing of the conv kernels with HIP events on the launch stream (bench.py's roofline leg; off by default).
- * abr_prof_end: out[id*3+{0,1,2}] = {launches, total ms, total flops} for id = 0 igemm 128x128, 1 igemm 128x64,
- * 2 igemm 64x64, 3 igemm small-C (stem), 4 wgrad; synchronises on the recorded events and stops profiling. */
+ * abr_prof_end: out[id*6+{0,1,2}] = {launches, total ms, total flops} of the launches that had the device to themselves,
+ * out[id*6+{3,4,5}] = the same for launches made while abr_prof_mark_overlap(1) was in force (the host runs weight-gradient
+ * kernels on a second stream next to the dgrad chain: those launches share CUs and their event-bracketed duration is not a
+ * property of the kernel).  id = 0 igemm 128x128, 1 igemm 128x64, 2 igemm 64x64, 3 igemm small-C (stem), 4 wgrad, 5/6 ROIAlign
+ * fwd/bwd.  Synchronises on the recorded events and stops profiling. */
 int abr_prof_begin(void);
+int abr_prof_mark_overlap(int on);
 int abr_prof_end(double* out_host, int n_ids);
 
 /* =====================================================================================================
