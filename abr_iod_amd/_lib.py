@@ -35,6 +35,7 @@ _SIGS = {
     "abr_device_info": (_i, [_vp]),
     "abr_prof_begin": (_i, []),
     "abr_prof_mark_overlap": (_i, [_i]),
+    "abr_prof_set_mask": (_i, [C.c_uint32, _i]),
     "abr_prof_end": (_i, [_vp, _i]),
     "abr_roi_align_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp]),
     "abr_roi_align_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -62,7 +63,7 @@ _SIGS = {
     "abr_maxpool3x3s2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "abr_avgpool_forward": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "abr_avgpool_backward": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "abr_relu_backward": (_i, [_vp, _vp, _i64, _vp]),
+    "abr_relu_backward": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "abr_add_inplace": (_i, [_vp, _vp, _i64, _vp]),
     "abr_scale_inplace": (_i, [_vp, _i64, _f, _vp, _vp]),
     "abr_grid_anchors": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

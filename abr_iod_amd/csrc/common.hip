@@ -17,6 +17,8 @@ void set_error(const char* fmt, ...) {
 struct ProfRec { hipEvent_t a, b; double work; int id; bool overlapped; };
 static bool g_prof = false;
 static bool g_overlap = false;
+static unsigned g_mask = 0xFFFFFFFFu;
+static unsigned g_every = 1, g_seen = 0;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 bool prof_enabled() { return g_prof; }
@@ -27,7 +29,8 @@ static hipEvent_t get_event() {
     return e;
 }
 int prof_start(hipStream_t st, int id, double work) {
-    if (!g_prof) return -1;
+    if (!g_prof || !((g_mask >> id) & 1u)) return -1;
+    if (g_every > 1 && (g_seen++ % g_every) != 0) return -1;  // sample every n-th eligible launch
     ProfRec r{get_event(), get_event(), work, id, g_overlap};
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
@@ -40,6 +43,12 @@ void prof_stop(hipStream_t st, int rec) {
 
 extern "C" int abr_prof_begin(void) {
     abr::g_prof = true;
+    return ABR_OK;
+}
+extern "C" int abr_prof_set_mask(uint32_t mask, int every_nth) {
+    abr::g_mask = mask;
+    abr::g_every = every_nth > 1 ? (unsigned)every_nth : 1u;
+    abr::g_seen = 0;
     return ABR_OK;
 }
 extern "C" int abr_prof_mark_overlap(int on) {

@@ -96,16 +96,17 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, int64_t n4, int64_t n) {
+// out may alias g (in place): no __restrict__ on those two
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* g, const float* __restrict__ y, int64_t n4, int64_t n, float* out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        float4 gv = reinterpret_cast<float4*>(g)[i];
+        float4 gv = reinterpret_cast<const float4*>(g)[i];
         const float4 yv = reinterpret_cast<const float4*>(y)[i];
         gv.x = yv.x > 0.f ? gv.x : 0.f; gv.y = yv.y > 0.f ? gv.y : 0.f;
         gv.z = yv.z > 0.f ? gv.z : 0.f; gv.w = yv.w > 0.f ? gv.w : 0.f;
-        reinterpret_cast<float4*>(g)[i] = gv;
+        reinterpret_cast<float4*>(out)[i] = gv;
     }
     if (blockIdx.x == 0)
-        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) g[i] = y[i] > 0.f ? g[i] : 0.f;
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) out[i] = y[i] > 0.f ? g[i] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n4, int64_t n) {
@@ -194,10 +195,10 @@ extern "C" int abr_avgpool_backward(const float* g, int N, int HW, int C, float*
     return ABR_OK;
 }
 
-extern "C" int abr_relu_backward(float* g, const float* y, int64_t n, void* stream) {
+extern "C" int abr_relu_backward(const float* g, const float* y, int64_t n, float* out, void* stream) {
     if (n == 0) return ABR_OK;
-    ABR_REQUIRE(g && y && n > 0, "relu_backward: bad args");
-    relu_bwd_kernel<<<(unsigned)std::min<int64_t>((n / 4 + 255) / 256 + 1, 8192), 256, 0, abr::as_stream(stream)>>>(g, y, n / 4, n);
+    ABR_REQUIRE(g && y && out && n > 0, "relu_backward: bad args");
+    relu_bwd_kernel<<<(unsigned)std::min<int64_t>((n / 4 + 255) / 256 + 1, 8192), 256, 0, abr::as_stream(stream)>>>(g, y, n / 4, n, out);
     ABR_CHECK_LAUNCH("relu_backward");
     return ABR_OK;
 }

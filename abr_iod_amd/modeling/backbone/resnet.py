@@ -116,14 +116,14 @@ class Bottleneck(nn.Module):
         out = ops.conv_forward(o2, self.conv3.weight, 1, 0, scale=s3, bias=b3, residual=idt, relu=True)
         return out, ((x, o1, o2, out, s) if save else None)
 
-    def bwd(self, saved, gout, need_dx, g_owned):
-        """gout = dL/d(out) (not yet masked by out's ReLU).  Writes weight grads into .grad; returns dL/dx or None."""
+    def bwd(self, saved, gout, need_dx, g_owned, g_masked=False, mask_dx=None):
+        """gout = dL/d(out), not yet masked by out's ReLU unless g_masked.  Writes weight grads into .grad; returns dL/dx or None.
+        mask_dx (the producer block's output, = this block's x): fuse THAT block's ReLU backward into the last dgrad launch."""
         x, o1, o2, out, s = saved
         s1, _ = self.bn1.scale_bias()
         s2, _ = self.bn2.scale_bias()
         s3, _ = self.bn3.scale_bias()
-        g = gout if g_owned else gout.clone()
-        ops.relu_backward_(g, out)                                             # through the block's final ReLU
+        g = gout if g_masked else ops.relu_backward(gout, out, inplace=g_owned)   # through the block's final ReLU
         ops.conv_wgrad_async(o2, g, _grad_buf(self.conv3.weight), 1, 0, scale=s3)
         g2 = ops.conv_forward(g, self.conv3.dgrad_weight(s3), 1, 0, mask=o2)    # dgrad + ReLU mask of o2
         ops.conv_wgrad_async(o1, g2, _grad_buf(self.conv2.weight), 1, 1, scale=s2)
@@ -138,10 +138,11 @@ class Bottleneck(nn.Module):
         if s == 1:
             if ds is not None:
                 gx = ops.conv_forward(g, ds[0].dgrad_weight(sd), 1, 0)
-                return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=gx, out=gx)
-            return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=g)
+                return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=gx, out=gx, mask=mask_dx)
+            return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=g, mask=mask_dx)
         # stride-2 1x1 convs: gradient rows land on the even pixels of a zeroed tensor
         B, H, W, _ = x.shape
+        assert mask_dx is None, "stride-2 blocks open a stage: their input is not a block output of the same stage"
         gx = ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, out_hw=(H, W), out_stride=(s, s))
         if ds is not None:
             ops.conv_forward(g, ds[0].dgrad_weight(sd), 1, 0, residual=gx, out=gx, out_hw=(H, W), out_stride=(s, s))
@@ -166,13 +167,15 @@ class _StageFn(Function):
     @staticmethod
     def backward(ctx, gout):
         g = as_nhwc(gout)
-        owned = False
+        owned = masked = False
         n = len(ctx.blocks)
         for i in range(n - 1, -1, -1):
             need = ctx.need_dx or i > 0
-            g = ctx.blocks[i].bwd(ctx.saved[i], g, need, owned)
+            # block i's input x is block i-1's (post-ReLU) output: its ReLU backward rides in block i's last dgrad epilogue
+            fuse = i > 0 and ctx.saved[i][4] == 1
+            g = ctx.blocks[i].bwd(ctx.saved[i], g, need, owned, masked, ctx.saved[i][0] if fuse else None)
             ctx.saved[i] = None
-            owned = True
+            owned, masked = True, fuse
         return (from_nhwc(g) if g is not None else None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 

@@ -356,9 +356,16 @@ def avgpool_backward(g, shape):
     return gx
 
 
+def relu_backward(g, y, inplace=False):
+    """g * (y > 0); a new tensor unless inplace (one pass either way: no clone + in-place pair)"""
+    g = L.f32c(g)
+    out = g if inplace else torch.empty_like(g)
+    L.check(L.lib().abr_relu_backward(L.ptr(g), L.ptr(y), g.numel(), L.ptr(out), L.stream()), "relu_backward")
+    return out
+
+
 def relu_backward_(g, y):
-    L.check(L.lib().abr_relu_backward(L.ptr(g), L.ptr(y), g.numel(), L.stream()), "relu_backward")
-    return g
+    return relu_backward(g, y, inplace=True)
 
 
 def add_(a, b):

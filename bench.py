@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--time-all-kernels", action="store_true", help="event-bracket every conv / ROIAlign launch, not only the dominant kernel")
     a = ap.parse_args()
 
     import torch
@@ -89,6 +90,10 @@ def main():
     time_kernels = (rank == 0) and not a.no_kernel_timing
     barrier()
     if time_kernels:
+        # default: only the dominant kernel (conv_igemm<128,128>, id 0) is event-bracketed, and only every 4th of its launches
+        # (73 per step, coprime to 4: every shape is sampled equally over 4 steps) -- an event pair costs a ~6 us bubble per
+        # launch, 1.6 ms/step if all ~250 conv/ROIAlign launches are timed.  --time-all-kernels fills the whole table.
+        _lib.check(_lib.lib().abr_prof_set_mask(0xFFFFFFFF if a.time_all_kernels else 0x1, 1 if a.time_all_kernels else 4), "prof_set_mask")
         _lib.check(_lib.lib().abr_prof_begin(), "prof_begin")
     t0 = time.perf_counter()
     last = None
@@ -145,14 +150,15 @@ def main():
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                               "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
+                               "launches": int(n), "sampling": "every launch" if a.time_all_kernels else "every 4th launch of this kernel",
+                               "avg_launch_ms": round(ms / max(n, 1), 4),
                                "avg_gflop_per_launch": round(flops / max(n, 1) / 1e9, 3),
                                "overlapped": {"launches": int(n_o), "avg_launch_ms": round(ms_o / max(n_o, 1), 4), "tflops": tf(flops_o, ms_o),
                                               "note": "dgrad launches issued while wgrad kernels run on the side stream (ABR_WGRAD_STREAM=0 serialises them)"},
                                "avg_launch_ms_all": round((ms + ms_o) / max(n + n_o, 1), 4),
                                "all_conv_kernels": {r[0]: {"launches": int(r[1]), "ms": round(r[2], 3), "tflops": tf(r[3], r[2]),
                                                            "overlapped_launches": int(r[4]), "overlapped_ms": round(r[5], 3),
-                                                           "overlapped_tflops": tf(r[6], r[5])} for r in prof}}
+                                                           "overlapped_tflops": tf(r[6], r[5])} for r in prof if r[1] + r[4] > 0}}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_target, images, targets, len(cfg_t.MODEL.ROI_BOX_HEAD.NAME_OLD_CLASSES))
         print(json.dumps(out), flush=True)

@@ -49,6 +49,9 @@ int abr_device_info(int32_t* out_host);
  * fwd/bwd.  Synchronises on the recorded events and stops profiling. */
 int abr_prof_begin(void);
 int abr_prof_mark_overlap(int on);
+/* bit id set = time that kernel (default all); every_nth > 1 = bracket only every n-th eligible launch (an event pair costs a
+ * ~6 us pipeline bubble per launch; with a per-step launch count coprime to n every shape is sampled equally often) */
+int abr_prof_set_mask(uint32_t id_mask, int every_nth);
 int abr_prof_end(double* out_host, int n_ids);
 
 /* =====================================================================================================
@@ -203,8 +206,8 @@ int abr_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* out, voi
 /* AdaptiveAvgPool2d(1)  roi_box_predictors.py:28 : x [N,HW,C] -> out [N,C] ; backward spreads g/HW */
 int abr_avgpool_forward(const float* x, int N, int HW, int C, float* out, void* stream);
 int abr_avgpool_backward(const float* g, int N, int HW, int C, float* gx, void* stream);
-/* g *= (y > 0) in place (ReLU backward) */
-int abr_relu_backward(float* g, const float* y, int64_t n, void* stream);
+/* out = g * (y > 0)  (ReLU backward); out == g is allowed (in place) */
+int abr_relu_backward(const float* g, const float* y, int64_t n, float* out, void* stream);
 int abr_add_inplace(float* a, const float* b, int64_t n, void* stream);
 /* x *= s * (s_dev ? *s_dev : 1): applies an upstream (device-resident) loss gradient without a host sync */
 int abr_scale_inplace(float* x, int64_t n, float s, const float* s_dev, void* stream);
