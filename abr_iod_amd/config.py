@@ -174,5 +174,11 @@ _C.INCREMENTAL = False
 _C.CLS_PER_STEP = -1
 _C.DTYPE = "float32"
 _C.OUTPUT_DIR = "."
+# Augmented box replay (defaults.py:488-492) + the keys tools/*.py set from the command line
+_C.MEM_BUFF = None
+_C.MEM_TYPE = False
+_C.STEP = 0
+_C.TASK = ""
+_C.NAME = ""
 
 cfg = _C

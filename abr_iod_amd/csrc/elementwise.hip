@@ -82,6 +82,26 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
     }
 }
 
+// x [rows, C] (NHWC rows = (roi, bin)) -> out[row] = mean over the C channels.  One wave per row: 16 B per lane per step, then a
+// wave reduction.  The rehearsal-buffer builder's `torch.mean(roi_align_features.cpu(), dim=1)` (tools/prototype_box_selection.py:84)
+// without shipping the [n,1024,7,7] tensor over PCIe first.
+__global__ __launch_bounds__(256) void channel_mean_kernel(const float* __restrict__ x, int64_t rows, int C, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int cv = C / 4;
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const float4* p = reinterpret_cast<const float4*>(x + r * C);
+        float a = 0.f;
+        for (int c = lane; c < cv; c += 64) {
+            const float4 v = p[c];
+            a += (v.x + v.y) + (v.z + v.w);
+        }
+        for (int c = cv * 4 + lane; c < C; c += 64) a += x[r * C + c];
+        a = abr::wave_sum(a);
+        if (lane == 0) out[r] = a / (float)C;
+    }
+}
+
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ g, int64_t N, int HW, int C,
                                                            float* __restrict__ gx) {
     const int cv = C / 4;
@@ -184,6 +204,14 @@ extern "C" int abr_avgpool_forward(const float* x, int N, int HW, int C, float* 
     const int64_t total = (int64_t)N * (C / 4);
     avgpool_fwd_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 8192), 256, 0, abr::as_stream(stream)>>>(x, N, HW, C, out);
     ABR_CHECK_LAUNCH("avgpool_forward");
+    return ABR_OK;
+}
+extern "C" int abr_channel_mean(const float* x, int64_t rows, int C, float* out, void* stream) {
+    ABR_REQUIRE(rows >= 0 && C > 0, "channel_mean: bad args");
+    if (rows == 0) return ABR_OK;
+    ABR_REQUIRE(x && out, "channel_mean: null pointer");
+    channel_mean_kernel<<<(unsigned)std::min<int64_t>((rows + 3) / 4, 16384), 256, 0, abr::as_stream(stream)>>>(x, rows, C, out);
+    ABR_CHECK_LAUNCH("channel_mean");
     return ABR_OK;
 }
 extern "C" int abr_avgpool_backward(const float* g, int N, int HW, int C, float* gx, void* stream) {

@@ -356,6 +356,15 @@ def avgpool_backward(g, shape):
     return gx
 
 
+def channel_mean(x):
+    """x [..., C] contiguous -> mean over the last (channel) axis, shape x.shape[:-1]"""
+    L.require_cuda(x)
+    x = L.f32c(x)
+    out = torch.empty(x.shape[:-1], dtype=_f32, device=x.device)
+    L.check(L.lib().abr_channel_mean(L.ptr(x), out.numel(), x.shape[-1], L.ptr(out), L.stream()), "channel_mean")
+    return out
+
+
 def relu_backward(g, y, inplace=False):
     """g * (y > 0); a new tensor unless inplace (one pass either way: no clone + in-place pair)"""
     g = L.f32c(g)

@@ -349,8 +349,47 @@ def gold_voc_eval():
     save("voc_eval", **out)
 
 
+def gold_rehearsal():
+    """F2: prototype box selection (tools/extract_memory.py Mem): which records the REFERENCE picks, and in which order, for the
+    'mean' and 'random' strategies (herding crashes in the reference: UnboundLocalError, extract_memory.py:203).  The image
+    writer is replaced by a recorder; 3 new classes with 40 / 9 / 3 candidates and 5 slots per class (the last is topped up)."""
+    import random
+    import tempfile
+    import types
+    sys.path.insert(0, "/root/reference")
+    from tools.extract_memory import Mem
+    rs = np.random.RandomState(5)
+    counts = [40, 9, 3]
+    feats = [np.abs(rs.randn(n, 7, 7)).astype(np.float32) * (1 + c) for c, n in enumerate(counts)]
+    out = {"counts": np.array(counts), "mem_size": 18}
+    for c, f in enumerate(feats):
+        out[f"feat{c}"] = f
+    for mem_type in ("mean", "random"):
+        cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(ROI_BOX_HEAD=types.SimpleNamespace(
+            NAME_OLD_CLASSES=["a"], NAME_NEW_CLASSES=["b", "c", "d"]), SOURCE_WEIGHT=""), MEM_TYPE=mem_type, MEM_BUFF=18,
+            TASK="t", NAME="n")
+        with tempfile.TemporaryDirectory() as d:
+            m = Mem(cfg, 0, d)
+            picked = []
+
+            def rec(self, info, ind, picked=picked, d=d):
+                picked.append((info["box_class"], ind, info["rid"]))
+                open(os.path.join(d, "{0}_{1:05d}_{2}.jpg".format(info["box_class"], ind, len(picked))), "w").close()
+            m.creat_and_save_box_image = types.MethodType(rec, m)
+            info = [[{"feature": feats[c][j].tolist(), "logits": None, "image_path": ["x"], "box_class": 2 + c, "box": [0, 0, 99, 99],
+                      "mode": "xyxy", "rid": j} for j in range(n)] for c, n in enumerate(counts)]
+            random.seed(3)
+            try:
+                m.update_memory(info)
+            except AssertionError:   # 4 classes x ceil(18/4)=5 slots, only the 3 new ones are written here: 15 < 18
+                pass
+            out[f"{mem_type}_picked"] = np.array(picked)
+            print(mem_type, picked[:6], len(picked))
+    save("rehearsal", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     gold_anchors(); gold_box_coder(); gold_matcher(); gold_nms(); gold_roi_align()
-    gold_elementwise(); gold_box_head_loss(); gold_roi_distill(); gold_ard(); gold_rpn(); gold_post_processor(); gold_voc_eval()
+    gold_elementwise(); gold_box_head_loss(); gold_roi_distill(); gold_ard(); gold_rpn(); gold_post_processor(); gold_voc_eval(); gold_rehearsal()
     print("done")
