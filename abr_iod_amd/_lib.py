@@ -53,6 +53,11 @@ _SIGS = {
     "abr_softmax_ce": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _f, _vp, _i, _vp]),
     "abr_roi_distill": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _f, _vp, _vp, _vp]),
     "abr_bce_logits_gather": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp]),
+    "abr_img_resample_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "abr_img_blend_paste_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.c_double, _vp]),
+    "abr_img_copy_rect_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "abr_img_fill_u8": (_i, [_vp, _i64, _i, _vp]),
+    "abr_img_normalize_to_batch": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _i, _i, _vp]),
     "abr_conv_forward": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "abr_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "abr_conv_dgrad_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

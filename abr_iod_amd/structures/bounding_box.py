@@ -5,6 +5,10 @@ indexing a BoxList indexes every field (:205-209)."""
 import torch
 
 
+FLIP_LEFT_RIGHT = 0
+FLIP_TOP_BOTTOM = 1
+
+
 class BoxList(object):
     def __init__(self, bbox, image_size, mode="xyxy"):
         dev = bbox.device if isinstance(bbox, torch.Tensor) else torch.device("cpu")
@@ -77,6 +81,22 @@ class BoxList(object):
         out = BoxList(box, size, "xyxy")
         for k, v in self.extra_fields.items():
             out.add_field(k, v if isinstance(v, torch.Tensor) else v.resize(size, *args, **kwargs))
+        return out.convert(self.mode)
+
+    def transpose(self, method):
+        """FLIP_LEFT_RIGHT (0) / FLIP_TOP_BOTTOM (1) of the boxes (bounding_box.py:128-167; TO_REMOVE = 1 for the x flip only)"""
+        if method not in (FLIP_LEFT_RIGHT, FLIP_TOP_BOTTOM):
+            raise NotImplementedError("Only FLIP_LEFT_RIGHT and FLIP_TOP_BOTTOM implemented")
+        w, h = self.size
+        b = self.convert("xyxy").bbox
+        x1, y1, x2, y2 = b[:, 0:1], b[:, 1:2], b[:, 2:3], b[:, 3:4]
+        if method == FLIP_LEFT_RIGHT:
+            box = torch.cat((w - x2 - 1, y1, w - x1 - 1, y2), dim=-1)
+        else:
+            box = torch.cat((x1, h - y2, x2, h - y1), dim=-1)
+        out = BoxList(box, self.size, "xyxy")
+        for k, v in self.extra_fields.items():
+            out.add_field(k, v if isinstance(v, torch.Tensor) else v.transpose(method))
         return out.convert(self.mode)
 
     # --- tensor-like

@@ -283,6 +283,29 @@ int abr_sgd_momentum(float* p, const float* g, float* m, int64_t total, const in
                      const float* lr_dev, const float* wd_dev, int n_seg, float momentum, float gscale,
                      int first_step, void* stream);
 
+/* =====================================================================================================
+ * 7. ABR data path pixel work: uint8 HWC RGB images resident on the device.
+ *    voc_abr.py:512-816 (box-crop resize, mixup blend, mosaic paste), transforms.py:64-165 (Resize, flip, ToTensor, Normalize),
+ *    image_list.py:57-70 (zero-padded batch).  All results are bit-identical to the Pillow / numpy / torch-CPU originals.
+ * ===================================================================================================== */
+/* Pillow's 8-bit separable resampler (Image.resize).  bounds_* [out,2] int32 = (first tap, tap count), coeffs_* [out,ksize] int32 =
+ * 22-bit fixed-point weights, both computed by the host exactly as Resample.c precompute_coeffs does (abr_iod_amd/data/resample.py);
+ * horizontal pass first; tmp [H,OW,3] is needed when both sizes change. */
+int abr_img_resample_u8(const uint8_t* src, int H, int W, uint8_t* dst, int OH, int OW, const int32_t* bounds_h,
+                        const int32_t* coeffs_h, int ksize_h, const int32_t* bounds_v, const int32_t* coeffs_v, int ksize_v,
+                        uint8_t* tmp, void* stream);
+/* img[y0:y0+rh, x0:x0+rw] = (uint8)(lam*img[...] + (1-lam)*crop[off_y:off_y+rh, off_x:off_x+rw]) in float64 (voc_abr.py:664-683) */
+int abr_img_blend_paste_u8(uint8_t* img, int H, int W, const uint8_t* crop, int CH, int CW, int x0, int y0, int rw, int rh,
+                           int off_x, int off_y, double lam, void* stream);
+/* dst[dy:dy+rh, dx:dx+rw] = src[sy:sy+rh, sx:sx+rw]  (mosaic tiles, voc_abr.py:765) */
+int abr_img_copy_rect_u8(uint8_t* dst, int DH, int DW, const uint8_t* src, int SH, int SW, int dx, int dy, int sx, int sy,
+                         int rw, int rh, void* stream);
+int abr_img_fill_u8(uint8_t* dst, int64_t n, int value, void* stream);
+/* one [3,HP,WP] fp32 slot of the batch tensor: (optional hflip) -> /255 -> [2,1,0]*255 (to_bgr255) -> (x-mean)/std, zeros outside
+ * [h,w] (transforms.py:108-165 + to_image_list).  mean/std are HOST pointers to 3 floats. */
+int abr_img_normalize_to_batch(const uint8_t* src, int h, int w, int flip, int to_bgr255, const float* mean3_host,
+                               const float* std3_host, float* out_slot, int HP, int WP, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
