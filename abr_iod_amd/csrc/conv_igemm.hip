@@ -61,15 +61,10 @@ struct ConvP {
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][TN], float* ep, int m_base, int n_base, int lane,
                                               float* __restrict__ out) {
-    constexpr int WR = TM * 32, WC = TN * 32, EP = WC + EPAD;
+    // one 32-row block of the wave tile at a time: the staging slice is 32 x (WC + EPAD) floats per wave (8.7 KB at WC = 64), so
+    // the whole workgroup needs 34.8 KB -- it fits the single-buffered operand LDS as well as the double-buffered one.
+    constexpr int WC = TN * 32, EP = WC + EPAD;
     const int l31 = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EP + j * 32 + l31] = acc[i][j][r];
     constexpr int LPR = WC / 4;    // lanes per row (16 B each)
     constexpr int RPI = 64 / LPR;  // rows per iteration of the wave
     const int c4 = (lane % LPR) * 4;
@@ -86,58 +81,68 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][
                 if (p.bias) b_[e] = p.bias[ncol + e];
             }
     }
-#pragma unroll 4
-    for (int it = 0; it < WR / RPI; it++) {
-        const int row = it * RPI + lane / LPR;
-        const int m = m_base + row;
-        if (m >= p.M || ncol >= p.Cout) continue;
-        size_t row_off;
-        if (p.scatter) {
-            unsigned b, rem, ho, wo;
-            p.d_howo.divmod((unsigned)m, b, rem);
-            p.d_wo.divmod(rem, ho, wo);
-            row_off = (((size_t)b * p.out_H + (size_t)ho * p.out_sh) * p.out_W + (size_t)wo * p.out_sw) * p.Cout;
-        } else {
-            row_off = (size_t)m * p.Cout;
-        }
-        float4 v = *reinterpret_cast<const float4*>(ep + row * EP + c4);
-        v.x = v.x * sc4.x + bi4.x; v.y = v.y * sc4.y + bi4.y; v.z = v.z * sc4.z + bi4.z; v.w = v.w * sc4.w + bi4.w;
-        float* o = out + row_off + ncol;
-        if (vec_ok) {
-            if (p.residual) {
-                const float4 rr = *reinterpret_cast<const float4*>(p.residual + row_off + ncol);
-                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-            }
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (p.mask) {
-                const float4 mm = *reinterpret_cast<const float4*>(p.mask + row_off + ncol);
-                v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f; v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
-            }
-            *reinterpret_cast<float4*>(o) = v;
-        } else {
-            const float* vv = reinterpret_cast<const float*>(&v);
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                if (ncol + e >= p.Cout) break;
-                float t = vv[e];
-                if (p.residual) t += p.residual[row_off + ncol + e];
-                if (p.relu) t = fmaxf(t, 0.f);
-                if (p.mask) t = p.mask[row_off + ncol + e] > 0.f ? t : 0.f;
-                o[e] = t;
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                ep[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + j * 32 + l31] = acc[i][j][r];
+#pragma unroll 4
+        for (int it = 0; it < 32 / RPI; it++) {
+            const int row = it * RPI + lane / LPR;
+            const int m = m_base + i * 32 + row;
+            if (m >= p.M || ncol >= p.Cout) continue;
+            size_t row_off;
+            if (p.scatter) {
+                unsigned b, rem, ho, wo;
+                p.d_howo.divmod((unsigned)m, b, rem);
+                p.d_wo.divmod(rem, ho, wo);
+                row_off = (((size_t)b * p.out_H + (size_t)ho * p.out_sh) * p.out_W + (size_t)wo * p.out_sw) * p.Cout;
+            } else {
+                row_off = (size_t)m * p.Cout;
+            }
+            float4 v = *reinterpret_cast<const float4*>(ep + row * EP + c4);
+            v.x = v.x * sc4.x + bi4.x; v.y = v.y * sc4.y + bi4.y; v.z = v.z * sc4.z + bi4.z; v.w = v.w * sc4.w + bi4.w;
+            float* o = out + row_off + ncol;
+            if (vec_ok) {
+                if (p.residual) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + row_off + ncol);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (p.mask) {
+                    const float4 mm = *reinterpret_cast<const float4*>(p.mask + row_off + ncol);
+                    v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f; v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(o) = v;
+            } else {
+                const float* vv = reinterpret_cast<const float*>(&v);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (ncol + e >= p.Cout) break;
+                    float t = vv[e];
+                    if (p.residual) t += p.residual[row_off + ncol + e];
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    if (p.mask) t = p.mask[row_off + ncol + e] > 0.f ? t : 0.f;
+                    o[e] = t;
+                }
             }
         }
     }
 }
 
 // SMALL_C: Cin is not a multiple of 32 (the 3->4 padded stem): (r,s,c) is derived per 16 B slot.
-template <int BM, int BN, int WM, int WN, bool SMALL_C>
+// SB: single-buffered operand LDS (two barriers per k-tile, half the LDS -> one more resident workgroup per CU).
+template <int BM, int BN, int WM, int WN, bool SMALL_C, bool SB>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const float* __restrict__ x,
                                                           const float* __restrict__ w, float* __restrict__ out) {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int NA = BM / 32, NB = BN / 32;  // float4 staging loads per thread for A and B
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                     // [2][BM][LDP]
-    float* Bs = smem + 2 * BM * LDP;      // [2][BN][LDP]
+    constexpr int NBUF = SB ? 1 : 2;
+    float* As = smem;                        // [NBUF][BM][LDP]
+    float* Bs = smem + NBUF * BM * LDP;      // [NBUF][BN][LDP]
 
     const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
+        const int cur = SB ? 0 : (kt & 1);
         if (kt + 1 < nk) load_tile(kt + 1);
         const float* a = As + cur * BM * LDP + a_row0 * LDP + lh * 4;
         const float* b = Bs + cur * BN * LDP + b_row0 * LDP + lh * 4;
@@ -251,7 +256,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (SB) {
+            __syncthreads();  // every wave is done reading the tile before it is overwritten
+            if (kt + 1 < nk) store_tile(0);
+        } else if (kt + 1 < nk) {
+            store_tile(cur ^ 1);
+        }
         __syncthreads();
     }
 
@@ -260,16 +270,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     // ~0.9 TB/s effective, 20-25 % of the kernel at K <= 1024).  Instead each wave transposes its TM*32 x TN*32 tile through its
     // own slice of the (now idle) operand LDS and streams whole rows: 16 B per lane, 128-256 B contiguous per row, with the
     // residual / mask read the same way.  Waves only touch their own slice, so no workgroup barrier is needed here.
-    epilogue_rows<TM, TN>(p, acc, smem + wave * (TM * 32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
 }
 
-template <int BM, int BN, int WM, int WN, bool SMALL_C>
+template <int BM, int BN, int WM, int WN, bool SMALL_C, bool SB = false>
 int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st, int prof_id) {
     ConvP q = p;
     q.tiles_m = (p.M + BM - 1) / BM;
     q.tiles_n = (p.Cout + BN - 1) / BN;
-    const size_t lds = sizeof(float) * 2 * (BM + BN) * LDP;
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, SMALL_C>;
+    constexpr size_t lds_op = sizeof(float) * (SB ? 1 : 2) * (BM + BN) * LDP;
+    constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
+    const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, SMALL_C, SB>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -356,6 +368,16 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
     const int cus = num_cus();
+    // 128x128 tile, single- vs double-buffered operand LDS: one buffer (36.9 KB) lets a third workgroup share the CU, which pays
+    // when prologue/epilogue are a large part of a tile's life (K <= 1024: +3..6 %) or when the grid fits 3 but not 2 workgroups
+    // per CU (the 600-tile RPN GEMM: +6 %); long-K GEMMs lose ~3 % to the second barrier per k-tile and keep two buffers.
+    static const int sb_mode = getenv("ABR_IGEMM_SB") ? atoi(getenv("ABR_IGEMM_SB")) : -1;
+    const bool sb = sb_mode >= 0 ? sb_mode != 0 : (p.K <= 1024 || (t128 > 2 * cus && t128 <= 3 * cus));
+    if (sb && !small_c && p.Cout > 64 && t128 >= 2 * cus) {
+        launch<128, 128, 2, 2, false, true>(p, x, w, out, st, abr::PROF_IGEMM_128x128);
+        ABR_CHECK_LAUNCH("conv_forward");
+        return ABR_OK;
+    }
     if (small_c) {
         launch<128, 64, 4, 1, true>(p, x, w, out, st, abr::PROF_IGEMM_SMALLC);
     } else if (p.Cout > 64 && t128 >= 2 * cus) {
