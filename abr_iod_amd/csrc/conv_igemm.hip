@@ -379,13 +379,13 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
         return ABR_OK;
     }
     if (small_c) {
-        launch<128, 64, 4, 1, true>(p, x, w, out, st, abr::PROF_IGEMM_SMALLC);
+        launch<128, 64, 4, 1, true, true>(p, x, w, out, st, abr::PROF_IGEMM_SMALLC);
     } else if (p.Cout > 64 && t128 >= 2 * cus) {
         launch<128, 128, 2, 2, false>(p, x, w, out, st, abr::PROF_IGEMM_128x128);
-    } else if (t12864 >= 2 * cus || p.Cout <= 64) {
-        launch<128, 64, 4, 1, false>(p, x, w, out, st, abr::PROF_IGEMM_128x64);
+    } else if (t12864 >= 2 * cus || p.Cout <= 64) {  // the smaller tiles are always single-buffered: +7..20 % (128x64), +2 % (64x64)
+        launch<128, 64, 4, 1, false, true>(p, x, w, out, st, abr::PROF_IGEMM_128x64);
     } else {
-        launch<64, 64, 2, 2, false>(p, x, w, out, st, abr::PROF_IGEMM_64x64);
+        launch<64, 64, 2, 2, false, true>(p, x, w, out, st, abr::PROF_IGEMM_64x64);
     }
     ABR_CHECK_LAUNCH("conv_forward");
     return ABR_OK;
