@@ -53,11 +53,14 @@ struct WgP {
     const float* scale;
 };
 
+// SB: single-buffered operand LDS (two barriers per stage, 32 KB instead of 64 KB -> a third resident workgroup per CU)
+template <bool SB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const float* __restrict__ x,
                                                           const float* __restrict__ gy, float* __restrict__ dw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Gs = smem;                    // [2][MR][TN_]
-    float* As = smem + 2 * MR * TN_;     // [2][MR][TK_]
+    constexpr int NBUF = SB ? 1 : 2;
+    float* Gs = smem;                       // [NBUF][MR][TN_]
+    float* As = smem + NBUF * MR * TN_;     // [NBUF][MR][TK_]
 
     const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
     const int split = bid % p.splits;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
     }
     __syncthreads();
     for (int mt = mt0; mt < mt1; mt++) {
-        const int cur = (mt - mt0) & 1;
+        const int cur = SB ? 0 : ((mt - mt0) & 1);
         if (mt + 1 < mt1) load_tile(mt + 1);
         const float* g = Gs + cur * MR * TN_ + wm * 64 + 2 * l31;
         const float* a = As + cur * MR * TK_ + wn * 64 + 2 * l31;
@@ -142,7 +145,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg.y, fa.x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg.y, fa.y, acc[1][1], 0, 0, 0);
         }
-        if (mt + 1 < mt1) store_tile(cur ^ 1);
+        if (SB) {
+            __syncthreads();
+            if (mt + 1 < mt1) store_tile(0);
+        } else if (mt + 1 < mt1) {
+            store_tile(cur ^ 1);
+        }
         __syncthreads();
     }
 
@@ -202,15 +210,20 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     }
     p.splits = splits;
     p.mt_per_split = (m_tiles + splits - 1) / splits;
-    const size_t lds = sizeof(float) * 2 * MR * (TN_ + TK_);
+    // single-buffered by default: every shape of the step is as fast or faster with three resident workgroups per CU (RPN 3x3
+    // 101 -> 109 TF, layer2 3x3 50 -> 62 TF, layer4 +2..3 %); ABR_WGRAD_SB=0 selects the double-buffered variant for comparison
+    static const int sb_mode = getenv("ABR_WGRAD_SB") ? atoi(getenv("ABR_WGRAD_SB")) : 1;
+    const bool sb = sb_mode != 0;
+    const size_t lds = sizeof(float) * (sb ? 1 : 2) * MR * (TN_ + TK_);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(float) * 2 * MR * (TN_ + TK_)));
         attr_set = true;
     }
     const int rec = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
-    conv_wgrad_kernel<<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
+    if (sb) conv_wgrad_kernel<true><<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
+    else conv_wgrad_kernel<false><<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
     abr::prof_stop(abr::as_stream(stream), rec);
     ABR_CHECK_LAUNCH("conv_wgrad");
     return ABR_OK;
