@@ -19,7 +19,15 @@ import torch
 import torch.distributed as dist
 
 from ..distillation.distillation import calculate_attentive_roi_feature_distillation, calculate_roi_distillation_losses
+import os
+
 from ..utils.comm import get_world_size
+
+# Distillation RoIs through layer4 together with the detection RoIs (GeneralizedRCNN.forward_joint).  Off by default: at the
+# benchmark geometry (4 x 512 RoIs = 1024 tiles of 128x128 = exactly 4 per CU) the extra 256 RoIs break the tile quantisation
+# (1152 tiles -> 5 rounds) and the step gets 0.5 ms SLOWER than two separate passes whose small GEMMs overlap with the side-stream
+# weight gradients anyway; it pays when RoI counts are not already multiples of the CU count.
+JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "0") != "0"
 
 
 def reduce_loss_dict(loss_dict):
@@ -51,14 +59,21 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
             if faithful_rng:
                 model_source.roi_heads.box.loss_evaluator.subsample(soften_proposal, targets)
 
-    loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results = \
-        model_target(images, targets, rpn_output_source=rpn_output_source)                                 # :89-90
+    joint = need_source and JOINT_ROI_PASS and hasattr(model_target, "forward_joint")
+    if joint:   # :89-95 as one pass: the distillation RoIs share the detection pass's trip through layer4
+        (loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results), \
+            (target_result, _, roi_align_features_target) = model_target.forward_joint(images, targets, soften_proposal,
+                                                                                       rpn_output_source=rpn_output_source)
+    else:
+        loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results = \
+            model_target(images, targets, rpn_output_source=rpn_output_source)                             # :89-90
     faster_rcnn_losses = sum(loss for loss in loss_dict_target.values())                                   # :91
 
     distillation_losses = torch.zeros((), device=faster_rcnn_losses.device)
     if need_source:
-        target_result, _, roi_align_features_target = model_target.forward(images, targets, features=feature_target,
-                                                                           proposals=soften_proposal)      # :93-95
+        if not joint:
+            target_result, _, roi_align_features_target = model_target.forward(images, targets, features=feature_target,
+                                                                               proposals=soften_proposal)  # :93-95
         if use_id:                                                                                         # :101-103
             distillation_losses = cfg.DIST.ALPHA * calculate_roi_distillation_losses(soften_result, target_result, dist=dist_type,
                                                                                      soften_proposal=None)

@@ -66,6 +66,23 @@ class GeneralizedRCNN(nn.Module):
         losses.update(proposal_losses)
         return losses, features, backbone_features, anchors, rpn_output, result, roi_align_features, soften_results
 
+    def forward_joint(self, images, targets, soften_proposals, rpn_output_source=None):
+        """`forward(images, targets)` followed by `forward(images, targets, features=..., proposals=soften_proposals)`
+        (train_incremental.py:89-95) as ONE pass: the 64 distillation RoIs per image ride along with the 512 detection RoIs through
+        layer4 and the predictor.  Returns (the training 8-tuple, the second call's 3-tuple); same values as the two calls."""
+        if targets is None:
+            raise ValueError("In training mode, targets should be passed")
+        images = to_image_list(images)
+        features, backbone_features = self.backbone(images.tensors)
+        (proposals, proposal_losses), anchors, rpn_output = self.rpn(images, features, targets, rpn_output_source)
+        (x, result, soften_results, detector_losses, roi_align_features), (t_scores, t_bboxes, mask_logits, t_raf) = \
+            self.roi_heads.forward_joint(features, proposals, targets, soften_proposals)
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        return ((losses, features, backbone_features, anchors, rpn_output, result, roi_align_features, soften_results),
+                ((t_scores, t_bboxes), mask_logits, t_raf))
+
     def generate_soften_proposal(self, images, targets=None, selected_indices=None):
         """Source-model pass (model.eval(), under no_grad in the trainer): top-128 by objectness, python `random.sample`
         picks 64 (:140-149).  `selected_indices` (list of index lists) injects that choice for parity tests."""

@@ -67,6 +67,18 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
         return x, roi_align_features
 
 
+    def forward_joint(self, x, det_proposals, soft_proposals):
+        """Detection RoIs and the source model's distillation RoIs through ONE layer4 pass (they share weights and are independent
+        rows of every GEMM): the detection RoIs are pooled on the even bins only, the distillation RoIs on all 7x7 bins (ARD reads
+        them) and then sub-sampled the way layer4's stride-2 1x1 convs would.  -> (head features [Kd+Ks,2048,4,4], detection
+        pooled [Kd,1024,4,4], distillation pooled [Ks,1024,7,7])"""
+        assert self.resolution % 2 == 1 and list(self.head.layer4)[0].stride == 2
+        det = self.pooler(x, det_proposals, bin_step=2)
+        soft = self.pooler(x, soft_proposals, bin_step=1)
+        joint = from_nhwc(torch.cat([as_nhwc(det), as_nhwc(soft)[:, ::2, ::2, :]], 0))
+        return self.head(joint, first_stride=1), det, soft
+
+
 # ------------------------------------------------------------------------------------------------ predictor
 class _PredictorFn(Function):
     @staticmethod
@@ -241,6 +253,7 @@ class FastRCNNLossComputation(object):
             drawn = [self.fg_bg_sampler.sample_padded(lab) for lab in labels]
             cnt = torch.cat([d[2] for d in drawn]).tolist()
             sampled_inds = [torch.cat((d[0][0, :c[0]], d[1][0, :c[1]])).sort()[0] for d, c in zip(drawn, cnt)]  # ascending (:114)
+        self.last_sampled_inds = sampled_inds  # (tests replay a draw through inject_sampled_inds)
         for i, (lab, tgt, p) in enumerate(zip(labels, regression_targets, proposals)):
             p.add_field("labels", lab)
             p.add_field("regression_targets", tgt)
@@ -302,6 +315,21 @@ class ROIBoxHead(nn.Module):
         class_logits, box_regression = fused[:, :K], fused[:, K:K + 4 * self.predictor.num_bbox_reg_classes]
         return (x, proposals, (class_logits, box_regression.reshape(-1, K, 4)),
                 dict(loss_classifier=loss_classifier, loss_box_reg=loss_box_reg), roi_align_features)
+
+    def forward_joint(self, features, proposals, targets, soften_proposals):
+        """training forward (as `forward`) AND the second RoI pass on `soften_proposals` (as `calculate_soften_label`) in one
+        trip through the head: -> (forward's 5-tuple, (soften_scores, soften_bboxes, roi_align_features [Ks,1024,7,7]))."""
+        with torch.no_grad():
+            proposals = self.loss_evaluator.subsample(proposals, targets)
+        x, raf_det, raf_soft = self.feature_extractor.forward_joint(features, proposals, soften_proposals)
+        fused = self.predictor.forward_fused(x)
+        K, R4 = self.predictor.num_classes, 4 * self.predictor.num_bbox_reg_classes
+        kd = sum(len(p) for p in proposals)
+        det, soft = fused[:kd], fused[kd:]
+        loss_classifier, loss_box_reg = self.loss_evaluator(K, None, fused=det)
+        first = (x[:kd], proposals, (det[:, :K], det[:, K:K + R4].reshape(-1, K, 4)),
+                 dict(loss_classifier=loss_classifier, loss_box_reg=loss_box_reg), raf_det)
+        return first, (soft[:, :K], soft[:, K:K + R4].reshape(-1, K, 4), raf_soft)
 
     def calculate_soften_label(self, features, proposals, targets=None):
         """box_head.py:60-78 -> (soften_scores [K,Kc], soften_bboxes [K,Kc,4], x, roi_align_features [K,1024,7,7])"""

@@ -21,6 +21,11 @@ class CombinedROIHeads(torch.nn.ModuleDict):
         losses.update(loss_box)
         return x, detections, soft_res, losses, roi_align_features
 
+    def forward_joint(self, features, proposals, targets, soften_proposals):
+        """training forward + calculate_soften_label(features, soften_proposals) sharing one head pass"""
+        (x, detections, soft_res, loss_box, raf), (s_score, s_bbox, s_raf) = self.box.forward_joint(features, proposals, targets, soften_proposals)
+        return (x, detections, soft_res, dict(loss_box), raf), (s_score, s_bbox, None, s_raf)
+
     def calculate_soften_label(self, features, proposals, targets=None):
         """-> (soften_score, soften_bbox, mask_logits=None, roi_align_features)  (roi_heads.py:65-72)"""
         soften_score, soften_bbox, _, roi_align_features = self.box.calculate_soften_label(features, proposals, targets)

@@ -193,3 +193,53 @@ def test_sgd_step_matches_torch_sgd(step_state):
     opt.step()
     for (n, p), r in zip(named, ref_p):
         assert torch.allclose(p.detach(), r.detach(), rtol=1e-6, atol=1e-7), n
+
+
+def test_joint_roi_pass_equals_two_calls(step_state):
+    """engine.trainer's default: the 64 distillation RoIs ride through layer4 with the 512 detection RoIs
+    (GeneralizedRCNN.forward_joint).  Same sampler draws injected -> the same losses, second-pass outputs and gradients as
+    `mt(images, targets)` followed by `mt.forward(..., features=, proposals=)` (train_incremental.py:89-95)."""
+    from abr_iod_amd.distillation.distillation import calculate_attentive_roi_feature_distillation, calculate_roi_distillation_losses
+    S = step_state
+    ms, mt, images, targets, cfg = S["ms"], S["mt"], S["images"], S["targets"], S["cfg_t"]
+    with torch.no_grad():
+        soften_result, _, soften_proposal, _, _, _, _, raf_s = ms.generate_soften_proposal(images)
+
+    def total_of(loss_dict, target_result, raf_t):
+        l_id = calculate_roi_distillation_losses(soften_result, target_result, dist="id")
+        l_ard = calculate_attentive_roi_feature_distillation(raf_s, raf_t, gamma=cfg.DIST.GAMMA)
+        return sum(loss_dict.values()) + cfg.DIST.ALPHA * l_id + cfg.DIST.BETA * l_ard, float(l_id), float(l_ard)
+
+    # run 1: two calls; record what the samplers drew
+    mt.flat.zero_grad()
+    loss_dict, feat_t, _, _, _, props, _, soft_res = mt(images, targets)
+    target_result, _, raf_t = mt.forward(images, targets, features=feat_t, proposals=soften_proposal)
+    total, l_id, l_ard = total_of(loss_dict, target_result, raf_t)
+    total.backward()
+    torch.cuda.synchronize()
+    g1 = mt.flat.grads.clone()
+    ev_rpn, ev_box = mt.rpn.loss_evaluator, mt.roi_heads.box.loss_evaluator
+    pos_idx, samp_idx = ev_rpn.last_sampled
+    # run 2: the joint pass with the same draws
+    ev_rpn.inject_sampled = (pos_idx[pos_idx >= 0], samp_idx[samp_idx >= 0])
+    ev_box.inject_sampled_inds = ev_box.last_sampled_inds
+    try:
+        mt.flat.zero_grad()
+        (loss_dict2, _, _, _, _, props2, _, soft_res2), (target_result2, _, raf_t2) = mt.forward_joint(images, targets, soften_proposal)
+        total2, l_id2, l_ard2 = total_of(loss_dict2, target_result2, raf_t2)
+        total2.backward()
+        torch.cuda.synchronize()
+    finally:
+        ev_rpn.inject_sampled = None
+        ev_box.inject_sampled_inds = None
+    for p, q in zip(props, props2):
+        assert torch.equal(p.bbox, q.bbox)
+    for k in loss_dict:
+        assert _close(float(loss_dict2[k]), float(loss_dict[k]), 1e-6), k
+    assert _close(l_id2, l_id, 1e-6) and _close(l_ard2, l_ard, 1e-6)
+    assert torch.equal(raf_t2, raf_t)                                     # same ROIAlign launch on the same features
+    np.testing.assert_allclose(target_result2[0].detach().cpu().numpy(), target_result[0].detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(soft_res2[0].detach().cpu().numpy(), soft_res[0].detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    g2 = mt.flat.grads
+    rel = float((g2 - g1).norm() / g1.norm())
+    assert rel < 1e-5, rel
