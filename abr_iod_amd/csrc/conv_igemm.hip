@@ -19,6 +19,8 @@
 // (issue loads for tile t+1, run the 16*TM*TN MFMAs of tile t, then write LDS): one barrier per k-tile.
 // fp32 MFMA is bit-for-bit an fmaf chain, so results are exact-fp32 (no TF32/bf16 anywhere).
 // Bound: MFMA (157.3 TFLOP/s fp32 matrix peak); DESIGN.md has the per-layer flop counts.
+#include <map>
+
 #include "common.h"
 
 namespace {
@@ -55,6 +57,12 @@ struct ConvP {
     const float* bias;
     const float* residual;
     const float* mask;
+    // split-K for badly quantised grids: tiles [0, n_full) are computed whole, every later tile by `split` workgroups that each take
+    // a contiguous K range, park their partial accumulators in `ws` and let the LAST one to arrive (ticket in `cnt`) add them up in
+    // fixed order and run the epilogue.
+    int n_full, split;
+    float* ws;
+    int* cnt;
 };
 
 
@@ -144,8 +152,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     float* As = smem;                        // [NBUF][BM][LDP]
     float* Bs = smem + NBUF * BM * LDP;      // [NBUF][BN][LDP]
 
-    const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+    int tile, unit = -1, kt0 = 0, kt1 = (p.K + BK - 1) / BK;
+    if ((int)blockIdx.x < p.n_full) {
+        tile = (int)abr::xcd_remap(blockIdx.x, (unsigned)p.n_full);
+    } else {  // the split tiles are the LAST workgroups of the grid: they start when the whole tiles have claimed their CUs
+        unit = (int)blockIdx.x - p.n_full;
+        tile = p.n_full + unit / p.split;
+        const int si = unit % p.split, nk_all = kt1;
+        kt0 = (int)((long)si * nk_all / p.split);
+        kt1 = (int)((long)(si + 1) * nk_all / p.split);
+    }
+    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -227,16 +244,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
     const int l31 = lane & 31, lh = lane >> 5;
     const int a_row0 = wm * (TM * 32) + l31, b_row0 = wn * (TN * 32) + l31;
 
-    load_tile(0);
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = SB ? 0 : (kt & 1);
-        if (kt + 1 < nk) load_tile(kt + 1);
+    for (int kt = kt0; kt < kt1; kt++) {
+        const int cur = SB ? 0 : ((kt - kt0) & 1);
+        if (kt + 1 < kt1) load_tile(kt + 1);
         const float* a = As + cur * BM * LDP + a_row0 * LDP + lh * 4;
         const float* b = Bs + cur * BN * LDP + b_row0 * LDP + lh * 4;
 #pragma unroll
@@ -258,11 +274,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
         }
         if (SB) {
             __syncthreads();  // every wave is done reading the tile before it is overwritten
-            if (kt + 1 < nk) store_tile(0);
-        } else if (kt + 1 < nk) {
+            if (kt + 1 < kt1) store_tile(0);
+        } else if (kt + 1 < kt1) {
             store_tile(cur ^ 1);
         }
         __syncthreads();
+    }
+
+    if (unit >= 0) {
+        // ---- split tile: park the partial sums (thread-major: one coalesced 1 KB store per accumulator register), take a ticket,
+        // and only the last arrival goes on.  It re-reads ALL `split` partials in index order -- its own included -- so the sum is
+        // the same whichever workgroup happens to finish last (deterministic), then resets the ticket for the next launch.
+        constexpr int NR = TM * TN * 16;
+        float* mine = p.ws + (size_t)unit * (NR * 256) + tid;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)  // agent-scope (sc1, write-through) stores: visible to the other XCDs without flushing L2
+                    __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 256, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // = wait for this wave's stores; no cache maintenance
+        __syncthreads();
+        __shared__ int s_last;
+        const int st = unit / p.split;  // index of this split tile
+        if (tid == 0) s_last = atomicAdd(p.cnt + st, 1) == p.split - 1;
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) p.cnt[st] = 0;
+        const float* all = p.ws + (size_t)st * p.split * (NR * 256) + tid;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    float v = 0.f;
+                    for (int q = 0; q < p.split; q++)  // agent-scope loads: served from the coherent level, not a stale local L2 line
+                        v += __hip_atomic_load(all + (size_t)q * (NR * 256) + ((i * TN + j) * 16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc[i][j][r] = v;
+                }
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col(n) = lane&31, row(m) = (r&3) + 8*(r>>2) + 4*(lane>>5): a lane holds ONE
@@ -273,11 +324,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
 }
 
+// split-K scratch: partial tiles (64 KB each for 128x128) + tickets, one set per stream (streams may run convs concurrently)
+struct SplitWs { float* ws = nullptr; int* cnt = nullptr; };
+constexpr int kMaxSplitUnits = 1024, kMaxSplitTiles = 512;
+static SplitWs* split_ws(hipStream_t st) {
+    static std::map<hipStream_t, SplitWs> pool;
+    SplitWs& w = pool[st];
+    if (!w.ws) {
+        if (hipMalloc(&w.ws, (size_t)kMaxSplitUnits * 128 * 128 * sizeof(float)) != hipSuccess) return nullptr;
+        if (hipMalloc(&w.cnt, kMaxSplitTiles * sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemset(w.cnt, 0, kMaxSplitTiles * sizeof(int)) != hipSuccess) return nullptr;
+    }
+    return &w;
+}
+
 template <int BM, int BN, int WM, int WN, bool SMALL_C, bool SB = false>
-int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st, int prof_id) {
+int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st, int prof_id, int n_full = -1, int split = 1) {
     ConvP q = p;
     q.tiles_m = (p.M + BM - 1) / BM;
     q.tiles_n = (p.Cout + BN - 1) / BN;
+    const int tiles = q.tiles_m * q.tiles_n;
+    q.n_full = (split > 1 && n_full >= 0) ? n_full : tiles;
+    q.split = split > 1 ? split : 1;
+    q.ws = nullptr; q.cnt = nullptr;
+    const int n_split = tiles - q.n_full;
+    if (n_split > 0) {
+        SplitWs* sw = (n_split * q.split <= kMaxSplitUnits && n_split <= kMaxSplitTiles) ? split_ws(st) : nullptr;
+        if (sw) { q.ws = sw->ws; q.cnt = sw->cnt; }
+        else { q.n_full = tiles; q.split = 1; }  // no scratch: plain launch
+    }
     constexpr size_t lds_op = sizeof(float) * (SB ? 1 : 2) * (BM + BN) * LDP;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
     const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
@@ -288,7 +363,7 @@ int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream
         attr_set = true;
     }
     const int rec = abr::prof_start(st, prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
-    kern<<<(unsigned)(q.tiles_m * q.tiles_n), 256, lds, st>>>(q, x, w, out);
+    kern<<<(unsigned)(q.n_full + (tiles - q.n_full) * q.split), 256, lds, st>>>(q, x, w, out);
     abr::prof_stop(st, rec);
     return 0;
 }
@@ -368,21 +443,46 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
     const int cus = num_cus();
+    // ---- split-K plan for the 128x128 tile (see ConvP::n_full).  Per-CU cost model in k-iterations: workgroups on one CU share
+    // its MFMA pipe, so a grid costs ceil(tiles / CUs) tile-times; splitting the LAST tiles (or all of them when there are fewer
+    // tiles than CUs) by s evens the rounds out at the price of the partial-sum round trip per unit.
+    static const int split_mode = getenv("ABR_IGEMM_SPLIT") ? atoi(getenv("ABR_IGEMM_SPLIT")) : 1;
+    const int nk = (p.K + BK - 1) / BK;
+    int best_nfull = -1, best_s = 1;
+    double cost128 = (double)((t128 + cus - 1) / cus) * nk;
+    if (split_mode && !small_c && p.Cout > 64) {
+        // Measured (tools/microbench.py): the RPN 3x3 (600 tiles, K = 9216) goes 101 -> 121 TF with its last 88 tiles split in two;
+        // GEMMs with K <= 4608 per tile LOSE (the partial-sum round trip costs ~25 k-iterations, not 6: layer3 3x3 84 -> 70 TF,
+        // layer2 3x3 82 -> 76), and so does splitting every tile of a grid smaller than the chip (64x64 tiles quantise better there).
+        // Hence: tail split only, >= 32 k-iterations per unit, overhead 24.
+        const long nfull = (t128 / cus) * cus, tail = t128 - nfull;
+        for (int sp = 2; sp <= 6 && tail > 0 && nfull > 0; sp++) {
+            if (nk / sp < 32 || tail * sp > kMaxSplitUnits || tail > kMaxSplitTiles) break;
+            const double c = (double)(nfull / cus) * nk + (double)((tail * sp + cus - 1) / cus) * ((double)nk / sp + 24.0);
+            if (c < cost128 * 0.93) { cost128 = c; best_nfull = (int)nfull; best_s = sp; }
+        }
+    }
+    // relative cost of the tile configurations the rules below would pick (work per tile x measured efficiency of the smaller tiles)
+    const int64_t t64 = (int64_t)((p.M + 63) / 64) * ((p.Cout + 63) / 64);
+    const double cost12864 = (double)((t12864 + cus - 1) / cus) * nk * 0.5 / 0.85;
+    const double cost64 = (double)((t64 + cus - 1) / cus) * nk * 0.25 / 0.80;
+    const bool rule128 = p.Cout > 64 && t128 >= 2 * cus;
+    const bool rule12864 = !rule128 && (t12864 >= 2 * cus || p.Cout <= 64);
+    const bool take_split128 = best_s > 1 && (rule128 || cost128 < 0.9 * (rule12864 ? cost12864 : cost64));
+
     // 128x128 tile, single- vs double-buffered operand LDS: one buffer (36.9 KB) lets a third workgroup share the CU, which pays
     // when prologue/epilogue are a large part of a tile's life (K <= 1024: +3..6 %) or when the grid fits 3 but not 2 workgroups
     // per CU (the 600-tile RPN GEMM: +6 %); long-K GEMMs lose ~3 % to the second barrier per k-tile and keep two buffers.
     static const int sb_mode = getenv("ABR_IGEMM_SB") ? atoi(getenv("ABR_IGEMM_SB")) : -1;
-    const bool sb = sb_mode >= 0 ? sb_mode != 0 : (p.K <= 1024 || (t128 > 2 * cus && t128 <= 3 * cus));
-    if (sb && !small_c && p.Cout > 64 && t128 >= 2 * cus) {
-        launch<128, 128, 2, 2, false, true>(p, x, w, out, st, abr::PROF_IGEMM_128x128);
-        ABR_CHECK_LAUNCH("conv_forward");
-        return ABR_OK;
-    }
+    const int64_t wgs128 = take_split128 ? best_nfull + (t128 - best_nfull) * best_s : t128;
+    const bool sb = sb_mode >= 0 ? sb_mode != 0 : (p.K <= 1024 || (wgs128 > 2 * cus && wgs128 <= 3 * cus) || take_split128);
     if (small_c) {
         launch<128, 64, 4, 1, true, true>(p, x, w, out, st, abr::PROF_IGEMM_SMALLC);
-    } else if (p.Cout > 64 && t128 >= 2 * cus) {
-        launch<128, 128, 2, 2, false>(p, x, w, out, st, abr::PROF_IGEMM_128x128);
-    } else if (t12864 >= 2 * cus || p.Cout <= 64) {  // the smaller tiles are always single-buffered: +7..20 % (128x64), +2 % (64x64)
+    } else if (rule128 || take_split128) {
+        const int nf = take_split128 ? best_nfull : -1, sp = take_split128 ? best_s : 1;
+        if (sb) launch<128, 128, 2, 2, false, true>(p, x, w, out, st, abr::PROF_IGEMM_128x128, nf, sp);
+        else launch<128, 128, 2, 2, false, false>(p, x, w, out, st, abr::PROF_IGEMM_128x128, nf, sp);
+    } else if (rule12864) {  // the smaller tiles are always single-buffered: +7..20 % (128x64), +2 % (64x64)
         launch<128, 64, 4, 1, false, true>(p, x, w, out, st, abr::PROF_IGEMM_128x64);
     } else {
         launch<64, 64, 2, 2, false, true>(p, x, w, out, st, abr::PROF_IGEMM_64x64);

@@ -439,3 +439,23 @@ def test_topk_sigmoid_matches_torch():
         same = (idx == ref_i)
         assert same[:, 1:-1][strict[:, :-1] & strict[:, 1:]].float().mean() > 0.999
     assert idx[0, :50].tolist() == sorted(idx[0, :50].tolist())               # tie group: ascending index
+
+
+def test_conv_split_k_equals_unsplit(tmp_path):
+    """abr_conv_forward splits the K range of badly quantised tiles over several workgroups (partial sums + last-arrival reduce).
+    Same inputs with the plan disabled (ABR_IGEMM_SPLIT=0, read once per process -> two child processes): equal up to fp32
+    re-association, and bitwise reproducible run to run (checked inside the child)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ("0", "1"):
+        f = str(tmp_path / ("split%s.npz" % mode))
+        env = dict(os.environ, ABR_IGEMM_SPLIT=mode)
+        subprocess.run([sys.executable, os.path.join(root, "tools", "conv_split_check.py"), f], check=True, env=env, timeout=600)
+        outs.append(np.load(f))
+    for k in outs[0].files:
+        a, b = outs[0][k], outs[1][k]
+        assert a.shape == b.shape
+        np.testing.assert_allclose(b, a, rtol=2e-5, atol=2e-5 * float(np.abs(a).max()))
