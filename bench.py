@@ -36,12 +36,17 @@ def cpu_baseline(model_target, images, targets, n_old):
     img = images[:1].cpu()
     gtb = [targets[0].bbox.cpu().numpy()]
     gtl = [targets[0].get_field("labels").cpu().numpy()]
-    tm = {}
-    cpu_forward_loss(sd, img, gtb, gtl, n_old, timings=tm)
-    return {"value": round(1.0 / tm["total"], 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "1 synthetic 600x1000 image, target-model forward + 4 detector losses only (the reference has no CPU "
-                      "backward: csrc/ROIAlign.h:44), torch-CPU convs + oracle.c ROIAlign/NMS single-threaded as the reference",
-            "seconds": {k: round(v, 3) for k, v in tm.items()}}
+    cpu_forward_loss(sd, img, gtb, gtl, n_old, timings={})  # warm-up (thread pools, oneDNN primitive caches)
+    reps, acc = 12, {}     # ~10 s of host work: a bounded sample, the same image each time
+    for _ in range(reps):
+        tm = {}
+        cpu_forward_loss(sd, img, gtb, gtl, n_old, timings=tm)
+        for k, v in tm.items():
+            acc[k] = acc.get(k, 0.0) + v
+    return {"value": round(reps / acc["total"], 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "{} passes over 1 synthetic 600x1000 image, target-model forward + 4 detector losses only (the reference has no "
+                      "CPU backward: csrc/ROIAlign.h:44), torch-CPU convs + oracle.c ROIAlign/NMS single-threaded as the reference".format(reps),
+            "seconds_per_image": {k: round(v / reps, 3) for k, v in acc.items()}}
 
 
 def main():
@@ -133,11 +138,14 @@ def main():
             dom = max(prof, key=lambda r: r[2] + r[5])  # by total kernel time
             if os.path.exists(pmc_file):  # HBM bytes/launch from separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.sh)
                 pk = json.load(open(pmc_file))["kernels"]
-                key = {"conv_igemm_kernel<128,128>": "conv_igemm_kernel<128, 128, 2, 2, false>", "conv_wgrad_kernel": "conv_wgrad_kernel",
-                       "conv_igemm_kernel<64,64>": "conv_igemm_kernel<64, 64, 2, 2, false>",
-                       "conv_igemm_kernel<128,64>": "conv_igemm_kernel<128, 64, 4, 1, false>"}.get(dom[0])
-                if key in pk:
-                    traffic, traffic_src = pk[key]["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+                prefix = {"conv_igemm_kernel<128,128>": "conv_igemm_kernel<128, 128,", "conv_wgrad_kernel": "conv_wgrad_kernel",
+                          "conv_igemm_kernel<64,64>": "conv_igemm_kernel<64, 64,", "conv_igemm_kernel<128,64>": "conv_igemm_kernel<128, 64, 4, 1, false"}.get(dom[0])
+                # the kernel has single-/double-buffered template instances: launch-weighted mean over all of them
+                hits = [v for k, v in pk.items() if prefix and k.startswith(prefix)]
+                if hits:
+                    n_l = sum(v["launches"] for v in hits)
+                    traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / max(n_l, 1))
+                    traffic_src = "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
 
             def tf(fl, ms):
                 return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0
