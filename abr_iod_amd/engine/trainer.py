@@ -27,6 +27,7 @@ from ..utils.comm import get_world_size
 # benchmark geometry (4 x 512 RoIs = 1024 tiles of 128x128 = exactly 4 per CU) the extra 256 RoIs break the tile quantisation
 # (1152 tiles -> 5 rounds) and the step gets 0.5 ms SLOWER than two separate passes whose small GEMMs overlap with the side-stream
 # weight gradients anyway; it pays when RoI counts are not already multiples of the CU count.
+SOURCE_OVERLAP = os.environ.get("ABR_SOURCE_OVERLAP", "1") != "0"
 JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "0") != "0"
 
 
@@ -52,14 +53,21 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
     need_source = use_id or use_ard or cfg.DIST.RPN or cfg.DIST.FEAT == "std"
 
     soften_result = soften_proposal = roi_align_features_source = rpn_output_source = None
+    deferred = None
     if need_source:
         with torch.no_grad():                                                                              # :82-86
-            soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
-                model_source.generate_soften_proposal(images)
-            if faithful_rng:
-                model_source.roi_heads.box.loss_evaluator.subsample(soften_proposal, targets)
+            on_gpu = (images.tensors if hasattr(images, "tensors") else images).is_cuda
+            if SOURCE_OVERLAP and not faithful_rng and on_gpu and hasattr(model_source, "soften_begin") and not model_source.training:
+                # source backbone + RPN head now, its proposal selection on a side stream; finished after the target's forward
+                deferred = model_source.soften_begin(images)
+                rpn_output_source = deferred["rpn_output"]
+            else:
+                soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
+                    model_source.generate_soften_proposal(images)
+                if faithful_rng:
+                    model_source.roi_heads.box.loss_evaluator.subsample(soften_proposal, targets)
 
-    joint = need_source and JOINT_ROI_PASS and hasattr(model_target, "forward_joint")
+    joint = need_source and JOINT_ROI_PASS and deferred is None and hasattr(model_target, "forward_joint")
     if joint:   # :89-95 as one pass: the distillation RoIs share the detection pass's trip through layer4
         (loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results), \
             (target_result, _, roi_align_features_target) = model_target.forward_joint(images, targets, soften_proposal,
@@ -68,6 +76,10 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results = \
             model_target(images, targets, rpn_output_source=rpn_output_source)                             # :89-90
     faster_rcnn_losses = sum(loss for loss in loss_dict_target.values())                                   # :91
+    if deferred is not None:
+        with torch.no_grad():
+            soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
+                model_source.soften_finish(deferred)
 
     distillation_losses = torch.zeros((), device=faster_rcnn_losses.device)
     if need_source:

@@ -86,9 +86,33 @@ class GeneralizedRCNN(nn.Module):
     def generate_soften_proposal(self, images, targets=None, selected_indices=None):
         """Source-model pass (model.eval(), under no_grad in the trainer): top-128 by objectness, python `random.sample`
         picks 64 (:140-149).  `selected_indices` (list of index lists) injects that choice for parity tests."""
+        if not self.training and targets is None:
+            return self.soften_finish(self.soften_begin(images, defer=False), selected_indices)
         images = to_image_list(images)
         features, backbone_features = self.backbone(images.tensors)
         (all_proposals, _), anchors, rpn_output = self.rpn(images, features, targets)
+        return self._soften_from_proposals(all_proposals, features, backbone_features, anchors, rpn_output, selected_indices)
+
+    def soften_begin(self, images, defer=True):
+        """First half of generate_soften_proposal for the frozen source model: backbone + RPN head on the current stream, the
+        proposal selection (top-k, decode, NMS) on a side stream with nothing read back.  The trainer enqueues the target model's
+        forward between `soften_begin` and `soften_finish`, so the selection's latency-bound kernels hide behind the target's
+        backbone convolutions."""
+        assert not self.training, "the soften pass runs the source model in eval mode (train_incremental.py:80)"
+        images = to_image_list(images)
+        features, backbone_features = self.backbone(images.tensors)
+        (pending, _), anchors, rpn_output = self.rpn(images, features, None, defer_proposals=defer and images.tensors.is_cuda)
+        return dict(features=features, backbone_features=backbone_features, pending=pending, anchors=anchors, rpn_output=rpn_output)
+
+    def soften_finish(self, state, selected_indices=None):
+        pending = state["pending"]
+        if isinstance(pending, dict):   # deferred: join the side stream, read the keep counts, cut the BoxLists
+            sel = self.rpn.box_selector_test
+            pending = sel.collect(sel.join(pending))
+        return self._soften_from_proposals(pending, state["features"], state["backbone_features"], state["anchors"],
+                                           state["rpn_output"], selected_indices)
+
+    def _soften_from_proposals(self, all_proposals, features, backbone_features, anchors, rpn_output, selected_indices=None):
         all_selected = []
         for k, props in enumerate(all_proposals):
             order = props.get_field("objectness").sort(descending=True)[1]

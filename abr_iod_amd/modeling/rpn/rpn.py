@@ -18,6 +18,8 @@ MI355X-first differences (results identical):
 import math
 
 import numpy as np
+import os
+
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -50,6 +52,9 @@ def generate_anchors(stride=16, sizes=(32, 64, 128, 256, 512), aspect_ratios=(0.
             w, h = w0 * sc, h0 * sc
             out.append([cx - 0.5 * (w - 1), cy - 0.5 * (h - 1), cx + 0.5 * (w - 1), cy + 0.5 * (h - 1)])
     return torch.tensor(np.array(out, dtype=np.float64)).float()
+
+
+PROPOSALS_SIDE_STREAM = os.environ.get("ABR_PROPOSAL_STREAM", "1") != "0"
 
 
 class AnchorGenerator(nn.Module):
@@ -231,8 +236,9 @@ class RPNPostProcessor(nn.Module):
             out.append(b)
         return out
 
-    def forward_fused(self, anchors, fused, num_anchors, targets=None):
-        """fused: logical [N,5A(+pad),H,W] head output.  anchors: list (per image) of [BoxList] as AnchorGenerator returns."""
+    def launch(self, anchors, fused, num_anchors):
+        """Device half of forward_fused: top-k -> decode -> clip -> NMS, all enqueued on the CURRENT stream, nothing read back.
+        Returns the pending state for `collect`."""
         y = as_nhwc(fused)
         N, H, W, Cf = y.shape
         A = num_anchors
@@ -251,16 +257,49 @@ class RPNPostProcessor(nn.Module):
         if self.min_size > 0:  # remove_small_boxes (boxlist_ops.py:34-48): with MIN_SIZE=0 (every voc config) nothing is dropped
             raise NotImplementedError("RPN.MIN_SIZE > 0 is not used by any configs/voc YAML")
         keep, n_keep = ops.nms_sorted_batched(props, counts, self.nms_thresh, self.post_nms_top_n)     # :113-116
-        nk = n_keep.tolist()  # the only host sync of the proposal path (the reference syncs inside every nms call)
+        return dict(props=props, scores=scores, keep=keep, n_keep=n_keep, sizes=[a[0].size for a in anchors], fused=yf)
+
+    def collect(self, pending, targets=None):
+        """Host half: read the per-image keep counts (the only host sync of the proposal path; the reference syncs inside every
+        nms call) and cut the BoxLists."""
+        props, scores, keep = pending["props"], pending["scores"], pending["keep"]
+        nk = pending["n_keep"].tolist()
         result = []
-        for i in range(N):
+        for i, size in enumerate(pending["sizes"]):
             ki = keep[i, : nk[i]].long()
-            b = BoxList(props[i].index_select(0, ki), anchors[i][0].size, mode="xyxy")
+            b = BoxList(props[i].index_select(0, ki), size, mode="xyxy")
             b.add_field("objectness", scores[i].index_select(0, ki))
             result.append(b)
         if self.training and targets is not None:
             result = self.add_gt_proposals(result, targets)                               # :144-145
         return result
+
+    def launch_on_side_stream(self, anchors, fused, num_anchors, tag="proposals"):
+        """`launch` on a side stream: the selection is a chain of latency-bound kernels (a 1024-thread top-k and a one-workgroup-per-
+        image NMS sweep, ~0.9 ms with a handful of CUs busy) that has no consumer until `collect`, so it runs NEXT to whatever the
+        caller enqueues on the current stream meanwhile (the RPN loss; for the frozen source model, the target's whole backbone)."""
+        cur = torch.cuda.current_stream()
+        side = ops.side_stream((fused.device.index, tag))
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            pending = self.launch(anchors, fused, num_anchors)
+        fused.record_stream(side)
+        pending["stream"] = side
+        return pending
+
+    def join(self, pending):
+        """Make the current stream (and the caching allocator) see the side stream's results."""
+        side = pending.pop("stream", None)
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(side)
+            for k in ("props", "scores", "keep", "n_keep"):
+                pending[k].record_stream(cur)
+        return pending
+
+    def forward_fused(self, anchors, fused, num_anchors, targets=None):
+        """fused: logical [N,5A(+pad),H,W] head output.  anchors: list (per image) of [BoxList] as AnchorGenerator returns."""
+        return self.collect(self.launch(anchors, fused, num_anchors), targets)
 
     def forward(self, anchors, objectness, box_regression, targets=None):
         """reference signature (lists of logical [N,A,H,W] / [N,4A,H,W]); re-fuses the two tensors (compat path)."""
@@ -375,7 +414,7 @@ class RPNModule(nn.Module):
         self.box_selector_test = make_rpn_postprocessor(cfg, rpn_box_coder, is_train=False)
         self.loss_evaluator = make_rpn_loss_evaluator(cfg, rpn_box_coder)
 
-    def forward(self, images, features, targets=None, rpn_output_source=None):
+    def forward(self, images, features, targets=None, rpn_output_source=None, defer_proposals=False):
         """-> ((boxes, losses), anchors, rpn_output) exactly as rpn.py:161-183."""
         fused = self.head.forward_fused(features[0])
         A = self.head.num_anchors
@@ -384,10 +423,18 @@ class RPNModule(nn.Module):
         if self.training:
             with torch.no_grad():
                 self.box_selector_train.train()
-                boxes = self.box_selector_train.forward_fused(anchors, fused.detach(), A, targets)
+                if PROPOSALS_SIDE_STREAM and fused.is_cuda:   # selection runs next to the loss kernels below
+                    pending = self.box_selector_train.launch_on_side_stream(anchors, fused.detach(), A)
+                else:
+                    pending = self.box_selector_train.launch(anchors, fused.detach(), A)
             loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, None, None, targets, rpn_output_source, fused=fused)
+            with torch.no_grad():
+                boxes = self.box_selector_train.collect(self.box_selector_train.join(pending), targets)
             return (boxes, {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}), anchors, rpn_output
         self.box_selector_test.eval()
+        if defer_proposals:   # the caller collects later (GeneralizedRCNN.soften_begin / soften_finish)
+            pending = self.box_selector_test.launch_on_side_stream(anchors, fused, A, tag="source-proposals")
+            return (pending, {}), anchors, rpn_output
         boxes = self.box_selector_test.forward_fused(anchors, fused, A)
         return (boxes, {}), anchors, rpn_output
 
