@@ -63,6 +63,7 @@ struct ConvP {
     int n_full, split;
     float* ws;
     int* cnt;
+    unsigned x_bytes, w_bytes;  // extents for the buffer-load range check
 };
 
 
@@ -170,8 +171,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     // ---- staging assignment: slot = tid + 256*i -> (row = slot/8, kq = slot%8)
     const int kq = tid & 7;
     const int srow = tid >> 3;  // 0..31 ; rows srow + 32*i
-    int a_hi0[NA], a_wi0[NA];
-    const float* a_base[NA];
+    // Operand fetch goes through BUFFER loads: 32-bit byte offsets against a resource descriptor whose range check returns zeros
+    // for anything outside [0, bytes) -- halo taps, rows past M / Cout and the K tail are given the offset kOOB and need neither a
+    // branch nor an exec mask, and the per-load address arithmetic is one add (was a 64-bit multiply-add chain inside an
+    // exec-masked block per load: 87 VALU + 8 branches per k-tile; now the loads schedule into the shadow of the MFMAs).
+    // Tensors on this path are < 2 GB (checked on the host), so offsets fit and kOOB = 2^31 is always out of range.
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, p.w_bytes, 0x00020000);
+    int a_hi0[NA], a_wi0[NA], a_off0[NA];  // a_off0: element offset of (b, hi0, wi0, kq*4); may be "negative" for halo rows
     bool a_ok[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
@@ -183,30 +191,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
         p.d_wo.divmod(rem, ho, wo);
         a_hi0[i] = (int)ho * p.stride - p.pad;
         a_wi0[i] = (int)wo * p.stride - p.pad;
-        a_base[i] = x + (size_t)b * p.H * p.W * p.Cin;
+        a_off0[i] = (((int)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + (SMALL_C ? 0 : kq * 4);
     }
-    const float* b_ptr[NB];
-    bool b_ok[NB];
+    unsigned b_off0[NB];  // byte offset of (n, kq*4), or kOOB for rows past Cout
 #pragma unroll
     for (int i = 0; i < NB; i++) {
         const int n = n0 + srow + 32 * i;
-        b_ok[i] = n < p.Cout;
-        b_ptr[i] = w + (size_t)(b_ok[i] ? n : 0) * p.K + kq * 4;
+        b_off0[i] = n < p.Cout ? (unsigned)(n * p.K + kq * 4) * 4u : kOOB;
     }
 
     float4 ra[NA], rb[NB];
+    auto fetch = [&](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) -> float4 {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
         if (!SMALL_C) {
             unsigned rs, c0, r, s;
             p.d_cin.divmod((unsigned)k0, rs, c0);
             p.d_s.divmod(rs, r, s);
+            const int delta = ((int)r * p.W + (int)s) * p.Cin + (int)c0;  // same for every row of the tile (scalar)
 #pragma unroll
             for (int i = 0; i < NA; i++) {
                 const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
                 const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                ra[i] = ok ? *reinterpret_cast<const float4*>(a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + c0 + kq * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[i] = fetch(rx, ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB, 0);
             }
         } else {
             const int k = k0 + kq * 4;
@@ -218,14 +229,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
             for (int i = 0; i < NA; i++) {
                 const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
                 const bool ok = kin && a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                ra[i] = ok ? *reinterpret_cast<const float4*>(a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + c)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[i] = fetch(rx, ok ? (unsigned)(a_off0[i] + ((int)r * p.W + (int)s) * p.Cin + (int)c) * 4u : kOOB, 0);
             }
         }
+        // weights: rows are K floats long; the K tail (only the stem has one) is cut by the descriptor's range for the last row and
+        // by `kin` for the others
         const bool kin = k0 + kq * 4 < p.K;
 #pragma unroll
-        for (int i = 0; i < NB; i++)
-            rb[i] = (b_ok[i] && kin) ? *reinterpret_cast<const float4*>(b_ptr[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < NB; i++) rb[i] = fetch(rw, kin ? b_off0[i] : kOOB, k0 * 4);
     };
     auto store_tile = [&](int buf) {
         float* a = As + buf * BM * LDP;
@@ -247,12 +258,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     const int l31 = lane & 31, lh = lane >> 5;
     const int a_row0 = wm * (TM * 32) + l31, b_row0 = wn * (TN * 32) + l31;
 
-    load_tile(kt0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; kt++) {
-        const int cur = SB ? 0 : ((kt - kt0) & 1);
-        if (kt + 1 < kt1) load_tile(kt + 1);
+    auto compute_tile = [&](int cur) {
         const float* a = As + cur * BM * LDP + a_row0 * LDP + lh * 4;
         const float* b = Bs + cur * BN * LDP + b_row0 * LDP + lh * 4;
 #pragma unroll
@@ -272,14 +278,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (SB) {
-            __syncthreads();  // every wave is done reading the tile before it is overwritten
-            if (kt + 1 < kt1) store_tile(0);
-        } else if (kt + 1 < kt1) {
-            store_tile(cur ^ 1);
-        }
+    };
+
+    load_tile(kt0);
+    store_tile(0);
+    __syncthreads();
+    // steady state is ONE basic block (the loads are unconditional buffer loads): fetch tile kt+1, multiply tile kt, park kt+1 in LDS.
+    // The last tile is peeled so that nothing is fetched or stored for a tile that does not exist.
+    int kt = kt0;
+    for (; kt + 1 < kt1; kt++) {
+        const int cur = SB ? 0 : ((kt - kt0) & 1);
+        load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the fetches AHEAD of the MFMA stream: their latency is what the MFMAs hide
+        compute_tile(cur);
+        if (SB) __syncthreads();  // every wave is done reading the tile before it is overwritten
+        store_tile(SB ? 0 : cur ^ 1);
         __syncthreads();
     }
+    compute_tile(SB ? 0 : ((kt - kt0) & 1));
+    __syncthreads();  // the epilogue reuses the operand LDS
 
     if (unit >= 0) {
         // ---- split tile: park the partial sums (thread-major: one coalesced 1 KB store per accumulator register), take a ticket,
@@ -436,6 +453,9 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     p.relu = d->relu;
     p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.mask = d->mask;
     p.tiles_m = p.tiles_n = 0;
+    const int64_t xb = (int64_t)d->B * d->H * d->W * d->Cin * 4, wb = (int64_t)d->Cout * p.K * 4;
+    ABR_REQUIRE(xb < (int64_t)0x7FFFFFF0 && wb < (int64_t)0x7FFFFFF0, "conv_forward: input / weight tensors must be < 2 GB (32-bit buffer offsets)");
+    p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     p.d_howo.init((unsigned)(p.Ho * p.Wo)); p.d_wo.init((unsigned)p.Wo); p.d_cin.init((unsigned)p.Cin); p.d_s.init((unsigned)p.S);
     hipStream_t st = abr::as_stream(stream);
     const bool small_c = (d->Cin % BK) != 0;
