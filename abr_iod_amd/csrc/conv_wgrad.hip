@@ -51,6 +51,7 @@ struct WgP {
     int plain;  // 1x1, stride 1, pad 0: A row m is x + m*Cin
     FastDiv d_howo, d_wo;
     const float* scale;
+    unsigned x_bytes, gy_bytes;  // extents for the buffer-load range check
 };
 
 // SB: single-buffered operand LDS (two barriers per stage, 32 KB instead of 64 KB -> a third resident workgroup per CU)
@@ -86,26 +87,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
     const int mt0 = split * p.mt_per_split;
     const int mt1 = min(mt0 + p.mt_per_split, (p.M + MR - 1) / MR);
 
+    // Operand fetch through buffer loads (see conv_igemm.hip): rows past M fall outside the descriptor's range and read as zeros,
+    // masked columns / halo taps get the out-of-range offset kOOB; 32-bit offsets, no branches.  gy rows and the A rows of a plain
+    // 1x1 conv advance by a constant per stage: one add per load.
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rgy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, p.gy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
+    const unsigned g_voff = g_ok ? (unsigned)(r8 * p.Cout + gn) * 4u : kOOB;
+    const unsigned a_voff_plain = k_ok ? (unsigned)(r8 * p.Cin + fc) * 4u : kOOB;
+    const int a_const = ((fr - p.pad) * p.W + (fs - p.pad)) * p.Cin + fc;  // non-plain: tap offset of this thread's k column
     float4 rg[4], ra[4];
+    auto fetch = [&](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) -> float4 {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
     auto load_tile = [&](int mt) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int m = mt * MR + r8 + 8 * i;
-            const bool m_ok = m < p.M;
-            rg[i] = (m_ok && g_ok) ? *reinterpret_cast<const float4*>(gy + (size_t)m * p.Cout + gn)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int mrow = mt * MR + 8 * i;  // scalar part of the row index (the lane adds r8)
+            // the row goes into the VECTOR offset: that is the part the hardware range-checks (kOOB + row stays >= 2^31)
+            rg[i] = fetch(rgy, g_voff + (unsigned)(mrow * p.Cout) * 4u, 0);
             if (p.plain) {
-                ra[i] = (m_ok && k_ok) ? *reinterpret_cast<const float4*>(x + (size_t)m * p.Cin + fc)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[i] = fetch(rxx, a_voff_plain + (unsigned)(mrow * p.Cin) * 4u, 0);
             } else {
-                const int mm = m_ok ? m : 0;
+                const int m = mrow + r8;
                 unsigned b, rem, ho, wo;
-                p.d_howo.divmod((unsigned)mm, b, rem);
+                p.d_howo.divmod((unsigned)m, b, rem);   // m >= M gives b >= B: the offset lands past the tensor -> zeros
                 p.d_wo.divmod(rem, ho, wo);
                 const int hi = (int)ho * p.stride - p.pad + fr, wi = (int)wo * p.stride - p.pad + fs;
-                const bool ok = m_ok && k_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                ra[i] = ok ? *reinterpret_cast<const float4*>(x + (((size_t)b * p.H + hi) * p.W + wi) * p.Cin + fc)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool ok = k_ok && m < p.M && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const int off = (((int)b * p.H + (int)ho * p.stride) * p.W + (int)wo * p.stride) * p.Cin + a_const;
+                ra[i] = fetch(rxx, ok ? (unsigned)off * 4u : kOOB, 0);
             }
         }
     };
@@ -126,14 +139,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
-    if (mt0 < mt1) {
-        load_tile(mt0);
-        store_tile(0);
-    }
-    __syncthreads();
-    for (int mt = mt0; mt < mt1; mt++) {
-        const int cur = SB ? 0 : ((mt - mt0) & 1);
-        if (mt + 1 < mt1) load_tile(mt + 1);
+    auto compute_tile = [&](int cur) {
         const float* g = Gs + cur * MR * TN_ + wm * 64 + 2 * l31;
         const float* a = As + cur * MR * TK_ + wn * 64 + 2 * l31;
 #pragma unroll
@@ -145,13 +151,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg.y, fa.x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fg.y, fa.y, acc[1][1], 0, 0, 0);
         }
-        if (SB) {
-            __syncthreads();
-            if (mt + 1 < mt1) store_tile(0);
-        } else if (mt + 1 < mt1) {
-            store_tile(cur ^ 1);
-        }
+    };
+    if (mt0 < mt1) {
+        load_tile(mt0);
+        store_tile(0);
         __syncthreads();
+        int mt = mt0;
+        for (; mt + 1 < mt1; mt++) {  // steady state: one basic block; the last stage is peeled (nothing to fetch for it)
+            const int cur = SB ? 0 : ((mt - mt0) & 1);
+            load_tile(mt + 1);
+            __builtin_amdgcn_sched_barrier(0);  // fetches stay ahead of the MFMA stream
+            compute_tile(cur);
+            if (SB) __syncthreads();
+            store_tile(SB ? 0 : cur ^ 1);
+            __syncthreads();
+        }
+        compute_tile(SB ? 0 : ((mt - mt0) & 1));
     }
 
     // epilogue: tile (tm,tn) element (row i, col j) is dW[n0 + wm*64 + 2i + tm][k0 + wn*64 + 2j + tn]
@@ -185,6 +200,9 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     p.K = d->R * d->S * d->Cin;
     p.plain = (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0);
     p.scale = d->scale;
+    const int64_t xb = (int64_t)d->B * d->H * d->W * d->Cin * 4, gb = (int64_t)p.M * d->Cout * 4;
+    ABR_REQUIRE(xb < (int64_t)0x7FFFFFF0 && gb < (int64_t)0x7FFFFFF0, "conv_wgrad: activation / gradient tensors must be < 2 GB (32-bit buffer offsets)");
+    p.x_bytes = (unsigned)xb; p.gy_bytes = (unsigned)gb;
     p.d_howo.init((unsigned)(d->Ho * d->Wo)); p.d_wo.init((unsigned)d->Wo);
     p.tiles_n = (p.Cout + TN_ - 1) / TN_;
     p.tiles_k = (p.K + TK_ - 1) / TK_;
