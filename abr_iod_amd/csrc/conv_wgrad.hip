@@ -214,6 +214,9 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     // split-M so that the grid fills the chip evenly: among the candidates pick the one with the best load balance
     // (workgroups / (ceil(workgroups / CUs) * CUs)), preferring fewer splits (less atomic traffic) on ties; every
     // workgroup keeps at least 8 stages (256 rows) of work.
+    // opt-in (ABR_WGRAD_OCC2=1): alone on the device the head 1x1 gradients gain 11-15 % from two workgroups per CU, but inside the
+    // training step they run next to the dgrad stream, which already fills the gaps -- measured no gain there.
+    static const bool occ2 = getenv("ABR_WGRAD_OCC2") && atoi(getenv("ABR_WGRAD_OCC2")) != 0;
     const int max_splits = std::max(1, (m_tiles + 7) / 8);
     int splits = 1;
     double best = -1.0;
@@ -223,6 +226,8 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
         const long rounds = (wgs + cus - 1) / cus;
         double eff = (double)wgs / (double)(rounds * cus);
         if (wgs < cus) eff *= 0.5;                 // not even one workgroup per CU
+        else if (occ2 && wgs < 2L * cus && m_tiles / (2 * sp) >= 64) eff *= 0.85;  // a lone workgroup per CU cannot hide its own prologue /
+                                                   // atomics epilogue: take two when each still gets >= 64 stages (head 1x1s: +11..15 %)
         eff -= 0.0002 * sp;                        // tie-break: fewer partial sums
         if (eff > best) { best = eff; splits = sp; }
     }
