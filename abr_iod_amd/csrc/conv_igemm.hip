@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
 #pragma unroll
             for (int i = 0; i < NA; i++) {
                 const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
-                const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const bool ok = a_ok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);  // no short circuit: no branch
                 ra[i] = fetch(rx, ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB, 0);
             }
         } else {
@@ -283,19 +283,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     load_tile(kt0);
     store_tile(0);
     __syncthreads();
-    // steady state is ONE basic block (the loads are unconditional buffer loads): fetch tile kt+1, multiply tile kt, park kt+1 in LDS.
-    // The last tile is peeled so that nothing is fetched or stored for a tile that does not exist.
+    // steady state is ONE basic block (the loads are unconditional buffer loads): multiply tile kt, park tile kt+1 in LDS, fetch
+    // tile kt+2.  The last tiles are peeled so that nothing is fetched or stored for a tile that does not exist.
     int kt = kt0;
-    for (; kt + 1 < kt1; kt++) {
-        const int cur = SB ? 0 : ((kt - kt0) & 1);
-        load_tile(kt + 1);
-        __builtin_amdgcn_sched_barrier(0);  // keep the fetches AHEAD of the MFMA stream: their latency is what the MFMAs hide
-        compute_tile(cur);
-        if (SB) __syncthreads();  // every wave is done reading the tile before it is overwritten
-        store_tile(SB ? 0 : cur ^ 1);
-        __syncthreads();
+    if (SB) {
+        for (; kt + 1 < kt1; kt++) {
+            load_tile(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the fetches AHEAD of the MFMA stream: their latency is what the MFMAs hide
+            compute_tile(0);
+            __syncthreads();  // every wave is done reading the tile before it is overwritten
+            store_tile(0);
+            __syncthreads();
+        }
+        compute_tile(0);
+    } else {
+        // double-buffered: the fetch of tile kt+2 is issued right behind the barrier of iteration kt (its registers were just
+        // emptied into LDS); the compiler sinks the tail of iteration kt's MFMAs below that barrier, so a fetch has a full
+        // k-tile of MFMAs (~1.7 us) to land before its ds_write instead of two thirds of one.
+        if (kt + 1 < kt1) load_tile(kt + 1);
+        for (; kt + 2 < kt1; kt++) {
+            const int cur = (kt - kt0) & 1;
+            compute_tile(cur);
+            store_tile(cur ^ 1);
+            load_tile(kt + 2);   // program order puts the fetch BEFORE the barrier: it is issued while the MFMA tail is still to come
+            __syncthreads();
+        }
+        if (kt + 1 < kt1) {
+            const int cur = (kt - kt0) & 1;
+            compute_tile(cur);
+            store_tile(cur ^ 1);
+            __syncthreads();
+            kt++;
+        }
+        compute_tile((kt - kt0) & 1);
     }
-    compute_tile(SB ? 0 : ((kt - kt0) & 1));
     __syncthreads();  // the epilogue reuses the operand LDS
 
     if (unit >= 0) {
