@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
                 p.d_howo.divmod((unsigned)m, b, rem);   // m >= M gives b >= B: the offset lands past the tensor -> zeros
                 p.d_wo.divmod(rem, ho, wo);
                 const int hi = (int)ho * p.stride - p.pad + fr, wi = (int)wo * p.stride - p.pad + fs;
-                const bool ok = k_ok && m < p.M && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const bool ok = k_ok & (m < p.M) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);  // no short circuit
                 const int off = (((int)b * p.H + (int)ho * p.stride) * p.W + (int)wo * p.stride) * p.Cin + a_const;
                 ra[i] = fetch(rxx, ok ? (unsigned)off * 4u : kOOB, 0);
             }
@@ -157,16 +157,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
         store_tile(0);
         __syncthreads();
         int mt = mt0;
-        for (; mt + 1 < mt1; mt++) {  // steady state: one basic block; the last stage is peeled (nothing to fetch for it)
-            const int cur = SB ? 0 : ((mt - mt0) & 1);
-            load_tile(mt + 1);
-            __builtin_amdgcn_sched_barrier(0);  // fetches stay ahead of the MFMA stream
-            compute_tile(cur);
-            if (SB) __syncthreads();
-            store_tile(SB ? 0 : cur ^ 1);
-            __syncthreads();
+        if (SB) {
+            for (; mt + 1 < mt1; mt++) {  // steady state: one basic block; the last stage is peeled (nothing to fetch for it)
+                load_tile(mt + 1);
+                __builtin_amdgcn_sched_barrier(0);  // fetches stay ahead of the MFMA stream
+                compute_tile(0);
+                __syncthreads();
+                store_tile(0);
+                __syncthreads();
+            }
+            compute_tile(0);
+        } else {  // double-buffered: stage mt+2 is fetched right behind the ds_writes of stage mt+1 (see conv_igemm.hip)
+            if (mt + 1 < mt1) load_tile(mt + 1);
+            for (; mt + 2 < mt1; mt++) {
+                const int cur = (mt - mt0) & 1;
+                compute_tile(cur);
+                store_tile(cur ^ 1);
+                load_tile(mt + 2);
+                __syncthreads();
+            }
+            if (mt + 1 < mt1) {
+                const int cur = (mt - mt0) & 1;
+                compute_tile(cur);
+                store_tile(cur ^ 1);
+                __syncthreads();
+                mt++;
+            }
+            compute_tile((mt - mt0) & 1);
         }
-        compute_tile(SB ? 0 : ((mt - mt0) & 1));
     }
 
     // epilogue: tile (tm,tn) element (row i, col j) is dW[n0 + wm*64 + 2i + tm][k0 + wn*64 + 2j + tn]
