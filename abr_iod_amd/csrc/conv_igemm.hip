@@ -512,11 +512,11 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     const bool take_split128 = best_s > 1 && (rule128 || cost128 < 0.9 * (rule12864 ? cost12864 : cost64));
 
     // 128x128 tile, single- vs double-buffered operand LDS: one buffer (36.9 KB) lets a third workgroup share the CU, which pays
-    // when prologue/epilogue are a large part of a tile's life (K <= 1024: +3..6 %) or when the grid fits 3 but not 2 workgroups
-    // per CU (the 600-tile RPN GEMM: +6 %); long-K GEMMs lose ~3 % to the second barrier per k-tile and keep two buffers.
+    // when prologue/epilogue are a large part of a tile's life (K <= 512: +2..5 %) or when the grid fits 3 but not 2 workgroups
+    // per CU (the 600-tile RPN GEMM); longer-K GEMMs are faster double-buffered (one barrier per k-tile, fetch two tiles ahead).
     static const int sb_mode = getenv("ABR_IGEMM_SB") ? atoi(getenv("ABR_IGEMM_SB")) : -1;
     const int64_t wgs128 = take_split128 ? best_nfull + (t128 - best_nfull) * best_s : t128;
-    const bool sb = sb_mode >= 0 ? sb_mode != 0 : (p.K <= 1024 || (wgs128 > 2 * cus && wgs128 <= 3 * cus) || take_split128);
+    const bool sb = sb_mode >= 0 ? sb_mode != 0 : (p.K <= 512 || (wgs128 > 2 * cus && wgs128 <= 3 * cus) || take_split128);
     if (small_c) {
         launch<128, 64, 4, 1, true, true>(p, x, w, out, st, abr::PROF_IGEMM_SMALLC);
     } else if (rule128 || take_split128) {
