@@ -9,6 +9,9 @@ synthetic 600x1000 images, fp32), data-parallel over N MI355X with one RCCL all-
 Rank 0 prints ONE JSON line (contract in the task description) plus the `roofline` and `cpu_baseline` objects.
 """
 import argparse
+import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool: RCCL needs it before HIP initialises
 import ctypes
 import json
 import os
