@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDP = BK + 4;  // LDS row pitch in floats
 
+constexpr int kMaxSplitUnits = 1024, kMaxSplitTiles = 512;  // split-K scratch capacity (units of one 128x128 partial tile)
 constexpr int EPAD = 4;  // epilogue LDS pitch = wave-tile columns + 4 floats (keeps 16 B alignment)
 
 // n / d for 0 <= n < 2^31 with a precomputed multiplier (the kernels divide by Ho*Wo, Wo, Cin, S on every tile / row;
@@ -323,15 +324,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
         // ---- split tile: park the partial sums (thread-major: one coalesced 1 KB store per accumulator register), take a ticket,
         // and only the last arrival goes on.  It re-reads ALL `split` partials in index order -- its own included -- so the sum is
         // the same whichever workgroup happens to finish last (deterministic), then resets the ticket for the next launch.
-        constexpr int NR = TM * TN * 16;
-        float* mine = p.ws + (size_t)unit * (NR * 256) + tid;
+        // Partials move as 16 B per lane through buffer accesses with sc0|sc1 set (system-coherent: written through / read past the
+        // XCD-local L2, so no cache flush or invalidate is needed around the ticket) -- plain loads and stores to the scheduler, so
+        // all of a reduction's loads are in flight at once (per-dword agent-scope atomics serialised into ~25 k-tiles of latency).
+        constexpr int NQ = TM * TN * 4;                // float4 per thread per partial
+        constexpr unsigned kPart = NQ * 256 * 16;      // bytes per partial tile
+        constexpr int kCoherent = 0x11;                // cache-policy operand on gfx94x/gfx950: bit 0 = sc0, bit 4 = sc1 (bit 1 is nt)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, (unsigned)kMaxSplitUnits * kPart, 0x00020000);
+        const unsigned my_off = (unsigned)unit * kPart + (unsigned)tid * 16u;
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++)  // agent-scope (sc1, write-through) stores: visible to the other XCDs without flushing L2
-                    __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 256, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int c = 0; c < 4; c++) {
+                    u32x4 v;
+                    v.x = __float_as_uint(acc[i][j][4 * c]); v.y = __float_as_uint(acc[i][j][4 * c + 1]);
+                    v.z = __float_as_uint(acc[i][j][4 * c + 2]); v.w = __float_as_uint(acc[i][j][4 * c + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rws, (int)(my_off + (unsigned)((i * TN + j) * 4 + c) * 4096u), 0, kCoherent);
+                }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // = wait for this wave's stores; no cache maintenance
         __syncthreads();
         __shared__ int s_last;
@@ -340,17 +352,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
         __syncthreads();
         if (!s_last) return;
         if (tid == 0) p.cnt[st] = 0;
-        const float* all = p.ws + (size_t)st * p.split * (NR * 256) + tid;
+        const unsigned base = (unsigned)st * (unsigned)p.split * kPart + (unsigned)tid * 16u;
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    float v = 0.f;
-                    for (int q = 0; q < p.split; q++)  // agent-scope loads: served from the coherent level, not a stale local L2 line
-                        v += __hip_atomic_load(all + (size_t)q * (NR * 256) + ((i * TN + j) * 16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    acc[i][j][r] = v;
+                for (int c = 0; c < 4; c++) {
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int q = 0; q < p.split; q++) {  // fixed order 0..split-1: the same sum whoever arrives last
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(base + (unsigned)q * kPart + (unsigned)((i * TN + j) * 4 + c) * 4096u), 0, kCoherent);
+                        sum.x += __uint_as_float(v.x); sum.y += __uint_as_float(v.y); sum.z += __uint_as_float(v.z); sum.w += __uint_as_float(v.w);
+                    }
+                    acc[i][j][4 * c] = sum.x; acc[i][j][4 * c + 1] = sum.y; acc[i][j][4 * c + 2] = sum.z; acc[i][j][4 * c + 3] = sum.w;
                 }
     }
 
@@ -364,7 +378,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
 
 // split-K scratch: partial tiles (64 KB each for 128x128) + tickets, one set per stream (streams may run convs concurrently)
 struct SplitWs { float* ws = nullptr; int* cnt = nullptr; };
-constexpr int kMaxSplitUnits = 1024, kMaxSplitTiles = 512;
 static SplitWs* split_ws(hipStream_t st) {
     static std::map<hipStream_t, SplitWs> pool;
     SplitWs& w = pool[st];
