@@ -64,7 +64,10 @@ struct ConvP {
     int n_full, split;
     float* ws;
     int* cnt;
-    unsigned x_bytes, w_bytes;  // extents for the buffer-load range check
+    unsigned x_bytes, w_bytes;  // extents for the buffer-load range check (per batch)
+    // batched mode (the 36 Winograd GEMMs): tile -> (batch, tile inside the batch); operands / output advance by the strides
+    int nbatch, tiles_pb;
+    long a_bs, w_bs, o_bs;
 };
 
 
@@ -145,8 +148,11 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][
 // SMALL_C: Cin is not a multiple of 32 (the 3->4 padded stem): (r,s,c) is derived per 16 B slot.
 // SB: single-buffered operand LDS (two barriers per k-tile, half the LDS -> one more resident workgroup per CU).
 template <int BM, int BN, int WM, int WN, bool SMALL_C, bool SB>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const float* __restrict__ x,
-                                                          const float* __restrict__ w, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const float* __restrict__ x_,
+                                                          const float* __restrict__ w_, float* __restrict__ out_) {
+    const float* x = x_;
+    const float* w = w_;
+    float* out = out_;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int NA = BM / 32, NB = BN / 32;  // float4 staging loads per thread for A and B
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -163,6 +169,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
         const int si = unit % p.split, nk_all = kt1;
         kt0 = (int)((long)si * nk_all / p.split);
         kt1 = (int)((long)(si + 1) * nk_all / p.split);
+    }
+    if (p.nbatch > 1) {
+        const int bt = tile / p.tiles_pb;
+        tile -= bt * p.tiles_pb;
+        x += bt * p.a_bs; w += bt * p.w_bs; out += bt * p.o_bs;
     }
     const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -394,7 +405,9 @@ int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream
     ConvP q = p;
     q.tiles_m = (p.M + BM - 1) / BM;
     q.tiles_n = (p.Cout + BN - 1) / BN;
-    const int tiles = q.tiles_m * q.tiles_n;
+    q.tiles_pb = q.tiles_m * q.tiles_n;
+    if (q.nbatch < 1) q.nbatch = 1;
+    const int tiles = q.tiles_pb * q.nbatch;
     q.n_full = (split > 1 && n_full >= 0) ? n_full : tiles;
     q.split = split > 1 ? split : 1;
     q.ws = nullptr; q.cnt = nullptr;
@@ -413,7 +426,7 @@ int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int rec = abr::prof_start(st, prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
+    const int rec = abr::prof_start(st, prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
     kern<<<(unsigned)(q.n_full + (tiles - q.n_full) * q.split), 256, lds, st>>>(q, x, w, out);
     abr::prof_stop(st, rec);
     return 0;
@@ -466,36 +479,13 @@ static int num_cus() {
     return n;
 }
 
-extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const float* w, float* out, void* stream) {
-    ABR_REQUIRE(d && x && w && out, "conv_forward: null pointer");
-    ABR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->R > 0 && d->S > 0 && d->stride > 0,
-                "conv_forward: bad shape");
-    ABR_REQUIRE(d->Cin % 4 == 0, "conv_forward: Cin must be a multiple of 4 (pad the 3-channel image to 4)");
-    ABR_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->R) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->S) / d->stride + 1,
-                "conv_forward: Ho/Wo inconsistent with H,W,R,S,stride,pad");
-    ConvP p;
-    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.R = d->R; p.S = d->S;
-    p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
-    p.M = d->B * d->Ho * d->Wo;
-    p.K = d->R * d->S * d->Cin;
-    p.out_H = d->out_H > 0 ? d->out_H : d->Ho;
-    p.out_W = d->out_W > 0 ? d->out_W : d->Wo;
-    p.out_sh = d->out_sh > 0 ? d->out_sh : 1;
-    p.out_sw = d->out_sw > 0 ? d->out_sw : 1;
-    p.scatter = !(p.out_H == p.Ho && p.out_W == p.Wo && p.out_sh == 1 && p.out_sw == 1);
-    ABR_REQUIRE((p.Ho - 1) * p.out_sh < p.out_H && (p.Wo - 1) * p.out_sw < p.out_W, "conv_forward: scatter out of range");
-    p.relu = d->relu;
-    p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.mask = d->mask;
-    p.tiles_m = p.tiles_n = 0;
-    const int64_t xb = (int64_t)d->B * d->H * d->W * d->Cin * 4, wb = (int64_t)d->Cout * p.K * 4;
-    ABR_REQUIRE(xb < (int64_t)0x7FFFFFF0 && wb < (int64_t)0x7FFFFFF0, "conv_forward: input / weight tensors must be < 2 GB (32-bit buffer offsets)");
-    p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
-    p.d_howo.init((unsigned)(p.Ho * p.Wo)); p.d_wo.init((unsigned)p.Wo); p.d_cin.init((unsigned)p.Cin); p.d_s.init((unsigned)p.S);
-    hipStream_t st = abr::as_stream(stream);
-    const bool small_c = (d->Cin % BK) != 0;
+// tile configuration + launch for one (possibly batched) implicit GEMM described by p
+static void dispatch_igemm(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
+    const int64_t nb = p.nbatch > 1 ? p.nbatch : 1;
+    const bool small_c = (p.Cin % BK) != 0;
     // tile choice: biggest tile that still gives >= 2 workgroups per CU; narrow-N layers use BN=64
-    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-    const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
+    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * nb;
+    const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64) * nb;
     const int cus = num_cus();
     // ---- split-K plan for the 128x128 tile (see ConvP::n_full).  Per-CU cost model in k-iterations: workgroups on one CU share
     // its MFMA pipe, so a grid costs ceil(tiles / CUs) tile-times; splitting the LAST tiles (or all of them when there are fewer
@@ -504,7 +494,7 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     const int nk = (p.K + BK - 1) / BK;
     int best_nfull = -1, best_s = 1;
     double cost128 = (double)((t128 + cus - 1) / cus) * nk;
-    if (split_mode && !small_c && p.Cout > 64) {
+    if (split_mode && !small_c && p.Cout > 64 && nb == 1) {
         // Measured (tools/microbench.py): the RPN 3x3 (600 tiles, K = 9216) goes 101 -> 121 TF with its last 88 tiles split in two;
         // GEMMs with K <= 4608 per tile LOSE (the partial-sum round trip costs ~25 k-iterations, not 6: layer3 3x3 84 -> 70 TF,
         // layer2 3x3 82 -> 76), and so does splitting every tile of a grid smaller than the chip (64x64 tiles quantise better there).
@@ -517,7 +507,7 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
         }
     }
     // relative cost of the tile configurations the rules below would pick (work per tile x measured efficiency of the smaller tiles)
-    const int64_t t64 = (int64_t)((p.M + 63) / 64) * ((p.Cout + 63) / 64);
+    const int64_t t64 = (int64_t)((p.M + 63) / 64) * ((p.Cout + 63) / 64) * nb;
     const double cost12864 = (double)((t12864 + cus - 1) / cus) * nk * 0.5 / 0.85;
     const double cost64 = (double)((t64 + cus - 1) / cus) * nk * 0.25 / 0.80;
     const bool rule128 = p.Cout > 64 && t128 >= 2 * cus;
@@ -541,6 +531,82 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     } else {
         launch<64, 64, 2, 2, false, true>(p, x, w, out, st, abr::PROF_IGEMM_64x64);
     }
+}
+
+// Winograd scratch (V, U, M), one grow-only allocation per stream
+struct WinoWs { float* buf = nullptr; size_t floats = 0; };
+static float* wino_ws(hipStream_t st, size_t floats) {
+    static std::map<hipStream_t, WinoWs> pool;
+    WinoWs& w = pool[st];
+    if (w.floats < floats) {
+        if (w.buf) { (void)hipStreamSynchronize(st); (void)hipFree(w.buf); w.buf = nullptr; w.floats = 0; }
+        if (hipMalloc(&w.buf, floats * sizeof(float)) != hipSuccess) return nullptr;
+        w.floats = floats;
+    }
+    return w.buf;
+}
+
+// stride-1 pad-1 3x3 conv as Winograd F(4x4,3x3): weight + input transforms, 36 batched GEMMs, output transform with the epilogue
+static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
+    const int th_n = (p.H + 3) / 4, tw_n = (p.W + 3) / 4;
+    const int64_t T = (int64_t)p.B * th_n * tw_n;
+    const size_t nV = (size_t)36 * T * p.Cin, nU = (size_t)36 * p.Cout * p.Cin, nM = (size_t)36 * T * p.Cout;
+    if (T * (int64_t)std::max(p.Cin, p.Cout) * 4 >= (int64_t)0x7FFFFFF0) return false;
+    float* ws = wino_ws(st, nV + nU + nM);
+    if (!ws) return false;
+    float *V = ws, *U = ws + nV, *Mm = ws + nV + nU;
+    if (abr::wino_weight_transform(w, p.Cout, p.Cin, U, st)) return false;
+    if (abr::wino_input_transform(x, p.B, p.H, p.W, p.Cin, V, st)) return false;
+    ConvP g = p;
+    g.B = (int)T; g.H = g.W = 1; g.R = g.S = 1; g.stride = 1; g.pad = 0; g.Ho = g.Wo = 1;
+    g.M = (int)T; g.K = p.Cin;
+    g.out_H = g.out_W = 1; g.out_sh = g.out_sw = 1; g.scatter = 0; g.relu = 0;
+    g.scale = g.bias = g.residual = g.mask = nullptr;
+    g.d_howo.init(1u); g.d_wo.init(1u); g.d_cin.init((unsigned)p.Cin); g.d_s.init(1u);
+    g.x_bytes = (unsigned)(T * p.Cin * 4); g.w_bytes = (unsigned)((int64_t)p.Cout * p.Cin * 4);
+    g.nbatch = 36; g.a_bs = (long)T * p.Cin; g.w_bs = (long)p.Cout * p.Cin; g.o_bs = (long)T * p.Cout;
+    dispatch_igemm(g, V, U, Mm, st);
+    return abr::wino_output_transform(Mm, p.B, p.H, p.W, p.Cout, p.scale, p.bias, p.relu, p.mask, out, st) == 0;
+}
+
+extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const float* w, float* out, void* stream) {
+    ABR_REQUIRE(d && x && w && out, "conv_forward: null pointer");
+    ABR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->R > 0 && d->S > 0 && d->stride > 0,
+                "conv_forward: bad shape");
+    ABR_REQUIRE(d->Cin % 4 == 0, "conv_forward: Cin must be a multiple of 4 (pad the 3-channel image to 4)");
+    ABR_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->R) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->S) / d->stride + 1,
+                "conv_forward: Ho/Wo inconsistent with H,W,R,S,stride,pad");
+    ConvP p;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.R = d->R; p.S = d->S;
+    p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.M = d->B * d->Ho * d->Wo;
+    p.K = d->R * d->S * d->Cin;
+    p.out_H = d->out_H > 0 ? d->out_H : d->Ho;
+    p.out_W = d->out_W > 0 ? d->out_W : d->Wo;
+    p.out_sh = d->out_sh > 0 ? d->out_sh : 1;
+    p.out_sw = d->out_sw > 0 ? d->out_sw : 1;
+    p.scatter = !(p.out_H == p.Ho && p.out_W == p.Wo && p.out_sh == 1 && p.out_sw == 1);
+    ABR_REQUIRE((p.Ho - 1) * p.out_sh < p.out_H && (p.Wo - 1) * p.out_sw < p.out_W, "conv_forward: scatter out of range");
+    p.relu = d->relu;
+    p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.mask = d->mask;
+    p.tiles_m = p.tiles_n = 0;
+    p.nbatch = 1; p.tiles_pb = 0; p.a_bs = p.w_bs = p.o_bs = 0;
+    const int64_t xb = (int64_t)d->B * d->H * d->W * d->Cin * 4, wb = (int64_t)d->Cout * p.K * 4;
+    ABR_REQUIRE(xb < (int64_t)0x7FFFFFF0 && wb < (int64_t)0x7FFFFFF0, "conv_forward: input / weight tensors must be < 2 GB (32-bit buffer offsets)");
+    p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+    p.d_howo.init((unsigned)(p.Ho * p.Wo)); p.d_wo.init((unsigned)p.Wo); p.d_cin.init((unsigned)p.Cin); p.d_s.init((unsigned)p.S);
+    hipStream_t st = abr::as_stream(stream);
+    // Winograd F(4x4,3x3) for the wide stride-1 3x3 convs: 4x fewer multiply-adds (RPN 3x3: 1.42 -> ~0.5 ms); the narrow ones
+    // (layer1/2) stay direct -- their 36 GEMMs would have K < 256 and the transforms' HBM traffic outweighs the saving.
+    static const int wino_min_c = getenv("ABR_WINOGRAD_MIN_C") ? atoi(getenv("ABR_WINOGRAD_MIN_C")) : 256;
+    if (wino_min_c > 0 && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && !p.scatter && !p.residual && p.Cin % BK == 0 &&
+        p.Cout % 4 == 0 && p.Cin >= wino_min_c && p.Cout >= 128) {
+        if (wino_conv(p, x, w, out, st)) {
+            ABR_CHECK_LAUNCH("conv_forward (winograd)");
+            return ABR_OK;
+        }
+    }
+    dispatch_igemm(p, x, w, out, st);
     ABR_CHECK_LAUNCH("conv_forward");
     return ABR_OK;
 }

@@ -1,0 +1,174 @@
+// Winograd F(4x4, 3x3) transforms for the stride-1, pad-1 3x3 convolutions of the path (RPN head conv, layer2-4 conv2 and
+// their dgrads): Y = A^T [ (G g G^T) (.) (B^T d B) ] A per 6x6 input tile / 4x4 output tile (Lavin & Gray, "Fast Algorithms for
+// Convolutional Neural Networks", 2015: the minimal-filtering matrices below are theirs).  The 36 element-wise products over the
+// channel axis are 36 independent GEMMs [tiles x Cin] x [Cin x Cout] -- 4x fewer multiply-adds than the direct implicit GEMM --
+// and run on the fp32 MFMA kernel of conv_igemm.hip in batched mode; this file holds the three HBM-bound transform kernels.
+//
+//   V[p][t][c]  = (B^T d B)[p]      p = 6*i + j, t = tile (image, tile row, tile col), c = input channel     (input transform)
+//   U[p][n][c]  = (G g G^T)[p]      n = output channel                                                      (weight transform)
+//   M[p][t][n]  = sum_c V[p][t][c] * U[p][n][c]                                                             (batched GEMM)
+//   out[b,y,x,n] = epilogue((A^T M A)[...])                                                                 (output transform)
+//
+// Arithmetic is fp32 throughout; the result differs from the direct convolution by re-association only (~1e-6 relative, the
+// tests bound it), well inside the 1e-4 the path is held to.  Reference semantics replaced: the same cuDNN conv + FrozenBN + ReLU
+// (+ ReLU mask in backward) as conv_igemm.hip.
+#include "common.h"
+
+namespace {
+
+// B^T (6x6), applied to columns then rows
+__device__ __forceinline__ void bt6(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
+                                    float& o0, float& o1, float& o2, float& o3, float& o4, float& o5) {
+    o0 = 4.f * d0 - 5.f * d2 + d4;
+    o1 = -4.f * d1 - 4.f * d2 + d3 + d4;
+    o2 = 4.f * d1 - 4.f * d2 - d3 + d4;
+    o3 = -2.f * d1 - d2 + 2.f * d3 + d4;
+    o4 = 2.f * d1 - d2 - 2.f * d3 + d4;
+    o5 = 4.f * d1 - 5.f * d3 + d5;
+}
+
+// grid-stride over (tile, channel); consecutive threads = consecutive channels (coalesced 256 B per wave)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int B, int H, int W, int C, int th_n, int tw_n,
+                                                         float* __restrict__ V) {
+    const int64_t T = (int64_t)B * th_n * tw_n;
+    const int64_t total = T * C;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const int64_t t = idx / C;
+        const int tw = (int)(t % tw_n), th = (int)((t / tw_n) % th_n), b = (int)(t / ((int64_t)tw_n * th_n));
+        const int y0 = 4 * th - 1, x0 = 4 * tw - 1;
+        float d[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int y = y0 + i;
+            const bool yin = (unsigned)y < (unsigned)H;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const int xx = x0 + j;
+                d[i][j] = (yin && (unsigned)xx < (unsigned)W) ? x[(((int64_t)b * H + y) * W + xx) * C + c] : 0.f;
+            }
+        }
+        float tcol[6][6];  // B^T d
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j], tcol[4][j], tcol[5][j]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {  // (B^T d) B : the same combination along the row
+            float v0, v1, v2, v3, v4, v5;
+            bt6(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], tcol[i][4], tcol[i][5], v0, v1, v2, v3, v4, v5);
+            float* o = V + ((int64_t)(6 * i) * T + t) * C + c;
+            const int64_t ps = T * C;
+            o[0] = v0; o[ps] = v1; o[2 * ps] = v2; o[3 * ps] = v3; o[4 * ps] = v4; o[5 * ps] = v5;
+        }
+    }
+}
+
+// G (6x3) on a 3-vector
+__device__ __forceinline__ void g6(const float g0, const float g1, const float g2, float& o0, float& o1, float& o2, float& o3, float& o4,
+                                   float& o5) {
+    o0 = 0.25f * g0;
+    o1 = (-1.f / 6.f) * (g0 + g1 + g2);
+    o2 = (-1.f / 6.f) * (g0 - g1 + g2);
+    o3 = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+    o4 = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+    o5 = g2;
+}
+
+// w [N][3][3][C] (OHWI) -> U [36][N][C]
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int N, int C, float* __restrict__ U) {
+    const int64_t total = (int64_t)N * C;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const int64_t n = idx / C;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) g[r][s] = w[((n * 3 + r) * 3 + s) * C + c];
+        float t[6][3];  // G g
+#pragma unroll
+        for (int s = 0; s < 3; s++) g6(g[0][s], g[1][s], g[2][s], t[0][s], t[1][s], t[2][s], t[3][s], t[4][s], t[5][s]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            float u0, u1, u2, u3, u4, u5;
+            g6(t[i][0], t[i][1], t[i][2], u0, u1, u2, u3, u4, u5);
+            float* o = U + ((int64_t)(6 * i) * N + n) * C + c;
+            const int64_t ps = (int64_t)N * C;
+            o[0] = u0; o[ps] = u1; o[2 * ps] = u2; o[3 * ps] = u3; o[4 * ps] = u4; o[5 * ps] = u5;
+        }
+    }
+}
+
+// A^T (4x6) on a 6-vector
+__device__ __forceinline__ void at4(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
+                                    float& o0, float& o1, float& o2, float& o3) {
+    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+    o0 = m0 + s12 + s34;
+    o1 = d12 + 2.f * d34;
+    o2 = s12 + 4.f * s34;
+    o3 = d12 + 8.f * d34 + m5;
+}
+
+// M [36][T][N] -> out [B,H,W,N] with the conv epilogue (scale, bias, ReLU, ReLU mask of the producer)
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mm, int B, int H, int W, int N, int th_n, int tw_n,
+                                                          const float* __restrict__ scale, const float* __restrict__ bias, int relu,
+                                                          const float* __restrict__ mask, float* __restrict__ out) {
+    const int64_t T = (int64_t)B * th_n * tw_n;
+    const int64_t total = T * N;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % N);
+        const int64_t t = idx / N;
+        const int tw = (int)(t % tw_n), th = (int)((t / tw_n) % th_n), b = (int)(t / ((int64_t)tw_n * th_n));
+        const int64_t ps = T * N;
+        const float* m = Mm + t * N + n;
+        float tcol[4][6];  // A^T M
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            at4(m[(0 + j) * ps], m[(6 + j) * ps], m[(12 + j) * ps], m[(18 + j) * ps], m[(24 + j) * ps], m[(30 + j) * ps], tcol[0][j], tcol[1][j],
+                tcol[2][j], tcol[3][j]);
+        const float sc = scale ? scale[n] : 1.f, bi = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float y[4];
+            at4(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], tcol[i][4], tcol[i][5], y[0], y[1], y[2], y[3]);
+            const int oy = 4 * th + i;
+            if (oy >= H) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ox = 4 * tw + j;
+                if (ox >= W) continue;
+                const int64_t o = (((int64_t)b * H + oy) * W + ox) * N + n;
+                float v = y[j] * sc + bi;
+                if (relu) v = fmaxf(v, 0.f);
+                if (mask) v = mask[o] > 0.f ? v : 0.f;
+                out[o] = v;
+            }
+        }
+    }
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 32768); }
+
+}  // namespace
+
+namespace abr {
+
+int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, hipStream_t st) {
+    const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
+    wino_input_kernel<<<grid_for((int64_t)B * th_n * tw_n * C), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st) {
+    wino_weight_kernel<<<grid_for((int64_t)N * C), 256, 0, st>>>(w, N, C, U);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int wino_output_transform(const float* Mm, int B, int H, int W, int N, const float* scale, const float* bias, int relu, const float* mask,
+                          float* out, hipStream_t st) {
+    const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
+    wino_output_kernel<<<grid_for((int64_t)B * th_n * tw_n * N), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+}  // namespace abr

@@ -459,3 +459,27 @@ def test_conv_split_k_equals_unsplit(tmp_path):
         a, b = outs[0][k], outs[1][k]
         assert a.shape == b.shape
         np.testing.assert_allclose(b, a, rtol=2e-5, atol=2e-5 * float(np.abs(a).max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 13, 18, 256, 128), (3, 4, 4, 512, 512), (1, 38, 63, 256, 256), (2, 8, 8, 1024, 160)])
+def test_conv3x3_winograd_matches_torch(shape):
+    """Wide stride-1 pad-1 3x3 convs take the Winograd F(4x4,3x3) path (conv_winograd.hip + 36 batched MFMA GEMMs).  Against
+    torch's CPU conv in float64: error stays at fp32 re-association level (the bound is relative to the largest output)."""
+    from abr_iod_amd import ops
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05
+    sc = torch.rand(Cout, generator=g) + 0.5
+    bi = torch.randn(Cout, generator=g)
+    mk = torch.randn(B, H, W, Cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), padding=1)
+    ref = ref * sc.double().view(1, -1, 1, 1) + bi.double().view(1, -1, 1, 1)
+    ref = ref.permute(0, 2, 3, 1)
+    y_plain = ops.conv_forward(x.cuda(), w.cuda(), 1, 1, scale=sc.cuda(), bias=bi.cuda()).cpu().double()
+    y_relu = ops.conv_forward(x.cuda(), w.cuda(), 1, 1, scale=sc.cuda(), bias=bi.cuda(), relu=True).cpu().double()
+    y_mask = ops.conv_forward(x.cuda(), w.cuda(), 1, 1, scale=sc.cuda(), bias=bi.cuda(), mask=mk.cuda()).cpu().double()
+    tol = 5e-5 * float(ref.abs().max())   # F(4x4,3x3) in fp32: ~2e-5 at Cin = 1024 (direct implicit GEMM: ~2e-6); the path's bar is 1e-4
+    assert float((y_plain - ref).abs().max()) <= tol, float((y_plain - ref).abs().max()) / float(ref.abs().max())
+    assert float((y_relu - ref.clamp(min=0)).abs().max()) <= tol
+    assert float((y_mask - torch.where(mk.double() > 0, ref, torch.zeros_like(ref))).abs().max()) <= tol
