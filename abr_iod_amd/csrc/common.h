@@ -72,6 +72,9 @@ int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, h
 int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st);
 int wino_output_transform(const float* M, int B, int H, int W, int N, const float* scale, const float* bias, int relu, const float* mask,
                           float* out, hipStream_t st);
+int wino_outgrad_transform(const float* gy, int B, int H, int W, int N, float* Mg, hipStream_t st);
+int wino_wgrad_inverse(const float* dU, int N, int C, const float* scale, float* dw, hipStream_t st);
+float* wino_ws(hipStream_t st, size_t floats);
 
 bool prof_enabled();
 int prof_start(hipStream_t st, int id, double work);  // returns record index (or -1)

@@ -533,26 +533,13 @@ static void dispatch_igemm(const ConvP& p, const float* x, const float* w, float
     }
 }
 
-// Winograd scratch (V, U, M), one grow-only allocation per stream
-struct WinoWs { float* buf = nullptr; size_t floats = 0; };
-static float* wino_ws(hipStream_t st, size_t floats) {
-    static std::map<hipStream_t, WinoWs> pool;
-    WinoWs& w = pool[st];
-    if (w.floats < floats) {
-        if (w.buf) { (void)hipStreamSynchronize(st); (void)hipFree(w.buf); w.buf = nullptr; w.floats = 0; }
-        if (hipMalloc(&w.buf, floats * sizeof(float)) != hipSuccess) return nullptr;
-        w.floats = floats;
-    }
-    return w.buf;
-}
-
 // stride-1 pad-1 3x3 conv as Winograd F(4x4,3x3): weight + input transforms, 36 batched GEMMs, output transform with the epilogue
 static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
     const int th_n = (p.H + 3) / 4, tw_n = (p.W + 3) / 4;
     const int64_t T = (int64_t)p.B * th_n * tw_n;
     const size_t nV = (size_t)36 * T * p.Cin, nU = (size_t)36 * p.Cout * p.Cin, nM = (size_t)36 * T * p.Cout;
     if (T * (int64_t)std::max(p.Cin, p.Cout) * 4 >= (int64_t)0x7FFFFFF0) return false;
-    float* ws = wino_ws(st, nV + nU + nM);
+    float* ws = abr::wino_ws(st, nV + nU + nM);
     if (!ws) return false;
     float *V = ws, *U = ws + nV, *Mm = ws + nV + nU;
     if (abr::wino_weight_transform(w, p.Cout, p.Cin, U, st)) return false;
@@ -596,9 +583,10 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     p.d_howo.init((unsigned)(p.Ho * p.Wo)); p.d_wo.init((unsigned)p.Wo); p.d_cin.init((unsigned)p.Cin); p.d_s.init((unsigned)p.S);
     hipStream_t st = abr::as_stream(stream);
-    // Winograd F(4x4,3x3) for the wide stride-1 3x3 convs: 4x fewer multiply-adds (RPN 3x3: 1.42 -> ~0.5 ms); the narrow ones
-    // (layer1/2) stay direct -- their 36 GEMMs would have K < 256 and the transforms' HBM traffic outweighs the saving.
-    static const int wino_min_c = getenv("ABR_WINOGRAD_MIN_C") ? atoi(getenv("ABR_WINOGRAD_MIN_C")) : 256;
+    // Winograd F(4x4,3x3) for the wide stride-1 3x3 convs: 4x fewer multiply-adds (RPN 3x3: 1.42 -> 0.50 ms, layer4 conv2 1.14 ->
+    // 0.41, layer2 conv2 0.122 -> 0.073); layer1's 64-channel conv stays direct -- its 36 GEMMs would have K = 64 and the transforms'
+    // HBM traffic outweighs the saving.
+    static const int wino_min_c = getenv("ABR_WINOGRAD_MIN_C") ? atoi(getenv("ABR_WINOGRAD_MIN_C")) : 128;
     if (wino_min_c > 0 && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && !p.scatter && !p.residual && p.Cin % BK == 0 &&
         p.Cout % 4 == 0 && p.Cin >= wino_min_c && p.Cout >= 128) {
         if (wino_conv(p, x, w, out, st)) {

@@ -51,13 +51,18 @@ struct WgP {
     int plain;  // 1x1, stride 1, pad 0: A row m is x + m*Cin
     FastDiv d_howo, d_wo;
     const float* scale;
-    unsigned x_bytes, gy_bytes;  // extents for the buffer-load range check
+    unsigned x_bytes, gy_bytes;  // extents for the buffer-load range check (per batch)
+    int nbatch, tiles_pb;        // batched mode (the 36 Winograd-domain gradients): tile -> (batch, tile inside the batch)
+    long x_bs, gy_bs, dw_bs;
 };
 
 // SB: single-buffered operand LDS (two barriers per stage, 32 KB instead of 64 KB -> a third resident workgroup per CU)
 template <bool SB>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const float* __restrict__ x,
-                                                          const float* __restrict__ gy, float* __restrict__ dw) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const float* __restrict__ x_,
+                                                          const float* __restrict__ gy_, float* __restrict__ dw_) {
+    const float* x = x_;
+    const float* gy = gy_;
+    float* dw = dw_;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NBUF = SB ? 1 : 2;
     float* Gs = smem;                       // [NBUF][MR][TN_]
@@ -65,7 +70,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
 
     const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
     const int split = bid % p.splits;
-    const int tile = bid / p.splits;
+    int tile = bid / p.splits;
+    if (p.nbatch > 1) {
+        const int bt = tile / p.tiles_pb;
+        tile -= bt * p.tiles_pb;
+        x += bt * p.x_bs; gy += bt * p.gy_bs; dw += bt * p.dw_bs;
+    }
     const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
     const int n0 = tile_n * TN_, k0 = tile_k * TK_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -206,29 +216,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
 
 }  // namespace
 
-extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const float* gy, float* dw, void* stream) {
-    ABR_REQUIRE(d && x && gy && dw, "conv_wgrad: null pointer");
-    ABR_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "conv_wgrad: Cin and Cout must be multiples of 4");
-    ABR_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->R) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->S) / d->stride + 1,
-                "conv_wgrad: Ho/Wo inconsistent");
-    WgP p;
-    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.R = d->R; p.S = d->S;
-    p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
-    p.M = d->B * d->Ho * d->Wo;
-    p.K = d->R * d->S * d->Cin;
-    p.plain = (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0);
-    p.scale = d->scale;
-    const int64_t xb = (int64_t)d->B * d->H * d->W * d->Cin * 4, gb = (int64_t)p.M * d->Cout * 4;
-    ABR_REQUIRE(xb < (int64_t)0x7FFFFFF0 && gb < (int64_t)0x7FFFFFF0, "conv_wgrad: activation / gradient tensors must be < 2 GB (32-bit buffer offsets)");
-    p.x_bytes = (unsigned)xb; p.gy_bytes = (unsigned)gb;
-    p.d_howo.init((unsigned)(d->Ho * d->Wo)); p.d_wo.init((unsigned)d->Wo);
-    p.tiles_n = (p.Cout + TN_ - 1) / TN_;
-    p.tiles_k = (p.K + TK_ - 1) / TK_;
-    if (p.M == 0) return ABR_OK;
+// split choice + launch for one (possibly batched) weight-gradient GEMM described by p (tiles_n / tiles_k / M / K filled in)
+static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void* stream) {
+    const int nb = p.nbatch > 1 ? p.nbatch : 1;
+    p.tiles_pb = p.tiles_n * p.tiles_k;
     const int m_tiles = (p.M + MR - 1) / MR;
     int32_t info[3];
     const int cus = abr_device_info(info) == ABR_OK ? info[0] : 256;
-    const int tiles = p.tiles_n * p.tiles_k;
+    const int tiles = p.tiles_n * p.tiles_k * nb;
     // split-M so that the grid fills the chip evenly: among the candidates pick the one with the best load balance
     // (workgroups / (ceil(workgroups / CUs) * CUs)), preferring fewer splits (less atomic traffic) on ties; every
     // workgroup keeps at least 8 stages (256 rows) of work.
@@ -262,10 +257,65 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
                                   (int)(sizeof(float) * 2 * MR * (TN_ + TK_)));
         attr_set = true;
     }
-    const int rec = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
+    const int rec = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
     if (sb) conv_wgrad_kernel<true><<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
     else conv_wgrad_kernel<false><<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
     abr::prof_stop(abr::as_stream(stream), rec);
+}
+
+extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const float* gy, float* dw, void* stream) {
+    ABR_REQUIRE(d && x && gy && dw, "conv_wgrad: null pointer");
+    ABR_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "conv_wgrad: Cin and Cout must be multiples of 4");
+    ABR_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->R) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->S) / d->stride + 1,
+                "conv_wgrad: Ho/Wo inconsistent");
+    WgP p;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.R = d->R; p.S = d->S;
+    p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.M = d->B * d->Ho * d->Wo;
+    p.K = d->R * d->S * d->Cin;
+    p.plain = (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0);
+    p.scale = d->scale;
+    const int64_t xb = (int64_t)d->B * d->H * d->W * d->Cin * 4, gb = (int64_t)p.M * d->Cout * 4;
+    ABR_REQUIRE(xb < (int64_t)0x7FFFFFF0 && gb < (int64_t)0x7FFFFFF0, "conv_wgrad: activation / gradient tensors must be < 2 GB (32-bit buffer offsets)");
+    p.x_bytes = (unsigned)xb; p.gy_bytes = (unsigned)gb;
+    p.d_howo.init((unsigned)(d->Ho * d->Wo)); p.d_wo.init((unsigned)d->Wo);
+    p.tiles_n = (p.Cout + TN_ - 1) / TN_;
+    p.tiles_k = (p.K + TK_ - 1) / TK_;
+    if (p.M == 0) return ABR_OK;
+    p.nbatch = 1; p.tiles_pb = 0; p.x_bs = p.gy_bs = p.dw_bs = 0;
+    hipStream_t st = abr::as_stream(stream);
+    // Winograd F(4x4,3x3) weight gradient for the wide stride-1 3x3 convs: dU[p] = sum_tiles (A dY A^T)[p]^T (B^T d B)[p] as 36 batched
+    // GEMMs over the tile axis (4x fewer multiply-adds than the direct form), then dW += scale * G^T dU G.
+    static const int wino_min_c = getenv("ABR_WINOGRAD_MIN_C") ? atoi(getenv("ABR_WINOGRAD_MIN_C")) : 128;
+    static const bool wino_wgrad = !(getenv("ABR_WINOGRAD_WGRAD") && atoi(getenv("ABR_WINOGRAD_WGRAD")) == 0);
+    if (wino_wgrad && wino_min_c > 0 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 4 == 0 &&
+        d->Cin >= wino_min_c && d->Cout >= 128) {
+        const int th_n = (d->H + 3) / 4, tw_n = (d->W + 3) / 4;
+        const int64_t T = (int64_t)d->B * th_n * tw_n;
+        const size_t nV = (size_t)36 * T * d->Cin, nM = (size_t)36 * T * d->Cout, nU = (size_t)36 * d->Cout * d->Cin;
+        float* ws = T * (int64_t)std::max(d->Cin, d->Cout) * 4 < (int64_t)0x7FFFFFF0 ? abr::wino_ws(st, nV + nM + nU) : nullptr;
+        if (ws) {
+            float *V = ws, *Mg = ws + nV, *dU = ws + nV + nM;
+            int bad = abr::wino_input_transform(x, d->B, d->H, d->W, d->Cin, V, st);
+            bad |= abr::wino_outgrad_transform(gy, d->B, d->H, d->W, d->Cout, Mg, st);
+            bad |= hipMemsetAsync(dU, 0, nU * sizeof(float), st) != hipSuccess;
+            if (!bad) {
+                WgP g = p;
+                g.B = (int)T; g.H = g.W = 1; g.R = g.S = 1; g.stride = 1; g.pad = 0; g.Ho = g.Wo = 1;
+                g.M = (int)T; g.K = d->Cin; g.plain = 1; g.scale = nullptr;
+                g.d_howo.init(1u); g.d_wo.init(1u);
+                g.tiles_n = (g.Cout + TN_ - 1) / TN_; g.tiles_k = (g.K + TK_ - 1) / TK_;
+                g.x_bytes = (unsigned)(T * d->Cin * 4); g.gy_bytes = (unsigned)(T * d->Cout * 4);
+                g.nbatch = 36; g.x_bs = (long)T * d->Cin; g.gy_bs = (long)T * d->Cout; g.dw_bs = (long)d->Cout * d->Cin;
+                launch_wgrad(g, V, Mg, dU, stream);
+                bad = abr::wino_wgrad_inverse(dU, d->Cout, d->Cin, d->scale, dw, st);
+            }
+            ABR_REQUIRE(!bad, "conv_wgrad: winograd launch failed");
+            ABR_CHECK_LAUNCH("conv_wgrad (winograd)");
+            return ABR_OK;
+        }
+    }
+    launch_wgrad(p, x, gy, dw, stream);
     ABR_CHECK_LAUNCH("conv_wgrad");
     return ABR_OK;
 }

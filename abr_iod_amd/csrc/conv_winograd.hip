@@ -12,6 +12,8 @@
 // Arithmetic is fp32 throughout; the result differs from the direct convolution by re-association only (~1e-6 relative, the
 // tests bound it), well inside the 1e-4 the path is held to.  Reference semantics replaced: the same cuDNN conv + FrozenBN + ReLU
 // (+ ReLU mask in backward) as conv_igemm.hip.
+#include <map>
+
 #include "common.h"
 
 namespace {
@@ -147,6 +149,83 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
+// A (6x4) on a 4-vector: the transpose of at4's matrix
+__device__ __forceinline__ void a6(const float y0, const float y1, const float y2, const float y3, float& o0, float& o1, float& o2, float& o3,
+                                   float& o4, float& o5) {
+    o0 = y0;
+    o1 = y0 + y1 + y2 + y3;
+    o2 = y0 - y1 + y2 - y3;
+    o3 = y0 + 2.f * y1 + 4.f * y2 + 8.f * y3;
+    o4 = y0 - 2.f * y1 + 4.f * y2 - 8.f * y3;
+    o5 = y3;
+}
+
+// weight gradient, step 1: gy [B,H,W,N] -> Mg [36][T][N] = A dY A^T per 4x4 output tile (zeros beyond the image)
+__global__ __launch_bounds__(256) void wino_outgrad_kernel(const float* __restrict__ gy, int B, int H, int W, int N, int th_n, int tw_n,
+                                                           float* __restrict__ Mg) {
+    const int64_t T = (int64_t)B * th_n * tw_n;
+    const int64_t total = T * N;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % N);
+        const int64_t t = idx / N;
+        const int tw = (int)(t % tw_n), th = (int)((t / tw_n) % th_n), b = (int)(t / ((int64_t)tw_n * th_n));
+        float y[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int oy = 4 * th + i;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ox = 4 * tw + j;
+                y[i][j] = (oy < H && ox < W) ? gy[(((int64_t)b * H + oy) * W + ox) * N + n] : 0.f;
+            }
+        }
+        float tcol[6][4];  // A dY
+#pragma unroll
+        for (int j = 0; j < 4; j++) a6(y[0][j], y[1][j], y[2][j], y[3][j], tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j], tcol[4][j], tcol[5][j]);
+        const int64_t ps = T * N;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            float v0, v1, v2, v3, v4, v5;
+            a6(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], v0, v1, v2, v3, v4, v5);
+            float* o = Mg + ((int64_t)(6 * i) * T + t) * N + n;
+            o[0] = v0; o[ps] = v1; o[2 * ps] = v2; o[3 * ps] = v3; o[4 * ps] = v4; o[5 * ps] = v5;
+        }
+    }
+}
+
+// G^T (3x6) on a 6-vector
+__device__ __forceinline__ void gt3(const float u0, const float u1, const float u2, const float u3, const float u4, const float u5, float& o0,
+                                    float& o1, float& o2) {
+    o0 = 0.25f * u0 - (1.f / 6.f) * (u1 + u2) + (1.f / 24.f) * (u3 + u4);
+    o1 = (1.f / 6.f) * (u2 - u1) + (1.f / 12.f) * (u3 - u4);
+    o2 = (1.f / 6.f) * (u3 + u4 - u1 - u2) + u5;
+}
+
+// weight gradient, step 3: dU [36][N][C] -> dw [N][3][3][C] += scale[n] * G^T dU G
+__global__ __launch_bounds__(256) void wino_wgrad_inverse_kernel(const float* __restrict__ dU, int N, int C, const float* __restrict__ scale,
+                                                                 float* __restrict__ dw) {
+    const int64_t total = (int64_t)N * C;
+    const int64_t ps = total;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const int64_t n = idx / C;
+        const float* u = dU + idx;
+        float tcol[3][6];  // G^T dU
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            gt3(u[(0 + j) * ps], u[(6 + j) * ps], u[(12 + j) * ps], u[(18 + j) * ps], u[(24 + j) * ps], u[(30 + j) * ps], tcol[0][j], tcol[1][j],
+                tcol[2][j]);
+        const float sc = scale ? scale[n] : 1.f;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            float g0, g1, g2;
+            gt3(tcol[r][0], tcol[r][1], tcol[r][2], tcol[r][3], tcol[r][4], tcol[r][5], g0, g1, g2);
+            float* o = dw + ((n * 3 + r) * 3) * C + c;
+            o[0] += sc * g0; o[C] += sc * g1; o[2 * C] += sc * g2;
+        }
+    }
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 32768); }
 
 }  // namespace
@@ -169,6 +248,30 @@ int wino_output_transform(const float* Mm, int B, int H, int W, int N, const flo
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
     wino_output_kernel<<<grid_for((int64_t)B * th_n * tw_n * N), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out);
     return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int wino_outgrad_transform(const float* gy, int B, int H, int W, int N, float* Mg, hipStream_t st) {
+    const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
+    wino_outgrad_kernel<<<grid_for((int64_t)B * th_n * tw_n * N), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int wino_wgrad_inverse(const float* dU, int N, int C, const float* scale, float* dw, hipStream_t st) {
+    wino_wgrad_inverse_kernel<<<grid_for((int64_t)N * C), 256, 0, st>>>(dU, N, C, scale, dw);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// Winograd scratch, one grow-only allocation per stream (forward / dgrad run on the main stream, weight gradients on the side one)
+float* wino_ws(hipStream_t st, size_t floats) {
+    struct Ws { float* buf = nullptr; size_t floats = 0; };
+    static std::map<hipStream_t, Ws> pool;
+    Ws& w = pool[st];
+    if (w.floats < floats) {
+        if (w.buf) { (void)hipStreamSynchronize(st); (void)hipFree(w.buf); w.buf = nullptr; w.floats = 0; }
+        if (hipMalloc(&w.buf, floats * sizeof(float)) != hipSuccess) return nullptr;
+        w.floats = floats;
+    }
+    return w.buf;
 }
 
 }  // namespace abr

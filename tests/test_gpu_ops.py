@@ -483,3 +483,13 @@ def test_conv3x3_winograd_matches_torch(shape):
     assert float((y_plain - ref).abs().max()) <= tol, float((y_plain - ref).abs().max()) / float(ref.abs().max())
     assert float((y_relu - ref.clamp(min=0)).abs().max()) <= tol
     assert float((y_mask - torch.where(mk.double() > 0, ref, torch.zeros_like(ref))).abs().max()) <= tol
+    # weight gradient through the Winograd domain (36 batched GEMMs over the tile axis + G^T dU G), accumulating into dw
+    gy = torch.randn(B, H, W, Cout, generator=g)
+    wd = w.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yy = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wd, padding=1) * sc.double().view(1, -1, 1, 1)
+    yy.backward(gy.permute(0, 3, 1, 2).double())
+    ref_dw = wd.grad.permute(0, 2, 3, 1)
+    dw0 = torch.randn(Cout, 3, 3, Cin, generator=g)
+    dw = ops.conv_wgrad(x.cuda(), gy.cuda(), dw0.clone().cuda(), 1, 1, scale=sc.cuda()).cpu().double()
+    err = float((dw - dw0.double() - ref_dw).abs().max()) / float(ref_dw.abs().max())
+    assert err <= 5e-5, err
