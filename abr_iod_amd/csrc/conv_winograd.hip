@@ -18,49 +18,61 @@
 
 namespace {
 
+// The transforms work on TWO adjacent channels per thread (8 B loads / stores, half the memory instructions of a scalar version;
+// four channels would need > 200 VGPRs for the 6x6 tile).
+struct f2 {
+    float x, y;
+};
+__device__ __forceinline__ f2 operator+(f2 a, f2 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a, f2 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a) { return {-a.x, -a.y}; }
+__device__ __forceinline__ f2 operator*(float s, f2 a) { return {s * a.x, s * a.y}; }
+__device__ __forceinline__ f2 ld2(const float* p) { const float2 v = *reinterpret_cast<const float2*>(p); return {v.x, v.y}; }
+__device__ __forceinline__ void st2(float* p, f2 v) { *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y); }
+
 // B^T (6x6), applied to columns then rows
-__device__ __forceinline__ void bt6(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
-                                    float& o0, float& o1, float& o2, float& o3, float& o4, float& o5) {
+template <typename T>
+__device__ __forceinline__ void bt6(const T d0, const T d1, const T d2, const T d3, const T d4, const T d5, T& o0, T& o1, T& o2, T& o3, T& o4,
+                                    T& o5) {
     o0 = 4.f * d0 - 5.f * d2 + d4;
-    o1 = -4.f * d1 - 4.f * d2 + d3 + d4;
+    o1 = d3 + d4 - 4.f * (d1 + d2);
     o2 = 4.f * d1 - 4.f * d2 - d3 + d4;
-    o3 = -2.f * d1 - d2 + 2.f * d3 + d4;
+    o3 = 2.f * (d3 - d1) - d2 + d4;
     o4 = 2.f * d1 - d2 - 2.f * d3 + d4;
     o5 = 4.f * d1 - 5.f * d3 + d5;
 }
 
-// grid-stride over (tile, channel); consecutive threads = consecutive channels (coalesced 256 B per wave)
+// grid-stride over (tile, channel pair); consecutive threads = consecutive channel pairs (coalesced 512 B per wave)
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int B, int H, int W, int C, int th_n, int tw_n,
                                                          float* __restrict__ V) {
     const int64_t T = (int64_t)B * th_n * tw_n;
-    const int64_t total = T * C;
+    const int C2 = C / 2;
+    const int64_t total = T * C2;
+    const int64_t ps = T * C;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const int64_t t = idx / C;
+        const int c = 2 * (int)(idx % C2);
+        const int64_t t = idx / C2;
         const int tw = (int)(t % tw_n), th = (int)((t / tw_n) % th_n), b = (int)(t / ((int64_t)tw_n * th_n));
         const int y0 = 4 * th - 1, x0 = 4 * tw - 1;
-        float d[6][6];
+        f2 tcol[6][6];  // B^T d, built column by column so that only one input column is live at a time
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const int y = y0 + i;
-            const bool yin = (unsigned)y < (unsigned)H;
+        for (int j = 0; j < 6; j++) {
+            const int xx = x0 + j;
+            const bool xin = (unsigned)xx < (unsigned)W;
+            f2 d[6];
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const int xx = x0 + j;
-                d[i][j] = (yin && (unsigned)xx < (unsigned)W) ? x[(((int64_t)b * H + y) * W + xx) * C + c] : 0.f;
+            for (int i = 0; i < 6; i++) {
+                const int y = y0 + i;
+                d[i] = (xin && (unsigned)y < (unsigned)H) ? ld2(x + (((int64_t)b * H + y) * W + xx) * C + c) : f2{0.f, 0.f};
             }
+            bt6(d[0], d[1], d[2], d[3], d[4], d[5], tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j], tcol[4][j], tcol[5][j]);
         }
-        float tcol[6][6];  // B^T d
-#pragma unroll
-        for (int j = 0; j < 6; j++)
-            bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j], tcol[4][j], tcol[5][j]);
 #pragma unroll
         for (int i = 0; i < 6; i++) {  // (B^T d) B : the same combination along the row
-            float v0, v1, v2, v3, v4, v5;
+            f2 v0, v1, v2, v3, v4, v5;
             bt6(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], tcol[i][4], tcol[i][5], v0, v1, v2, v3, v4, v5);
             float* o = V + ((int64_t)(6 * i) * T + t) * C + c;
-            const int64_t ps = T * C;
-            o[0] = v0; o[ps] = v1; o[2 * ps] = v2; o[3 * ps] = v3; o[4 * ps] = v4; o[5 * ps] = v5;
+            st2(o, v0); st2(o + ps, v1); st2(o + 2 * ps, v2); st2(o + 3 * ps, v3); st2(o + 4 * ps, v4); st2(o + 5 * ps, v5);
         }
     }
 }
@@ -102,36 +114,37 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 }
 
 // A^T (4x6) on a 6-vector
-__device__ __forceinline__ void at4(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
-                                    float& o0, float& o1, float& o2, float& o3) {
-    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+template <typename T>
+__device__ __forceinline__ void at4(const T m0, const T m1, const T m2, const T m3, const T m4, const T m5, T& o0, T& o1, T& o2, T& o3) {
+    const T s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
     o0 = m0 + s12 + s34;
     o1 = d12 + 2.f * d34;
     o2 = s12 + 4.f * s34;
     o3 = d12 + 8.f * d34 + m5;
 }
 
-// M [36][T][N] -> out [B,H,W,N] with the conv epilogue (scale, bias, ReLU, ReLU mask of the producer)
+// M [36][T][N] -> out [B,H,W,N] with the conv epilogue (scale, bias, ReLU, ReLU mask of the producer); two channels per thread
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mm, int B, int H, int W, int N, int th_n, int tw_n,
                                                           const float* __restrict__ scale, const float* __restrict__ bias, int relu,
                                                           const float* __restrict__ mask, float* __restrict__ out) {
     const int64_t T = (int64_t)B * th_n * tw_n;
-    const int64_t total = T * N;
+    const int N2 = N / 2;
+    const int64_t total = T * N2;
+    const int64_t ps = T * N;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(idx % N);
-        const int64_t t = idx / N;
+        const int n = 2 * (int)(idx % N2);
+        const int64_t t = idx / N2;
         const int tw = (int)(t % tw_n), th = (int)((t / tw_n) % th_n), b = (int)(t / ((int64_t)tw_n * th_n));
-        const int64_t ps = T * N;
         const float* m = Mm + t * N + n;
-        float tcol[4][6];  // A^T M
+        f2 tcol[4][6];  // A^T M
 #pragma unroll
         for (int j = 0; j < 6; j++)
-            at4(m[(0 + j) * ps], m[(6 + j) * ps], m[(12 + j) * ps], m[(18 + j) * ps], m[(24 + j) * ps], m[(30 + j) * ps], tcol[0][j], tcol[1][j],
-                tcol[2][j], tcol[3][j]);
-        const float sc = scale ? scale[n] : 1.f, bi = bias ? bias[n] : 0.f;
+            at4(ld2(m + (0 + j) * ps), ld2(m + (6 + j) * ps), ld2(m + (12 + j) * ps), ld2(m + (18 + j) * ps), ld2(m + (24 + j) * ps),
+                ld2(m + (30 + j) * ps), tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j]);
+        const f2 sc = scale ? ld2(scale + n) : f2{1.f, 1.f}, bi = bias ? ld2(bias + n) : f2{0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            float y[4];
+            f2 y[4];
             at4(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], tcol[i][4], tcol[i][5], y[0], y[1], y[2], y[3]);
             const int oy = 4 * th + i;
             if (oy >= H) continue;
@@ -140,18 +153,21 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                 const int ox = 4 * tw + j;
                 if (ox >= W) continue;
                 const int64_t o = (((int64_t)b * H + oy) * W + ox) * N + n;
-                float v = y[j] * sc + bi;
-                if (relu) v = fmaxf(v, 0.f);
-                if (mask) v = mask[o] > 0.f ? v : 0.f;
-                out[o] = v;
+                f2 v = {y[j].x * sc.x + bi.x, y[j].y * sc.y + bi.y};
+                if (relu) v = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)};
+                if (mask) {
+                    const f2 mk = ld2(mask + o);
+                    v = {mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f};
+                }
+                st2(out + o, v);
             }
         }
     }
 }
 
 // A (6x4) on a 4-vector: the transpose of at4's matrix
-__device__ __forceinline__ void a6(const float y0, const float y1, const float y2, const float y3, float& o0, float& o1, float& o2, float& o3,
-                                   float& o4, float& o5) {
+template <typename T>
+__device__ __forceinline__ void a6(const T y0, const T y1, const T y2, const T y3, T& o0, T& o1, T& o2, T& o3, T& o4, T& o5) {
     o0 = y0;
     o1 = y0 + y1 + y2 + y3;
     o2 = y0 - y1 + y2 - y3;
@@ -164,31 +180,31 @@ __device__ __forceinline__ void a6(const float y0, const float y1, const float y
 __global__ __launch_bounds__(256) void wino_outgrad_kernel(const float* __restrict__ gy, int B, int H, int W, int N, int th_n, int tw_n,
                                                            float* __restrict__ Mg) {
     const int64_t T = (int64_t)B * th_n * tw_n;
-    const int64_t total = T * N;
+    const int N2 = N / 2;
+    const int64_t total = T * N2;
+    const int64_t ps = T * N;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(idx % N);
-        const int64_t t = idx / N;
+        const int n = 2 * (int)(idx % N2);
+        const int64_t t = idx / N2;
         const int tw = (int)(t % tw_n), th = (int)((t / tw_n) % th_n), b = (int)(t / ((int64_t)tw_n * th_n));
-        float y[4][4];
+        f2 tcol[6][4];  // A dY
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int oy = 4 * th + i;
+        for (int j = 0; j < 4; j++) {
+            const int ox = 4 * tw + j;
+            f2 y[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int ox = 4 * tw + j;
-                y[i][j] = (oy < H && ox < W) ? gy[(((int64_t)b * H + oy) * W + ox) * N + n] : 0.f;
+            for (int i = 0; i < 4; i++) {
+                const int oy = 4 * th + i;
+                y[i] = (oy < H && ox < W) ? ld2(gy + (((int64_t)b * H + oy) * W + ox) * N + n) : f2{0.f, 0.f};
             }
+            a6(y[0], y[1], y[2], y[3], tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j], tcol[4][j], tcol[5][j]);
         }
-        float tcol[6][4];  // A dY
-#pragma unroll
-        for (int j = 0; j < 4; j++) a6(y[0][j], y[1][j], y[2][j], y[3][j], tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j], tcol[4][j], tcol[5][j]);
-        const int64_t ps = T * N;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            float v0, v1, v2, v3, v4, v5;
+            f2 v0, v1, v2, v3, v4, v5;
             a6(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], v0, v1, v2, v3, v4, v5);
             float* o = Mg + ((int64_t)(6 * i) * T + t) * N + n;
-            o[0] = v0; o[ps] = v1; o[2 * ps] = v2; o[3 * ps] = v3; o[4 * ps] = v4; o[5 * ps] = v5;
+            st2(o, v0); st2(o + ps, v1); st2(o + 2 * ps, v2); st2(o + 3 * ps, v3); st2(o + 4 * ps, v4); st2(o + 5 * ps, v5);
         }
     }
 }
@@ -234,7 +250,7 @@ namespace abr {
 
 int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, hipStream_t st) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
-    wino_input_kernel<<<grid_for((int64_t)B * th_n * tw_n * C), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V);
+    wino_input_kernel<<<grid_for((int64_t)B * th_n * tw_n * (C / 2)), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -246,13 +262,13 @@ int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st
 int wino_output_transform(const float* Mm, int B, int H, int W, int N, const float* scale, const float* bias, int relu, const float* mask,
                           float* out, hipStream_t st) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
-    wino_output_kernel<<<grid_for((int64_t)B * th_n * tw_n * N), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out);
+    wino_output_kernel<<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int wino_outgrad_transform(const float* gy, int B, int H, int W, int N, float* Mg, hipStream_t st) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
-    wino_outgrad_kernel<<<grid_for((int64_t)B * th_n * tw_n * N), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg);
+    wino_outgrad_kernel<<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
