@@ -52,6 +52,7 @@ struct WgP {
     FastDiv d_howo, d_wo;
     const float* scale;
     unsigned x_bytes, gy_bytes;  // extents for the buffer-load range check (per batch)
+    int overwrite;               // splits == 1 only: plain stores instead of atomic accumulation (the caller wants dw = ..., not +=)
     int nbatch, tiles_pb;        // batched mode (the 36 Winograd-domain gradients): tile -> (batch, tile inside the batch)
     long x_bs, gy_bs, dw_bs;
 };
@@ -209,7 +210,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
 #pragma unroll
             for (int tn = 0; tn < 2; tn++) {
                 const int k = k0 + wn * 64 + 2 * l31 + tn;
-                if (k < p.K) unsafeAtomicAdd(dw + (size_t)n * p.K + k, acc[tm][tn][r] * sc);
+                if (k < p.K) {
+                    if (p.overwrite) dw[(size_t)n * p.K + k] = acc[tm][tn][r] * sc;
+                    else unsafeAtomicAdd(dw + (size_t)n * p.K + k, acc[tm][tn][r] * sc);
+                }
             }
         }
 }
@@ -244,6 +248,7 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
         eff -= 0.0002 * sp;                        // tie-break: fewer partial sums
         if (eff > best) { best = eff; splits = sp; }
     }
+    if (p.overwrite) splits = 1;  // one workgroup per output tile owns it: no zero-fill, no atomics
     p.splits = splits;
     p.mt_per_split = (m_tiles + splits - 1) / splits;
     // single-buffered by default: every shape of the step is as fast or faster with three resident workgroups per CU (RPN 3x3
@@ -282,7 +287,7 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     p.tiles_n = (p.Cout + TN_ - 1) / TN_;
     p.tiles_k = (p.K + TK_ - 1) / TK_;
     if (p.M == 0) return ABR_OK;
-    p.nbatch = 1; p.tiles_pb = 0; p.x_bs = p.gy_bs = p.dw_bs = 0;
+    p.nbatch = 1; p.tiles_pb = 0; p.x_bs = p.gy_bs = p.dw_bs = 0; p.overwrite = 0;
     hipStream_t st = abr::as_stream(stream);
     // Winograd F(4x4,3x3) weight gradient for the wide stride-1 3x3 convs: dU[p] = sum_tiles (A dY A^T)[p]^T (B^T d B)[p] as 36 batched
     // GEMMs over the tile axis (4x fewer multiply-adds than the direct form), then dW += scale * G^T dU G.
@@ -298,9 +303,16 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
             float *V = ws, *Mg = ws + nV, *dU = ws + nV + nM;
             int bad = abr::wino_input_transform(x, d->B, d->H, d->W, d->Cin, V, st);
             bad |= abr::wino_outgrad_transform(gy, d->B, d->H, d->W, d->Cout, Mg, st);
-            bad |= hipMemsetAsync(dU, 0, nU * sizeof(float), st) != hipSuccess;
+            // enough output tiles to fill the chip without splitting the tile axis -> each workgroup owns its dU tile and writes
+            // it directly; otherwise split-M with atomics into a zeroed dU
+            int32_t info[3];
+            const int cus_ = abr_device_info(info) == ABR_OK ? info[0] : 256;
+            const long out_tiles = 36L * ((d->Cout + TN_ - 1) / TN_) * ((d->Cin + TK_ - 1) / TK_);
+            const int own = out_tiles >= 2L * cus_;
+            if (!own) bad |= hipMemsetAsync(dU, 0, nU * sizeof(float), st) != hipSuccess;
             if (!bad) {
                 WgP g = p;
+                g.overwrite = own;
                 g.B = (int)T; g.H = g.W = 1; g.R = g.S = 1; g.stride = 1; g.pad = 0; g.Ho = g.Wo = 1;
                 g.M = (int)T; g.K = d->Cin; g.plain = 1; g.scale = nullptr;
                 g.d_howo.init(1u); g.d_wo.init(1u);
