@@ -15,6 +15,8 @@ backbone -> rpn -> roi_heads orchestration with the reference's three entry poin
 import random
 
 import torch
+
+from ... import ops
 from torch import nn
 
 from ...structures.bounding_box import BoxList
@@ -113,10 +115,8 @@ class GeneralizedRCNN(nn.Module):
                                            state["rpn_output"], selected_indices)
 
     def _soften_from_proposals(self, all_proposals, features, backbone_features, anchors, rpn_output, selected_indices=None):
-        all_selected = []
+        picks = []
         for k, props in enumerate(all_proposals):
-            order = props.get_field("objectness").sort(descending=True)[1]
-            props = props[order]
             n = len(props)
             if selected_indices is not None:
                 sel = list(selected_indices[k])
@@ -126,7 +126,17 @@ class GeneralizedRCNN(nn.Module):
                 sel = random.sample(range(0, n, 1), 64)
             else:
                 sel = random.sample(range(0, 128, 1), 64)
-            idx = torch.tensor(sel, dtype=torch.int64, device=props.bbox.device)
+            picks.append(sel)
+        # one pinned, asynchronous upload for the whole batch's picks (a pageable torch.tensor(..., device=) per image would make the
+        # host wait for everything queued on the stream -- here, the target's entire forward)
+        dev = all_proposals[0].bbox.device if all_proposals else None
+        flat_idx = ops.h2d([i for sel in picks for i in sel], torch.int64, dev) if picks else None
+        all_selected, off = [], 0
+        for props, sel in zip(all_proposals, picks):
+            order = props.get_field("objectness").sort(descending=True)[1]
+            props = props[order]
+            idx = flat_idx[off:off + len(sel)]
+            off += len(sel)
             chosen = BoxList(props.bbox.index_select(0, idx).view(-1, 4), props.size, props.mode)
             chosen.add_field("objectness", props.get_field("objectness").index_select(0, idx).view(-1))
             all_selected.append(chosen)

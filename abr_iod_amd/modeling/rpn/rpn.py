@@ -222,6 +222,7 @@ class RPNPostProcessor(nn.Module):
     def __init__(self, pre_nms_top_n, post_nms_top_n, nms_thresh, min_size, box_coder=None, fpn_post_nms_top_n=None,
                  fpn_post_nms_per_batch=True):
         super().__init__()
+        self._hw_cache = {}
         self.pre_nms_top_n, self.post_nms_top_n = pre_nms_top_n, post_nms_top_n
         self.nms_thresh, self.min_size = nms_thresh, min_size
         self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
@@ -250,7 +251,12 @@ class RPNPostProcessor(nn.Module):
         else:            # beyond the in-LDS sort capacity (no voc config gets here: PRE_NMS_TOP_N is 12000 / 6000)
             scores, topk_idx = yf[:, :, :A].reshape(N, n_anchor).sigmoid().topk(k, dim=1, sorted=True)
         same = all(a[0].bbox.data_ptr() == anchors[0][0].bbox.data_ptr() for a in anchors)
-        img_hw = torch.tensor([[a[0].size[1], a[0].size[0]] for a in anchors], dtype=torch.int32, device=y.device)
+        hw_key = (tuple((a[0].size[1], a[0].size[0]) for a in anchors), y.device)
+        img_hw = self._hw_cache.get(hw_key)   # image sizes repeat from step to step: keep the device copy
+        if img_hw is None:
+            if len(self._hw_cache) > 64:
+                self._hw_cache.clear()
+            img_hw = self._hw_cache[hw_key] = ops.h2d([list(v) for v in hw_key[0]], torch.int32, y.device)
         assert same, "per-image anchor grids of one batch share (H,W): they differ only in the visibility field"
         props = ops.rpn_decode_clip(yf, A, anchors[0][0].bbox, topk_idx, img_hw, self.box_coder.weights, A=A)  # :101-112
         counts = torch.full((N,), k, dtype=torch.int32, device=y.device)

@@ -251,6 +251,16 @@ _side_streams = {}
 _join_pending = [False]
 
 
+def h2d(values, dtype, device):
+    """Small host list -> device tensor WITHOUT stalling the host: a pageable-memory copy (`torch.tensor(..., device=)`) waits for
+    everything queued on the stream (measured: ~3 ms per call inside the training step, six calls per step); staging through the
+    caching pinned allocator makes it a true async copy."""
+    t = torch.tensor(values, dtype=dtype)
+    if torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def side_stream(key):
     """key = device index (the wgrad stream) or (device index, tag)"""
     s = _side_streams.get(key)

@@ -50,7 +50,8 @@ class FusedSGD(object):
         self.all_reduce_grads()
         lrs = [g["lr"] for g in self.param_groups]
         if lrs != self._lr_host:  # only re-upload when the scheduler changed something
-            self._lr.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=True)
+            src = torch.tensor(lrs, dtype=torch.float32)
+            self._lr.copy_(src.pin_memory() if self._lr.is_cuda else src, non_blocking=True)  # pageable source = host stall
             self._lr_host = lrs
         n = self.flat.n_trainable
         ops.sgd_momentum_(self.flat.params[:n], self.flat.grads, self.momentum_buffer, self._seg_end, self._lr, self._wd,
