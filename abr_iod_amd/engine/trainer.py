@@ -72,6 +72,17 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         (loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results), \
             (target_result, _, roi_align_features_target) = model_target.forward_joint(images, targets, soften_proposal,
                                                                                        rpn_output_source=rpn_output_source)
+    elif deferred is not None and hasattr(model_target, "forward_begin"):
+        # the target's backbone / RPN head / RPN loss are queued and its proposal selection is in flight on a side stream; the source
+        # model's selection finished long ago, so its head pass (a few ms of small GEMMs) goes in NOW: the device has work while
+        # the target's top-k / NMS run and while the host waits for their counts
+        begun = model_target.forward_begin(images, targets, rpn_output_source=rpn_output_source)               # :89-90 (first half)
+        with torch.no_grad():
+            soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
+                model_source.soften_finish(deferred)
+        deferred = None
+        loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results = \
+            model_target.forward_finish(begun)                                                             # :89-90 (second half)
     else:
         loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results = \
             model_target(images, targets, rpn_output_source=rpn_output_source)                             # :89-90

@@ -56,17 +56,32 @@ class GeneralizedRCNN(nn.Module):
         if features is not None and proposals is not None:
             target_scores, target_bboxes, mask_logits, roi_align_features = self.roi_heads.calculate_soften_label(features, proposals)
             return (target_scores, target_bboxes), mask_logits, roi_align_features
+        if self.training:
+            return self.forward_finish(self.forward_begin(images, targets, rpn_output_source))
         images = to_image_list(images)
         features, backbone_features = self.backbone(images.tensors)
         (proposals, proposal_losses), anchors, rpn_output = self.rpn(images, features, targets, rpn_output_source)
-        if not self.training:  # generalized_rcnn.py:76-78 -> (detections, features, background detections)
-            x, result, results_background, _ = self.roi_heads(features, proposals, targets)
-            return result, features, results_background
+        # generalized_rcnn.py:76-78 -> (detections, features, background detections)
+        x, result, results_background, _ = self.roi_heads(features, proposals, targets)
+        return result, features, results_background
+
+    def forward_begin(self, images, targets, rpn_output_source=None):
+        """Training forward up to the point where the host needs the proposal counts: backbone, RPN head, RPN loss, and the
+        proposal selection in flight on its side stream.  The trainer slots the source model's head pass between `forward_begin`
+        and `forward_finish`, so the selection (and the host's read-back of its counts) hides behind real work."""
+        images = to_image_list(images)
+        features, backbone_features = self.backbone(images.tensors)
+        return dict(features=features, backbone_features=backbone_features, targets=targets,
+                    rpn=self.rpn.forward_begin(images, features, targets, rpn_output_source))
+
+    def forward_finish(self, state):
+        features, targets = state["features"], state["targets"]
+        (proposals, proposal_losses), anchors, rpn_output = self.rpn.forward_finish(state["rpn"])
         x, result, soften_results, detector_losses, roi_align_features = self.roi_heads(features, proposals, targets)
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)
-        return losses, features, backbone_features, anchors, rpn_output, result, roi_align_features, soften_results
+        return losses, features, state["backbone_features"], anchors, rpn_output, result, roi_align_features, soften_results
 
     def forward_joint(self, images, targets, soften_proposals, rpn_output_source=None):
         """`forward(images, targets)` followed by `forward(images, targets, features=..., proposals=soften_proposals)`
@@ -110,7 +125,7 @@ class GeneralizedRCNN(nn.Module):
         pending = state["pending"]
         if isinstance(pending, dict):   # deferred: join the side stream, read the keep counts, cut the BoxLists
             sel = self.rpn.box_selector_test
-            pending = sel.collect(sel.join(pending))
+            pending = sel.collect(pending)
         return self._soften_from_proposals(pending, state["features"], state["backbone_features"], state["anchors"],
                                            state["rpn_output"], selected_indices)
 

@@ -268,8 +268,16 @@ class RPNPostProcessor(nn.Module):
     def collect(self, pending, targets=None):
         """Host half: read the per-image keep counts (the only host sync of the proposal path; the reference syncs inside every
         nms call) and cut the BoxLists."""
+        side = pending.get("stream")
+        if side is not None:
+            # read the counts ON THE SIDE STREAM: the copy then waits for the selection only, not for whatever the caller has queued
+            # on the main stream in the meantime (a main-stream read-back would stall the host behind all of it)
+            with torch.cuda.stream(side):
+                nk = pending["n_keep"].tolist()
+            self.join(pending)
+        else:
+            nk = pending["n_keep"].tolist()
         props, scores, keep = pending["props"], pending["scores"], pending["keep"]
-        nk = pending["n_keep"].tolist()
         result = []
         for i, size in enumerate(pending["sizes"]):
             ki = keep[i, : nk[i]].long()
@@ -422,27 +430,40 @@ class RPNModule(nn.Module):
 
     def forward(self, images, features, targets=None, rpn_output_source=None, defer_proposals=False):
         """-> ((boxes, losses), anchors, rpn_output) exactly as rpn.py:161-183."""
+        if self.training:
+            return self.forward_finish(self.forward_begin(images, features, targets, rpn_output_source))
         fused = self.head.forward_fused(features[0])
         A = self.head.num_anchors
         anchors = self.anchor_generator(images, features)
         rpn_output = ([fused[:, :A]], [fused[:, A:5 * A]])
-        if self.training:
-            with torch.no_grad():
-                self.box_selector_train.train()
-                if PROPOSALS_SIDE_STREAM and fused.is_cuda:   # selection runs next to the loss kernels below
-                    pending = self.box_selector_train.launch_on_side_stream(anchors, fused.detach(), A)
-                else:
-                    pending = self.box_selector_train.launch(anchors, fused.detach(), A)
-            loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, None, None, targets, rpn_output_source, fused=fused)
-            with torch.no_grad():
-                boxes = self.box_selector_train.collect(self.box_selector_train.join(pending), targets)
-            return (boxes, {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}), anchors, rpn_output
         self.box_selector_test.eval()
         if defer_proposals:   # the caller collects later (GeneralizedRCNN.soften_begin / soften_finish)
             pending = self.box_selector_test.launch_on_side_stream(anchors, fused, A, tag="source-proposals")
             return (pending, {}), anchors, rpn_output
         boxes = self.box_selector_test.forward_fused(anchors, fused, A)
         return (boxes, {}), anchors, rpn_output
+
+    def forward_begin(self, images, features, targets, rpn_output_source=None):
+        """Training forward up to (not including) the read-back of the proposal counts: head conv, anchors, the proposal selection
+        launched on a side stream, the loss on the current stream."""
+        fused = self.head.forward_fused(features[0])
+        A = self.head.num_anchors
+        anchors = self.anchor_generator(images, features)
+        rpn_output = ([fused[:, :A]], [fused[:, A:5 * A]])
+        with torch.no_grad():
+            self.box_selector_train.train()
+            if PROPOSALS_SIDE_STREAM and fused.is_cuda:   # selection runs next to the loss kernels below
+                pending = self.box_selector_train.launch_on_side_stream(anchors, fused.detach(), A)
+            else:
+                pending = self.box_selector_train.launch(anchors, fused.detach(), A)
+        loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, None, None, targets, rpn_output_source, fused=fused)
+        return dict(pending=pending, targets=targets, anchors=anchors, rpn_output=rpn_output,
+                    losses={"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg})
+
+    def forward_finish(self, state):
+        with torch.no_grad():
+            boxes = self.box_selector_train.collect(state["pending"], state["targets"])
+        return (boxes, state["losses"]), state["anchors"], state["rpn_output"]
 
 
 def build_rpn(cfg, in_channels):
