@@ -15,10 +15,17 @@
 // 32x32 (16 VGPR each).  LDS tiles are [row][36] floats: the +4 pad makes the ds_read_b128 fragment reads
 // conflict-free (16-lane groups land on 16 distinct 16 B slots).  A lane reads 4 consecutive k with one
 // b128 and feeds them to 4 successive MFMAs; the lane-half h supplies k = 8u+4h+t for both operands, so the
-// products match (k order inside a tile is a free permutation).  Global->LDS is register-staged and split
-// (issue loads for tile t+1, run the 16*TM*TN MFMAs of tile t, then write LDS): one barrier per k-tile.
+// products match (k order inside a tile is a free permutation).
+// Operand fetch: BUFFER loads with 32-bit offsets against range-checked descriptors (halo taps, tail rows and
+// the K tail read as zeros in hardware: no branches), register-staged into LDS.  Two loop shapes: double-buffered
+// LDS (one barrier per k-tile, tile kt+2 fetched right behind the ds_writes of kt+1; 2 workgroups/CU) for long K,
+// single-buffered (two barriers, 3+ workgroups/CU) for K <= 512 and the smaller tiles.  The last k-tile is peeled,
+// so the steady-state loop is one basic block.
+// Grid shaping: XCD-aware tile order; split-K of the LAST round's tiles for long-K GEMMs whose grid does not fill
+// it (partials through system-coherent buffer accesses, deterministic last-arrival reduce); batched mode for the
+// 36 GEMMs of a Winograd F(4x4,3x3) convolution (conv_winograd.hip), which every wide stride-1 3x3 conv takes.
 // fp32 MFMA is bit-for-bit an fmaf chain, so results are exact-fp32 (no TF32/bf16 anywhere).
-// Bound: MFMA (157.3 TFLOP/s fp32 matrix peak); DESIGN.md has the per-layer flop counts.
+// Bound: MFMA (157.3 TFLOP/s fp32 matrix peak); DESIGN.md has the per-layer flop counts and measured rates.
 #include <map>
 
 #include "common.h"

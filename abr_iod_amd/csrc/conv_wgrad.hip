@@ -16,6 +16,8 @@
 // memory: rows are staged as-is into LDS ([m][128], 512 B coalesced per row) and a lane picks its operand
 // with one ds_read_b64 = two adjacent n (or k) of row m; accumulator tile t then holds n = base + 2i + t.
 // That interleave is undone in the epilogue addressing, so no transpose is ever materialised.
+// Operand fetch is buffer loads with hardware range checking (no branches), single-buffered LDS (3 workgroups/CU); wide
+// stride-1 3x3 convs go through the Winograd domain instead (36 batched plain GEMMs over the tile axis, conv_winograd.hip).
 #include <algorithm>
 
 #include "common.h"
