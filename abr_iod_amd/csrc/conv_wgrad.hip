@@ -233,9 +233,9 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
     // split-M so that the grid fills the chip evenly: among the candidates pick the one with the best load balance
     // (workgroups / (ceil(workgroups / CUs) * CUs)), preferring fewer splits (less atomic traffic) on ties; every
     // workgroup keeps at least 8 stages (256 rows) of work.
-    // opt-in (ABR_WGRAD_OCC2=1): alone on the device the head 1x1 gradients gain 11-15 % from two workgroups per CU, but inside the
-    // training step they run next to the dgrad stream, which already fills the gaps -- measured no gain there.
-    static const bool occ2 = getenv("ABR_WGRAD_OCC2") && atoi(getenv("ABR_WGRAD_OCC2")) != 0;
+    // Prefer two workgroups per CU when each still gets >= 64 stages: a lone workgroup cannot hide its own prologue / atomics
+    // epilogue (head 1x1 gradients: 113 -> 126..134 TF alone; -1.0 ms per training step).  ABR_WGRAD_OCC2=0 turns it off.
+    static const bool occ2 = !(getenv("ABR_WGRAD_OCC2") && atoi(getenv("ABR_WGRAD_OCC2")) == 0);
     const int max_splits = std::max(1, (m_tiles + 7) / 8);
     int splits = 1;
     double best = -1.0;
