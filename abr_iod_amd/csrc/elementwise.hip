@@ -149,23 +149,64 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64
 // (solver/build.py:7-21) -> 52 x (wd add, momentum mul/add, update) tiny launches; here one streaming pass:
 // reads p,g,m and writes p,m = 5 x 4 B per element.  torch.optim.SGD semantics (dampening 0, no nesterov):
 //   d = g + wd*p ; m = first ? d : mu*m + d ; p -= lr*m.
-// seg_end is ascending; a thread finds its tensor by binary search over <= a few hundred segments.
+// seg_end is ascending and every segment starts on a 64-float boundary (modeling/_flat.py ALIGN), so a float4 never straddles two
+// tensors: 16 B accesses, one segment lookup per float4, the (<= 256-entry) tables staged in LDS once per workgroup.
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    int64_t total, const int64_t* __restrict__ seg_end,
                                                    const float* __restrict__ lr, const float* __restrict__ wd, int n_seg,
                                                    float mu, float gscale, int first) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    __shared__ int64_t s_end[256];
+    __shared__ float s_lr[256], s_wd[256];
+    const bool staged = n_seg <= 256;
+    if (staged)
+        for (int i = threadIdx.x; i < n_seg; i += blockDim.x) { s_end[i] = seg_end[i]; s_lr[i] = lr[i]; s_wd[i] = wd[i]; }
+    __syncthreads();
+    const int64_t* se = staged ? s_end : seg_end;
+    const float* lrs = staged ? s_lr : lr;
+    const float* wds = staged ? s_wd : wd;
+    const int64_t n4 = total / 4;
+    for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = i4 * 4;
         int lo = 0, hi = n_seg - 1;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (i < seg_end[mid]) hi = mid; else lo = mid + 1;
+            if (i < se[mid]) hi = mid; else lo = mid + 1;
         }
-        const float pv = p[i];
-        const float d = g[i] * gscale + wd[lo] * pv;
-        const float mv = first ? d : mu * m[i] + d;
-        m[i] = mv;
-        p[i] = pv - lr[lo] * mv;
+        if (i + 4 > se[lo]) {  // a float4 that straddles two tensors (only with unaligned segment tables): element by element
+            for (int e = 0; e < 4; e++) {
+                int sg = lo;
+                while (i + e >= se[sg] && sg < n_seg - 1) sg++;
+                const float pe = p[i + e];
+                const float d = g[i + e] * gscale + wds[sg] * pe;
+                const float me = first ? d : mu * m[i + e] + d;
+                m[i + e] = me;
+                p[i + e] = pe - lrs[sg] * me;
+            }
+            continue;
+        }
+        const float w_ = wds[lo], l_ = lrs[lo];
+        float4 pv = reinterpret_cast<float4*>(p)[i4];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i4];
+        float4 mv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4*>(m)[i4];
+        const float dx = gv.x * gscale + w_ * pv.x, dy = gv.y * gscale + w_ * pv.y, dz = gv.z * gscale + w_ * pv.z, dw = gv.w * gscale + w_ * pv.w;
+        mv.x = first ? dx : mu * mv.x + dx; mv.y = first ? dy : mu * mv.y + dy; mv.z = first ? dz : mu * mv.z + dz; mv.w = first ? dw : mu * mv.w + dw;
+        pv.x -= l_ * mv.x; pv.y -= l_ * mv.y; pv.z -= l_ * mv.z; pv.w -= l_ * mv.w;
+        reinterpret_cast<float4*>(m)[i4] = mv;
+        reinterpret_cast<float4*>(p)[i4] = pv;
     }
+    if (blockIdx.x == 0)  // tail (total is a multiple of 64 for flat buffers; kept for arbitrary callers)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < total; i += blockDim.x) {
+            int lo = 0, hi = n_seg - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (i < se[mid]) hi = mid; else lo = mid + 1;
+            }
+            const float pv = p[i];
+            const float d = g[i] * gscale + wds[lo] * pv;
+            const float mv = first ? d : mu * m[i] + d;
+            m[i] = mv;
+            p[i] = pv - lrs[lo] * mv;
+        }
 }
 
 }  // namespace
@@ -251,7 +292,7 @@ extern "C" int abr_sgd_momentum(float* p, const float* g, float* m, int64_t tota
                                 int first_step, void* stream) {
     if (total == 0) return ABR_OK;
     ABR_REQUIRE(p && g && m && seg_end_dev && lr_dev && wd_dev && n_seg > 0, "sgd_momentum: bad args");
-    sgd_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, abr::as_stream(stream)>>>(
+    sgd_kernel<<<(unsigned)std::min<int64_t>((total / 4 + 255) / 256 + 1, 8192), 256, 0, abr::as_stream(stream)>>>(
         p, g, m, total, seg_end_dev, lr_dev, wd_dev, n_seg, momentum, gscale, first_step);
     ABR_CHECK_LAUNCH("sgd_momentum");
     return ABR_OK;
