@@ -1,0 +1,53 @@
+"""GPU, one rank: the data-parallel step through RCCL itself (backend "nccl" on ROCm).  A 1-GPU box cannot show scaling, but it
+does exercise what bench.py --gpus N does on every rank: process-group initialisation over 127.0.0.1, the all-reduce of the flat
+gradient buffer issued after the side-stream weight gradients are joined, and the 1/world scaling in the update -- and with one
+rank the result must equal the run without the collective bit for bit."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_single_rank_rccl_step_equals_local_step():
+    from abr_iod_amd.engine import train_step
+    from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
+    from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer
+    tiny = ["MODEL.RESNETS.STEM_OUT_CHANNELS", 16, "MODEL.RESNETS.RES2_OUT_CHANNELS", 32, "MODEL.RESNETS.WIDTH_PER_GROUP", 8,
+            "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 128]
+    images, targets = synthetic_batch(2, 160, 224, seed=1)
+
+    def run(collective):
+        import random
+        cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, overrides=tiny)
+        ms, mt = build_models(cfg_s, cfg_t, seed=0)
+        opt = make_optimizer(cfg_t, mt)
+        opt.force_all_reduce = collective
+        sch = make_lr_scheduler(cfg_t, opt)
+        torch.manual_seed(3); random.seed(3)
+        for _ in range(3):
+            train_step(ms, mt, images, targets, opt, sch, cfg_t)
+        torch.cuda.synchronize()
+        return mt.flat.params.clone()
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:{}".format(_free_port()), rank=0, world_size=1)
+    try:
+        with_rccl = run(True)
+    finally:
+        dist.destroy_process_group()
+    local = run(False)
+    assert torch.isfinite(with_rccl).all()
+    # atomically accumulated weight gradients make two runs differ in the last bits; the collective adds nothing on top
+    assert float((with_rccl - local).norm() / local.norm()) < 1e-5
