@@ -161,6 +161,8 @@ def main():
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                               "flops_counted": "executed multiply-adds of each launch (a Winograd F(4x4,3x3) conv executes 1/4 of its algorithmic "
+                                                "MACs, so conv_roofline_frac_whole_step -- algorithmic -- can exceed this kernel fraction)",
                                "launches": int(n), "sampling": "every launch" if a.time_all_kernels else "every 4th launch of this kernel",
                                "avg_launch_ms": round(ms / max(n, 1), 4),
                                "avg_gflop_per_launch": round(flops / max(n, 1) / 1e9, 3),
