@@ -526,7 +526,8 @@ static void dispatch_igemm(const ConvP& p, const float* x, const float* w, float
     // per CU (the 600-tile RPN GEMM); longer-K GEMMs are faster double-buffered (one barrier per k-tile, fetch two tiles ahead).
     static const int sb_mode = getenv("ABR_IGEMM_SB") ? atoi(getenv("ABR_IGEMM_SB")) : -1;
     const int64_t wgs128 = take_split128 ? best_nfull + (t128 - best_nfull) * best_s : t128;
-    const bool sb = sb_mode >= 0 ? sb_mode != 0 : (p.K <= 512 || (wgs128 > 2 * cus && wgs128 <= 3 * cus) || take_split128);
+    static const int sb_maxk = getenv("ABR_IGEMM_SB_MAXK") ? atoi(getenv("ABR_IGEMM_SB_MAXK")) : 512;
+    const bool sb = sb_mode >= 0 ? sb_mode != 0 : (p.K <= sb_maxk || (wgs128 > 2 * cus && wgs128 <= 3 * cus) || take_split128);
     if (small_c) {
         launch<128, 64, 4, 1, true, true>(p, x, w, out, st, abr::PROF_IGEMM_SMALLC);
     } else if (rule128 || take_split128) {
