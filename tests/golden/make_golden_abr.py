@@ -95,5 +95,34 @@ def main():
     print("wrote abr_data.npz", os.path.getsize(os.path.join(HERE, "abr_data.npz")) / 1e6, "MB")
 
 
+from mini_voc import make_mini_voc  # noqa: E402  (shared with the tests: no reference dependency)
+
+
+def gold_voc_dataset():
+    """Image lists and filtered ground truth of the reference's PascalVOCDataset (voc_abr.py:25-300) on the mini VOC directory, for
+    training and testing, with / without difficult objects."""
+    import json
+    rs = np.random.RandomState(3)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        make_mini_voc(d, rs)
+        old, new, excl = ["dog", "person", "cat"], ["sofa", "train", "tvmonitor"], ["bird"]
+        for tag, (is_train, split, diff) in {"train": (True, "trainval", False), "test": (False, "test", False),
+                                             "test_difficult": (False, "test", True)}.items():
+            ds = voc_abr.PascalVOCDataset(d, split, use_difficult=diff, transforms=None, old_classes=old, new_classes=new,
+                                          excluded_classes=excl, is_train=is_train, is_father=True)
+            rec = {"ids": list(ds.final_ids), "gt": []}
+            for i in range(len(ds)):
+                t = ds.get_groundtruth(i)
+                rec["gt"].append({"boxes": t.bbox.tolist(), "labels": t.get_field("labels").tolist(),
+                                  "difficult": [bool(v) for v in t.get_field("difficult").tolist()], "size": list(t.size),
+                                  "info": ds.get_img_info(i)})
+            out[tag] = rec
+            print(tag, rec["ids"], [g["labels"] for g in rec["gt"]])
+    with open(os.path.join(HERE, "voc_dataset.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
     main()
+    gold_voc_dataset()
