@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the ABR data path: device pipeline (abr_iod_amd/data) vs the host pipeline the reference runs
-in its DataLoader workers (Pillow + numpy + torch CPU, restated in oracle/abr_data_ref.py), on VOC-sized synthetic images
+in its DataLoader workers (Pillow + numpy + torch CPU, the same calls the reference makes), on VOC-sized synthetic images
 (375x500 -> 600x800) with a synthetic rehearsal memory.  One process, one CPU core for the host leg.  GPU box only.
 Prints one JSON line: images/s for both, per-stage device times."""
 import json
@@ -61,8 +61,18 @@ def main():
 
         # host leg: the same stages with Pillow / numpy / torch CPU (resize to 600x800 BILINEAR + ToTensor/normalise + pad; a BICUBIC
         # crop resize + float64 blend for the replayed quarter), single core like one DataLoader worker
-        from oracle import abr_data_ref as R
         torch.set_num_threads(1)
+
+        def pil_resize(a, w, h, res):
+            return np.asarray(Image.fromarray(a).resize((w, h), res))
+
+        def to_tensor_normalize(a, flip):
+            if flip:
+                a = a[:, ::-1]
+            t = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+            t = t[[2, 1, 0]] * 255
+            return ((t - torch.tensor(cfg.INPUT.PIXEL_MEAN).view(-1, 1, 1)) / torch.tensor(cfg.INPUT.PIXEL_STD).view(-1, 1, 1)).numpy()
+
         crops = [np.asarray(Image.open(os.path.join(d, n)).convert("RGB")) for n in names[:32]]
         random.seed(1)
         t0 = time.perf_counter()
@@ -73,14 +83,16 @@ def main():
                 r = random.randint(0, 3)
                 if r == 0:     # mixup: two crops
                     for c in crops[k:k + 2]:
-                        c2 = R.pil_resize(c, 150, 150, R.BICUBIC)
-                        R.blend_paste(im, c2, 20, 20, 170, 170, 0, 0, 0.3)
+                        c2 = pil_resize(c, 150, 150, Image.BICUBIC)
+                        im[20:170, 20:170] = 0.3 * im[20:170, 20:170] + (1 - 0.3) * c2
                 elif r == 1:   # mosaic: four crops on a 437-square canvas
-                    im = R.mosaic_canvas(437, [(R.pil_resize(c, 200, 200, R.BICUBIC), (q % 2 * 218, q // 2 * 218, q % 2 * 218 + 200, q // 2 * 218 + 200), (0, 0, 200, 200))
-                                               for q, c in enumerate(crops[k:k + 4])])
+                    canvas = np.full((437, 437, 3), 114.0, dtype=np.float32)
+                    for q, c in enumerate(crops[k:k + 4]):
+                        canvas[q // 2 * 218: q // 2 * 218 + 200, q % 2 * 218: q % 2 * 218 + 200] = pil_resize(c, 200, 200, Image.BICUBIC)
+                    im = np.uint8(canvas)
                 h, w = im.shape[:2]
                 oh, ow = tf.resize.get_size((w, h))
-                outs.append(R.to_tensor_normalize(R.pil_resize(im, ow, oh, R.BILINEAR), cfg.INPUT.PIXEL_MEAN, cfg.INPUT.PIXEL_STD, True, k % 2 == 0))
+                outs.append(to_tensor_normalize(pil_resize(im, ow, oh, Image.BILINEAR), k % 2 == 0))
             HP, WP = max(o.shape[1] for o in outs), max(o.shape[2] for o in outs)
             batch_t = torch.zeros((batch, 3, HP, WP))
             for slot, o in zip(batch_t, outs):
