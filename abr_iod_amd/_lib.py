@@ -51,6 +51,8 @@ _SIGS = {
     "abr_smooth_l1": (_i, [_vp, _vp, _i64, _f, _f, _vp, _f, _vp, _vp]),
     "abr_smooth_l1_rows": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _f, _vp, _vp]),
     "abr_softmax_ce": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _f, _vp, _i, _vp]),
+    "abr_feat_distill": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _vp, _vp]),
+    "abr_rpn_distill": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i64, _i, _f, _i, _vp, _f, _vp, _vp, _i, _i, _vp]),
     "abr_roi_distill": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _f, _vp, _vp, _vp]),
     "abr_bce_logits_gather": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp]),
     "abr_img_resample_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),

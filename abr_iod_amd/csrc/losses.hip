@@ -268,6 +268,81 @@ __global__ __launch_bounds__(256) void bce_gather_kernel(const float* __restrict
     if (threadIdx.x == 0) atomicAdd(loss_out, acc * inv);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ablation distillation losses -- distillation/distillation.py:18-84 (RPN) and :133-161 (backbone features)
+// ------------------------------------------------------------------------------------------------
+// pass 1 of the feature loss: sums of both maps (their means normalise the difference)
+__global__ __launch_bounds__(256) void feat_distill_sums_kernel(const float* __restrict__ s, const float* __restrict__ t, int64_t n,
+                                                                 float* __restrict__ stats) {
+    __shared__ float sm[4];
+    float a = 0.f, b = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { a += s[i]; b += t[i]; }
+    a = abr::block_sum<4>(a, sm);
+    b = abr::block_sum<4>(b, sm);
+    if (threadIdx.x == 0) { atomicAdd(stats, a); atomicAdd(stats + 1, b); }
+}
+
+// pass 2: loss = mean(max((s - mean s) - (t - mean t), 0)), and the number of positive differences (the mean's share of the gradient)
+__global__ __launch_bounds__(256) void feat_distill_loss_kernel(const float* __restrict__ s, const float* __restrict__ t, int64_t n,
+                                                                 float* __restrict__ stats, float* __restrict__ loss_out) {
+    __shared__ float sm[4];
+    const float inv = 1.f / (float)n;
+    const float shift = stats[1] * inv - stats[0] * inv;  // d_i = s_i - t_i + (mean t - mean s)
+    float l = 0.f, c = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = s[i] - t[i] + shift;
+        if (d > 0.f) { l += d; c += 1.f; }
+    }
+    l = abr::block_sum<4>(l, sm);
+    c = abr::block_sum<4>(c, sm);
+    if (threadIdx.x == 0) { atomicAdd(loss_out, l * inv); atomicAdd(stats + 2, c); }
+}
+
+// pass 3: d loss / d t_j = (1/n) * (mean(mask) - mask_j)
+__global__ __launch_bounds__(256) void feat_distill_grad_kernel(const float* __restrict__ s, const float* __restrict__ t, int64_t n,
+                                                                 const float* __restrict__ stats, float gscale, float* __restrict__ g) {
+    const float inv = 1.f / (float)n;
+    const float shift = stats[1] * inv - stats[0] * inv;
+    const float mmean = stats[2] * inv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = s[i] - t[i] + shift;
+        g[i] = gscale * inv * (mmean - (d > 0.f ? 1.f : 0.f));
+    }
+}
+
+// RPN distillation on the NHWC head outputs: row r = (image, y, x), anchor a: objectness at obj[r*ld_o + a], deltas at reg[r*ld_r + 4a..]
+//   cls  = mean_anchors max(o_s - o_t, 0)^2        ("filtered_l2")
+//   bbox = mean_anchors [o_s - o_t > thr] * sum_4 (d_s - d_t)^2   ("l2" on the masked deltas; the mask carries no gradient)
+__global__ __launch_bounds__(256) void rpn_distill_kernel(const float* __restrict__ obj_s, const float* __restrict__ reg_s, int ld_os, int ld_rs,
+                                                           const float* __restrict__ obj_t, const float* __restrict__ reg_t, int ld_ot, int ld_rt,
+                                                           int64_t rows, int A, float thr, int use_bbox, float* __restrict__ loss_out,
+                                                           float gscale, float* __restrict__ g_obj, float* __restrict__ g_reg, int ld_go,
+                                                           int ld_gr) {
+    __shared__ float sm[4];
+    const int64_t n = rows * A;
+    const float inv = 1.f / (float)n;
+    float l = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / A;
+        const int a = (int)(i % A);
+        const float diff = obj_s[r * ld_os + a] - obj_t[r * ld_ot + a];
+        const float pos = fmaxf(diff, 0.f);
+        l += pos * pos;
+        if (g_obj) g_obj[r * ld_go + a] = -2.f * pos * inv * gscale;
+        const bool m = use_bbox && diff > thr;
+        const float* ds = reg_s + r * ld_rs + 4 * a;
+        const float* dt = reg_t + r * ld_rt + 4 * a;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float dd = m ? ds[e] - dt[e] : 0.f;
+            l += dd * dd;
+            if (g_reg) g_reg[r * ld_gr + 4 * a + e] = -2.f * dd * inv * gscale;
+        }
+    }
+    l = abr::block_sum<4>(l, sm);
+    if (threadIdx.x == 0) atomicAdd(loss_out, l * inv);
+}
+
 }  // namespace
 
 extern "C" int abr_sigmoid_focal_forward(const float* logits, const int32_t* targets, int N, int C, float gamma,
@@ -378,5 +453,37 @@ extern "C" int abr_bce_logits_gather(const float* x, const float* y, const int64
     ABR_REQUIRE(x && y && idx, "bce_logits_gather: null pointer");
     bce_gather_kernel<<<std::min(abr::cdiv(n_idx, 256), 256u), 256, 0, st>>>(x, y, idx, yidx, n_idx, denom_dev, loss_out, gscale, grad);
     ABR_CHECK_LAUNCH("bce_logits_gather");
+    return ABR_OK;
+}
+
+extern "C" int abr_feat_distill(const float* src, const float* tgt, int64_t n, float* loss_out, float* stats3, float gscale, float* d_tgt,
+                                void* stream) {
+    ABR_REQUIRE(n >= 0 && loss_out && stats3, "feat_distill: bad args");
+    hipStream_t st = abr::as_stream(stream);
+    if (int e = zero_loss(loss_out, 1, st, "feat_distill")) return e;
+    if (hipMemsetAsync(stats3, 0, 3 * sizeof(float), st) != hipSuccess) return ABR_E_LAUNCH;
+    if (n == 0) return ABR_OK;
+    ABR_REQUIRE(src && tgt, "feat_distill: null pointer");
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    feat_distill_sums_kernel<<<grid, 256, 0, st>>>(src, tgt, n, stats3);
+    feat_distill_loss_kernel<<<grid, 256, 0, st>>>(src, tgt, n, stats3, loss_out);
+    if (d_tgt) feat_distill_grad_kernel<<<grid, 256, 0, st>>>(src, tgt, n, stats3, gscale, d_tgt);
+    ABR_CHECK_LAUNCH("feat_distill");
+    return ABR_OK;
+}
+
+extern "C" int abr_rpn_distill(const float* obj_s, const float* reg_s, int ld_obj_s, int ld_reg_s, const float* obj_t, const float* reg_t,
+                               int ld_obj_t, int ld_reg_t, int64_t rows, int A, float bbox_threshold, int use_bbox, float* loss_out,
+                               float gscale, float* d_obj_t, float* d_reg_t, int ld_d_obj, int ld_d_reg, void* stream) {
+    ABR_REQUIRE(rows >= 0 && A > 0 && loss_out, "rpn_distill: bad args");
+    hipStream_t st = abr::as_stream(stream);
+    if (int e = zero_loss(loss_out, 1, st, "rpn_distill")) return e;
+    if (rows == 0) return ABR_OK;
+    ABR_REQUIRE(obj_s && reg_s && obj_t && reg_t, "rpn_distill: null pointer");
+    ABR_REQUIRE((d_obj_t == nullptr) == (d_reg_t == nullptr), "rpn_distill: gradients come together");
+    rpn_distill_kernel<<<(unsigned)std::min<int64_t>((rows * A + 255) / 256, 2048), 256, 0, st>>>(
+        obj_s, reg_s, ld_obj_s, ld_reg_s, obj_t, reg_t, ld_obj_t, ld_reg_t, rows, A, bbox_threshold, use_bbox, loss_out, gscale, d_obj_t,
+        d_reg_t, ld_d_obj, ld_d_reg);
+    ABR_CHECK_LAUNCH("rpn_distill");
     return ABR_OK;
 }

@@ -13,6 +13,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib, ops
+from ..layers._layout import as_nhwc, from_nhwc
 
 
 class _ARDFn(Function):
@@ -84,3 +85,69 @@ def calculate_roi_distillation_losses(soften_results, target_results, dist="l2",
         return calculate_roi_distillation_loss(soften_results, target_results, "inclusive_distillation", "unbiased-cross-entropy",
                                                "l2", 1, soften_proposal)
     return calculate_roi_distillation_loss(soften_results, target_results, "normalization", "l2", "l2", 1, soften_proposal)
+
+
+# ------------------------------------------------------------------------------------------------ ablation-only losses
+class _FeatDistillFn(Function):
+    @staticmethod
+    def forward(ctx, src, tgt):
+        loss, d = ops.feat_distill(src, tgt, want_grad=tgt.requires_grad)
+        ctx.save_for_backward(d)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        ops.scale_(d, 1.0, g.contiguous())
+        return None, d
+
+
+def calculate_feature_distillation_loss(source_features, target_features, loss=None):
+    """distillation.py:133-161 (DIST.FEAT == 'std'): per feature level mean(max((s - mean s) - (t - mean t), 0)), summed over levels.
+    Both maps of a level must share one memory layout (they do: both are the models' channels-last C4 features)."""
+    if len(source_features) != len(target_features):
+        raise ValueError("Number of source features must equal to number of target features")
+    if loss != "normalized_filtered_l1":
+        raise ValueError("Wrong loss function for feature distillation")
+    total = 0
+    for s, t in zip(source_features, target_features):
+        if s.stride() != t.stride():
+            s = s.contiguous(); t = t.contiguous()
+        total = total + _FeatDistillFn.apply(s.detach(), t)
+    return total
+
+
+class _RPNDistillFn(Function):
+    @staticmethod
+    def forward(ctx, obj_s, reg_s, obj_t, reg_t, thr, use_bbox):
+        want = obj_t.requires_grad or reg_t.requires_grad
+        loss, d_o, d_r = ops.rpn_distill(as_nhwc(obj_s), as_nhwc(reg_s), as_nhwc(obj_t), as_nhwc(reg_t), thr, use_bbox, want_grad=want)
+        ctx.save_for_backward(d_o, d_r)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d_o, d_r = ctx.saved_tensors
+        g = g.contiguous()
+        ops.scale_(d_o, 1.0, g)
+        ops.scale_(d_r, 1.0, g)
+        return None, None, from_nhwc(d_o), from_nhwc(d_r), None, None
+
+
+def calculate_rpn_distillation_loss(rpn_output_source, rpn_output_target, cls_loss=None, bbox_loss=None, bbox_threshold=None):
+    """distillation.py:18-84 (DIST.RPN): filtered-L2 on the objectness logits + L2 on the box deltas of the anchors whose source
+    objectness exceeds the target's by more than `bbox_threshold`; both averaged over anchors, divided by the number of levels."""
+    obj_s, reg_s = rpn_output_source
+    obj_t, reg_t = rpn_output_target
+    if len(obj_s) != len(obj_t):
+        raise ValueError("Wrong rpn objectness output")
+    if len(reg_s) != len(reg_t):
+        raise ValueError("Wrong RPN bounding box regression output")
+    if cls_loss != "filtered_l2":
+        raise ValueError("Wrong loss function for rpn classification distillation")
+    if bbox_loss not in ("l2", "None"):
+        raise ValueError("Wrong loss function for rpn bounding box regression distillation")
+    total = 0
+    for os_, rs_, ot_, rt_ in zip(obj_s, reg_s, obj_t, reg_t):
+        total = total + _RPNDistillFn.apply(os_.detach(), rs_.detach(), ot_, rt_, float(bbox_threshold), bbox_loss == "l2")
+    return total / len(obj_s)

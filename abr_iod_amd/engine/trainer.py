@@ -18,7 +18,8 @@ import time
 import torch
 import torch.distributed as dist
 
-from ..distillation.distillation import calculate_attentive_roi_feature_distillation, calculate_roi_distillation_losses
+from ..distillation.distillation import (calculate_attentive_roi_feature_distillation, calculate_feature_distillation_loss,
+                                         calculate_roi_distillation_losses, calculate_rpn_distillation_loss)
 import os
 
 from ..utils.comm import get_world_size
@@ -100,12 +101,17 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         if use_id:                                                                                         # :101-103
             distillation_losses = cfg.DIST.ALPHA * calculate_roi_distillation_losses(soften_result, target_result, dist=dist_type,
                                                                                      soften_proposal=None)
-        if use_ard:                                                                                        # :113-116
+        if cfg.DIST.FEAT == "std":                                                                         # :108-112 (ablation)
+            distillation_losses = distillation_losses + calculate_feature_distillation_loss(feature_source, feature_target,
+                                                                                          loss="normalized_filtered_l1")
+        elif use_ard:                                                                                      # :113-116
             feature_distillation_losses = calculate_attentive_roi_feature_distillation(roi_align_features_source,
                                                                                        roi_align_features_target, gamma=cfg.DIST.GAMMA)
             distillation_losses = distillation_losses + cfg.DIST.BETA * feature_distillation_losses
-        elif cfg.DIST.FEAT == "std" or cfg.DIST.RPN:
-            raise NotImplementedError("DIST.FEAT='std' / DIST.RPN are ablation-only and hard-code 'cuda' in the reference; next-tier")
+        if cfg.DIST.RPN:                                                                                   # :120-122 (ablation)
+            distillation_losses = distillation_losses + calculate_rpn_distillation_loss(rpn_output_source, rpn_output_target,
+                                                                                        cls_loss="filtered_l2", bbox_loss="l2",
+                                                                                        bbox_threshold=0.1)
 
     loss_dict_target = dict(loss_dict_target)
     loss_dict_target["distillation_loss"] = distillation_losses.clone().detach()                           # :124-126

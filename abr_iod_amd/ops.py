@@ -526,3 +526,31 @@ def det_select(prob, boxes, row_off, N, C, r_max, score_thresh, nms_thresh, dete
                                    float(nms_thresh), int(detections_per_img), cap, L.ptr(ob), L.ptr(os_), L.ptr(ol), L.ptr(oc),
                                    L.ptr(bb), L.ptr(bs), L.ptr(bc), L.ptr(ws), ws_bytes, L.stream()), "det_select")
     return ob, os_, ol, oc, bb, bs, bc
+
+
+# ----------------------------------------------------------------------------------------------- ablation distillation losses
+def feat_distill(src, tgt, want_grad=False):
+    """normalized_filtered_l1 between two feature maps of equal size (any layout, both the same) -> (loss[1], d_tgt or None)"""
+    L.require_cuda(src, tgt)
+    assert src.numel() == tgt.numel()
+    loss = torch.empty((1,), dtype=_f32, device=tgt.device)
+    stats = torch.empty((3,), dtype=_f32, device=tgt.device)
+    d = torch.empty_like(tgt, memory_format=torch.preserve_format) if want_grad else None
+    L.check(L.lib().abr_feat_distill(L.ptr(src), L.ptr(tgt), tgt.numel(), L.ptr(loss), L.ptr(stats), 1.0, L.ptr(d), L.stream()), "feat_distill")
+    return loss, d
+
+
+def rpn_distill(obj_s, reg_s, obj_t, reg_t, thr, use_bbox, want_grad=False):
+    """obj_* [N,H,W,A] / reg_* [N,H,W,4A] NHWC views (row-strided slices of the fused head outputs are fine) ->
+    (loss[1], d_obj_t [N,H,W,A] or None, d_reg_t [N,H,W,4A] or None)"""
+    L.require_cuda(obj_s, reg_s, obj_t, reg_t)
+    N, H, W, A = obj_t.shape
+    for t in (obj_s, reg_s, obj_t, reg_t):
+        assert t.stride(-1) == 1 and t.stride(0) == H * W * t.stride(2) and t.stride(1) == W * t.stride(2), "expected row-strided NHWC views"
+    loss = torch.empty((1,), dtype=_f32, device=obj_t.device)
+    d_o = torch.empty((N, H, W, A), dtype=_f32, device=obj_t.device) if want_grad else None
+    d_r = torch.empty((N, H, W, 4 * A), dtype=_f32, device=obj_t.device) if want_grad else None
+    L.check(L.lib().abr_rpn_distill(L.ptr(obj_s), L.ptr(reg_s), obj_s.stride(2), reg_s.stride(2), L.ptr(obj_t), L.ptr(reg_t), obj_t.stride(2),
+                                    reg_t.stride(2), N * H * W, A, float(thr), int(bool(use_bbox)), L.ptr(loss), 1.0, L.ptr(d_o), L.ptr(d_r),
+                                    A, 4 * A, L.stream()), "rpn_distill")
+    return loss, d_o, d_r

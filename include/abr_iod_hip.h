@@ -145,6 +145,19 @@ int abr_softmax_ce(const float* logits, int ld_logits /* row pitch, <=0: K */, c
                    int inclusive, int n_old, float* loss_out, float gscale, float* d_logits, int ld_dlogits,
                    void* stream);
 
+/* calculate_feature_distillation_loss(..., loss='normalized_filtered_l1')  distillation.py:133-161 (ablation DIST.FEAT='std'), one
+ * feature level: loss = mean(max((s - mean s) - (t - mean t), 0)) over all n elements (any memory order).  stats3: 3-float scratch.
+ * d_tgt (optional, n floats) = gscale * dloss/dt. */
+int abr_feat_distill(const float* src, const float* tgt, int64_t n, float* loss_out, float* stats3, float gscale, float* d_tgt,
+                     void* stream);
+/* calculate_rpn_distillation_loss(cls_loss='filtered_l2', bbox_loss='l2'|'None', bbox_threshold)  distillation.py:18-84 (ablation
+ * DIST.RPN), one level, NHWC head outputs: anchor a of row r has objectness obj[r*ld_obj + a] and deltas reg[r*ld_reg + 4a .. +3].
+ * loss = mean_anchors max(o_s-o_t,0)^2 + mean_anchors [o_s-o_t > thr] sum_4 (d_s-d_t)^2.  d_obj_t / d_reg_t optional (same pitches
+ * ld_d_obj / ld_d_reg), = gscale * dloss/d(target). */
+int abr_rpn_distill(const float* obj_s, const float* reg_s, int ld_obj_s, int ld_reg_s, const float* obj_t, const float* reg_t,
+                    int ld_obj_t, int ld_reg_t, int64_t rows, int A, float bbox_threshold, int use_bbox, float* loss_out,
+                    float gscale, float* d_obj_t, float* d_reg_t, int ld_d_obj, int ld_d_reg, void* stream);
+
 /* calculate_roi_distillation_losses(soften, target, dist)   distillation/distillation.py:164-240
  *   dist_id!=0 -> unbiased cross-entropy + L2 boxes ; else mean-centred L2 + L2 boxes
  * z_s [n,K_old], b_s [n,K_old,4], z_t [n,K_all], b_t [n,K_all,4]; d_zt/d_bt optional. */

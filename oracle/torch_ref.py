@@ -139,6 +139,31 @@ def rpn_post_process(objectness, box_regression, anchors, image_sizes, pre_nms_t
     return out
 
 
+# ------------------------------------------------------------------ ablation distillation losses
+def feature_distillation_loss(source_features, target_features):
+    """distillation/distillation.py:133-161, loss='normalized_filtered_l1': sum over levels of mean(max((s - mean s) - (t - mean t), 0))"""
+    total = 0
+    for s, t in zip(source_features, target_features):
+        diff = (s - s.mean()) - (t - t.mean())
+        total = total + torch.max(diff, torch.zeros_like(diff)).mean()
+    return total
+
+
+def rpn_distillation_loss(rpn_output_source, rpn_output_target, bbox_threshold=0.1, bbox_loss="l2"):
+    """distillation/distillation.py:18-84 with cls_loss='filtered_l2': objectness lists of [N,A,H,W], delta lists of [N,4A,H,W]."""
+    (obj_s, reg_s), (obj_t, reg_t) = rpn_output_source, rpn_output_target
+    cls, box = [], []
+    for os_, rs_, ot_, rt_ in zip(obj_s, reg_s, obj_t, reg_t):
+        diff = os_ - ot_
+        cls.append((torch.max(diff, torch.zeros_like(diff)) ** 2).mean())
+        N, A, H, W = diff.shape
+        mask = (permute_and_flatten(diff, N, A, 1, H, W) > bbox_threshold).to(diff.dtype).detach()
+        ms = permute_and_flatten(rs_, N, A, 4, H, W) * mask
+        mt = permute_and_flatten(rt_, N, A, 4, H, W) * mask
+        box.append(((ms - mt) ** 2).sum(dim=2).mean(dim=1).mean(dim=0) if bbox_loss == "l2" else 0)
+    return sum(cls) / len(obj_s) + sum(box) / len(reg_s)
+
+
 # ------------------------------------------------------------------ F4  test-time PostProcessor
 def det_softmax_decode(class_logits, box_regression, proposals, image_sizes_wh, weights=(10.0, 10.0, 5.0, 5.0),
                        cls_agnostic=False):

@@ -388,8 +388,42 @@ def gold_rehearsal():
     save("rehearsal", **out)
 
 
+def gold_ablation_distill():
+    """The two ablation losses (distillation.py:18-84, :133-161).  The reference functions allocate their zero filters with
+    `.to('cuda')`; on this CPU-only container that one device move is neutralised (Tensor.to ignoring the 'cuda' target) so that the
+    reference's own arithmetic runs and produces the golden numbers."""
+    from maskrcnn_benchmark.distillation.distillation import calculate_feature_distillation_loss, calculate_rpn_distillation_loss
+    g = torch.Generator().manual_seed(31)
+    fs = [torch.randn(2, 24, 10, 14, generator=g)]
+    ft = [(fs[0] + 0.3 * torch.randn(2, 24, 10, 14, generator=g)).requires_grad_(True)]
+    N, A, H, W = 2, 15, 10, 14
+    obj_s = [torch.randn(N, A, H, W, generator=g)]; reg_s = [torch.randn(N, 4 * A, H, W, generator=g) * 0.5]
+    obj_t = [(obj_s[0] + 0.4 * torch.randn(N, A, H, W, generator=g)).requires_grad_(True)]
+    reg_t = [(reg_s[0] + 0.2 * torch.randn(N, 4 * A, H, W, generator=g)).requires_grad_(True)]
+    orig_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        if a and a[0] == "cuda":
+            return self
+        return orig_to(self, *a, **k)
+    torch.Tensor.to = to_cpu
+    orig_empty_cache = torch.cuda.empty_cache
+    torch.cuda.empty_cache = lambda: None
+    try:
+        lf = calculate_feature_distillation_loss(fs, ft, loss="normalized_filtered_l1")
+        lf.backward()
+        lr = calculate_rpn_distillation_loss((obj_s, reg_s), (obj_t, reg_t), cls_loss="filtered_l2", bbox_loss="l2", bbox_threshold=0.1)
+        lr.backward()
+    finally:
+        torch.Tensor.to = orig_to
+        torch.cuda.empty_cache = orig_empty_cache
+    save("ablation_distill", feat_s=fs[0], feat_t=ft[0], loss_feat=lf.detach(), d_feat_t=ft[0].grad,
+         obj_s=obj_s[0], reg_s=reg_s[0], obj_t=obj_t[0], reg_t=reg_t[0], loss_rpn=lr.detach(), d_obj_t=obj_t[0].grad, d_reg_t=reg_t[0].grad)
+    print(float(lf), float(lr))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     gold_anchors(); gold_box_coder(); gold_matcher(); gold_nms(); gold_roi_align()
-    gold_elementwise(); gold_box_head_loss(); gold_roi_distill(); gold_ard(); gold_rpn(); gold_post_processor(); gold_voc_eval(); gold_rehearsal()
+    gold_elementwise(); gold_box_head_loss(); gold_roi_distill(); gold_ard(); gold_rpn(); gold_post_processor(); gold_voc_eval(); gold_rehearsal(); gold_ablation_distill()
     print("done")

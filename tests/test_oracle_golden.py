@@ -187,3 +187,19 @@ def test_post_processor_against_reference(gold):
             np.testing.assert_allclose(b, g[f"{tag}_boxes{i}"], rtol=1e-5, atol=2e-4)
         np.testing.assert_allclose(bg[1], g[f"{tag}_bg_scores"], rtol=1e-6)
         np.testing.assert_allclose(bg[0], g[f"{tag}_bg_boxes"], rtol=1e-5, atol=2e-4)
+
+
+def test_ablation_distillation_losses_against_reference(gold):
+    """DIST.FEAT='std' / DIST.RPN ablation losses: the oracle restatement reproduces the reference's values and gradients."""
+    g = gold("ablation_distill")
+    ft = T(g["feat_t"]).requires_grad_(True)
+    lf = R.feature_distillation_loss([T(g["feat_s"])], [ft])
+    lf.backward()
+    assert abs(float(lf) - float(g["loss_feat"])) < 1e-6
+    np.testing.assert_allclose(ft.grad.numpy(), g["d_feat_t"], rtol=1e-5, atol=1e-9)
+    ot, rt = T(g["obj_t"]).requires_grad_(True), T(g["reg_t"]).requires_grad_(True)
+    lr = R.rpn_distillation_loss(([T(g["obj_s"])], [T(g["reg_s"])]), ([ot], [rt]), 0.1)
+    lr.backward()
+    assert abs(float(lr) - float(g["loss_rpn"])) < 1e-6
+    np.testing.assert_allclose(ot.grad.numpy(), g["d_obj_t"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(rt.grad.numpy(), g["d_reg_t"], rtol=1e-5, atol=1e-9)
