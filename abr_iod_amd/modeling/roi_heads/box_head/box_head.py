@@ -30,10 +30,20 @@ from ...matcher import Matcher
 
 
 # ------------------------------------------------------------------------------------------------ pooler
+_roi_id_cache = {}
+
+
 def convert_to_roi_format(boxes):
-    """poolers.py:73-86: [K,5] = (batch index, x1, y1, x2, y2)"""
+    """poolers.py:73-86: [K,5] = (batch index, x1, y1, x2, y2).  The batch-index column only depends on the per-image box counts,
+    which repeat from step to step (512 sampled RoIs / 64 distillation RoIs per image): it is cached instead of being rebuilt from
+    2N tiny kernels each time."""
     concat = torch.cat([b.bbox for b in boxes], dim=0)
-    ids = torch.cat([torch.full((len(b), 1), i, dtype=concat.dtype, device=concat.device) for i, b in enumerate(boxes)], dim=0)
+    key = (tuple(len(b) for b in boxes), concat.device, concat.dtype)
+    ids = _roi_id_cache.get(key)
+    if ids is None:
+        if len(_roi_id_cache) > 256:
+            _roi_id_cache.clear()
+        ids = _roi_id_cache[key] = torch.cat([torch.full((len(b), 1), i, dtype=concat.dtype, device=concat.device) for i, b in enumerate(boxes)], dim=0)
     return torch.cat([ids, concat], dim=1)
 
 
