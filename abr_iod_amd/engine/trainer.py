@@ -8,8 +8,9 @@ Work the reference does whose results are never used is skipped, with identical 
   * with DIST.ALPHA == 0 and DIST.FEAT != 'ard' (the finetune configs) the source pass and the second RoI pass feed nothing;
   * `model_source.roi_heads.box.loss_evaluator.subsample(soften_proposal, targets)` (train_incremental.py:86) is dead: its result
     is overwritten with None at :102.  It is still executed when `faithful_rng=True` because it consumes device RNG.
-Data parallelism: one process per GPU; gradients are summed over ranks by ONE RCCL all-reduce of the flat gradient buffer inside
-optimizer.step() (DistributedDataParallel in the reference, train_incremental.py:231-235).
+Data parallelism: one process per GPU; gradients are summed over ranks by three large RCCL all-reduces of the flat gradient buffer
+(DistributedDataParallel in the reference, train_incremental.py:231-235): the RoI-head and RPN buckets leave during backward from
+gradient hooks (`_arm_overlap`, solver/grad_reducer.py), the backbone bucket inside optimizer.step().
 """
 import datetime
 import logging
@@ -46,6 +47,32 @@ def reduce_loss_dict(loss_dict):
         return {k: v for k, v in zip(names, all_losses)}
 
 
+def _arm_overlap(optimizer, head_inputs, features):
+    """Gradient hooks that hand finished buckets of the flat gradient to the optimiser's GradReducer while backward is still running:
+    layer4 + predictor once every RoI pass's pooled input has its gradient, the RPN once the C4 feature map has its own."""
+    reducer = getattr(optimizer, "reducer", None)
+    if reducer is None or not reducer.active:
+        return
+    heads = [t for t in head_inputs if torch.is_tensor(t) and t.requires_grad]
+    left = [len(heads)]
+
+    def head_done(g):
+        left[0] -= 1
+        if left[0] == 0:
+            reducer.reduce_bucket_async("roi_heads")
+        return None
+
+    for t in heads:
+        t.register_hook(head_done)
+    f = features[0] if isinstance(features, (list, tuple)) else features
+    if heads and torch.is_tensor(f) and f.requires_grad:
+        def features_done(g):
+            reducer.reduce_bucket_async("roi_heads")   # (no-op when already sent)
+            reducer.reduce_bucket_async("rpn")
+            return None
+        f.register_hook(features_done)
+
+
 def train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg, faithful_rng=False, log=None):
     """One iteration of tools/train_incremental.py:77-147.  Returns (loss_dict_target incl. 'distillation_loss', total loss)."""
     dist_type = cfg.DIST.TYPE
@@ -53,7 +80,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
     use_ard = cfg.DIST.FEAT == "ard"
     need_source = use_id or use_ard or cfg.DIST.RPN or cfg.DIST.FEAT == "std"
 
-    soften_result = soften_proposal = roi_align_features_source = rpn_output_source = None
+    soften_result = soften_proposal = roi_align_features_source = rpn_output_source = roi_align_features_target = None
     deferred = None
     if need_source:
         with torch.no_grad():                                                                              # :82-86
@@ -70,7 +97,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
 
     joint = need_source and JOINT_ROI_PASS and deferred is None and hasattr(model_target, "forward_joint")
     if joint:   # :89-95 as one pass: the distillation RoIs share the detection pass's trip through layer4
-        (loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results), \
+        (loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results), \
             (target_result, _, roi_align_features_target) = model_target.forward_joint(images, targets, soften_proposal,
                                                                                        rpn_output_source=rpn_output_source)
     elif deferred is not None and hasattr(model_target, "forward_begin"):
@@ -82,10 +109,10 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
             soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
                 model_source.soften_finish(deferred)
         deferred = None
-        loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results = \
+        loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results = \
             model_target.forward_finish(begun)                                                             # :89-90 (second half)
     else:
-        loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, _, target_soften_results = \
+        loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results = \
             model_target(images, targets, rpn_output_source=rpn_output_source)                             # :89-90
     faster_rcnn_losses = sum(loss for loss in loss_dict_target.values())                                   # :91
     if deferred is not None:
@@ -118,6 +145,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
     losses = faster_rcnn_losses + distillation_losses                                                      # :128
 
     optimizer.zero_grad()                                                                                  # :142
+    _arm_overlap(optimizer, [det_pooled, roi_align_features_target if need_source else None], feature_target)
     losses.backward()                                                                                      # :144-145 (amp O0 = identity)
     optimizer.step()                                                                                       # :146 (+ RCCL all-reduce)
     scheduler.step()                                                                                       # :147

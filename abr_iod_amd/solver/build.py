@@ -3,12 +3,14 @@
 The reference builds one torch.optim.SGD param group PER TENSOR (weights: lr=BASE_LR, wd=WEIGHT_DECAY; any name containing
 "bias": lr*BIAS_LR_FACTOR, wd=WEIGHT_DECAY_BIAS) -> 52 x 3 tiny launches per step.  FusedSGD keeps exactly those per-tensor
 hyper-parameters but applies the whole update as ONE kernel over the model's flat parameter buffer, and owns the
-data-parallel gradient exchange (one RCCL all-reduce of the flat gradient buffer over xGMI)."""
+data-parallel gradient exchange (a few large RCCL all-reduces of the flat gradient buffer over xGMI, the first ones issued during
+the backward pass: solver/grad_reducer.py)."""
 import torch
 import torch.distributed as dist
 
 from .. import ops
 from ..modeling.backbone.resnet import bump_param_version
+from .grad_reducer import GradReducer
 from .lr_scheduler import WarmupMultiStepLR
 
 
@@ -35,16 +37,28 @@ class FusedSGD(object):
         self._lr_host = None
         self._steps = 0
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.force_all_reduce = False
+        self.reducer = GradReducer(self.flat.grads, self.flat.segments, side_streams=self._grad_writer_streams)
+
+    @property
+    def force_all_reduce(self):  # single-rank RCCL run in tests/test_gpu_dist.py
+        return self.reducer.force
+
+    @force_all_reduce.setter
+    def force_all_reduce(self, on):
+        self.reducer.force = bool(on)
+
+    def _grad_writer_streams(self):
+        s = ops._side_streams.get(self.flat.grads.device.index) if self.flat.grads.is_cuda else None
+        return [s] if s is not None else []
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
+        self.reducer.begin()
 
     def all_reduce_grads(self):
-        """DistributedDataParallel's job in the reference (train_incremental.py:231): sum the flat gradient over ranks;
-        the 1/world factor is folded into the SGD kernel."""
-        if self.world_size > 1 or self.force_all_reduce:  # (force: single-rank RCCL run in tests/test_gpu_dist.py)
-            dist.all_reduce(self.flat.grads, op=dist.ReduceOp.SUM)
+        """DistributedDataParallel's job in the reference (train_incremental.py:231): sum the flat gradient over ranks -- the
+        buckets the trainer's gradient hooks did not already send during backward, then wait for all of them."""
+        self.reducer.finish()
 
     def step(self):
         ops.join_side_stream()  # weight gradients queued on the side stream (no-op when already joined after backward)

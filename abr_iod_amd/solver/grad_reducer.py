@@ -1,0 +1,94 @@
+"""Data-parallel gradient exchange over the flat gradient buffer (DistributedDataParallel's job in the reference,
+tools/train_incremental.py:231-235), laid out for xGMI: a handful of LARGE sum all-reduces instead of DDP's 25 MB buckets.
+
+The flat buffer is cut into three buckets by the order their gradients become final during the backward pass:
+    roi_heads  (layer4 + predictor, 15.1 M floats)  -> final once both RoI passes' pooled inputs have their gradient
+    rpn        (3x3 conv + fused heads, 9.5 M)      -> final once the C4 feature map has its gradient
+    backbone   (layer2 + layer3, 8.3 M)             -> final at the end of backward
+`reduce_bucket_async(name)` is called from gradient hooks the trainer arms on those tensors (engine/trainer.py::_arm_overlap), so
+the first two exchanges (75 % of the bytes) run on RCCL's stream underneath the rest of the backward pass; `finish()` issues whatever
+is left and makes the current stream wait for all of them.  Every rank fires the hooks in the same order (same graph), so the
+collectives are issued in the same order everywhere.  The 1/world factor is folded into the SGD kernel."""
+import os
+
+import torch
+import torch.distributed as dist
+
+OVERLAP = os.environ.get("ABR_ALLREDUCE_OVERLAP", "1") != "0"
+
+BUCKET_ORDER = ("roi_heads", "rpn", "backbone")
+
+
+def bucket_of(name):
+    for b in BUCKET_ORDER[:-1]:
+        if name.startswith(b + ".") or (".%s." % b) in name:
+            return b
+    return BUCKET_ORDER[-1]
+
+
+def make_buckets(segments):
+    """segments: FlatParams.segments [(name, start, end, is_bias)] ascending -> {bucket: [(a, b), ...]} with adjacent ranges merged."""
+    out = {b: [] for b in BUCKET_ORDER}
+    for name, a, b, _ in segments:
+        r = out[bucket_of(name)]
+        if r and r[-1][1] == a:
+            r[-1] = (r[-1][0], b)
+        else:
+            r.append((a, b))
+    return out
+
+
+class GradReducer(object):
+    def __init__(self, grads, segments, side_streams=()):
+        """grads: the flat gradient tensor; side_streams: callable returning the streams (besides the current one) that write it."""
+        self.grads = grads
+        self.buckets = make_buckets(segments)
+        self.side_streams = side_streams
+        self.force = False          # single-rank RCCL runs in tests
+        self._works, self._done = [], set()
+        self._comm = None
+
+    @property
+    def active(self):
+        return self.force or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+    def begin(self):
+        """new backward pass: nothing reduced yet"""
+        assert not self._works, "finish() was not called for the previous step"
+        self._done.clear()
+
+    def _issue(self, name):
+        if name in self._done:
+            return
+        self._done.add(name)
+        for a, b in self.buckets[name]:
+            self._works.append(dist.all_reduce(self.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def reduce_bucket_async(self, name):
+        """Called when every kernel that writes bucket `name` has been ENQUEUED (on the current stream or a side stream)."""
+        if not (self.active and OVERLAP) or name in self._done:
+            return
+        if self.grads.is_cuda:
+            cur = torch.cuda.current_stream()
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=self.grads.device)
+            self._comm.wait_stream(cur)
+            for s in self.side_streams():
+                self._comm.wait_stream(s)
+            with torch.cuda.stream(self._comm):   # ProcessGroupNCCL orders its own stream after the CURRENT one
+                self._issue(name)
+        else:
+            self._issue(name)
+
+    def finish(self):
+        """Issue the buckets still outstanding (the caller has joined its side streams) and wait for all of them."""
+        if self.active:
+            if not self._done and not self._works:   # nothing overlapped: ONE all-reduce of the whole buffer
+                self._works.append(dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                for name in BUCKET_ORDER:
+                    self._issue(name)
+        for w in self._works:
+            w.wait()                                  # GPU: the current stream waits on RCCL's; CPU (gloo): blocks
+        self._works = []
+        self._done.clear()

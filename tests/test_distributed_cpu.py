@@ -133,3 +133,60 @@ def test_eval_predictions_merge_across_ranks():
         assert p.exitcode == 0
     assert got[1] is None
     assert got[0] == [(i + 1, (100 + i, 50), float(i), [float(v) for v in range(i + 1)]) for i in range(6)]
+
+
+SEGMENTS = [  # the layout flatten_parameters produces: fused-head groups first, then named_parameters order (trainable region)
+    ("rpn.head.cls_logits.weight", 0, 128, False), ("roi_heads.box.predictor.cls_score.weight", 128, 320, False),
+    ("backbone.body.layer2.0.conv1.weight", 320, 448, False), ("backbone.body.layer3.5.conv3.weight", 448, 704, False),
+    ("rpn.head.conv.weight", 704, 960, False), ("rpn.head.conv.bias", 960, 1024, True),
+    ("roi_heads.box.feature_extractor.head.layer4.0.conv1.weight", 1024, 1536, False),
+    ("roi_heads.box.feature_extractor.head.layer4.2.conv3.weight", 1536, 2048, False),
+]
+
+
+def test_grad_buckets_cover_the_flat_buffer_once():
+    sys.path.insert(0, ROOT)
+    from abr_iod_amd.solver.grad_reducer import BUCKET_ORDER, make_buckets
+    b = make_buckets(SEGMENTS)
+    assert b["roi_heads"] == [(128, 320), (1024, 2048)] and b["rpn"] == [(0, 128), (704, 1024)] and b["backbone"] == [(320, 704)]
+    covered = sorted(r for name in BUCKET_ORDER for r in b[name])
+    assert covered[0][0] == 0 and covered[-1][1] == 2048 and all(x[1] == y[0] for x, y in zip(covered, covered[1:]))
+
+
+def _reducer_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from abr_iod_amd.solver.grad_reducer import GradReducer
+    results = []
+    for early in ((), ("roi_heads",), ("roi_heads", "rpn"), ("rpn", "roi_heads", "rpn")):
+        grads = torch.arange(2048, dtype=torch.float32) * (rank + 1)
+        red = GradReducer(grads, SEGMENTS)
+        assert red.active
+        red.begin()
+        for name in early:              # what the trainer's gradient hooks do during backward
+            red.reduce_bucket_async(name)
+        red.finish()                    # FusedSGD.all_reduce_grads
+        red.begin()                     # the next step starts clean
+        results.append(grads.clone())
+    out.put((rank, results))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bucketed_overlapped_allreduce_equals_one_allreduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    want = torch.arange(2048, dtype=torch.float32) * 3   # rank 0 holds 1x, rank 1 holds 2x: every element summed exactly once
+    for rank, results in got:
+        for r in results:
+            assert torch.equal(r, want)

@@ -1,7 +1,8 @@
 """GPU, one rank: the data-parallel step through RCCL itself (backend "nccl" on ROCm).  A 1-GPU box cannot show scaling, but it
 does exercise what bench.py --gpus N does on every rank: process-group initialisation over 127.0.0.1, the all-reduce of the flat
-gradient buffer issued after the side-stream weight gradients are joined, and the 1/world scaling in the update -- and with one
-rank the result must equal the run without the collective bit for bit."""
+gradient buffer in three buckets -- the RoI-head and RPN buckets from gradient hooks during backward, ordered after the side-stream
+weight gradients (solver/grad_reducer.py), the backbone bucket in optimizer.step() -- and the 1/world scaling in the update; with
+one rank the result must equal the run without the collective."""
 import os
 import socket
 
@@ -34,11 +35,18 @@ def test_single_rank_rccl_step_equals_local_step():
         ms, mt = build_models(cfg_s, cfg_t, seed=0)
         opt = make_optimizer(cfg_t, mt)
         opt.force_all_reduce = collective
+        sent, inner = [], opt.reducer.reduce_bucket_async
+        opt.reducer.reduce_bucket_async = lambda name: (sent.append((name, name in opt.reducer._done)), inner(name))
         sch = make_lr_scheduler(cfg_t, opt)
         torch.manual_seed(3); random.seed(3)
         for _ in range(3):
             train_step(ms, mt, images, targets, opt, sch, cfg_t)
         torch.cuda.synchronize()
+        if collective:  # the trainer's gradient hooks sent the RoI-head bucket, then the RPN bucket, DURING each backward pass
+            first = [name for name, already in sent if not already]
+            assert first == ["roi_heads", "rpn"] * 3, sent
+        else:
+            assert sent == []
         return mt.flat.params.clone()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
