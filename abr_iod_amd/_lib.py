@@ -27,6 +27,7 @@ class ConvDesc(C.Structure):
         ("scale", _vp), ("bias", _vp), ("residual", _vp), ("mask", _vp),
         ("relu", _i),
         ("out_H", _i), ("out_W", _i), ("out_sh", _i), ("out_sw", _i),
+        ("math", _i),
     ]
 
 

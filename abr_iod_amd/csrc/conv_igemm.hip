@@ -394,6 +394,151 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// bf16 math mode (abr_conv_desc::math == ABR_MATH_BF16; BASELINE.json configs[4] "bf16 MFMA backbone"): the SAME implicit GEMM
+// with both operands rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their way from the fetch registers into LDS
+// and multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors in HBM stay fp32, so every other kernel of the
+// step is unchanged and the epilogue is shared.  A bf16 x bf16 product is exact in fp32, so the result equals an fp32 (or
+// float64) convolution of the ROUNDED operands up to summation order -- that is what the parity tests check.
+// k-tile = 64 (all of this path's channel counts are multiples of 64; the 4-channel stem stays fp32); LDS rows are 64 bf16 +
+// 8 pad = 144 B, the same conflict-free pitch as the fp32 tiles; a lane's fragment is one ds_read_b128 = 8 consecutive k.
+// 32x32x16 bf16 issues 16x the flops per LDS byte of the fp32 MFMA: the kernel is bound by operand delivery (L2 -> LDS,
+// fp32 sources), not by the matrix pipe.
+// ------------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int BKH = 64;        // k per tile
+constexpr int LDH = BKH + 8;   // LDS row pitch in bf16 elements (144 B)
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvP p, const float* __restrict__ x, const float* __restrict__ w,
+                                                               float* __restrict__ out) {
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int NA = BM / 16, NB = BN / 16;  // float4 staging loads per thread (16 rows x 16 float4 per pass)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);  // [BM][LDH]
+    __bf16* Bs = As + BM * LDH;                    // [BN][LDH]
+
+    const int tile = (int)abr::xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kq = tid & 15, srow = tid >> 4;  // 16 B slot inside the 256 B row segment, row srow + 16*i
+
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, p.w_bytes, 0x00020000);
+    int a_hi0[NA], a_wi0[NA], a_off0[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int m = m0 + srow + 16 * i;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        unsigned b, rem, ho, wo;
+        p.d_howo.divmod((unsigned)mm, b, rem);
+        p.d_wo.divmod(rem, ho, wo);
+        a_hi0[i] = (int)ho * p.stride - p.pad;
+        a_wi0[i] = (int)wo * p.stride - p.pad;
+        a_off0[i] = (((int)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + kq * 4;
+    }
+    unsigned b_off0[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const int n = n0 + srow + 16 * i;
+        b_off0[i] = n < p.Cout ? (unsigned)(n * p.K + kq * 4) * 4u : kOOB;
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[NA], rb[NB];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BKH;
+        unsigned rs, c0, r, s;
+        p.d_cin.divmod((unsigned)k0, rs, c0);
+        p.d_s.divmod(rs, r, s);
+        const int delta = ((int)r * p.W + (int)s) * p.Cin + (int)c0;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
+            const bool ok = a_ok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB), 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)b_off0[i], k0 * 4, 0);
+    };
+    auto pack = [](const u32x4 v) -> uint2 {
+        const f32x4v f = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        const bf16x4 h = __builtin_convertvector(f, bf16x4);   // RNE
+        return *reinterpret_cast<const uint2*>(&h);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; i++) *reinterpret_cast<uint2*>(As + (srow + 16 * i) * LDH + kq * 4) = pack(ra[i]);
+#pragma unroll
+        for (int i = 0; i < NB; i++) *reinterpret_cast<uint2*>(Bs + (srow + 16 * i) * LDH + kq * 4) = pack(rb[i]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const __bf16* a_frag = As + (wm * (TM * 32) + l31) * LDH + lh * 8;
+    const __bf16* b_frag = Bs + (wn * (TN * 32) + l31) * LDH + lh * 8;
+    auto compute_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < BKH / 16; u++) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const bf16x8*>(a_frag + i * 32 * LDH + u * 16);
+#pragma unroll
+            for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const bf16x8*>(b_frag + j * 32 * LDH + u * 16);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = p.K / BKH;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt + 1 < nk; kt++) {
+        load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tile();
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+    }
+    compute_tile();
+    __syncthreads();  // the epilogue reuses the operand LDS
+    epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_bf16(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
+    ConvP q = p;
+    q.tiles_m = (p.M + BM - 1) / BM;
+    q.tiles_n = (p.Cout + BN - 1) / BN;
+    q.tiles_pb = q.tiles_m * q.tiles_n;
+    q.nbatch = 1; q.n_full = q.tiles_pb; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
+    constexpr size_t lds_op = sizeof(__bf16) * (BM + BN) * LDH;
+    constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
+    const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
+    const int rec = abr::prof_start(st, abr::PROF_IGEMM_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
+    conv_igemm_bf16_kernel<BM, BN, WM, WN><<<(unsigned)q.tiles_pb, 256, lds, st>>>(q, x, w, out);
+    abr::prof_stop(st, rec);
+    return 0;
+}
+
 // split-K scratch: partial tiles (64 KB each for 128x128) + tickets, one set per stream (streams may run convs concurrently)
 struct SplitWs { float* ws = nullptr; int* cnt = nullptr; };
 static SplitWs* split_ws(hipStream_t st) {
@@ -541,6 +686,16 @@ static void dispatch_igemm(const ConvP& p, const float* x, const float* w, float
     }
 }
 
+// bf16 math mode: biggest tile that still gives every CU a couple of workgroups
+static void dispatch_igemm_bf16(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
+    const int cus = num_cus();
+    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
+    if (p.Cout > 64 && t128 >= 2 * cus) launch_bf16<128, 128, 2, 2>(p, x, w, out, st);
+    else if (t12864 >= 2 * cus || p.Cout <= 64) launch_bf16<128, 64, 4, 1>(p, x, w, out, st);
+    else launch_bf16<64, 64, 2, 2>(p, x, w, out, st);
+}
+
 // stride-1 pad-1 3x3 conv as Winograd F(4x4,3x3): weight + input transforms, 36 batched GEMMs, output transform with the epilogue
 static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
     const int th_n = (p.H + 3) / 4, tw_n = (p.W + 3) / 4;
@@ -591,6 +746,12 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     p.d_howo.init((unsigned)(p.Ho * p.Wo)); p.d_wo.init((unsigned)p.Wo); p.d_cin.init((unsigned)p.Cin); p.d_s.init((unsigned)p.S);
     hipStream_t st = abr::as_stream(stream);
+    ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16, "conv_forward: unknown math mode");
+    if (d->math == ABR_MATH_BF16 && p.Cin % BKH == 0) {   // (the 4-channel stem has no 64-wide k-tile: it stays fp32)
+        dispatch_igemm_bf16(p, x, w, out, st);
+        ABR_CHECK_LAUNCH("conv_forward (bf16)");
+        return ABR_OK;
+    }
     // Winograd F(4x4,3x3) for the wide stride-1 3x3 convs: 4x fewer multiply-adds (RPN 3x3: 1.42 -> 0.50 ms, layer4 conv2 1.14 ->
     // 0.41, layer2 conv2 0.122 -> 0.073); layer1's 64-channel conv stays direct -- its 36 GEMMs would have K = 64 and the transforms'
     // HBM traffic outweighs the saving.

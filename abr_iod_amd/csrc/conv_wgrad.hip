@@ -220,6 +220,161 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// bf16 math mode (abr_conv_desc::math == ABR_MATH_BF16): the same split-M tile scheme on v_mfma_f32_32x32x16_bf16, fp32
+// accumulate, fp32 tensors in memory.  The reduction index m is still the slow axis in memory, and this MFMA wants 8 CONSECUTIVE
+// reduction elements per lane -- but the order of k inside an MFMA is a free permutation as long as both operands agree, so no
+// transpose is needed: a thread fetches the same 16 B column group of rows m and m+1, rounds both to bf16 (RNE) and stores the
+// four (m, m+1) pairs as one ds_write_b128 into an LDS tile of [m-pair][column] dwords; a lane's operand is four ds_read_b64
+// (m-pairs 8s+4h+{0..3}, columns 2*l31 and 2*l31+1), whose low / high dwords are the operands of the even / odd column sub-tile.
+// Stage = 64 rows (four MFMA k-steps); operand LDS 32 KB single-buffered.
+// ------------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MRH = 64;  // m rows per stage in bf16 mode
+
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgP p, const float* __restrict__ x, const float* __restrict__ gy,
+                                                               float* __restrict__ dw) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned* Gs = reinterpret_cast<unsigned*>(smem);   // [MRH/2][TN_] (bf16 m, bf16 m+1)
+    unsigned* As = Gs + (MRH / 2) * TN_;                // [MRH/2][TK_]
+
+    const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
+    const int split = bid % p.splits;
+    const int tile = bid / p.splits;
+    const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
+    const int n0 = tile_n * TN_, k0 = tile_k * TK_;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // staging: q = 16 B column group, rp = row pair; pairs rp + 8*i (i < 4) -> rows 2*(rp + 8i), +1
+    const int q = tid & 31, rp = tid >> 5;
+    const int gn = n0 + q * 4;
+    const bool g_ok = gn < p.Cout;
+    const int ak = k0 + q * 4;
+    const bool k_ok = ak < p.K;
+    int fr = 0, fs = 0, fc = 0;
+    if (k_ok) {
+        const int rs = ak / p.Cin;
+        fc = ak % p.Cin;
+        fr = rs / p.S;
+        fs = rs % p.S;
+    }
+    const int mt0 = split * p.mt_per_split;
+    const int mt1 = min(mt0 + p.mt_per_split, (p.M + MRH - 1) / MRH);
+
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rgy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, p.gy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
+    const unsigned g_voff = g_ok ? (unsigned)(2 * rp * p.Cout + gn) * 4u : kOOB;
+    const unsigned a_voff_plain = k_ok ? (unsigned)(2 * rp * p.Cin + fc) * 4u : kOOB;
+    const int a_const = ((fr - p.pad) * p.W + (fs - p.pad)) * p.Cin + fc;
+    u32x4 rg[4][2], ra[4][2];
+    auto load_tile = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int mrow = mt * MRH + 16 * i + e;  // scalar part of the row index (the lane adds 2*rp)
+                rg[i][e] = __builtin_amdgcn_raw_buffer_load_b128(rgy, (int)(g_voff + (unsigned)(mrow * p.Cout) * 4u), 0, 0);
+                if (p.plain) {
+                    ra[i][e] = __builtin_amdgcn_raw_buffer_load_b128(rxx, (int)(a_voff_plain + (unsigned)(mrow * p.Cin) * 4u), 0, 0);
+                } else {
+                    const int m = mrow + 2 * rp;
+                    unsigned b, rem, ho, wo;
+                    p.d_howo.divmod((unsigned)m, b, rem);
+                    p.d_wo.divmod(rem, ho, wo);
+                    const int hi = (int)ho * p.stride - p.pad + fr, wi = (int)wo * p.stride - p.pad + fs;
+                    const bool ok = k_ok & (m < p.M) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+                    const int off = (((int)b * p.H + (int)ho * p.stride) * p.W + (int)wo * p.stride) * p.Cin + a_const;
+                    ra[i][e] = __builtin_amdgcn_raw_buffer_load_b128(rxx, (int)(ok ? (unsigned)off * 4u : kOOB), 0, 0);
+                }
+            }
+    };
+    auto pack2 = [](unsigned lo, unsigned hi) -> unsigned {   // (row m, row m+1) of one column -> bf16x2, RNE
+        const f32x2v f = {__uint_as_float(lo), __uint_as_float(hi)};
+        const bf16x2 h = __builtin_convertvector(f, bf16x2);
+        return *reinterpret_cast<const unsigned*>(&h);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            u32x4 g, a;
+            g.x = pack2(rg[i][0].x, rg[i][1].x); g.y = pack2(rg[i][0].y, rg[i][1].y);
+            g.z = pack2(rg[i][0].z, rg[i][1].z); g.w = pack2(rg[i][0].w, rg[i][1].w);
+            a.x = pack2(ra[i][0].x, ra[i][1].x); a.y = pack2(ra[i][0].y, ra[i][1].y);
+            a.z = pack2(ra[i][0].z, ra[i][1].z); a.w = pack2(ra[i][0].w, ra[i][1].w);
+            *reinterpret_cast<u32x4*>(Gs + (rp + 8 * i) * TN_ + q * 4) = g;
+            *reinterpret_cast<u32x4*>(As + (rp + 8 * i) * TK_ + q * 4) = a;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    auto compute_tile = [&]() {
+        const unsigned* g = Gs + wm * 64 + 2 * l31 + 4 * lh * TN_;
+        const unsigned* a = As + wn * 64 + 2 * l31 + 4 * lh * TK_;
+#pragma unroll
+        for (int s = 0; s < MRH / 16; s++) {
+            uint2 fg[4], fa[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                fg[t] = *reinterpret_cast<const uint2*>(g + (8 * s + t) * TN_);
+                fa[t] = *reinterpret_cast<const uint2*>(a + (8 * s + t) * TK_);
+            }
+            const u32x4 g0 = {fg[0].x, fg[1].x, fg[2].x, fg[3].x}, g1 = {fg[0].y, fg[1].y, fg[2].y, fg[3].y};
+            const u32x4 a0 = {fa[0].x, fa[1].x, fa[2].x, fa[3].x}, a1 = {fa[0].y, fa[1].y, fa[2].y, fa[3].y};
+            const bf16x8 G0 = *reinterpret_cast<const bf16x8*>(&g0), G1 = *reinterpret_cast<const bf16x8*>(&g1);
+            const bf16x8 A0 = *reinterpret_cast<const bf16x8*>(&a0), A1 = *reinterpret_cast<const bf16x8*>(&a1);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G0, A0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G0, A1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, A0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, A1, acc[1][1], 0, 0, 0);
+        }
+    };
+    if (mt0 < mt1) {
+        load_tile(mt0);
+        store_tile();
+        __syncthreads();
+        int mt = mt0;
+        for (; mt + 1 < mt1; mt++) {
+            load_tile(mt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile();
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+        }
+        compute_tile();
+    }
+
+    // epilogue: same interleave as the fp32 kernel -- tile (tm,tn) element (row i, col j) is dW[n0 + wm*64 + 2i + tm][k0 + wn*64 + 2j + tn]
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int n = n0 + wm * 64 + 2 * i + tm;
+            if (n >= p.Cout) continue;
+            const float sc = p.scale ? p.scale[n] : 1.f;
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) {
+                const int k = k0 + wn * 64 + 2 * l31 + tn;
+                if (k < p.K) unsafeAtomicAdd(dw + (size_t)n * p.K + k, acc[tm][tn][r] * sc);
+            }
+        }
+}
+
 }  // namespace
 
 // split choice + launch for one (possibly batched) weight-gradient GEMM described by p (tiles_n / tiles_k / M / K filled in)
@@ -270,6 +425,33 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
     abr::prof_stop(abr::as_stream(stream), rec);
 }
 
+
+// bf16 math mode: the same split-M choice, in 64-row stages
+static void launch_wgrad_bf16(WgP p, const float* x, const float* gy, float* dw, void* stream) {
+    const int m_tiles = (p.M + MRH - 1) / MRH;
+    int32_t info[3];
+    const int cus = abr_device_info(info) == ABR_OK ? info[0] : 256;
+    const int tiles = p.tiles_n * p.tiles_k;
+    const int max_splits = std::max(1, (m_tiles + 3) / 4);
+    int splits = 1;
+    double best = -1.0;
+    for (int sp = 1; sp <= max_splits; sp++) {
+        const long wgs = (long)tiles * sp;
+        if (wgs > 8L * cus && sp > 1) break;
+        const long rounds = (wgs + cus - 1) / cus;
+        double eff = (double)wgs / (double)(rounds * cus);
+        if (wgs < 2L * cus) eff *= 0.5 + 0.25 * (double)wgs / (double)(2L * cus);   // latency-bound kernel: wants >= 2 workgroups per CU
+        eff -= 0.0002 * sp;
+        if (eff > best) { best = eff; splits = sp; }
+    }
+    p.splits = splits;
+    p.mt_per_split = (m_tiles + splits - 1) / splits;
+    const size_t lds = sizeof(unsigned) * (MRH / 2) * (TN_ + TK_);
+    const int rec = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
+    conv_wgrad_bf16_kernel<<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
+    abr::prof_stop(abr::as_stream(stream), rec);
+}
+
 extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const float* gy, float* dw, void* stream) {
     ABR_REQUIRE(d && x && gy && dw, "conv_wgrad: null pointer");
     ABR_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "conv_wgrad: Cin and Cout must be multiples of 4");
@@ -291,6 +473,12 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     if (p.M == 0) return ABR_OK;
     p.nbatch = 1; p.tiles_pb = 0; p.x_bs = p.gy_bs = p.dw_bs = 0; p.overwrite = 0;
     hipStream_t st = abr::as_stream(stream);
+    ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16, "conv_wgrad: unknown math mode");
+    if (d->math == ABR_MATH_BF16 && d->Cin % 64 == 0) {   // same layer set as the bf16 forward (the stem stays fp32)
+        launch_wgrad_bf16(p, x, gy, dw, stream);
+        ABR_CHECK_LAUNCH("conv_wgrad (bf16)");
+        return ABR_OK;
+    }
     // Winograd F(4x4,3x3) weight gradient for the wide stride-1 3x3 convs: dU[p] = sum_tiles (A dY A^T)[p]^T (B^T d B)[p] as 36 batched
     // GEMMs over the tile axis (4x fewer multiply-adds than the direct form), then dW += scale * G^T dU G.
     static const int wino_min_c = getenv("ABR_WINOGRAD_MIN_C") ? atoi(getenv("ABR_WINOGRAD_MIN_C")) : 128;

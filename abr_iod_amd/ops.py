@@ -198,8 +198,11 @@ def bce_logits_gather(x, y, idx, gscale=1.0, want_grad=False, yidx=None, denom_d
 
 
 # ----------------------------------------------------------------------------------------------- conv
+MATH_F32, MATH_BF16 = 0, 1   # abr_conv_desc::math (include/abr_iod_hip.h)
+
+
 def conv_desc(x_shape, w_shape, stride, pad, scale=None, bias=None, residual=None, mask=None, relu=False,
-              out_hw=None, out_stride=(1, 1)):
+              out_hw=None, out_stride=(1, 1), math=MATH_F32):
     B, H, W, Cin = x_shape
     Cout, R, S, Cin2 = w_shape
     if Cin != Cin2:
@@ -216,15 +219,17 @@ def conv_desc(x_shape, w_shape, stride, pad, scale=None, bias=None, residual=Non
     else:
         d.out_H, d.out_W = out_hw
         d.out_sh, d.out_sw = out_stride
+    d.math = int(math)
     return d
 
 
 def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, mask=None, relu=False,
-                 out=None, out_hw=None, out_stride=(1, 1)):
-    """x [B,H,W,Cin] NHWC, w [Cout,R,S,Cin] OHWI -> [B,Ho,Wo,Cout] (or scattered into `out` [B,out_H,out_W,Cout])"""
+                 out=None, out_hw=None, out_stride=(1, 1), math=MATH_F32):
+    """x [B,H,W,Cin] NHWC, w [Cout,R,S,Cin] OHWI -> [B,Ho,Wo,Cout] (or scattered into `out` [B,out_H,out_W,Cout]).
+    math=MATH_BF16: operands rounded to bf16 inside the kernel, bf16 MFMA, fp32 accumulate (fp32 tensors in and out)."""
     L.require_cuda(x, w)
     x, w = L.f32c(x), L.f32c(w)
-    d = conv_desc(x.shape, w.shape, stride, pad, scale, bias, residual, mask, relu, out_hw, out_stride)
+    d = conv_desc(x.shape, w.shape, stride, pad, scale, bias, residual, mask, relu, out_hw, out_stride, math)
     if out is None:
         if out_hw is not None:
             out = torch.zeros((d.B, d.out_H, d.out_W, d.Cout), dtype=_f32, device=x.device)
@@ -234,11 +239,11 @@ def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, ma
     return out
 
 
-def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None):
+def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32):
     """dw [Cout,R,S,Cin] += scale * gy^T im2col(x) (fp32 atomics; caller zeroes dw once per step)"""
     L.require_cuda(x, gy, dw)
     x, gy = L.f32c(x), L.f32c(gy)
-    d = conv_desc(x.shape, dw.shape, stride, pad, scale=scale)
+    d = conv_desc(x.shape, dw.shape, stride, pad, scale=scale, math=math)
     L.check(L.lib().abr_conv_wgrad(C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.stream()), "conv_wgrad")
     return dw
 
@@ -286,10 +291,10 @@ def join_side_stream():
             torch.cuda.current_stream().wait_stream(s)
 
 
-def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None):
+def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32):
     """conv_wgrad on the side stream.  Only for use inside an autograd backward (the join is an engine callback)."""
     if not WGRAD_SIDE_STREAM:
-        return conv_wgrad(x, gy, dw, stride, pad, scale)
+        return conv_wgrad(x, gy, dw, stride, pad, scale, math)
     cur = torch.cuda.current_stream()
     side = side_stream(x.device.index)
     if not _join_pending[0]:
@@ -298,7 +303,7 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None):
         torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
     side.wait_stream(cur)  # x, gy (and the zeroed gradient buffer) are produced on the current stream
     with torch.cuda.stream(side):
-        conv_wgrad(x, gy, dw, stride, pad, scale)
+        conv_wgrad(x, gy, dw, stride, pad, scale, math)
     x.record_stream(side)  # the caching allocator must not recycle them for the main stream while the side kernel reads
     gy.record_stream(side)
     return dw

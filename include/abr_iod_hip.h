@@ -46,7 +46,7 @@ int abr_device_info(int32_t* out_host);
  * out[id*6+{3,4,5}] = the same for launches made while abr_prof_mark_overlap(1) was in force (the host runs weight-gradient
  * kernels on a second stream next to the dgrad chain: those launches share CUs and their event-bracketed duration is not a
  * property of the kernel).  id = 0 igemm 128x128, 1 igemm 128x64, 2 igemm 64x64, 3 igemm small-C (stem), 4 wgrad, 5/6 ROIAlign
- * fwd/bwd.  Synchronises on the recorded events and stops profiling. */
+ * fwd/bwd, 7 igemm bf16, 8 wgrad bf16.  Synchronises on the recorded events and stops profiling. */
 int abr_prof_begin(void);
 int abr_prof_mark_overlap(int on);
 /* bit id set = time that kernel (default all); every_nth > 1 = bracket only every n-th eligible launch (an event pair costs a
@@ -180,6 +180,9 @@ int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, co
  *    modeling/backbone/resnet.py:327-346,363-368, layers/batch_norm.py:19-31, modeling/rpn/rpn.py:114-121,
  *    roi_box_predictors.py:27-32 (Linear = 1x1 conv on a 1x1 map).
  * ===================================================================================================== */
+#define ABR_MATH_F32 0
+#define ABR_MATH_BF16 1
+
 typedef struct {
     int B, H, W, Cin;        /* input  [B,H,W,Cin]  (Cin % 4 == 0) */
     int Cout, R, S;          /* weight [Cout,R,S,Cin] (OHWI)       */
@@ -194,6 +197,10 @@ typedef struct {
     /* output placement: row (b,ho,wo) is stored at pixel (b, ho*out_sh, wo*out_sw) of [B,out_H,out_W,Cout]
        (out_sh=out_sw=1, out_H=Ho, out_W=Wo for an ordinary conv; 2 for the dgrad of a stride-2 1x1 conv) */
     int out_H, out_W, out_sh, out_sw;
+    /* arithmetic of the contraction: ABR_MATH_F32 = fp32 MFMA (exact fp32, the default and the parity path);
+       ABR_MATH_BF16 = both operands rounded to bf16 (RNE) inside the kernel, bf16 MFMA, fp32 accumulate, fp32 tensors in
+       memory (BASELINE.json configs[4]); layers whose Cin is not a multiple of 64 (the stem) compute in fp32 either way */
+    int math;
 } abr_conv_desc;
 
 int abr_conv_forward(const abr_conv_desc* d_host, const float* x, const float* w, float* out, void* stream);

@@ -493,3 +493,81 @@ def test_conv3x3_winograd_matches_torch(shape):
     dw = ops.conv_wgrad(x.cuda(), gy.cuda(), dw0.clone().cuda(), 1, 1, scale=sc.cuda()).cpu().double()
     err = float((dw - dw0.double() - ref_dw).abs().max()) / float(ref_dw.abs().max())
     assert err <= 5e-5, err
+
+
+# ---------------------------------------------------------------------------------------------- bf16 math mode (BASELINE configs[4])
+BF16_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad
+    (2, 64, 19, 23, 64, 1, 1, 0),       # one k-tile, BN=64 tiles
+    (2, 64, 19, 23, 256, 3, 1, 1),      # 3x3 halo (direct: no Winograd in bf16 mode)
+    (1, 256, 38, 63, 512, 1, 2, 0),     # stride-2 1x1
+    (2, 128, 16, 16, 76, 1, 1, 0),      # Cout not a multiple of 32
+    (4, 256, 38, 63, 256, 3, 1, 1),     # layer3 conv2 at full size, 128x128 tiles, ragged M
+    (64, 512, 4, 4, 2048, 1, 1, 0),     # layer4 expand
+]
+
+
+def _bf16r(t):
+    return t.bfloat16().float()   # round-to-nearest-even, what v_cvt_pk_bf16_f32 does
+
+
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_conv_bf16_mode_equals_float64_conv_of_rounded_operands(case):
+    """bf16 x bf16 products are exact in fp32, so the bf16 MFMA path must agree with a float64 convolution of the ROUNDED operands
+    up to fp32 summation order -- and must differ from the unrounded result by a bf16-sized amount (the mode is really on)."""
+    from abr_iod_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    torch.manual_seed(7 + Cin + Cout)
+    x = torch.randn(B, Cin, H, W); w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout) + 0.5; bias = torch.randn(Cout) * 0.1
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = torch.randn(B, Cout, Ho, Wo)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda(); wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    got = ops.conv_forward(xg, wg, s, p, scale=scale.cuda(), bias=bias.cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda(),
+                           relu=True, math=ops.MATH_BF16).permute(0, 3, 1, 2).cpu().double()
+    y64 = torch.nn.functional.conv2d(_bf16r(x).double(), _bf16r(w).double(), stride=s, padding=p)
+    want = torch.relu(y64 * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1) + res.double())
+    tol = 2e-5 * max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() < tol
+    exact = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), stride=s, padding=p) * scale.double().view(1, -1, 1, 1)
+                       + bias.double().view(1, -1, 1, 1) + res.double())
+    rel = ((got - exact).norm() / exact.norm()).item()
+    assert 1e-4 < rel < 2e-2, rel
+    # default mode is untouched: exact fp32
+    f32 = ops.conv_forward(xg, wg, s, p).permute(0, 3, 1, 2).cpu().double()
+    plain = torch.nn.functional.conv2d(x.double(), w.double(), stride=s, padding=p)
+    assert (f32 - plain).abs().max().item() < 1e-4 * max(1.0, plain.abs().max().item())
+
+
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_conv_bf16_mode_backward(case):
+    from abr_iod_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    torch.manual_seed(11 + Cin + Cout)
+    x = torch.randn(B, Cin, H, W); w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout) + 0.5
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    gy = torch.randn(B, Cout, Ho, Wo)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda(); wg = w.permute(0, 2, 3, 1).contiguous().cuda()
+    gyg = gy.permute(0, 2, 3, 1).contiguous().cuda(); sc = scale.cuda()
+    # weight gradient: dW = scale * sum_m r(gy)^T r(im2col(x))
+    dw = torch.zeros_like(wg)
+    ops.conv_wgrad(xg, gyg, dw, s, p, scale=sc, math=ops.MATH_BF16)
+    xr = _bf16r(x).double().requires_grad_(True); wr = _bf16r(w).double().requires_grad_(True)
+    y = torch.nn.functional.conv2d(xr, wr, stride=s, padding=p)
+    y.backward(_bf16r(gy).double())
+    want = (wr.grad * scale.double().view(-1, 1, 1, 1)).permute(0, 2, 3, 1)
+    assert (dw.cpu().double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    # input gradient = forward kernel on gy with the flipped, scale-folded weight copy (that copy is what gets rounded)
+    wt = ops.conv_dgrad_weights(wg, sc)
+    if s == 1:
+        dx = ops.conv_forward(gyg, wt, 1, k - 1 - p, math=ops.MATH_BF16)
+    else:
+        dx = ops.conv_forward(gyg, wt, 1, 0, out_hw=(H, W), out_stride=(s, s), math=ops.MATH_BF16)
+    # (a dgrad whose reduction width Cout is not a multiple of 64 has no bf16 k-tile and computes in exact fp32, like the stem)
+    rnd = _bf16r if Cout % 64 == 0 else (lambda t: t)
+    wsr = rnd(w * scale.view(-1, 1, 1, 1)).double()
+    xr2 = x.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xr2, wsr, stride=s, padding=p).backward(rnd(gy).double())
+    want = xr2.grad.permute(0, 2, 3, 1)
+    assert (dx.cpu().double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
