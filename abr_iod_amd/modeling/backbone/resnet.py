@@ -99,6 +99,7 @@ class Bottleneck(nn.Module):
         for l in (self.conv1, self.conv2, self.conv3):
             l.kaiming_uniform_()
         self.stride = stride
+        self.math = ops.MATH_F32   # ops.MATH_BF16: bf16 MFMA contractions (cfg.DTYPE == "bfloat16", see set_conv_math)
 
     # x, returns NHWC tensors.  `stride` may be overridden to 1 when the caller already sub-sampled (bin_step=2 ROIAlign)
     def fwd(self, x, save, stride=None):
@@ -106,14 +107,14 @@ class Bottleneck(nn.Module):
         s1, b1 = self.bn1.scale_bias()
         s2, b2 = self.bn2.scale_bias()
         s3, b3 = self.bn3.scale_bias()
-        o1 = ops.conv_forward(x, self.conv1.weight, s, 0, scale=s1, bias=b1, relu=True)
-        o2 = ops.conv_forward(o1, self.conv2.weight, 1, 1, scale=s2, bias=b2, relu=True)
+        o1 = ops.conv_forward(x, self.conv1.weight, s, 0, scale=s1, bias=b1, relu=True, math=self.math)
+        o2 = ops.conv_forward(o1, self.conv2.weight, 1, 1, scale=s2, bias=b2, relu=True, math=self.math)
         if self.downsample is not None:
             sd, bd = self.downsample[1].scale_bias()
-            idt = ops.conv_forward(x, self.downsample[0].weight, s, 0, scale=sd, bias=bd)
+            idt = ops.conv_forward(x, self.downsample[0].weight, s, 0, scale=sd, bias=bd, math=self.math)
         else:
             idt = x
-        out = ops.conv_forward(o2, self.conv3.weight, 1, 0, scale=s3, bias=b3, residual=idt, relu=True)
+        out = ops.conv_forward(o2, self.conv3.weight, 1, 0, scale=s3, bias=b3, residual=idt, relu=True, math=self.math)
         return out, ((x, o1, o2, out, s) if save else None)
 
     def bwd(self, saved, gout, need_dx, g_owned, g_masked=False, mask_dx=None):
@@ -124,28 +125,28 @@ class Bottleneck(nn.Module):
         s2, _ = self.bn2.scale_bias()
         s3, _ = self.bn3.scale_bias()
         g = gout if g_masked else ops.relu_backward(gout, out, inplace=g_owned)   # through the block's final ReLU
-        ops.conv_wgrad_async(o2, g, _grad_buf(self.conv3.weight), 1, 0, scale=s3)
-        g2 = ops.conv_forward(g, self.conv3.dgrad_weight(s3), 1, 0, mask=o2)    # dgrad + ReLU mask of o2
-        ops.conv_wgrad_async(o1, g2, _grad_buf(self.conv2.weight), 1, 1, scale=s2)
-        g1 = ops.conv_forward(g2, self.conv2.dgrad_weight(s2), 1, 1, mask=o1)   # 3x3 dgrad: pad = 3-1-1
-        ops.conv_wgrad_async(x, g1, _grad_buf(self.conv1.weight), s, 0, scale=s1)
+        ops.conv_wgrad_async(o2, g, _grad_buf(self.conv3.weight), 1, 0, scale=s3, math=self.math)
+        g2 = ops.conv_forward(g, self.conv3.dgrad_weight(s3), 1, 0, mask=o2, math=self.math)    # dgrad + ReLU mask of o2
+        ops.conv_wgrad_async(o1, g2, _grad_buf(self.conv2.weight), 1, 1, scale=s2, math=self.math)
+        g1 = ops.conv_forward(g2, self.conv2.dgrad_weight(s2), 1, 1, mask=o1, math=self.math)   # 3x3 dgrad: pad = 3-1-1
+        ops.conv_wgrad_async(x, g1, _grad_buf(self.conv1.weight), s, 0, scale=s1, math=self.math)
         ds = self.downsample
         if ds is not None:
             sd, _ = ds[1].scale_bias()
-            ops.conv_wgrad_async(x, g, _grad_buf(ds[0].weight), s, 0, scale=sd)
+            ops.conv_wgrad_async(x, g, _grad_buf(ds[0].weight), s, 0, scale=sd, math=self.math)
         if not need_dx:
             return None
         if s == 1:
             if ds is not None:
-                gx = ops.conv_forward(g, ds[0].dgrad_weight(sd), 1, 0)
-                return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=gx, out=gx, mask=mask_dx)
-            return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=g, mask=mask_dx)
+                gx = ops.conv_forward(g, ds[0].dgrad_weight(sd), 1, 0, math=self.math)
+                return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=gx, out=gx, mask=mask_dx, math=self.math)
+            return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=g, mask=mask_dx, math=self.math)
         # stride-2 1x1 convs: gradient rows land on the even pixels of a zeroed tensor
         B, H, W, _ = x.shape
         assert mask_dx is None, "stride-2 blocks open a stage: their input is not a block output of the same stage"
-        gx = ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, out_hw=(H, W), out_stride=(s, s))
+        gx = ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, out_hw=(H, W), out_stride=(s, s), math=self.math)
         if ds is not None:
-            ops.conv_forward(g, ds[0].dgrad_weight(sd), 1, 0, residual=gx, out=gx, out_hw=(H, W), out_stride=(s, s))
+            ops.conv_forward(g, ds[0].dgrad_weight(sd), 1, 0, residual=gx, out=gx, out_hw=(H, W), out_stride=(s, s), math=self.math)
         return gx
 
 
@@ -188,6 +189,16 @@ def run_stage(x, blocks, first_stride=None, need_dx=True):
     for i, blk in enumerate(blocks):
         h, _ = blk.fwd(h, False, stride=first_stride if i == 0 else None)
     return from_nhwc(h)
+
+
+def set_conv_math(module, math):
+    """Select the contraction arithmetic (ops.MATH_F32 / ops.MATH_BF16) of every bottleneck / conv head under `module`."""
+    n = 0
+    for m in module.modules():
+        if hasattr(m, "math"):
+            m.math = math
+            n += 1
+    return n
 
 
 def _make_stage(in_channels, bottleneck_channels, out_channels, block_count, first_stride):
@@ -234,6 +245,11 @@ class ResNet(nn.Module):
             self.stages.append(name)
             self.return_features[name] = spec.return_features
         self._freeze_backbone(cfg.MODEL.BACKBONE.FREEZE_CONV_BODY_AT)
+        if cfg.DTYPE == "bfloat16":   # BASELINE.json configs[4]: "bf16 MFMA backbone" (fp32 tensors, fp32 accumulate; the stem stays fp32)
+            set_conv_math(self, ops.MATH_BF16)
+        elif cfg.DTYPE != "float32":
+            raise NotImplementedError("DTYPE {!r}: this build computes in float32 or with a bfloat16 MFMA backbone "
+                                      "(the reference's float16 = apex amp O1, train_incremental.py:194)".format(cfg.DTYPE))
 
     def _freeze_backbone(self, freeze_at):
         for stage_index in range(max(freeze_at, 0)):

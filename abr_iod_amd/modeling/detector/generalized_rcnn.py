@@ -12,12 +12,13 @@ backbone -> rpn -> roi_heads orchestration with the reference's three entry poin
                              -> ((target_scores, target_bboxes), mask_logits, features, backbone_features,
                                  roi_align_features)                                                            (:169-175)
 """
+import os
 import random
 
 import torch
+from torch import nn
 
 from ... import ops
-from torch import nn
 
 from ...structures.bounding_box import BoxList
 from ...structures.image_list import to_image_list
@@ -37,6 +38,12 @@ class GeneralizedRCNN(nn.Module):
         assert not cfg.MODEL.RPN.EXTERNAL_PROPOSAL, "external (EdgeBoxes) proposals are outside the hot path"
         self.rpn = build_rpn(cfg, self.backbone.out_channels)
         self.roi_heads = build_roi_heads(cfg, self.backbone.out_channels)
+        # cfg.DTYPE == "bfloat16" = BASELINE.json configs[4] "bf16 MFMA backbone" (backbone/resnet.py).  ABR_BF16_SCOPE=all extends the
+        # bf16 contractions to the RPN head and layer4 as well (the predictor FCs and every loss stay fp32).
+        if cfg.DTYPE == "bfloat16" and os.environ.get("ABR_BF16_SCOPE", "backbone") == "all":
+            from ..backbone.resnet import set_conv_math
+            set_conv_math(self.rpn, ops.MATH_BF16)
+            set_conv_math(self.roi_heads, ops.MATH_BF16)
         self.flat = None
 
     # --- storage: one flat fp32 buffer for parameters, one for gradients (RCCL all-reduce + fused SGD work on them)

@@ -102,8 +102,8 @@ class _RPNHeadFn(Function):
     @staticmethod
     def forward(ctx, x, head, *params):
         xh = as_nhwc(x)
-        t = ops.conv_forward(xh, head.conv.weight, 1, 1, bias=head.conv.bias, relu=True)
-        y = ops.conv_forward(t, head.fused_weight, 1, 0, bias=head.fused_bias)
+        t = ops.conv_forward(xh, head.conv.weight, 1, 1, bias=head.conv.bias, relu=True, math=head.math)
+        y = ops.conv_forward(t, head.fused_weight, 1, 0, bias=head.fused_bias, math=head.math)
         ctx.head, ctx.saved = head, (xh, t)
         ctx.need_dx = x.requires_grad
         return from_nhwc(y)
@@ -115,12 +115,12 @@ class _RPNHeadFn(Function):
         g = as_nhwc(gy)
         if not g.is_contiguous():
             g = g.contiguous()
-        ops.conv_wgrad_async(t, g, head.fused_weight_grad, 1, 0)
+        ops.conv_wgrad_async(t, g, head.fused_weight_grad, 1, 0, math=head.math)
         ops.bias_grad(g, head.fused_bias_grad)
-        gt = ops.conv_forward(g, head.fused_dgrad_weight(), 1, 0, mask=t)
-        ops.conv_wgrad_async(xh, gt, _grad_buf(head.conv.weight), 1, 1)
+        gt = ops.conv_forward(g, head.fused_dgrad_weight(), 1, 0, mask=t, math=head.math)   # (reduction width 76: exact fp32 either way)
+        ops.conv_wgrad_async(xh, gt, _grad_buf(head.conv.weight), 1, 1, math=head.math)
         ops.bias_grad(gt, _grad_buf(head.conv.bias))
-        gx = from_nhwc(ops.conv_forward(gt, head.conv.dgrad_weight(), 1, 1)) if ctx.need_dx else None
+        gx = from_nhwc(ops.conv_forward(gt, head.conv.dgrad_weight(), 1, 1, math=head.math)) if ctx.need_dx else None
         ctx.saved = None
         return (gx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
@@ -132,6 +132,7 @@ class RPNHead(nn.Module):
     def __init__(self, cfg, in_channels, num_anchors):
         super().__init__()
         self.num_anchors = num_anchors
+        self.math = ops.MATH_F32   # see backbone.resnet.set_conv_math
         self.conv = Conv2d(in_channels, in_channels, 3, stride=1, padding=1)
         self.cls_logits = Conv2d(in_channels, num_anchors, 1)
         self.bbox_pred = Conv2d(in_channels, num_anchors * 4, 1)
@@ -203,8 +204,8 @@ class RPNHead(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
             return _RPNHeadFn.apply(x, self, *params)
         xh = as_nhwc(x)
-        t = ops.conv_forward(xh, self.conv.weight, 1, 1, bias=self.conv.bias, relu=True)
-        return from_nhwc(ops.conv_forward(t, self.fused_weight, 1, 0, bias=self.fused_bias))
+        t = ops.conv_forward(xh, self.conv.weight, 1, 1, bias=self.conv.bias, relu=True, math=self.math)
+        return from_nhwc(ops.conv_forward(t, self.fused_weight, 1, 0, bias=self.fused_bias, math=self.math))
 
     def forward(self, x):
         logits, bbox_reg = [], []

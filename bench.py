@@ -23,8 +23,9 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMG_ARD = 1304.0   # algorithmic conv/linear FLOPs of one ARD training image
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense
 PROF_NAMES = ["conv_igemm_kernel<128,128>", "conv_igemm_kernel<128,64>", "conv_igemm_kernel<64,64>", "conv_igemm_kernel<128,64,small_c>",
-              "conv_wgrad_kernel"]
+              "conv_wgrad_kernel", "roi_align_fwd", "roi_align_bwd", "conv_igemm_bf16_kernel", "conv_wgrad_bf16_kernel"]
 
 
 def cpu_baseline(model_target, images, targets, n_old):
@@ -60,6 +61,9 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--math", choices=["f32", "bf16", "bf16-all"], default="f32",
+                    help="f32 (default, the BASELINE metric); bf16 = BASELINE.json configs[4]'s bf16 MFMA backbone (cfg.DTYPE bfloat16: operands "
+                         "rounded in-kernel, fp32 accumulate, fp32 tensors); bf16-all = RPN head and layer4 as well.  Not the headline number.")
     ap.add_argument("--time-all-kernels", action="store_true", help="event-bracket every conv / ROIAlign launch, not only the dominant kernel")
     a = ap.parse_args()
 
@@ -81,7 +85,10 @@ def main():
     from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer
 
     B = a.batch_per_gpu
-    cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, ims_per_batch=B * world)
+    if a.math == "bf16-all":
+        os.environ["ABR_BF16_SCOPE"] = "all"
+    cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, ims_per_batch=B * world,
+                             overrides=("DTYPE", "bfloat16") if a.math != "f32" else ())
     model_source, model_target = build_models(cfg_s, cfg_t, seed=0)       # same seed on every rank = broadcast weights
     optimizer = make_optimizer(cfg_t, model_target)
     scheduler = make_lr_scheduler(cfg_t, optimizer)
@@ -101,7 +108,8 @@ def main():
         # default: only the dominant kernel (conv_igemm<128,128>, id 0) is event-bracketed, and only every 4th of its launches
         # (73 per step, coprime to 4: every shape is sampled equally over 4 steps) -- an event pair costs a ~6 us bubble per
         # launch, 1.6 ms/step if all ~250 conv/ROIAlign launches are timed.  --time-all-kernels fills the whole table.
-        _lib.check(_lib.lib().abr_prof_set_mask(0xFFFFFFFF if a.time_all_kernels else 0x1, 1 if a.time_all_kernels else 4), "prof_set_mask")
+        dom_mask = 0x1 if a.math == "f32" else 0x81   # + id 7: the bf16 implicit GEMM
+        _lib.check(_lib.lib().abr_prof_set_mask(0xFFFFFFFF if a.time_all_kernels else dom_mask, 1 if a.time_all_kernels else 4), "prof_set_mask")
         _lib.check(_lib.lib().abr_prof_begin(), "prof_begin")
     t0 = time.perf_counter()
     last = None
@@ -127,10 +135,12 @@ def main():
         out = {
             "metric": "training images/sec (R50-C4 Faster R-CNN + ARD)", "value": round(value, 3), "unit": "img/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+            "dtype": "f32" if a.math == "f32" else "bf16 MFMA operands / f32 accumulate / f32 tensors ({}); f32 elsewhere".format(
+                "backbone layer1-3" if a.math == "bf16" else "backbone, RPN head, layer4"),
             "config": {"workload": "BASELINE.json configs[2]: task 15-5 ABR step, --feat ard --dist_type id (alpha .5, beta 1, gamma 1), "
                                    "R50-C4, 600x1000, 512 RoIs/img + 64 distillation RoIs/img, source+target models, SGD step",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "math": a.math,
                        "gflop_per_img_algorithmic": GFLOP_PER_IMG_ARD},
             "final_losses": {k: round(float(v), 5) for k, v in loss_dict.items()},
             "conv_roofline_frac_whole_step": round(value / world * GFLOP_PER_IMG_ARD / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -159,8 +169,9 @@ def main():
             if n == 0:
                 n, ms, flops, n_o, ms_o, flops_o = n_o, ms_o, flops_o, 0, 0.0, 0.0
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+            peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
+                               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                "flops_counted": "executed multiply-adds of each launch (a Winograd F(4x4,3x3) conv executes 1/4 of its algorithmic "
                                                 "MACs, so conv_roofline_frac_whole_step -- algorithmic -- can exceed this kernel fraction)",
                                "launches": int(n), "sampling": "every launch" if a.time_all_kernels else "every 4th launch of this kernel",

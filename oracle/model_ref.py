@@ -29,7 +29,8 @@ class _RoiAlignRef(torch.autograd.Function):
 class RefModel(object):
     BLOCKS = {"layer1": 3, "layer2": 4, "layer3": 6}
 
-    def __init__(self, sd, trainable_prefixes=("backbone.body.layer2", "backbone.body.layer3", "rpn.", "roi_heads.")):
+    def __init__(self, sd, trainable_prefixes=("backbone.body.layer2", "backbone.body.layer3", "rpn.", "roi_heads."), bf16_backbone=False):
+        self.bf16_backbone = bf16_backbone   # cfg.DTYPE == "bfloat16": layer1-3 convs on bf16-rounded operands (the stem stays fp32)
         self.p = {}
         for k, v in sd.items():
             t = v.detach().cpu().float().clone()
@@ -40,7 +41,7 @@ class RefModel(object):
     def _bn(self, prefix):
         return tuple(self.p[f"{prefix}.{n}"] for n in ("weight", "bias", "running_mean", "running_var"))
 
-    def _block(self, x, prefix, stride):
+    def _block(self, x, prefix, stride, bf16=False):
         has_ds = f"{prefix}.downsample.0.weight" in self.p
         q = {"conv1.weight": self.p[f"{prefix}.conv1.weight"], "conv2.weight": self.p[f"{prefix}.conv2.weight"],
              "conv3.weight": self.p[f"{prefix}.conv3.weight"], "bn1": self._bn(f"{prefix}.bn1"), "bn2": self._bn(f"{prefix}.bn2"),
@@ -48,7 +49,7 @@ class RefModel(object):
         if has_ds:
             q["downsample.0.weight"] = self.p[f"{prefix}.downsample.0.weight"]
             q["ds_bn"] = self._bn(f"{prefix}.downsample.1")
-        return R.bottleneck(x, q, stride, has_ds)
+        return R.bottleneck(x, q, stride, has_ds, bf16=bf16)
 
     def backbone(self, images):
         b = "backbone.body"
@@ -56,7 +57,7 @@ class RefModel(object):
         x = F.max_pool2d(x, 3, 2, 1)
         for name, n in self.BLOCKS.items():
             for i in range(n):
-                x = self._block(x, f"{b}.{name}.{i}", (2 if name != "layer1" else 1) if i == 0 else 1)
+                x = self._block(x, f"{b}.{name}.{i}", (2 if name != "layer1" else 1) if i == 0 else 1, bf16=self.bf16_backbone)
         return x
 
     def rpn_head(self, feat):

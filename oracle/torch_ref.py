@@ -231,14 +231,22 @@ def frozen_bn(x, w, b, rm, rv):
     return x * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
 
 
-def bottleneck(x, p, stride, has_ds):
-    """modeling/backbone/resnet.py:327-346 with STRIDE_IN_1X1=True (:278): stride sits in conv1 and the downsample."""
+def bf16_round(t):
+    """round-to-nearest-even to bfloat16 and back: what the bf16 math mode does to both conv operands (BASELINE.json configs[4])"""
+    return t.bfloat16().float()
+
+
+def bottleneck(x, p, stride, has_ds, bf16=False):
+    """modeling/backbone/resnet.py:327-346 with STRIDE_IN_1X1=True (:278): stride sits in conv1 and the downsample.
+    bf16=True restates the "bf16 MFMA backbone" configuration: every conv sees bf16-rounded activations and weights, products and
+    sums in fp32 (a bf16 x bf16 product is exact in fp32), everything else unchanged."""
+    r = bf16_round if bf16 else (lambda t: t)
     idt = x
-    o = F.relu(frozen_bn(F.conv2d(x, p["conv1.weight"], stride=stride), *p["bn1"]))
-    o = F.relu(frozen_bn(F.conv2d(o, p["conv2.weight"], padding=1), *p["bn2"]))
-    o = frozen_bn(F.conv2d(o, p["conv3.weight"]), *p["bn3"])
+    o = F.relu(frozen_bn(F.conv2d(r(x), r(p["conv1.weight"]), stride=stride), *p["bn1"]))
+    o = F.relu(frozen_bn(F.conv2d(r(o), r(p["conv2.weight"]), padding=1), *p["bn2"]))
+    o = frozen_bn(F.conv2d(r(o), r(p["conv3.weight"])), *p["bn3"])
     if has_ds:
-        idt = frozen_bn(F.conv2d(x, p["downsample.0.weight"], stride=stride), *p["ds_bn"])
+        idt = frozen_bn(F.conv2d(r(x), r(p["downsample.0.weight"]), stride=stride), *p["ds_bn"])
     return F.relu(o + idt)
 
 

@@ -53,7 +53,10 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--only", default="")
+    ap.add_argument("--math", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--convs-only", action="store_true")
     a = ap.parse_args()
+    mth = ops.MATH_BF16 if a.math == "bf16" else ops.MATH_F32
     dev = "cuda"
     print(f"{'layer':10s} {'M':>7s} {'N':>5s} {'K':>5s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
     for name, N, H, W, Cin, Cout, k, s, p in conv_cases(a.batch, a.rois):
@@ -63,20 +66,22 @@ def main():
         w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
         sc = torch.rand(Cout, device=dev) + 0.5
         bi = torch.randn(Cout, device=dev)
-        y = ops.conv_forward(x, w, s, p, scale=sc, bias=bi, relu=True)
+        y = ops.conv_forward(x, w, s, p, scale=sc, bias=bi, relu=True, math=mth)
         M = y.numel() // Cout
         K = k * k * Cin
         fl = 2.0 * M * Cout * K
-        t_f = timeit(lambda: ops.conv_forward(x, w, s, p, scale=sc, bias=bi, relu=True))
+        t_f = timeit(lambda: ops.conv_forward(x, w, s, p, scale=sc, bias=bi, relu=True, math=mth))
         line = f"{name:10s} {M:7d} {Cout:5d} {K:5d} | {t_f:8.3f} {fl / t_f / 1e9:6.1f}"
         if k != 7 and s == 1:
             gy = torch.randn_like(y)
             wt = ops.conv_dgrad_weights(w, sc)
-            t_d = timeit(lambda: ops.conv_forward(gy, wt, 1, k - 1 - p, mask=x))
+            t_d = timeit(lambda: ops.conv_forward(gy, wt, 1, k - 1 - p, mask=x, math=mth))
             dw = torch.zeros_like(w)
-            t_w = timeit(lambda: ops.conv_wgrad(x, gy, dw, s, p, scale=sc))
+            t_w = timeit(lambda: ops.conv_wgrad(x, gy, dw, s, p, scale=sc, math=mth))
             line += f" | {t_d:8.3f} {fl / t_d / 1e9:6.1f} | {t_w:8.3f} {fl / t_w / 1e9:6.1f}"
         print(line, flush=True)
+    if a.convs_only:
+        return
     # HBM-bound kernels
     B, Rr = a.batch, a.rois
     feat = torch.randn(B, 38, 63, 1024, device=dev)
