@@ -412,14 +412,15 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int BKH = 64;        // k per tile
 constexpr int LDH = BKH + 8;   // LDS row pitch in bf16 elements (144 B)
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DB>
 __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvP p, const float* __restrict__ x, const float* __restrict__ w,
                                                                float* __restrict__ out) {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int NA = BM / 16, NB = BN / 16;  // float4 staging loads per thread (16 rows x 16 float4 per pass)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* As = reinterpret_cast<__bf16*>(smem);  // [BM][LDH]
-    __bf16* Bs = As + BM * LDH;                    // [BN][LDH]
+    constexpr int NBUF = DB ? 2 : 1;
+    __bf16* As = reinterpret_cast<__bf16*>(smem);  // [NBUF][BM][LDH]
+    __bf16* Bs = As + NBUF * BM * LDH;             // [NBUF][BN][LDH]
 
     const int tile = (int)abr::xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
@@ -473,11 +474,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvP p, con
         const bf16x4 h = __builtin_convertvector(f, bf16x4);   // RNE
         return *reinterpret_cast<const uint2*>(&h);
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        __bf16* a = As + buf * BM * LDH;
+        __bf16* b = Bs + buf * BN * LDH;
 #pragma unroll
-        for (int i = 0; i < NA; i++) *reinterpret_cast<uint2*>(As + (srow + 16 * i) * LDH + kq * 4) = pack(ra[i]);
+        for (int i = 0; i < NA; i++) *reinterpret_cast<uint2*>(a + (srow + 16 * i) * LDH + kq * 4) = pack(ra[i]);
 #pragma unroll
-        for (int i = 0; i < NB; i++) *reinterpret_cast<uint2*>(Bs + (srow + 16 * i) * LDH + kq * 4) = pack(rb[i]);
+        for (int i = 0; i < NB; i++) *reinterpret_cast<uint2*>(b + (srow + 16 * i) * LDH + kq * 4) = pack(rb[i]);
     };
 
     f32x16 acc[TM][TN];
@@ -491,14 +494,16 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvP p, con
     const int l31 = lane & 31, lh = lane >> 5;
     const __bf16* a_frag = As + (wm * (TM * 32) + l31) * LDH + lh * 8;
     const __bf16* b_frag = Bs + (wn * (TN * 32) + l31) * LDH + lh * 8;
-    auto compute_tile = [&]() {
+    auto compute_tile = [&](int cur) {
+        const __bf16* af = a_frag + cur * BM * LDH;
+        const __bf16* bf = b_frag + cur * BN * LDH;
 #pragma unroll
         for (int u = 0; u < BKH / 16; u++) {
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const bf16x8*>(a_frag + i * 32 * LDH + u * 16);
+            for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const bf16x8*>(af + i * 32 * LDH + u * 16);
 #pragma unroll
-            for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const bf16x8*>(b_frag + j * 32 * LDH + u * 16);
+            for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const bf16x8*>(bf + j * 32 * LDH + u * 16);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -508,33 +513,59 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvP p, con
 
     const int nk = p.K / BKH;
     load_tile(0);
-    store_tile();
+    store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt + 1 < nk; kt++) {
-        load_tile(kt + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tile();
-        __syncthreads();
-        store_tile();
-        __syncthreads();
+    int kt = 0;
+    if (!DB) {
+        for (; kt + 1 < nk; kt++) {
+            load_tile(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(0);
+            __syncthreads();
+            store_tile(0);
+            __syncthreads();
+        }
+        compute_tile(0);
+    } else {  // one barrier per k-tile, tile kt+2 fetched right behind the ds_writes of kt+1 (same shape as the fp32 loop)
+        if (kt + 1 < nk) load_tile(kt + 1);
+        for (; kt + 2 < nk; kt++) {
+            const int cur = kt & 1;
+            compute_tile(cur);
+            store_tile(cur ^ 1);
+            load_tile(kt + 2);
+            __syncthreads();
+        }
+        if (kt + 1 < nk) {
+            const int cur = kt & 1;
+            compute_tile(cur);
+            store_tile(cur ^ 1);
+            __syncthreads();
+            kt++;
+        }
+        compute_tile(kt & 1);
     }
-    compute_tile();
     __syncthreads();  // the epilogue reuses the operand LDS
     epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DB>
 int launch_bf16(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
     ConvP q = p;
     q.tiles_m = (p.M + BM - 1) / BM;
     q.tiles_n = (p.Cout + BN - 1) / BN;
     q.tiles_pb = q.tiles_m * q.tiles_n;
     q.nbatch = 1; q.n_full = q.tiles_pb; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
-    constexpr size_t lds_op = sizeof(__bf16) * (BM + BN) * LDH;
+    constexpr size_t lds_op = sizeof(__bf16) * (DB ? 2 : 1) * (BM + BN) * LDH;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
     const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
+    auto kern = conv_igemm_bf16_kernel<BM, BN, WM, WN, DB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     const int rec = abr::prof_start(st, abr::PROF_IGEMM_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
-    conv_igemm_bf16_kernel<BM, BN, WM, WN><<<(unsigned)q.tiles_pb, 256, lds, st>>>(q, x, w, out);
+    kern<<<(unsigned)q.tiles_pb, 256, lds, st>>>(q, x, w, out);
     abr::prof_stop(st, rec);
     return 0;
 }
@@ -691,9 +722,20 @@ static void dispatch_igemm_bf16(const ConvP& p, const float* x, const float* w, 
     const int cus = num_cus();
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
-    if (p.Cout > 64 && t128 >= 2 * cus) launch_bf16<128, 128, 2, 2>(p, x, w, out, st);
-    else if (t12864 >= 2 * cus || p.Cout <= 64) launch_bf16<128, 64, 4, 1>(p, x, w, out, st);
-    else launch_bf16<64, 64, 2, 2>(p, x, w, out, st);
+    // double-buffered operand LDS (73.7 KB, still two workgroups per CU by registers) once there are enough k-tiles to pipeline:
+    // +3..10 % on the 128x128 tile (layer4 / RPN shapes).  What bounds these launches is operand delivery, not the matrix pipe:
+    // every workgroup pulls (BM + BN) x K fp32 through L2 (layer4 downsample: 4.3 GB per launch = 13.7 TB/s at 0.31 ms), 16x the
+    // bytes per flop of the fp32 MFMA it replaces.
+    static const int db_mink = getenv("ABR_BF16_DB_MINK") ? atoi(getenv("ABR_BF16_DB_MINK")) : 512;
+    const bool db = p.K >= db_mink;
+    if (p.Cout > 64 && t128 >= 2 * cus) {
+        if (db) launch_bf16<128, 128, 2, 2, true>(p, x, w, out, st);
+        else launch_bf16<128, 128, 2, 2, false>(p, x, w, out, st);
+    } else if (t12864 >= 2 * cus || p.Cout <= 64) {   // (measured: the narrower tiles are faster single-buffered, 3 workgroups / CU)
+        launch_bf16<128, 64, 4, 1, false>(p, x, w, out, st);
+    } else {
+        launch_bf16<64, 64, 2, 2, false>(p, x, w, out, st);
+    }
 }
 
 // stride-1 pad-1 3x3 conv as Winograd F(4x4,3x3): weight + input transforms, 36 batched GEMMs, output transform with the epilogue
