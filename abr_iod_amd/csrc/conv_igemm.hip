@@ -75,6 +75,7 @@ struct ConvP {
     // batched mode (the 36 Winograd GEMMs): tile -> (batch, tile inside the batch); operands / output advance by the strides
     int nbatch, tiles_pb;
     long a_bs, w_bs, o_bs;
+    int math;  // ABR_MATH_*
 };
 
 
@@ -570,6 +571,198 @@ int launch_bf16(const ConvP& p, const float* x, const float* w, float* out, hipS
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// fp32-accurate math on the bf16 matrix cores (abr_conv_desc::math == ABR_MATH_BF16X6; opt-in, not the default).
+// Every fp32 operand is split EXACTLY into three bf16 terms, x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0
+// - x1): 3 x (8 bits + sign) cover the 24-bit significand; both subtractions are exact in fp32), and the product is formed from
+// the six cross terms with i + j <= 2 -- x0w0, x0w1, x1w0, x0w2, x1w1, x2w0 -- each an exact bf16 x bf16 product accumulated in
+// fp32 by v_mfma_f32_32x32x16_bf16.  The three dropped terms are below 2^-26 |x||w|, under the rounding of a single fp32
+// product, so the result carries the same error bound as an fp32 FMA chain (tests: 1e-5 of the output scale against float64,
+// TIGHTER than the fp32 kernels' criterion).  Six bf16 MFMAs deliver 2.5 PF / 6 = 417 TFLOP/s of fp32-equivalent work against
+// 157 for v_mfma_f32_32x32x2_f32.
+// k-tile 32; three bf16 planes per operand in LDS (pitch 80 B: conflict-free ds_read_b128), 61.4 KB single-buffered = two
+// workgroups per CU; per 16-k step a wave reads (TM + TN) x 3 fragments for TM x TN x 6 MFMAs.  Handles the batched
+// (Winograd-domain) GEMMs like the fp32 kernel.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int BKX = 32;
+constexpr int LDX = BKX + 8;   // LDS row pitch in bf16 elements (80 B)
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const float* __restrict__ x_, const float* __restrict__ w_,
+                                                             float* __restrict__ out_) {
+    const float* x = x_;
+    const float* w = w_;
+    float* out = out_;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int NA = BM / 32, NB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);  // [3][BM][LDX]
+    __bf16* Bs = As + 3 * BM * LDX;                // [3][BN][LDX]
+
+    int tile = (int)abr::xcd_remap(blockIdx.x, gridDim.x);
+    if (p.nbatch > 1) {
+        const int bt = tile / p.tiles_pb;
+        tile -= bt * p.tiles_pb;
+        x += bt * p.a_bs; w += bt * p.w_bs; out += bt * p.o_bs;
+    }
+    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kq = tid & 7, srow = tid >> 3;
+
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, p.w_bytes, 0x00020000);
+    int a_hi0[NA], a_wi0[NA], a_off0[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int m = m0 + srow + 32 * i;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        unsigned b, rem, ho, wo;
+        p.d_howo.divmod((unsigned)mm, b, rem);
+        p.d_wo.divmod(rem, ho, wo);
+        a_hi0[i] = (int)ho * p.stride - p.pad;
+        a_wi0[i] = (int)wo * p.stride - p.pad;
+        a_off0[i] = (((int)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + kq * 4;
+    }
+    unsigned b_off0[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const int n = n0 + srow + 32 * i;
+        b_off0[i] = n < p.Cout ? (unsigned)(n * p.K + kq * 4) * 4u : kOOB;
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // TWO tiles in flight: a k-tile is only 48 MFMAs (~1500 cycles) per wave, well under the latency of the loads, so tile kt+2 is
+    // requested before tile kt is multiplied and is split / parked in LDS one iteration later (register sets alternate by parity)
+    u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+    auto load_tile = [&](int kt, u32x4 (&ra)[NA], u32x4 (&rb)[NB], bool valid) {
+        const int k0 = kt * BKX;
+        unsigned rs, c0, r, s;
+        p.d_cin.divmod((unsigned)k0, rs, c0);
+        p.d_s.divmod(rs, r, s);
+        const int delta = ((int)r * p.W + (int)s) * p.Cin + (int)c0;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
+            const bool ok = valid & a_ok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB), 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(valid ? b_off0[i] : kOOB), k0 * 4, 0);
+    };
+    // exact three-way split of four fp32 values into bf16 planes
+    auto split_store = [](const u32x4 v, __bf16* dst, int plane_stride) {
+        const f32x4v f = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        const bf16x4 h0 = __builtin_convertvector(f, bf16x4);
+        const f32x4v r1 = f - __builtin_convertvector(h0, f32x4v);
+        const bf16x4 h1 = __builtin_convertvector(r1, bf16x4);
+        const f32x4v r2 = r1 - __builtin_convertvector(h1, f32x4v);
+        const bf16x4 h2 = __builtin_convertvector(r2, bf16x4);
+        *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(&h0);
+        *reinterpret_cast<uint2*>(dst + plane_stride) = *reinterpret_cast<const uint2*>(&h1);
+        *reinterpret_cast<uint2*>(dst + 2 * plane_stride) = *reinterpret_cast<const uint2*>(&h2);
+    };
+    auto store_tile = [&](u32x4 (&ra)[NA], u32x4 (&rb)[NB]) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) split_store(ra[i], As + (srow + 32 * i) * LDX + kq * 4, BM * LDX);
+#pragma unroll
+        for (int i = 0; i < NB; i++) split_store(rb[i], Bs + (srow + 32 * i) * LDX + kq * 4, BN * LDX);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const __bf16* a_frag = As + (wm * (TM * 32) + l31) * LDX + lh * 8;
+    const __bf16* b_frag = Bs + (wn * (TN * 32) + l31) * LDX + lh * 8;
+    auto compute_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < BKX / 16; u++) {
+            bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * BM * LDX + i * 32 * LDX + u * 16);
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) fb[j][pl] = *reinterpret_cast<const bf16x8*>(b_frag + pl * BN * LDX + j * 32 * LDX + u * 16);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {   // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    const int nk = p.K / BKX;
+    load_tile(0, ra0, rb0, true);
+    load_tile(1, ra1, rb1, nk > 1);
+    store_tile(ra0, rb0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {   // LDS holds tile kt, set 1 holds tile kt+1 (possibly still in flight), set 0 is free
+        load_tile(kt + 2, ra0, rb0, true);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tile();
+        __syncthreads();
+        store_tile(ra1, rb1);
+        __syncthreads();
+        load_tile(kt + 3, ra1, rb1, kt + 3 < nk);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tile();
+        __syncthreads();
+        store_tile(ra0, rb0);
+        __syncthreads();
+    }
+    if (kt + 1 < nk) {   // one more tile, waiting in set 1
+        compute_tile();
+        __syncthreads();
+        store_tile(ra1, rb1);
+        __syncthreads();
+    }
+    compute_tile();
+    __syncthreads();  // the epilogue reuses the operand LDS
+    epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_x6(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
+    ConvP q = p;
+    q.tiles_m = (p.M + BM - 1) / BM;
+    q.tiles_n = (p.Cout + BN - 1) / BN;
+    q.tiles_pb = q.tiles_m * q.tiles_n;
+    if (q.nbatch < 1) q.nbatch = 1;
+    q.n_full = q.tiles_pb * q.nbatch; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
+    constexpr size_t lds_op = sizeof(__bf16) * 3 * (BM + BN) * LDX;
+    constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
+    const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
+    auto kern = conv_igemm_x6_kernel<BM, BN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int rec = abr::prof_start(st, abr::PROF_IGEMM_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
+    kern<<<(unsigned)(q.tiles_pb * q.nbatch), 256, lds, st>>>(q, x, w, out);
+    abr::prof_stop(st, rec);
+    return 0;
+}
+
 // split-K scratch: partial tiles (64 KB each for 128x128) + tickets, one set per stream (streams may run convs concurrently)
 struct SplitWs { float* ws = nullptr; int* cnt = nullptr; };
 static SplitWs* split_ws(hipStream_t st) {
@@ -738,6 +931,17 @@ static void dispatch_igemm_bf16(const ConvP& p, const float* x, const float* w, 
     }
 }
 
+// bf16x6 math mode (fp32-accurate): same tile rules as the bf16 mode
+static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
+    const int cus = num_cus();
+    const int64_t nb = p.nbatch > 1 ? p.nbatch : 1;
+    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * nb;
+    const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64) * nb;
+    if (p.Cout > 64 && t128 >= 2 * cus) launch_x6<128, 128, 2, 2>(p, x, w, out, st);
+    else if (t12864 >= 2 * cus || p.Cout <= 64) launch_x6<128, 64, 4, 1>(p, x, w, out, st);
+    else launch_x6<64, 64, 2, 2>(p, x, w, out, st);
+}
+
 // stride-1 pad-1 3x3 conv as Winograd F(4x4,3x3): weight + input transforms, 36 batched GEMMs, output transform with the epilogue
 static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
     const int th_n = (p.H + 3) / 4, tw_n = (p.W + 3) / 4;
@@ -757,7 +961,8 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
     g.d_howo.init(1u); g.d_wo.init(1u); g.d_cin.init((unsigned)p.Cin); g.d_s.init(1u);
     g.x_bytes = (unsigned)(T * p.Cin * 4); g.w_bytes = (unsigned)((int64_t)p.Cout * p.Cin * 4);
     g.nbatch = 36; g.a_bs = (long)T * p.Cin; g.w_bs = (long)p.Cout * p.Cin; g.o_bs = (long)T * p.Cout;
-    dispatch_igemm(g, V, U, Mm, st);
+    if (p.math == ABR_MATH_BF16X6) dispatch_igemm_x6(g, V, U, Mm, st);
+    else dispatch_igemm(g, V, U, Mm, st);
     return abr::wino_output_transform(Mm, p.B, p.H, p.W, p.Cout, p.scale, p.bias, p.relu, p.mask, out, st) == 0;
 }
 
@@ -788,7 +993,9 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     p.d_howo.init((unsigned)(p.Ho * p.Wo)); p.d_wo.init((unsigned)p.Wo); p.d_cin.init((unsigned)p.Cin); p.d_s.init((unsigned)p.S);
     hipStream_t st = abr::as_stream(stream);
-    ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16, "conv_forward: unknown math mode");
+    ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16 || d->math == ABR_MATH_BF16X6, "conv_forward: unknown math mode");
+    p.math = d->math;
+    if (p.math == ABR_MATH_BF16X6 && p.Cin % BKX != 0) p.math = ABR_MATH_F32;   // the 4-channel stem: fp32 MFMA
     if (d->math == ABR_MATH_BF16 && p.Cin % BKH == 0) {   // (the 4-channel stem has no 64-wide k-tile: it stays fp32)
         dispatch_igemm_bf16(p, x, w, out, st);
         ABR_CHECK_LAUNCH("conv_forward (bf16)");
@@ -805,7 +1012,8 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
             return ABR_OK;
         }
     }
-    dispatch_igemm(p, x, w, out, st);
+    if (p.math == ABR_MATH_BF16X6) dispatch_igemm_x6(p, x, w, out, st);
+    else dispatch_igemm(p, x, w, out, st);
     ABR_CHECK_LAUNCH("conv_forward");
     return ABR_OK;
 }

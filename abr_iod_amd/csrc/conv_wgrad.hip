@@ -57,6 +57,7 @@ struct WgP {
     int overwrite;               // splits == 1 only: plain stores instead of atomic accumulation (the caller wants dw = ..., not +=)
     int nbatch, tiles_pb;        // batched mode (the 36 Winograd-domain gradients): tile -> (batch, tile inside the batch)
     long x_bs, gy_bs, dw_bs;
+    int math;                    // ABR_MATH_F32 or ABR_MATH_BF16X6 (the bf16 mode has its own launch)
 };
 
 // SB: single-buffered operand LDS (two barriers per stage, 32 KB instead of 64 KB -> a third resident workgroup per CU)
@@ -375,6 +376,182 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgP p, const
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// fp32-accurate weight gradient on the bf16 matrix cores (ABR_MATH_BF16X6, see conv_igemm.hip): each operand value is split
+// exactly into three bf16 terms, the six cross products with i + j <= 2 are accumulated in fp32.  Same [m-pair][column] LDS
+// tiles as the bf16 kernel, three planes per operand; stage = 32 rows (48 KB of operand LDS, 48 MFMAs per wave and stage).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int MRX = 32;
+
+__global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const float* __restrict__ x_, const float* __restrict__ gy_,
+                                                             float* __restrict__ dw_) {
+    const float* x = x_;
+    const float* gy = gy_;
+    float* dw = dw_;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PL = (MRX / 2) * TN_;                  // dwords per plane (TN_ == TK_)
+    unsigned* Gs = reinterpret_cast<unsigned*>(smem);    // [3][MRX/2][TN_]
+    unsigned* As = Gs + 3 * PL;                          // [3][MRX/2][TK_]
+
+    const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
+    const int split = bid % p.splits;
+    int tile = bid / p.splits;
+    if (p.nbatch > 1) {
+        const int bt = tile / p.tiles_pb;
+        tile -= bt * p.tiles_pb;
+        x += bt * p.x_bs; gy += bt * p.gy_bs; dw += bt * p.dw_bs;
+    }
+    const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
+    const int n0 = tile_n * TN_, k0 = tile_k * TK_;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int q = tid & 31, rp = tid >> 5;   // 16 B column group; row pairs rp + 8*i (i < 2)
+    const int gn = n0 + q * 4;
+    const bool g_ok = gn < p.Cout;
+    const int ak = k0 + q * 4;
+    const bool k_ok = ak < p.K;
+    int fr = 0, fs = 0, fc = 0;
+    if (k_ok) {
+        const int rs = ak / p.Cin;
+        fc = ak % p.Cin;
+        fr = rs / p.S;
+        fs = rs % p.S;
+    }
+    const int mt0 = split * p.mt_per_split;
+    const int mt1 = min(mt0 + p.mt_per_split, (p.M + MRX - 1) / MRX);
+
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rgy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, p.gy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
+    const unsigned g_voff = g_ok ? (unsigned)(2 * rp * p.Cout + gn) * 4u : kOOB;
+    const unsigned a_voff_plain = k_ok ? (unsigned)(2 * rp * p.Cin + fc) * 4u : kOOB;
+    const int a_const = ((fr - p.pad) * p.W + (fs - p.pad)) * p.Cin + fc;
+    u32x4 rg[2][2], ra[2][2];
+    auto load_tile = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int mrow = mt * MRX + 16 * i + e;
+                rg[i][e] = __builtin_amdgcn_raw_buffer_load_b128(rgy, (int)(g_voff + (unsigned)(mrow * p.Cout) * 4u), 0, 0);
+                if (p.plain) {
+                    ra[i][e] = __builtin_amdgcn_raw_buffer_load_b128(rxx, (int)(a_voff_plain + (unsigned)(mrow * p.Cin) * 4u), 0, 0);
+                } else {
+                    const int m = mrow + 2 * rp;
+                    unsigned b, rem, ho, wo;
+                    p.d_howo.divmod((unsigned)m, b, rem);
+                    p.d_wo.divmod(rem, ho, wo);
+                    const int hi = (int)ho * p.stride - p.pad + fr, wi = (int)wo * p.stride - p.pad + fs;
+                    const bool ok = k_ok & (m < p.M) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+                    const int off = (((int)b * p.H + (int)ho * p.stride) * p.W + (int)wo * p.stride) * p.Cin + a_const;
+                    ra[i][e] = __builtin_amdgcn_raw_buffer_load_b128(rxx, (int)(ok ? (unsigned)off * 4u : kOOB), 0, 0);
+                }
+            }
+    };
+    // rows (m, m+1) of one 16 B column group -> three planes of four bf16x2 dwords
+    auto split_store = [](const u32x4 lo, const u32x4 hi, unsigned* dst, int plane) {
+        u32x4 o0, o1, o2;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const f32x2v f = {__uint_as_float(lo[c]), __uint_as_float(hi[c])};
+            const bf16x2 h0 = __builtin_convertvector(f, bf16x2);
+            const f32x2v r1 = f - __builtin_convertvector(h0, f32x2v);
+            const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
+            const f32x2v r2 = r1 - __builtin_convertvector(h1, f32x2v);
+            const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
+            o0[c] = *reinterpret_cast<const unsigned*>(&h0);
+            o1[c] = *reinterpret_cast<const unsigned*>(&h1);
+            o2[c] = *reinterpret_cast<const unsigned*>(&h2);
+        }
+        *reinterpret_cast<u32x4*>(dst) = o0;
+        *reinterpret_cast<u32x4*>(dst + plane) = o1;
+        *reinterpret_cast<u32x4*>(dst + 2 * plane) = o2;
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            split_store(rg[i][0], rg[i][1], Gs + (rp + 8 * i) * TN_ + q * 4, PL);
+            split_store(ra[i][0], ra[i][1], As + (rp + 8 * i) * TK_ + q * 4, PL);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    auto compute_tile = [&]() {
+        const unsigned* g = Gs + wm * 64 + 2 * l31 + 4 * lh * TN_;
+        const unsigned* a = As + wn * 64 + 2 * l31 + 4 * lh * TK_;
+#pragma unroll
+        for (int s = 0; s < MRX / 16; s++) {
+            bf16x8 G[2][3], A[2][3];   // [column sub-tile][plane]
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                uint2 fg[4], fa[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    fg[t] = *reinterpret_cast<const uint2*>(g + pl * PL + (8 * s + t) * TN_);
+                    fa[t] = *reinterpret_cast<const uint2*>(a + pl * PL + (8 * s + t) * TK_);
+                }
+                const u32x4 g0 = {fg[0].x, fg[1].x, fg[2].x, fg[3].x}, g1 = {fg[0].y, fg[1].y, fg[2].y, fg[3].y};
+                const u32x4 a0 = {fa[0].x, fa[1].x, fa[2].x, fa[3].x}, a1 = {fa[0].y, fa[1].y, fa[2].y, fa[3].y};
+                G[0][pl] = *reinterpret_cast<const bf16x8*>(&g0); G[1][pl] = *reinterpret_cast<const bf16x8*>(&g1);
+                A[0][pl] = *reinterpret_cast<const bf16x8*>(&a0); A[1][pl] = *reinterpret_cast<const bf16x8*>(&a1);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {   // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][2], A[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][0], A[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][1], A[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][1], A[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][0], A[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][0], A[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    if (mt0 < mt1) {
+        load_tile(mt0);
+        store_tile();
+        __syncthreads();
+        int mt = mt0;
+        for (; mt + 1 < mt1; mt++) {
+            load_tile(mt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile();
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+        }
+        compute_tile();
+    }
+
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int n = n0 + wm * 64 + 2 * i + tm;
+            if (n >= p.Cout) continue;
+            const float sc = p.scale ? p.scale[n] : 1.f;
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) {
+                const int k = k0 + wn * 64 + 2 * l31 + tn;
+                if (k < p.K) {
+                    if (p.overwrite) dw[(size_t)n * p.K + k] = acc[tm][tn][r] * sc;
+                    else unsafeAtomicAdd(dw + (size_t)n * p.K + k, acc[tm][tn][r] * sc);
+                }
+            }
+        }
+}
+
 }  // namespace
 
 // split choice + launch for one (possibly batched) weight-gradient GEMM described by p (tiles_n / tiles_k / M / K filled in)
@@ -418,6 +595,18 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(sizeof(float) * 2 * MR * (TN_ + TK_)));
         attr_set = true;
+    }
+    if (p.math == ABR_MATH_BF16X6) {   // same split plan (MRX == MR), three-plane LDS
+        static bool attr6 = false;
+        const size_t lds6 = sizeof(unsigned) * 3 * (MRX / 2) * (TN_ + TK_);
+        if (!attr6) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
+            attr6 = true;
+        }
+        const int rec6 = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
+        conv_wgrad_x6_kernel<<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
+        abr::prof_stop(abr::as_stream(stream), rec6);
+        return;
     }
     const int rec = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
     if (sb) conv_wgrad_kernel<true><<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
@@ -472,8 +661,9 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     p.tiles_k = (p.K + TK_ - 1) / TK_;
     if (p.M == 0) return ABR_OK;
     p.nbatch = 1; p.tiles_pb = 0; p.x_bs = p.gy_bs = p.dw_bs = 0; p.overwrite = 0;
+    p.math = d->math == ABR_MATH_BF16X6 ? ABR_MATH_BF16X6 : ABR_MATH_F32;   // (x6 handles any Cin % 4 == 0: no k-tile constraint here)
     hipStream_t st = abr::as_stream(stream);
-    ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16, "conv_wgrad: unknown math mode");
+    ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16 || d->math == ABR_MATH_BF16X6, "conv_wgrad: unknown math mode");
     if (d->math == ABR_MATH_BF16 && d->Cin % 64 == 0) {   // same layer set as the bf16 forward (the stem stays fp32)
         launch_wgrad_bf16(p, x, gy, dw, stream);
         ABR_CHECK_LAUNCH("conv_wgrad (bf16)");

@@ -44,6 +44,12 @@ class GeneralizedRCNN(nn.Module):
             from ..backbone.resnet import set_conv_math
             set_conv_math(self.rpn, ops.MATH_BF16)
             set_conv_math(self.roi_heads, ops.MATH_BF16)
+        # ABR_CONV_MATH=bf16x6 (opt-in): fp32-ACCURATE contractions on the bf16 matrix cores for every bottleneck / RPN conv -- each
+        # operand split exactly into three bf16 terms, six cross products, fp32 accumulate (csrc/conv_igemm.hip); cfg.DTYPE stays float32
+        if cfg.DTYPE == "float32" and os.environ.get("ABR_CONV_MATH", "f32") == "bf16x6":
+            from ..backbone.resnet import set_conv_math
+            for m in (self.backbone, self.rpn, self.roi_heads):
+                set_conv_math(m, ops.MATH_BF16X6)
         self.flat = None
 
     # --- storage: one flat fp32 buffer for parameters, one for gradients (RCCL all-reduce + fused SGD work on them)

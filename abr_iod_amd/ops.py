@@ -198,7 +198,7 @@ def bce_logits_gather(x, y, idx, gscale=1.0, want_grad=False, yidx=None, denom_d
 
 
 # ----------------------------------------------------------------------------------------------- conv
-MATH_F32, MATH_BF16 = 0, 1   # abr_conv_desc::math (include/abr_iod_hip.h)
+MATH_F32, MATH_BF16, MATH_BF16X6 = 0, 1, 2   # abr_conv_desc::math (include/abr_iod_hip.h)
 
 
 def conv_desc(x_shape, w_shape, stride, pad, scale=None, bias=None, residual=None, mask=None, relu=False,

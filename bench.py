@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--math", choices=["f32", "bf16", "bf16-all"], default="f32",
+    ap.add_argument("--math", choices=["f32", "bf16", "bf16-all", "bf16x6"], default="f32",
                     help="f32 (default, the BASELINE metric); bf16 = BASELINE.json configs[4]'s bf16 MFMA backbone (cfg.DTYPE bfloat16: operands "
                          "rounded in-kernel, fp32 accumulate, fp32 tensors); bf16-all = RPN head and layer4 as well.  Not the headline number.")
     ap.add_argument("--time-all-kernels", action="store_true", help="event-bracket every conv / ROIAlign launch, not only the dominant kernel")
@@ -87,8 +87,10 @@ def main():
     B = a.batch_per_gpu
     if a.math == "bf16-all":
         os.environ["ABR_BF16_SCOPE"] = "all"
+    if a.math == "bf16x6":
+        os.environ["ABR_CONV_MATH"] = "bf16x6"
     cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, ims_per_batch=B * world,
-                             overrides=("DTYPE", "bfloat16") if a.math != "f32" else ())
+                             overrides=("DTYPE", "bfloat16") if a.math in ("bf16", "bf16-all") else ())
     model_source, model_target = build_models(cfg_s, cfg_t, seed=0)       # same seed on every rank = broadcast weights
     optimizer = make_optimizer(cfg_t, model_target)
     scheduler = make_lr_scheduler(cfg_t, optimizer)
@@ -136,7 +138,8 @@ def main():
             "metric": "training images/sec (R50-C4 Faster R-CNN + ARD)", "value": round(value, 3), "unit": "img/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-            "dtype": "f32" if a.math == "f32" else "bf16 MFMA operands / f32 accumulate / f32 tensors ({}); f32 elsewhere".format(
+            "dtype": "f32" if a.math == "f32" else "f32 emulated on bf16 MFMA (exact 3-term split, 6 cross products, f32 accumulate); f32 elsewhere"
+            if a.math == "bf16x6" else "bf16 MFMA operands / f32 accumulate / f32 tensors ({}); f32 elsewhere".format(
                 "backbone layer1-3" if a.math == "bf16" else "backbone, RPN head, layer4"),
             "config": {"workload": "BASELINE.json configs[2]: task 15-5 ABR step, --feat ard --dist_type id (alpha .5, beta 1, gamma 1), "
                                    "R50-C4, 600x1000, 512 RoIs/img + 64 distillation RoIs/img, source+target models, SGD step",
@@ -169,7 +172,7 @@ def main():
             if n == 0:
                 n, ms, flops, n_o, ms_o, flops_o = n_o, ms_o, flops_o, 0, 0.0, 0.0
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
+            peak = (PEAK_BF16_MFMA_TFLOPS / (6.0 if a.math == "bf16x6" else 1.0)) if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
                                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                "flops_counted": "executed multiply-adds of each launch (a Winograd F(4x4,3x3) conv executes 1/4 of its algorithmic "

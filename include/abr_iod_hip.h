@@ -182,6 +182,7 @@ int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, co
  * ===================================================================================================== */
 #define ABR_MATH_F32 0
 #define ABR_MATH_BF16 1
+#define ABR_MATH_BF16X6 2
 
 typedef struct {
     int B, H, W, Cin;        /* input  [B,H,W,Cin]  (Cin % 4 == 0) */
@@ -199,7 +200,9 @@ typedef struct {
     int out_H, out_W, out_sh, out_sw;
     /* arithmetic of the contraction: ABR_MATH_F32 = fp32 MFMA (exact fp32, the default and the parity path);
        ABR_MATH_BF16 = both operands rounded to bf16 (RNE) inside the kernel, bf16 MFMA, fp32 accumulate, fp32 tensors in
-       memory (BASELINE.json configs[4]); layers whose Cin is not a multiple of 64 (the stem) compute in fp32 either way */
+       memory (BASELINE.json configs[4]); layers whose Cin is not a multiple of 64 (the stem) compute in fp32 either way;
+       ABR_MATH_BF16X6 = fp32-ACCURATE arithmetic on the bf16 matrix cores: each fp32 operand split exactly into three bf16
+       terms, the six cross products with i + j <= 2 accumulated in fp32 (same error bound as an fp32 FMA chain; opt-in) */
     int math;
 } abr_conv_desc;
 

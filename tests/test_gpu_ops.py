@@ -571,3 +571,44 @@ def test_conv_bf16_mode_backward(case):
     torch.nn.functional.conv2d(xr2, wsr, stride=s, padding=p).backward(rnd(gy).double())
     want = xr2.grad.permute(0, 2, 3, 1)
     assert (dx.cpu().double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------- bf16x6: fp32-accurate on bf16 MFMA
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] % 32 == 0] + BF16_CASES[4:])
+def test_conv_bf16x6_mode_is_fp32_accurate(case):
+    """Exact three-way bf16 split of both operands, six cross products, fp32 accumulate: the result must meet the SAME criterion
+    against float64 as the fp32 MFMA kernels (and does so with a smaller error), forward, input gradient and weight gradient."""
+    from abr_iod_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    torch.manual_seed(23 + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, dtype=torch.float64) / (Cin * k * k) ** 0.5).requires_grad_(True)
+    scale = torch.rand(Cout) + 0.5
+    y = torch.nn.functional.conv2d(x, w, stride=s, padding=p)
+    gy = torch.randn_like(y)
+    (y * scale.double().view(1, -1, 1, 1)).backward(gy)
+    xg = x.detach().float().permute(0, 2, 3, 1).contiguous().cuda(); wg = w.detach().float().permute(0, 2, 3, 1).contiguous().cuda()
+    gyg = gy.float().permute(0, 2, 3, 1).contiguous().cuda(); sc = scale.cuda()
+    # the fp32 inputs ARE the operands: compare with float64 arithmetic on exactly those values
+    x64 = xg.cpu().double().permute(0, 3, 1, 2); w64 = wg.cpu().double().permute(0, 3, 1, 2); gy64 = gyg.cpu().double().permute(0, 3, 1, 2)
+    xr = x64.clone().requires_grad_(True); wr = w64.clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, stride=s, padding=p)
+    (yr * scale.double().view(1, -1, 1, 1)).backward(gy64)
+
+    def close(got, want, tol):
+        return (got.cpu().double() - want).abs().max().item() < tol * max(1.0, want.abs().max().item())
+    tol = 5e-5 if (k == 3 and Cin >= 128) else 1e-5   # Winograd-domain GEMMs carry the transforms' fp32 rounding, as in fp32 mode
+    got = ops.conv_forward(xg, wg, s, p, math=ops.MATH_BF16X6).permute(0, 3, 1, 2)
+    assert close(got, yr.detach(), tol)
+    f32 = ops.conv_forward(xg, wg, s, p).permute(0, 3, 1, 2)
+    err6 = (got.cpu().double() - yr.detach()).norm().item(); err32 = (f32.cpu().double() - yr.detach()).norm().item()
+    assert err6 < 1.5 * err32 + 1e-12, (err6, err32)     # never meaningfully worse than the fp32 MFMA chain
+    dw = torch.zeros_like(wg)
+    ops.conv_wgrad(xg, gyg, dw, s, p, scale=sc, math=ops.MATH_BF16X6)
+    assert close(dw, wr.grad.permute(0, 2, 3, 1), tol * 2)
+    wt = ops.conv_dgrad_weights(wg, sc)
+    if s == 1:
+        dx = ops.conv_forward(gyg, wt, 1, k - 1 - p, math=ops.MATH_BF16X6)
+    else:
+        dx = ops.conv_forward(gyg, wt, 1, 0, out_hw=(H, W), out_stride=(s, s), math=ops.MATH_BF16X6)
+    assert close(dx, xr.grad.permute(0, 2, 3, 1), tol * 2)

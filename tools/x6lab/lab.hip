@@ -1,0 +1,133 @@
+// ablation harness for the bf16x6 main loop (plain TN GEMM, M x N x K fp32 sources)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int BM = 128, BN = 128, BKX = 32, LDX = 40;
+// MODE bits: 1 = global loads, 2 = split + LDS store, 4 = LDS fragment reads, 8 = MFMA
+template <int MODE>
+__global__ __launch_bounds__(256) void k(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);
+    __bf16* Bs = As + 3 * BM * LDX;
+    const int tiles_n = N / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int kq = tid & 7, srow = tid >> 3;
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (unsigned)((size_t)M * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (unsigned)((size_t)N * K * 4), 0x00020000);
+    unsigned ao[4], bo[4];
+    for (int i = 0; i < 4; i++) { ao[i] = ((m0 + srow + 32 * i) * K + kq * 4) * 4u; bo[i] = ((n0 + srow + 32 * i) * K + kq * 4) * 4u; }
+    u32x4 ra[4], rb[4];
+    for (int i = 0; i < 4; i++) { ra[i] = (u32x4){0x3f800000u + tid, 0x3f812345u, 0x3f854321u, 0x3f8abcdeu}; rb[i] = ra[i]; }
+    auto load_tile = [&](int kt) {
+        if (MODE & 1) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)ao[i], kt * BKX * 4, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rb_, (int)bo[i], kt * BKX * 4, 0);
+        }
+    };
+    auto split_store = [](const u32x4 v, __bf16* dst, int ps) {
+        const f32x4v f = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        const bf16x4 h0 = __builtin_convertvector(f, bf16x4);
+        const f32x4v r1 = f - __builtin_convertvector(h0, f32x4v);
+        const bf16x4 h1 = __builtin_convertvector(r1, bf16x4);
+        const f32x4v r2 = r1 - __builtin_convertvector(h1, f32x4v);
+        const bf16x4 h2 = __builtin_convertvector(r2, bf16x4);
+        *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(&h0);
+        *reinterpret_cast<uint2*>(dst + ps) = *reinterpret_cast<const uint2*>(&h1);
+        *reinterpret_cast<uint2*>(dst + 2 * ps) = *reinterpret_cast<const uint2*>(&h2);
+    };
+    auto store_tile = [&]() {
+        if (MODE & 2) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) split_store(ra[i], As + (srow + 32 * i) * LDX + kq * 4, BM * LDX);
+#pragma unroll
+            for (int i = 0; i < 4; i++) split_store(rb[i], Bs + (srow + 32 * i) * LDX + kq * 4, BN * LDX);
+        }
+    };
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const __bf16* af = As + (wm * 64 + l31) * LDX + lh * 8;
+    const __bf16* bf = Bs + (wn * 64 + l31) * LDX + lh * 8;
+    bf16x8 fa[2][3], fb[2][3];
+    for (int i = 0; i < 2; i++) for (int p = 0; p < 3; p++) { for (int e = 0; e < 8; e++) { fa[i][p][e] = (__bf16)(1.0f + tid * 0.001f); fb[i][p][e] = (__bf16)(0.5f); } }
+    auto compute_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (MODE & 4) {
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++) {
+                        fa[i][pl] = *reinterpret_cast<const bf16x8*>(af + pl * BM * LDX + i * 32 * LDX + u * 16);
+                        fb[i][pl] = *reinterpret_cast<const bf16x8*>(bf + pl * BN * LDX + i * 32 * LDX + u * 16);
+                    }
+            }
+            if (MODE & 8) {
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    }
+            } else {
+                for (int i = 0; i < 2; i++) for (int pl = 0; pl < 3; pl++) { acc[i][0][pl] += (float)fa[i][pl][0]; acc[i][1][pl] += (float)fb[i][pl][1]; }
+            }
+        }
+    };
+    const int nk = K / BKX;
+    load_tile(0); store_tile(); __syncthreads();
+    for (int kt = 0; kt + 1 < nk; kt++) {
+        load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tile();
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+    }
+    compute_tile();
+    // minimal epilogue so nothing is optimised away
+    float s = 0.f;
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) s += acc[i][j][r];
+    if (!(MODE & 2)) for (int i = 0; i < 4; i++) s += __uint_as_float(ra[i].x ^ rb[i].y);
+    C[(size_t)blockIdx.x * 256 + tid] = s;
+}
+template <int MODE> void run(const char* name, const float* A, const float* B, float* C, int M, int N, int K) {
+    const size_t lds = sizeof(__bf16) * 3 * (BM + BN) * LDX;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((M / BM) * (N / BN));
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; i++) k<MODE><<<grid, 256, lds>>>(A, B, C, M, N, K);
+    hipEventRecord(a);
+    for (int i = 0; i < 10; i++) k<MODE><<<grid, 256, lds>>>(A, B, C, M, N, K);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= 10;
+    printf("%-34s %.3f ms  %.1f TF fp32-equivalent (%.0f TF bf16 issue rate)\n", name, ms, 2.0 * M * N * K / ms / 1e9, 12.0 * M * N * K / ms / 1e9);
+}
+int main() {
+    const int M = 32768, N = 2048, K = 1024;
+    float *A, *B, *C;
+    hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)N * K * 4); hipMalloc(&C, (size_t)(M / BM) * (N / BN) * 256 * 4);
+    hipMemset(A, 0x3c, (size_t)M * K * 4); hipMemset(B, 0x3c, (size_t)N * K * 4);
+    run<8>("mfma only", A, B, C, M, N, K);
+    run<12>("mfma + lds reads", A, B, C, M, N, K);
+    run<14>("mfma + lds reads + split/store", A, B, C, M, N, K);
+    run<15>("all (loads too)", A, B, C, M, N, K);
+    run<7>("all but mfma", A, B, C, M, N, K);
+    run<3>("loads + split/store only", A, B, C, M, N, K);
+    run<1>("loads only", A, B, C, M, N, K);
+    return 0;
+}
