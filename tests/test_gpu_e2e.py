@@ -19,9 +19,13 @@ def _close(a, b, tol=1e-4):
     return abs(a - b) <= tol * max(1.0, abs(b))
 
 
-@pytest.fixture(scope="module")
-def step_state():
+@pytest.fixture(scope="module", params=["f32", "bf16x6"])
+def step_state(request):
+    """f32 = the default fp32 MFMA arithmetic; bf16x6 = the opt-in fp32-accurate arithmetic on the bf16 matrix cores
+    (ABR_CONV_MATH=bf16x6): the SAME oracle comparisons at the SAME tolerances must hold for both."""
+    import os
     import random
+    os.environ["ABR_CONV_MATH"] = request.param
 
     from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
     from abr_iod_amd.utils.checkpoint import reference_state_dict
@@ -42,6 +46,10 @@ def step_state():
     for t in targets:
         t.bbox[:, 0::2].clamp_(max=223); t.bbox[:, 1::2].clamp_(max=159)
         t.bbox[:, 2] = torch.max(t.bbox[:, 2], t.bbox[:, 0] + 8).clamp(max=223); t.bbox[:, 3] = torch.max(t.bbox[:, 3], t.bbox[:, 1] + 8).clamp(max=159)
+    os.environ.pop("ABR_CONV_MATH", None)   # read at model construction only
+    from abr_iod_amd import ops
+    want = ops.MATH_BF16X6 if request.param == "bf16x6" else ops.MATH_F32
+    assert all(m.math == want for m in mt.modules() if hasattr(m, "math"))
     return dict(cfg_s=cfg_s, cfg_t=cfg_t, ms=ms, mt=mt, images=images, targets=targets,
                 sd_s=reference_state_dict(ms), sd_t=reference_state_dict(mt))
 
