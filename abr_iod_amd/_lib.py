@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
         ("relu", _i),
         ("out_H", _i), ("out_W", _i), ("out_sh", _i), ("out_sw", _i),
         ("math", _i),
+        ("wino_v", _vp),
     ]
 
 
@@ -63,6 +64,7 @@ _SIGS = {
     "abr_img_normalize_to_batch": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _i, _i, _vp]),
     "abr_conv_forward": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "abr_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "abr_conv_wino_v_floats": (_i64, [C.POINTER(ConvDesc)]),
     "abr_conv_dgrad_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "abr_bias_grad": (_i, [_vp, _i64, _i, _vp, _vp]),
     "abr_nchw_to_nhwc_pad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

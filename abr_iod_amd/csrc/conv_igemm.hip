@@ -26,6 +26,7 @@
 // 36 GEMMs of a Winograd F(4x4,3x3) convolution (conv_winograd.hip), which every wide stride-1 3x3 conv takes.
 // fp32 MFMA is bit-for-bit an fmaf chain, so results are exact-fp32 (no TF32/bf16 anywhere).
 // Bound: MFMA (157.3 TFLOP/s fp32 matrix peak); DESIGN.md has the per-layer flop counts and measured rates.
+#include <algorithm>
 #include <map>
 
 #include "common.h"
@@ -76,6 +77,7 @@ struct ConvP {
     int nbatch, tiles_pb;
     long a_bs, w_bs, o_bs;
     int math;  // ABR_MATH_*
+    float* v_out;  // Winograd path: keep the transformed input here (abr_conv_desc::wino_v)
 };
 
 
@@ -948,9 +950,10 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
     const int64_t T = (int64_t)p.B * th_n * tw_n;
     const size_t nV = (size_t)36 * T * p.Cin, nU = (size_t)36 * p.Cout * p.Cin, nM = (size_t)36 * T * p.Cout;
     if (T * (int64_t)std::max(p.Cin, p.Cout) * 4 >= (int64_t)0x7FFFFFF0) return false;
-    float* ws = abr::wino_ws(st, nV + nU + nM);
+    float* ws = abr::wino_ws(st, (p.v_out ? 0 : nV) + nU + nM);
     if (!ws) return false;
-    float *V = ws, *U = ws + nV, *Mm = ws + nV + nU;
+    float* V = p.v_out ? p.v_out : ws;
+    float *U = ws + (p.v_out ? 0 : nV), *Mm = U + nU;
     if (abr::wino_weight_transform(w, p.Cout, p.Cin, U, st)) return false;
     if (abr::wino_input_transform(x, p.B, p.H, p.W, p.Cin, V, st)) return false;
     ConvP g = p;
@@ -961,9 +964,27 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
     g.d_howo.init(1u); g.d_wo.init(1u); g.d_cin.init((unsigned)p.Cin); g.d_s.init(1u);
     g.x_bytes = (unsigned)(T * p.Cin * 4); g.w_bytes = (unsigned)((int64_t)p.Cout * p.Cin * 4);
     g.nbatch = 36; g.a_bs = (long)T * p.Cin; g.w_bs = (long)p.Cout * p.Cin; g.o_bs = (long)T * p.Cout;
+    g.v_out = nullptr;
     if (p.math == ABR_MATH_BF16X6) dispatch_igemm_x6(g, V, U, Mm, st);
     else dispatch_igemm(g, V, U, Mm, st);
     return abr::wino_output_transform(Mm, p.B, p.H, p.W, p.Cout, p.scale, p.bias, p.relu, p.mask, out, st) == 0;
+}
+
+static int wino_min_c() {
+    static const int v = getenv("ABR_WINOGRAD_MIN_C") ? atoi(getenv("ABR_WINOGRAD_MIN_C")) : 128;
+    return v;
+}
+
+extern "C" int64_t abr_conv_wino_v_floats(const abr_conv_desc* d) {
+    if (!d || d->math == ABR_MATH_BF16) return 0;
+    static const bool wino_wgrad = !(getenv("ABR_WINOGRAD_WGRAD") && atoi(getenv("ABR_WINOGRAD_WGRAD")) == 0);
+    const bool scatter = !((d->out_H <= 0 || d->out_H == d->Ho) && (d->out_W <= 0 || d->out_W == d->Wo) && d->out_sh <= 1 && d->out_sw <= 1);
+    const bool ok = wino_wgrad && wino_min_c() > 0 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && !scatter && !d->residual &&
+                    d->Cin % BK == 0 && d->Cout % 4 == 0 && d->Cin >= wino_min_c() && d->Cout >= 128;
+    if (!ok) return 0;
+    const int64_t T = (int64_t)d->B * ((d->H + 3) / 4) * ((d->W + 3) / 4);
+    if (T * (int64_t)std::max(d->Cin, d->Cout) * 4 >= (int64_t)0x7FFFFFF0) return 0;
+    return 36 * T * d->Cin;
 }
 
 extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const float* w, float* out, void* stream) {
@@ -988,6 +1009,7 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.mask = d->mask;
     p.tiles_m = p.tiles_n = 0;
     p.nbatch = 1; p.tiles_pb = 0; p.a_bs = p.w_bs = p.o_bs = 0;
+    p.v_out = d->wino_v;
     const int64_t xb = (int64_t)d->B * d->H * d->W * d->Cin * 4, wb = (int64_t)d->Cout * p.K * 4;
     ABR_REQUIRE(xb < (int64_t)0x7FFFFFF0 && wb < (int64_t)0x7FFFFFF0, "conv_forward: input / weight tensors must be < 2 GB (32-bit buffer offsets)");
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
@@ -1004,9 +1026,8 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     // Winograd F(4x4,3x3) for the wide stride-1 3x3 convs: 4x fewer multiply-adds (RPN 3x3: 1.42 -> 0.50 ms, layer4 conv2 1.14 ->
     // 0.41, layer2 conv2 0.122 -> 0.073); layer1's 64-channel conv stays direct -- its 36 GEMMs would have K = 64 and the transforms'
     // HBM traffic outweighs the saving.
-    static const int wino_min_c = getenv("ABR_WINOGRAD_MIN_C") ? atoi(getenv("ABR_WINOGRAD_MIN_C")) : 128;
-    if (wino_min_c > 0 && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && !p.scatter && !p.residual && p.Cin % BK == 0 &&
-        p.Cout % 4 == 0 && p.Cin >= wino_min_c && p.Cout >= 128) {
+    if (wino_min_c() > 0 && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && !p.scatter && !p.residual && p.Cin % BK == 0 &&
+        p.Cout % 4 == 0 && p.Cin >= wino_min_c() && p.Cout >= 128) {
         if (wino_conv(p, x, w, out, st)) {
             ABR_CHECK_LAUNCH("conv_forward (winograd)");
             return ABR_OK;

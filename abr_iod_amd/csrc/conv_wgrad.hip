@@ -678,10 +678,12 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
         const int th_n = (d->H + 3) / 4, tw_n = (d->W + 3) / 4;
         const int64_t T = (int64_t)d->B * th_n * tw_n;
         const size_t nV = (size_t)36 * T * d->Cin, nM = (size_t)36 * T * d->Cout, nU = (size_t)36 * d->Cout * d->Cin;
-        float* ws = T * (int64_t)std::max(d->Cin, d->Cout) * 4 < (int64_t)0x7FFFFFF0 ? abr::wino_ws(st, nV + nM + nU) : nullptr;
+        float* vin = d->wino_v;   // the forward pass kept its transformed input: no second B^T d B over x
+        float* ws = T * (int64_t)std::max(d->Cin, d->Cout) * 4 < (int64_t)0x7FFFFFF0 ? abr::wino_ws(st, (vin ? 0 : nV) + nM + nU) : nullptr;
         if (ws) {
-            float *V = ws, *Mg = ws + nV, *dU = ws + nV + nM;
-            int bad = abr::wino_input_transform(x, d->B, d->H, d->W, d->Cin, V, st);
+            float* V = vin ? vin : ws;
+            float *Mg = ws + (vin ? 0 : nV), *dU = Mg + nM;
+            int bad = vin ? 0 : abr::wino_input_transform(x, d->B, d->H, d->W, d->Cin, V, st);
             bad |= abr::wino_outgrad_transform(gy, d->B, d->H, d->W, d->Cout, Mg, st);
             // enough output tiles to fill the chip without splitting the tile axis -> each workgroup owns its dU tile and writes
             // it directly; otherwise split-M with atomics into a zeroed dU

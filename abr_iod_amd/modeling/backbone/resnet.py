@@ -108,26 +108,28 @@ class Bottleneck(nn.Module):
         s2, b2 = self.bn2.scale_bias()
         s3, b3 = self.bn3.scale_bias()
         o1 = ops.conv_forward(x, self.conv1.weight, s, 0, scale=s1, bias=b1, relu=True, math=self.math)
-        o2 = ops.conv_forward(o1, self.conv2.weight, 1, 1, scale=s2, bias=b2, relu=True, math=self.math)
+        # the weight gradient of conv2 transforms the same o1 with the same B^T d B: keep the forward's V for it when training
+        v2 = ops.wino_v_alloc(o1, self.conv2.weight, 1, 1, self.math) if (save and self.conv2.weight.requires_grad) else None
+        o2 = ops.conv_forward(o1, self.conv2.weight, 1, 1, scale=s2, bias=b2, relu=True, math=self.math, wino_v=v2)
         if self.downsample is not None:
             sd, bd = self.downsample[1].scale_bias()
             idt = ops.conv_forward(x, self.downsample[0].weight, s, 0, scale=sd, bias=bd, math=self.math)
         else:
             idt = x
         out = ops.conv_forward(o2, self.conv3.weight, 1, 0, scale=s3, bias=b3, residual=idt, relu=True, math=self.math)
-        return out, ((x, o1, o2, out, s) if save else None)
+        return out, ((x, o1, o2, out, s, v2) if save else None)
 
     def bwd(self, saved, gout, need_dx, g_owned, g_masked=False, mask_dx=None):
         """gout = dL/d(out), not yet masked by out's ReLU unless g_masked.  Writes weight grads into .grad; returns dL/dx or None.
         mask_dx (the producer block's output, = this block's x): fuse THAT block's ReLU backward into the last dgrad launch."""
-        x, o1, o2, out, s = saved
+        x, o1, o2, out, s, v2 = saved
         s1, _ = self.bn1.scale_bias()
         s2, _ = self.bn2.scale_bias()
         s3, _ = self.bn3.scale_bias()
         g = gout if g_masked else ops.relu_backward(gout, out, inplace=g_owned)   # through the block's final ReLU
         ops.conv_wgrad_async(o2, g, _grad_buf(self.conv3.weight), 1, 0, scale=s3, math=self.math)
         g2 = ops.conv_forward(g, self.conv3.dgrad_weight(s3), 1, 0, mask=o2, math=self.math)    # dgrad + ReLU mask of o2
-        ops.conv_wgrad_async(o1, g2, _grad_buf(self.conv2.weight), 1, 1, scale=s2, math=self.math)
+        ops.conv_wgrad_async(o1, g2, _grad_buf(self.conv2.weight), 1, 1, scale=s2, math=self.math, wino_v=v2)
         g1 = ops.conv_forward(g2, self.conv2.dgrad_weight(s2), 1, 1, mask=o1, math=self.math)   # 3x3 dgrad: pad = 3-1-1
         ops.conv_wgrad_async(x, g1, _grad_buf(self.conv1.weight), s, 0, scale=s1, math=self.math)
         ds = self.downsample

@@ -102,23 +102,24 @@ class _RPNHeadFn(Function):
     @staticmethod
     def forward(ctx, x, head, *params):
         xh = as_nhwc(x)
-        t = ops.conv_forward(xh, head.conv.weight, 1, 1, bias=head.conv.bias, relu=True, math=head.math)
+        v = ops.wino_v_alloc(xh, head.conv.weight, 1, 1, head.math) if head.conv.weight.requires_grad else None
+        t = ops.conv_forward(xh, head.conv.weight, 1, 1, bias=head.conv.bias, relu=True, math=head.math, wino_v=v)
         y = ops.conv_forward(t, head.fused_weight, 1, 0, bias=head.fused_bias, math=head.math)
-        ctx.head, ctx.saved = head, (xh, t)
+        ctx.head, ctx.saved = head, (xh, t, v)
         ctx.need_dx = x.requires_grad
         return from_nhwc(y)
 
     @staticmethod
     def backward(ctx, gy):
         head = ctx.head
-        xh, t = ctx.saved
+        xh, t, v = ctx.saved
         g = as_nhwc(gy)
         if not g.is_contiguous():
             g = g.contiguous()
         ops.conv_wgrad_async(t, g, head.fused_weight_grad, 1, 0, math=head.math)
         ops.bias_grad(g, head.fused_bias_grad)
         gt = ops.conv_forward(g, head.fused_dgrad_weight(), 1, 0, mask=t, math=head.math)   # (reduction width 76: exact fp32 either way)
-        ops.conv_wgrad_async(xh, gt, _grad_buf(head.conv.weight), 1, 1, math=head.math)
+        ops.conv_wgrad_async(xh, gt, _grad_buf(head.conv.weight), 1, 1, math=head.math, wino_v=v)
         ops.bias_grad(gt, _grad_buf(head.conv.bias))
         gx = from_nhwc(ops.conv_forward(gt, head.conv.dgrad_weight(), 1, 1, math=head.math)) if ctx.need_dx else None
         ctx.saved = None

@@ -223,13 +223,28 @@ def conv_desc(x_shape, w_shape, stride, pad, scale=None, bias=None, residual=Non
     return d
 
 
+KEEP_WINO_V = os.environ.get("ABR_WINOGRAD_KEEP_V", "1") != "0"
+
+
+def wino_v_alloc(x, w, stride, pad, math=MATH_F32):
+    """Buffer for the Winograd-domain input V of conv(x, w) if both its forward pass and its weight gradient take the Winograd path
+    (abr_conv_wino_v_floats), else None.  Passed to conv_forward(wino_v=) to be filled and to conv_wgrad(wino_v=) to be reused:
+    the gradient then skips its own input transform (the same B^T d B over the same x)."""
+    if not KEEP_WINO_V:
+        return None
+    d = conv_desc(x.shape, w.shape, stride, pad, math=math)
+    n = int(L.lib().abr_conv_wino_v_floats(C.byref(d)))
+    return torch.empty(n, dtype=_f32, device=x.device) if n > 0 else None
+
+
 def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, mask=None, relu=False,
-                 out=None, out_hw=None, out_stride=(1, 1), math=MATH_F32):
+                 out=None, out_hw=None, out_stride=(1, 1), math=MATH_F32, wino_v=None):
     """x [B,H,W,Cin] NHWC, w [Cout,R,S,Cin] OHWI -> [B,Ho,Wo,Cout] (or scattered into `out` [B,out_H,out_W,Cout]).
     math=MATH_BF16: operands rounded to bf16 inside the kernel, bf16 MFMA, fp32 accumulate (fp32 tensors in and out)."""
     L.require_cuda(x, w)
     x, w = L.f32c(x), L.f32c(w)
     d = conv_desc(x.shape, w.shape, stride, pad, scale, bias, residual, mask, relu, out_hw, out_stride, math)
+    d.wino_v = L.ptr(wino_v)
     if out is None:
         if out_hw is not None:
             out = torch.zeros((d.B, d.out_H, d.out_W, d.Cout), dtype=_f32, device=x.device)
@@ -239,11 +254,12 @@ def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, ma
     return out
 
 
-def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32):
+def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino_v=None):
     """dw [Cout,R,S,Cin] += scale * gy^T im2col(x) (fp32 atomics; caller zeroes dw once per step)"""
     L.require_cuda(x, gy, dw)
     x, gy = L.f32c(x), L.f32c(gy)
     d = conv_desc(x.shape, dw.shape, stride, pad, scale=scale, math=math)
+    d.wino_v = L.ptr(wino_v)
     L.check(L.lib().abr_conv_wgrad(C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.stream()), "conv_wgrad")
     return dw
 
@@ -291,10 +307,10 @@ def join_side_stream():
             torch.cuda.current_stream().wait_stream(s)
 
 
-def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32):
+def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino_v=None):
     """conv_wgrad on the side stream.  Only for use inside an autograd backward (the join is an engine callback)."""
     if not WGRAD_SIDE_STREAM:
-        return conv_wgrad(x, gy, dw, stride, pad, scale, math)
+        return conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v)
     cur = torch.cuda.current_stream()
     side = side_stream(x.device.index)
     if not _join_pending[0]:
@@ -303,7 +319,9 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32):
         torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
     side.wait_stream(cur)  # x, gy (and the zeroed gradient buffer) are produced on the current stream
     with torch.cuda.stream(side):
-        conv_wgrad(x, gy, dw, stride, pad, scale, math)
+        conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v)
+    if wino_v is not None:
+        wino_v.record_stream(side)
     x.record_stream(side)  # the caching allocator must not recycle them for the main stream while the side kernel reads
     gy.record_stream(side)
     return dw

@@ -204,9 +204,18 @@ typedef struct {
        ABR_MATH_BF16X6 = fp32-ACCURATE arithmetic on the bf16 matrix cores: each fp32 operand split exactly into three bf16
        terms, the six cross products with i + j <= 2 accumulated in fp32 (same error bound as an fp32 FMA chain; opt-in) */
     int math;
+    /* Winograd-domain input reuse between a convolution's forward pass and its weight gradient (both transform the SAME input
+       with B^T d B).  abr_conv_forward: if wino_v is non-NULL and the conv takes the Winograd path, the transformed input V
+       (abr_conv_wino_v_floats floats) is written THERE instead of scratch.  abr_conv_wgrad: if wino_v is non-NULL and the
+       gradient takes the Winograd path, V is read from there and the input transform is skipped (x is not touched).  NULL =
+       self-contained calls. */
+    float* wino_v;
 } abr_conv_desc;
 
 int abr_conv_forward(const abr_conv_desc* d_host, const float* x, const float* w, float* out, void* stream);
+/* floats of the Winograd-domain input V = 36 * B*ceil(H/4)*ceil(W/4) * Cin if BOTH abr_conv_forward and abr_conv_wgrad take the
+ * Winograd F(4x4,3x3) path for this descriptor (wide stride-1 pad-1 3x3, no residual / scatter, fp32 or bf16x6 math), else 0 */
+int64_t abr_conv_wino_v_floats(const abr_conv_desc* d_host);
 
 /* dW[Cout,R,S,Cin] (+)= sum_m gy[m,Cout]^T * im2col(x)[m,RSCin], columns scaled by d->scale (FrozenBN).
  * Accumulates with fp32 atomics into dw (caller zeroes it once per step). */

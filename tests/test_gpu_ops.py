@@ -612,3 +612,31 @@ def test_conv_bf16x6_mode_is_fp32_accurate(case):
     else:
         dx = ops.conv_forward(gyg, wt, 1, 0, out_hw=(H, W), out_stride=(s, s), math=ops.MATH_BF16X6)
     assert close(dx, xr.grad.permute(0, 2, 3, 1), tol * 2)
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x6"])
+def test_winograd_input_transform_is_shared_between_forward_and_wgrad(math):
+    """abr_conv_desc::wino_v: the forward pass keeps its Winograd-domain input V and the weight gradient reads it instead of
+    transforming x again -- same outputs as the self-contained calls (the gradient call must not even look at x)."""
+    from abr_iod_amd import ops
+    m = ops.MATH_BF16X6 if math == "bf16x6" else ops.MATH_F32
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for (B, H, W, Cin, Cout) in [(2, 38, 63, 256, 256), (96, 7, 7, 512, 512), (1, 21, 10, 128, 192)]:
+        x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+        w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) / (9 * Cin) ** 0.5
+        gy = torch.randn(B, H, W, Cout, device="cuda", generator=g)
+        sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
+        v = ops.wino_v_alloc(x, w, 1, 1, m)
+        assert v is not None and v.numel() == 36 * B * ((H + 3) // 4) * ((W + 3) // 4) * Cin
+        y_keep = ops.conv_forward(x, w, 1, 1, scale=sc, relu=True, math=m, wino_v=v)
+        assert torch.equal(y_keep, ops.conv_forward(x, w, 1, 1, scale=sc, relu=True, math=m))
+        dw_ref = torch.zeros_like(w); dw = torch.zeros_like(w)
+        ops.conv_wgrad(x, gy, dw_ref, 1, 1, scale=sc, math=m)
+        ops.conv_wgrad(torch.full_like(x, float("nan")), gy, dw, 1, 1, scale=sc, math=m, wino_v=v)   # x is NOT read
+        assert torch.isfinite(dw).all()
+        assert (dw - dw_ref).abs().max().item() <= 1e-5 * max(1.0, dw_ref.abs().max().item())
+    # not a Winograd conv (stride 2 / 1x1 / narrow): nothing to keep
+    x = torch.randn(1, 16, 16, 64, device="cuda")
+    assert ops.wino_v_alloc(x, torch.zeros(64, 3, 3, 64, device="cuda"), 1, 1, m) is None
+    assert ops.wino_v_alloc(torch.randn(1, 16, 16, 256, device="cuda"), torch.zeros(256, 1, 1, 256, device="cuda"), 1, 0, m) is None
+    assert ops.wino_v_alloc(torch.randn(1, 16, 16, 256, device="cuda"), torch.zeros(256, 3, 3, 256, device="cuda"), 1, 1, ops.MATH_BF16) is None
