@@ -78,6 +78,8 @@ struct ConvP {
     long a_bs, w_bs, o_bs;
     int math;  // ABR_MATH_*
     float* v_out;  // Winograd path: keep the transformed input here (abr_conv_desc::wino_v)
+    const void* w_planes;  // bf16x6: pre-split weight planes (abr_conv_desc::w_planes), or NULL
+    unsigned w_plane_bytes;  // distance between two planes
 };
 
 
@@ -589,14 +591,16 @@ int launch_bf16(const ConvP& p, const float* x, const float* w, float* out, hipS
 constexpr int BKX = 32;
 constexpr int LDX = BKX + 8;   // LDS row pitch in bf16 elements (80 B)
 
-template <int BM, int BN, int WM, int WN>
+// PB: the weight operand arrives ALREADY split (three bf16 planes [3][Cout][K] from abr_split_bf16x3, made once per optimiser step):
+// its tiles go global -> registers -> LDS as 16 B chunks with no arithmetic, instead of every workgroup re-splitting them.
+template <int BM, int BN, int WM, int WN, bool PB>
 __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const float* __restrict__ x_, const float* __restrict__ w_,
                                                              float* __restrict__ out_) {
     const float* x = x_;
     const float* w = w_;
     float* out = out_;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int NA = BM / 32, NB = BN / 32;
+    constexpr int NA = BM / 32, NB = PB ? 3 * BN / 64 : BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* As = reinterpret_cast<__bf16*>(smem);  // [3][BM][LDX]
     __bf16* Bs = As + 3 * BM * LDX;                // [3][BN][LDX]
@@ -630,13 +634,21 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
         a_wi0[i] = (int)wo * p.stride - p.pad;
         a_off0[i] = (((int)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + kq * 4;
     }
+    // fp32 weights: slot i = row srow + 32 i, 16 B = 4 k.  Planes: slot i = plane i / (BN/64), row (i % (BN/64)) * 64 + tid/4, 16 B = 8 k
     unsigned b_off0[NB];
+    const int prow = tid >> 2, pkc = tid & 3;
 #pragma unroll
     for (int i = 0; i < NB; i++) {
-        const int n = n0 + srow + 32 * i;
-        b_off0[i] = n < p.Cout ? (unsigned)(n * p.K + kq * 4) * 4u : kOOB;
+        if (PB) {
+            const int n = n0 + (i % (BN / 64)) * 64 + prow;
+            b_off0[i] = n < p.Cout ? (unsigned)(i / (BN / 64)) * p.w_plane_bytes + (unsigned)(n * p.K + pkc * 8) * 2u : kOOB;
+        } else {
+            const int n = n0 + srow + 32 * i;
+            b_off0[i] = n < p.Cout ? (unsigned)(n * p.K + kq * 4) * 4u : kOOB;
+        }
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_planes), 0, PB ? 2u * p.w_plane_bytes + p.w_bytes / 2 : 0u, 0x00020000);
     // TWO tiles in flight: a k-tile is only 48 MFMAs (~1500 cycles) per wave, well under the latency of the loads, so tile kt+2 is
     // requested before tile kt is multiplied and is split / parked in LDS one iteration later (register sets alternate by parity)
     u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
@@ -653,7 +665,9 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
             ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB), 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NB; i++) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(valid ? b_off0[i] : kOOB), k0 * 4, 0);
+        for (int i = 0; i < NB; i++)
+            rb[i] = PB ? __builtin_amdgcn_raw_buffer_load_b128(rwp, (int)(valid ? b_off0[i] : kOOB), k0 * 2, 0)
+                       : __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(valid ? b_off0[i] : kOOB), k0 * 4, 0);
     };
     // exact three-way split of four fp32 values into bf16 planes
     auto split_store = [](const u32x4 v, __bf16* dst, int plane_stride) {
@@ -671,7 +685,10 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
 #pragma unroll
         for (int i = 0; i < NA; i++) split_store(ra[i], As + (srow + 32 * i) * LDX + kq * 4, BM * LDX);
 #pragma unroll
-        for (int i = 0; i < NB; i++) split_store(rb[i], Bs + (srow + 32 * i) * LDX + kq * 4, BN * LDX);
+        for (int i = 0; i < NB; i++) {
+            if (PB) *reinterpret_cast<u32x4*>(Bs + (i / (BN / 64)) * BN * LDX + ((i % (BN / 64)) * 64 + prow) * LDX + pkc * 8) = rb[i];
+            else split_store(rb[i], Bs + (srow + 32 * i) * LDX + kq * 4, BN * LDX);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -712,37 +729,51 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
     };
 
     const int nk = p.K / BKX;
-    load_tile(0, ra0, rb0, true);
-    load_tile(1, ra1, rb1, nk > 1);
-    store_tile(ra0, rb0);
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 2 < nk; kt += 2) {   // LDS holds tile kt, set 1 holds tile kt+1 (possibly still in flight), set 0 is free
-        load_tile(kt + 2, ra0, rb0, true);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tile();
-        __syncthreads();
-        store_tile(ra1, rb1);
-        __syncthreads();
-        load_tile(kt + 3, ra1, rb1, kt + 3 < nk);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tile();
-        __syncthreads();
+    if (PB) {   // one tile in flight: the plane loads need six registers more per set, and two sets would halve the occupancy
+        load_tile(0, ra0, rb0, true);
         store_tile(ra0, rb0);
         __syncthreads();
-    }
-    if (kt + 1 < nk) {   // one more tile, waiting in set 1
-        compute_tile();
+        for (int kt = 0; kt + 1 < nk; kt++) {
+            load_tile(kt + 1, ra0, rb0, true);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile();
+            __syncthreads();
+            store_tile(ra0, rb0);
+            __syncthreads();
+        }
+    } else {
+        load_tile(0, ra0, rb0, true);
+        load_tile(1, ra1, rb1, nk > 1);
+        store_tile(ra0, rb0);
         __syncthreads();
-        store_tile(ra1, rb1);
-        __syncthreads();
+        int kt = 0;
+        for (; kt + 2 < nk; kt += 2) {   // LDS holds tile kt, set 1 holds tile kt+1 (possibly still in flight), set 0 is free
+            load_tile(kt + 2, ra0, rb0, true);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile();
+            __syncthreads();
+            store_tile(ra1, rb1);
+            __syncthreads();
+            load_tile(kt + 3, ra1, rb1, kt + 3 < nk);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile();
+            __syncthreads();
+            store_tile(ra0, rb0);
+            __syncthreads();
+        }
+        if (kt + 1 < nk) {   // one more tile, waiting in set 1
+            compute_tile();
+            __syncthreads();
+            store_tile(ra1, rb1);
+            __syncthreads();
+        }
     }
     compute_tile();
     __syncthreads();  // the epilogue reuses the operand LDS
     epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool PB>
 int launch_x6(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
     ConvP q = p;
     q.tiles_m = (p.M + BM - 1) / BM;
@@ -753,7 +784,7 @@ int launch_x6(const ConvP& p, const float* x, const float* w, float* out, hipStr
     constexpr size_t lds_op = sizeof(__bf16) * 3 * (BM + BN) * LDX;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
     const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
-    auto kern = conv_igemm_x6_kernel<BM, BN, WM, WN>;
+    auto kern = conv_igemm_x6_kernel<BM, BN, WM, WN, PB>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -812,7 +843,7 @@ int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream
 
 // (Cout, R*S, Cin) -> (Cin, R*S flipped, Cout), scaled by scale[cout]; 32x32 LDS transpose per (rs) plane.
 __global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                                             int Cout, int RS, int Cin, float* __restrict__ wt) {
+                                                             int Cout, int RS, int Cin, float* __restrict__ wt, __bf16* __restrict__ planes) {
     __shared__ float t[32][33];
     const int rs = blockIdx.z;
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
@@ -826,7 +857,19 @@ __global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restr
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int ci = ci0 + i, co = co0 + tx;
-        if (ci < Cin && co < Cout) wt[((size_t)ci * RS + (RS - 1 - rs)) * Cout + co] = t[tx][i];
+        if (ci < Cin && co < Cout) {
+            const size_t o = ((size_t)ci * RS + (RS - 1 - rs)) * Cout + co;
+            const float v = t[tx][i];
+            wt[o] = v;
+            if (planes) {   // the bf16x6 planes of the same copy (exact three-way split, see conv_igemm_x6_kernel)
+                const size_t n = (size_t)Cin * RS * Cout;
+                const __bf16 h0 = (__bf16)v;
+                const float r1 = v - (float)h0;
+                const __bf16 h1 = (__bf16)r1;
+                const __bf16 h2 = (__bf16)(r1 - (float)h1);
+                planes[o] = h0; planes[n + o] = h1; planes[2 * n + o] = h2;
+            }
+        }
     }
 }
 
@@ -939,9 +982,17 @@ static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, fl
     const int64_t nb = p.nbatch > 1 ? p.nbatch : 1;
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * nb;
     const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64) * nb;
-    if (p.Cout > 64 && t128 >= 2 * cus) launch_x6<128, 128, 2, 2>(p, x, w, out, st);
-    else if (t12864 >= 2 * cus || p.Cout <= 64) launch_x6<128, 64, 4, 1>(p, x, w, out, st);
-    else launch_x6<64, 64, 2, 2>(p, x, w, out, st);
+    const bool pb = p.w_planes != nullptr && nb == 1;
+    if (p.Cout > 64 && t128 >= 2 * cus) {
+        if (pb) launch_x6<128, 128, 2, 2, true>(p, x, w, out, st);
+        else launch_x6<128, 128, 2, 2, false>(p, x, w, out, st);
+    } else if (t12864 >= 2 * cus || p.Cout <= 64) {
+        if (pb) launch_x6<128, 64, 4, 1, true>(p, x, w, out, st);
+        else launch_x6<128, 64, 4, 1, false>(p, x, w, out, st);
+    } else {
+        if (pb) launch_x6<64, 64, 2, 2, true>(p, x, w, out, st);
+        else launch_x6<64, 64, 2, 2, false>(p, x, w, out, st);
+    }
 }
 
 // stride-1 pad-1 3x3 conv as Winograd F(4x4,3x3): weight + input transforms, 36 batched GEMMs, output transform with the epilogue
@@ -964,7 +1015,7 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
     g.d_howo.init(1u); g.d_wo.init(1u); g.d_cin.init((unsigned)p.Cin); g.d_s.init(1u);
     g.x_bytes = (unsigned)(T * p.Cin * 4); g.w_bytes = (unsigned)((int64_t)p.Cout * p.Cin * 4);
     g.nbatch = 36; g.a_bs = (long)T * p.Cin; g.w_bs = (long)p.Cout * p.Cin; g.o_bs = (long)T * p.Cout;
-    g.v_out = nullptr;
+    g.v_out = nullptr; g.w_planes = nullptr; g.w_plane_bytes = 0;
     if (p.math == ABR_MATH_BF16X6) dispatch_igemm_x6(g, V, U, Mm, st);
     else dispatch_igemm(g, V, U, Mm, st);
     return abr::wino_output_transform(Mm, p.B, p.H, p.W, p.Cout, p.scale, p.bias, p.relu, p.mask, out, st) == 0;
@@ -1010,6 +1061,11 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     p.tiles_m = p.tiles_n = 0;
     p.nbatch = 1; p.tiles_pb = 0; p.a_bs = p.w_bs = p.o_bs = 0;
     p.v_out = d->wino_v;
+    p.w_planes = d->math == ABR_MATH_BF16X6 ? d->w_planes : nullptr;
+    const int64_t wps = d->w_plane_stride > 0 ? d->w_plane_stride : (int64_t)d->Cout * d->R * d->S * d->Cin;
+    ABR_REQUIRE(!p.w_planes || (wps >= (int64_t)d->Cout * d->R * d->S * d->Cin && wps * 4 + (int64_t)d->Cout * d->R * d->S * d->Cin * 2 < (int64_t)0xFFFFFFF0),
+                "conv_forward: bad w_plane_stride");
+    p.w_plane_bytes = (unsigned)(wps * 2);
     const int64_t xb = (int64_t)d->B * d->H * d->W * d->Cin * 4, wb = (int64_t)d->Cout * p.K * 4;
     ABR_REQUIRE(xb < (int64_t)0x7FFFFFF0 && wb < (int64_t)0x7FFFFFF0, "conv_forward: input / weight tensors must be < 2 GB (32-bit buffer offsets)");
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
@@ -1043,8 +1099,17 @@ extern "C" int abr_conv_dgrad_weights(const float* w, const float* scale, int Co
                                       void* stream) {
     ABR_REQUIRE(w && wt && Cout > 0 && R > 0 && S > 0 && Cin > 0, "conv_dgrad_weights: bad args");
     dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, R * S);
-    dgrad_weights_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(w, scale, Cout, R * S, Cin, wt);
+    dgrad_weights_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(w, scale, Cout, R * S, Cin, wt, nullptr);
     ABR_CHECK_LAUNCH("conv_dgrad_weights");
+    return ABR_OK;
+}
+
+extern "C" int abr_conv_dgrad_weights_planes(const float* w, const float* scale, int Cout, int R, int S, int Cin, float* wt, void* planes,
+                                             void* stream) {
+    ABR_REQUIRE(w && wt && planes && Cout > 0 && R > 0 && S > 0 && Cin > 0, "conv_dgrad_weights_planes: bad args");
+    dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, R * S);
+    dgrad_weights_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(w, scale, Cout, R * S, Cin, wt, reinterpret_cast<__bf16*>(planes));
+    ABR_CHECK_LAUNCH("conv_dgrad_weights_planes");
     return ABR_OK;
 }
 

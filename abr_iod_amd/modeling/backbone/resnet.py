@@ -13,6 +13,7 @@ add and the ReLU fused in its epilogue.  A whole stage (3-6 bottlenecks) is a si
 hand-scheduled: dgrad is the same kernel on a flipped/transposed weight copy with the ReLU mask of the producer
 fused in the epilogue, wgrad accumulates atomically into the flat gradient buffer.  Activations are NHWC.
 """
+import os
 from collections import namedtuple
 
 import torch
@@ -26,6 +27,11 @@ from ...layers._layout import as_nhwc, from_nhwc
 StageSpec = namedtuple("StageSpec", ["index", "block_count", "return_features"])
 ResNet50StagesTo4 = tuple(StageSpec(index=i, block_count=c, return_features=r) for (i, c, r) in ((1, 3, False), (2, 4, False), (3, 6, True)))
 ResNet50StagesTo5 = tuple(StageSpec(index=i, block_count=c, return_features=r) for (i, c, r) in ((1, 3, False), (2, 4, False), (3, 6, False), (4, 3, True)))
+
+# bf16x6 arithmetic: hand the kernels weights that were split into bf16 planes once per step (abr_conv_desc::w_planes) instead of letting every
+# workgroup split its weight tile.  Measured NEUTRAL (layer4 GEMMs 0.39-0.95 ms either way, step 32.1 vs 31.8 ms with the extra split
+# launches): under real data the x6 loop is bound by the matrix pipe's sustained clock, not by the split's VALU work -- off by default.
+X6_WEIGHT_PLANES = os.environ.get("ABR_X6_WEIGHT_PLANES", "0") != "0"
 
 # bumped by the optimiser after every step: cached dgrad weight copies are rebuilt lazily when stale
 _PARAM_VERSION = [0]
@@ -48,6 +54,8 @@ class Conv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         self._wt = None
         self._wt_version = -1
+        self._wtp = None          # bf16x3 planes of the dgrad copy (bf16x6 arithmetic)
+        self._flat = None         # the model's FlatParams (set by GeneralizedRCNN.flatten_parameters): source of weight planes
 
     def kaiming_uniform_(self, a=1):
         """nn.init.kaiming_uniform_(w, a=1) of the reference (resnet.py:270,315,325,361), fan_in = Cin*R*S of the REAL channels."""
@@ -67,12 +75,26 @@ class Conv2d(nn.Module):
     def oihw(self):
         return self.weight.detach()[..., : self.in_channels].permute(0, 3, 1, 2).contiguous()
 
-    def dgrad_weight(self, scale=None):
-        """[Cin,R,S,Cout] flipped copy with the FrozenBN scale folded in; rebuilt only after an optimiser step."""
-        if self._wt is None or self._wt_version != _PARAM_VERSION[0] or self._wt.device != self.weight.device:
-            self._wt = ops.conv_dgrad_weights(self.weight.detach(), scale, out=self._wt if self._wt is not None and self._wt.device == self.weight.device else None)
+    def dgrad_weight(self, scale=None, planes=False):
+        """[Cin,R,S,Cout] flipped copy with the FrozenBN scale folded in; rebuilt only after an optimiser step.
+        planes=True (bf16x6 arithmetic) also keeps its exact bf16x3 split in self._wtp, made by the same launch."""
+        if (self._wt is None or self._wt_version != _PARAM_VERSION[0] or self._wt.device != self.weight.device
+                or (planes and self._wtp is None)):
+            same = self._wt is not None and self._wt.device == self.weight.device
+            if planes and (self._wtp is None or self._wtp.device != self.weight.device):
+                self._wtp = torch.empty((3, self.weight.numel()), dtype=torch.int16, device=self.weight.device)
+            self._wt = ops.conv_dgrad_weights(self.weight.detach(), scale, out=self._wt if same else None, planes=self._wtp if planes else None)
             self._wt_version = _PARAM_VERSION[0]
         return self._wt
+
+    def weight_planes(self):
+        """(plane-0 view of this weight inside the model's split parameter buffer, elements between planes) or (None, 0)"""
+        flat = self._flat
+        if flat is None or flat.params is None or not self.weight.is_cuda:
+            return None, 0
+        pl = flat.planes(_PARAM_VERSION[0])
+        off = (self.weight.data_ptr() - flat.params.data_ptr()) // 4
+        return pl[0, off:off + self.weight.numel()], pl.shape[1]
 
 
 def _grad_buf(p):
@@ -101,22 +123,37 @@ class Bottleneck(nn.Module):
         self.stride = stride
         self.math = ops.MATH_F32   # ops.MATH_BF16: bf16 MFMA contractions (cfg.DTYPE == "bfloat16", see set_conv_math)
 
+    def _conv(self, x, conv, stride, pad, **kw):
+        """conv_forward in this block's arithmetic; bf16x6 also hands over the weight's pre-split planes"""
+        if X6_WEIGHT_PLANES and self.math == ops.MATH_BF16X6:
+            pl, st = conv.weight_planes()
+            if pl is not None:
+                kw.update(w_planes=pl, w_plane_stride=st)
+        return ops.conv_forward(x, conv.weight, stride, pad, math=self.math, **kw)
+
+    def _dgrad(self, g, conv, scale, pad, **kw):
+        x6 = X6_WEIGHT_PLANES and self.math == ops.MATH_BF16X6
+        wt = conv.dgrad_weight(scale, planes=x6)
+        if x6:
+            kw.update(w_planes=conv._wtp)
+        return ops.conv_forward(g, wt, 1, pad, math=self.math, **kw)
+
     # x, returns NHWC tensors.  `stride` may be overridden to 1 when the caller already sub-sampled (bin_step=2 ROIAlign)
     def fwd(self, x, save, stride=None):
         s = self.stride if stride is None else stride
         s1, b1 = self.bn1.scale_bias()
         s2, b2 = self.bn2.scale_bias()
         s3, b3 = self.bn3.scale_bias()
-        o1 = ops.conv_forward(x, self.conv1.weight, s, 0, scale=s1, bias=b1, relu=True, math=self.math)
+        o1 = self._conv(x, self.conv1, s, 0, scale=s1, bias=b1, relu=True)
         # the weight gradient of conv2 transforms the same o1 with the same B^T d B: keep the forward's V for it when training
         v2 = ops.wino_v_alloc(o1, self.conv2.weight, 1, 1, self.math) if (save and self.conv2.weight.requires_grad) else None
-        o2 = ops.conv_forward(o1, self.conv2.weight, 1, 1, scale=s2, bias=b2, relu=True, math=self.math, wino_v=v2)
+        o2 = self._conv(o1, self.conv2, 1, 1, scale=s2, bias=b2, relu=True, wino_v=v2)
         if self.downsample is not None:
             sd, bd = self.downsample[1].scale_bias()
-            idt = ops.conv_forward(x, self.downsample[0].weight, s, 0, scale=sd, bias=bd, math=self.math)
+            idt = self._conv(x, self.downsample[0], s, 0, scale=sd, bias=bd)
         else:
             idt = x
-        out = ops.conv_forward(o2, self.conv3.weight, 1, 0, scale=s3, bias=b3, residual=idt, relu=True, math=self.math)
+        out = self._conv(o2, self.conv3, 1, 0, scale=s3, bias=b3, residual=idt, relu=True)
         return out, ((x, o1, o2, out, s, v2) if save else None)
 
     def bwd(self, saved, gout, need_dx, g_owned, g_masked=False, mask_dx=None):
@@ -128,9 +165,9 @@ class Bottleneck(nn.Module):
         s3, _ = self.bn3.scale_bias()
         g = gout if g_masked else ops.relu_backward(gout, out, inplace=g_owned)   # through the block's final ReLU
         ops.conv_wgrad_async(o2, g, _grad_buf(self.conv3.weight), 1, 0, scale=s3, math=self.math)
-        g2 = ops.conv_forward(g, self.conv3.dgrad_weight(s3), 1, 0, mask=o2, math=self.math)    # dgrad + ReLU mask of o2
+        g2 = self._dgrad(g, self.conv3, s3, 0, mask=o2)    # dgrad + ReLU mask of o2
         ops.conv_wgrad_async(o1, g2, _grad_buf(self.conv2.weight), 1, 1, scale=s2, math=self.math, wino_v=v2)
-        g1 = ops.conv_forward(g2, self.conv2.dgrad_weight(s2), 1, 1, mask=o1, math=self.math)   # 3x3 dgrad: pad = 3-1-1
+        g1 = self._dgrad(g2, self.conv2, s2, 1, mask=o1)   # 3x3 dgrad: pad = 3-1-1
         ops.conv_wgrad_async(x, g1, _grad_buf(self.conv1.weight), s, 0, scale=s1, math=self.math)
         ds = self.downsample
         if ds is not None:
@@ -140,15 +177,15 @@ class Bottleneck(nn.Module):
             return None
         if s == 1:
             if ds is not None:
-                gx = ops.conv_forward(g, ds[0].dgrad_weight(sd), 1, 0, math=self.math)
-                return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=gx, out=gx, mask=mask_dx, math=self.math)
-            return ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, residual=g, mask=mask_dx, math=self.math)
+                gx = self._dgrad(g, ds[0], sd, 0)
+                return self._dgrad(g1, self.conv1, s1, 0, residual=gx, out=gx, mask=mask_dx)
+            return self._dgrad(g1, self.conv1, s1, 0, residual=g, mask=mask_dx)
         # stride-2 1x1 convs: gradient rows land on the even pixels of a zeroed tensor
         B, H, W, _ = x.shape
         assert mask_dx is None, "stride-2 blocks open a stage: their input is not a block output of the same stage"
-        gx = ops.conv_forward(g1, self.conv1.dgrad_weight(s1), 1, 0, out_hw=(H, W), out_stride=(s, s), math=self.math)
+        gx = self._dgrad(g1, self.conv1, s1, 0, out_hw=(H, W), out_stride=(s, s))
         if ds is not None:
-            ops.conv_forward(g, ds[0].dgrad_weight(sd), 1, 0, residual=gx, out=gx, out_hw=(H, W), out_stride=(s, s), math=self.math)
+            self._dgrad(g, ds[0], sd, 0, residual=gx, out=gx, out_hw=(H, W), out_stride=(s, s))
         return gx
 
 

@@ -55,6 +55,10 @@ class GeneralizedRCNN(nn.Module):
     # --- storage: one flat fp32 buffer for parameters, one for gradients (RCCL all-reduce + fused SGD work on them)
     def flatten_parameters(self):
         self.flat = flatten_parameters(self)
+        from ..backbone.resnet import Conv2d
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                m._flat = self.flat
         return self.flat
 
     def _apply(self, fn, *a, **k):

@@ -238,13 +238,14 @@ def wino_v_alloc(x, w, stride, pad, math=MATH_F32):
 
 
 def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, mask=None, relu=False,
-                 out=None, out_hw=None, out_stride=(1, 1), math=MATH_F32, wino_v=None):
+                 out=None, out_hw=None, out_stride=(1, 1), math=MATH_F32, wino_v=None, w_planes=None, w_plane_stride=0):
     """x [B,H,W,Cin] NHWC, w [Cout,R,S,Cin] OHWI -> [B,Ho,Wo,Cout] (or scattered into `out` [B,out_H,out_W,Cout]).
     math=MATH_BF16: operands rounded to bf16 inside the kernel, bf16 MFMA, fp32 accumulate (fp32 tensors in and out)."""
     L.require_cuda(x, w)
     x, w = L.f32c(x), L.f32c(w)
     d = conv_desc(x.shape, w.shape, stride, pad, scale, bias, residual, mask, relu, out_hw, out_stride, math)
     d.wino_v = L.ptr(wino_v)
+    d.w_planes, d.w_plane_stride = L.ptr(w_planes), int(w_plane_stride)
     if out is None:
         if out_hw is not None:
             out = torch.zeros((d.B, d.out_H, d.out_W, d.Cout), dtype=_f32, device=x.device)
@@ -327,12 +328,27 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino
     return dw
 
 
-def conv_dgrad_weights(w, scale=None, out=None):
-    """w [Cout,R,S,Cin] -> [Cin,R,S,Cout] flipped, scaled by scale[Cout]"""
+def split_bf16x3(x, out=None):
+    """exact three-way bf16 split of an fp32 tensor -> int16 [3, numel] (planes p0, p1, p2 with x == p0 + p1 + p2)"""
+    L.require_cuda(x)
+    x = L.f32c(x)
+    n = x.numel()
+    if out is None:
+        out = torch.empty((3, n), dtype=torch.int16, device=x.device)
+    L.check(L.lib().abr_split_bf16x3(L.ptr(x), n, L.ptr(out), L.stream()), "split_bf16x3")
+    return out
+
+
+def conv_dgrad_weights(w, scale=None, out=None, planes=None):
+    """w [Cout,R,S,Cin] -> [Cin,R,S,Cout] flipped, scaled by scale[Cout]; `planes` (int16 [3, numel]) also receives its bf16x3 split"""
     w = L.f32c(w)
     Cout, R, S, Cin = w.shape
     if out is None:
         out = _empty((Cin, R, S, Cout), w)
+    if planes is not None:
+        L.check(L.lib().abr_conv_dgrad_weights_planes(L.ptr(w), L.ptr(scale), Cout, R, S, Cin, L.ptr(out), L.ptr(planes), L.stream()),
+                "dgrad_weights_planes")
+        return out
     L.check(L.lib().abr_conv_dgrad_weights(L.ptr(w), L.ptr(scale), Cout, R, S, Cin, L.ptr(out), L.stream()), "dgrad_weights")
     return out
 

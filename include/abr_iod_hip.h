@@ -210,12 +210,20 @@ typedef struct {
        gradient takes the Winograd path, V is read from there and the input transform is skipped (x is not touched).  NULL =
        self-contained calls. */
     float* wino_v;
+    /* ABR_MATH_BF16X6, abr_conv_forward only: the weight tensor already split into three bf16 planes by abr_split_bf16x3
+       ([3][Cout*R*S*Cin]); the kernel then loads the planes instead of splitting w in every workgroup.  NULL = split in-kernel. */
+    const void* w_planes;
+    int64_t w_plane_stride;  /* elements between two planes (0 = Cout*R*S*Cin: a stand-alone abr_split_bf16x3 of w); larger when
+                                the planes are a slice of a bigger split buffer, e.g. the whole flat parameter buffer split at once */
 } abr_conv_desc;
 
 int abr_conv_forward(const abr_conv_desc* d_host, const float* x, const float* w, float* out, void* stream);
 /* floats of the Winograd-domain input V = 36 * B*ceil(H/4)*ceil(W/4) * Cin if BOTH abr_conv_forward and abr_conv_wgrad take the
  * Winograd F(4x4,3x3) path for this descriptor (wide stride-1 pad-1 3x3, no residual / scatter, fp32 or bf16x6 math), else 0 */
 int64_t abr_conv_wino_v_floats(const abr_conv_desc* d_host);
+/* exact three-way split x = p0 + p1 + p2 with p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (round to nearest even):
+ * planes [3][n] bf16 (6 n bytes).  n % 4 == 0. */
+int abr_split_bf16x3(const float* x, int64_t n, void* planes, void* stream);
 
 /* dW[Cout,R,S,Cin] (+)= sum_m gy[m,Cout]^T * im2col(x)[m,RSCin], columns scaled by d->scale (FrozenBN).
  * Accumulates with fp32 atomics into dw (caller zeroes it once per step). */
@@ -225,6 +233,9 @@ int abr_conv_wgrad(const abr_conv_desc* d_host, const float* x, const float* gy,
  * that turns dgrad into abr_conv_forward(gy, wt). */
 int abr_conv_dgrad_weights(const float* w, const float* scale, int Cout, int R, int S, int Cin, float* wt,
                            void* stream);
+/* the same, also emitting the three bf16 planes of wt ([3][Cin*R*S*Cout]) for abr_conv_desc::w_planes */
+int abr_conv_dgrad_weights_planes(const float* w, const float* scale, int Cout, int R, int S, int Cin, float* wt, void* planes,
+                                  void* stream);
 /* db[c] += sum_m gy[m,c] (bias gradient of nn.Conv2d / nn.Linear) */
 int abr_bias_grad(const float* gy, int64_t M, int C, float* db, void* stream);
 

@@ -640,3 +640,37 @@ def test_winograd_input_transform_is_shared_between_forward_and_wgrad(math):
     assert ops.wino_v_alloc(x, torch.zeros(64, 3, 3, 64, device="cuda"), 1, 1, m) is None
     assert ops.wino_v_alloc(torch.randn(1, 16, 16, 256, device="cuda"), torch.zeros(256, 1, 1, 256, device="cuda"), 1, 0, m) is None
     assert ops.wino_v_alloc(torch.randn(1, 16, 16, 256, device="cuda"), torch.zeros(256, 3, 3, 256, device="cuda"), 1, 1, ops.MATH_BF16) is None
+
+
+def test_bf16x6_presplit_weight_planes_give_identical_results():
+    """abr_split_bf16x3 + abr_conv_desc::w_planes: splitting the weights once (whole buffers, strided planes) must give bit-identical
+    outputs to splitting them inside every workgroup; the planes themselves add back to the fp32 value exactly."""
+    from abr_iod_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    buf = torch.randn(3 * 64 * 1024, device="cuda", generator=g) * torch.logspace(-6, 3, 3 * 64 * 1024, device="cuda")
+    pl = ops.split_bf16x3(buf)
+    back = sum(pl[i].view(torch.bfloat16).double() for i in range(3))
+    assert torch.equal(back.float(), buf) and torch.equal(back, buf.double())          # exact, not merely close
+    for (B, H, W, Cin, Cout, k, s, p, off) in [(8, 16, 16, 256, 512, 1, 1, 0, 0), (2, 38, 63, 256, 76, 1, 1, 0, 64),
+                                               (2, 19, 23, 64, 64, 3, 1, 1, 128), (1, 38, 63, 128, 256, 1, 2, 0, 4096)]:
+        n = Cout * k * k * Cin
+        w = buf[off:off + n].view(Cout, k, k, Cin) * 0.05
+        flat = buf.clone(); flat[off:off + n] = w.reshape(-1)
+        planes = ops.split_bf16x3(flat)                                                # planes of a bigger buffer: stride = its numel
+        x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+        sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
+        want = ops.conv_forward(x, flat[off:off + n].view(Cout, k, k, Cin), s, p, scale=sc, relu=True, math=ops.MATH_BF16X6)
+        got = ops.conv_forward(x, flat[off:off + n].view(Cout, k, k, Cin), s, p, scale=sc, relu=True, math=ops.MATH_BF16X6,
+                               w_planes=planes[0, off:off + n], w_plane_stride=planes.shape[1])
+        assert torch.equal(got, want)
+        # dgrad copy + its planes from one launch
+        wt_planes = torch.empty((3, n), dtype=torch.int16, device="cuda")
+        wsrc = flat[off:off + n].view(Cout, k, k, Cin).contiguous()
+        wt = ops.conv_dgrad_weights(wsrc, sc, planes=wt_planes)
+        assert torch.equal(wt, ops.conv_dgrad_weights(wsrc, sc))
+        assert torch.equal(sum(wt_planes[i].view(torch.bfloat16).double() for i in range(3)).float().view_as(wt), wt)
+        if s == 1:
+            gy = torch.randn(B, H, W, Cout, device="cuda", generator=g)
+            a = ops.conv_forward(gy, wt, 1, k - 1 - p, math=ops.MATH_BF16X6)
+            b = ops.conv_forward(gy, wt, 1, k - 1 - p, math=ops.MATH_BF16X6, w_planes=wt_planes)
+            assert torch.equal(a, b)

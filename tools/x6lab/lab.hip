@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -122,6 +123,20 @@ int main() {
     float *A, *B, *C;
     hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)N * K * 4); hipMalloc(&C, (size_t)(M / BM) * (N / BN) * 256 * 4);
     hipMemset(A, 0x3c, (size_t)M * K * 4); hipMemset(B, 0x3c, (size_t)N * K * 4);
+    printf("-- constant operands\n");
+    run<15>("all (loads too)", A, B, C, M, N, K);
+    {   // random operands: data-dependent switching power lowers the sustained MFMA clock
+        std::vector<float> h((size_t)M * K);
+        unsigned st = 12345u;
+        for (auto& v : h) { st = st * 1664525u + 1013904223u; v = ((int)(st >> 8) - (1 << 23)) * (1.0f / (1 << 23)); }
+        hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
+    }
+    printf("-- random operands\n");
+    run<15>("all (loads too)", A, B, C, M, N, K);
+    run<14>("mfma + lds reads + split/store", A, B, C, M, N, K);
+    run<7>("all but mfma", A, B, C, M, N, K);
+    printf("-- register-constant operands (no memory)\n");
     run<8>("mfma only", A, B, C, M, N, K);
     run<12>("mfma + lds reads", A, B, C, M, N, K);
     run<14>("mfma + lds reads + split/store", A, B, C, M, N, K);
