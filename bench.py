@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-math", action="store_true", help="skip the short informational re-run in the bf16x6 (fp32-accurate) arithmetic")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--math", choices=["f32", "bf16", "bf16-all", "bf16x6"], default="f32",
                     help="f32 (default, the BASELINE metric); bf16 = BASELINE.json configs[4]'s bf16 MFMA backbone (cfg.DTYPE bfloat16: operands "
@@ -188,6 +189,28 @@ def main():
                                                            "overlapped_tflops": tf(r[6], r[5])} for r in prof if r[1] + r[4] > 0}}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_target, images, targets, len(cfg_t.MODEL.ROI_BOX_HEAD.NAME_OLD_CLASSES))
+        if world == 1 and a.math == "f32" and not a.no_alt_math:
+            # Informational only, AFTER the timed region above and never part of `value`: the same workload in the opt-in bf16x6
+            # arithmetic (fp32 operands split exactly into three bf16 terms, six cross products, fp32 accumulate: DESIGN.md section 5),
+            # which meets every fp32 parity criterion of the test-suite.
+            os.environ["ABR_CONV_MATH"] = "bf16x6"
+            try:
+                ms6, mt6 = build_models(cfg_s, cfg_t, seed=0)
+                opt6 = make_optimizer(cfg_t, mt6)
+                sch6 = make_lr_scheduler(cfg_t, opt6)
+                for _ in range(3):
+                    train_step(ms6, mt6, images, targets, opt6, sch6, cfg_t)
+                torch.cuda.synchronize()
+                t6 = time.perf_counter()
+                for _ in range(10):
+                    l6 = train_step(ms6, mt6, images, targets, opt6, sch6, cfg_t)
+                torch.cuda.synchronize()
+                e6 = time.perf_counter() - t6
+                out["alt_math_bf16x6"] = {"value": round(B * 10 / e6, 3), "unit": "img/s", "ms_per_step": round(1e3 * e6 / 10, 3), "steps": 10,
+                                          "note": "informational: fp32-accurate arithmetic on the bf16 matrix cores (opt-in, ABR_CONV_MATH=bf16x6); "
+                                                  "not the reported value", "final_total_loss": round(float(l6[1].detach()), 5)}
+            finally:
+                os.environ.pop("ABR_CONV_MATH", None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
