@@ -47,6 +47,7 @@ class GradReducer(object):
         self.force = False          # single-rank RCCL runs in tests
         self._works, self._done = [], set()
         self._comm = None
+        self._warm = False
 
     @property
     def active(self):
@@ -56,6 +57,11 @@ class GradReducer(object):
         """new backward pass: nothing reduced yet"""
         assert not self._works, "finish() was not called for the previous step"
         self._done.clear()
+        if not self._warm and self.active:
+            # the first collective creates the RCCL communicator; do that HERE, on the caller's thread, not inside a gradient hook
+            # running on the autograd engine's thread in the middle of backward
+            dist.all_reduce(torch.zeros(1, dtype=self.grads.dtype, device=self.grads.device))
+            self._warm = True
 
     def _issue(self, name):
         if name in self._done:

@@ -79,6 +79,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", init_method="env://")  # "nccl" IS RCCL on ROCm
+        dist.barrier()   # creates the communicator before any timed or hook-issued collective
 
     from abr_iod_amd import _lib
     from abr_iod_amd.engine import train_step
