@@ -674,3 +674,17 @@ def test_bf16x6_presplit_weight_planes_give_identical_results():
             a = ops.conv_forward(gy, wt, 1, k - 1 - p, math=ops.MATH_BF16X6)
             b = ops.conv_forward(gy, wt, 1, k - 1 - p, math=ops.MATH_BF16X6, w_planes=wt_planes)
             assert torch.equal(a, b)
+
+
+def test_bf16x6_optional_loops_pass_the_same_parity_tests():
+    """The opt-in variants of the bf16x6 arithmetic (ABR_X6_V2=1: double-buffered k-16 loop; ABR_X6_WEIGHT_PLANES=1: weights split
+    once per step in the model) are selected by process-wide environment switches: run their parity tests in child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_extra, target in (({"ABR_X6_V2": "1"}, "tests/test_gpu_ops.py::test_conv_bf16x6_mode_is_fp32_accurate"),
+                              ({"ABR_X6_WEIGHT_PLANES": "1"}, "tests/test_gpu_e2e.py::test_train_step_losses_and_grads_vs_oracle")):
+        r = subprocess.run([sys.executable, "-m", "pytest", target, "-x", "-q", "-p", "no:cacheprovider"], cwd=root,
+                           env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
