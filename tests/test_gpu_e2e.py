@@ -19,39 +19,42 @@ def _close(a, b, tol=1e-4):
     return abs(a - b) <= tol * max(1.0, abs(b))
 
 
-@pytest.fixture(scope="module", params=["f32", "bf16x6"])
+CASES = [("15-5", "f32"), ("15-5", "bf16x6"), ("10-10", "f32"), ("10-5", "f32"), ("finetune", "f32")]
+
+
+@pytest.fixture(scope="module", params=CASES, ids=["{}-{}".format(*c) for c in CASES])
 def step_state(request):
-    """f32 = the default fp32 MFMA arithmetic; bf16x6 = the opt-in fp32-accurate arithmetic on the bf16 matrix cores
-    (ABR_CONV_MATH=bf16x6): the SAME oracle comparisons at the SAME tolerances must hold for both."""
+    """Every BASELINE.json configuration (tests/e2e_common.py: finetune = configs[1], 15-5 = configs[2], 10-10 = configs[3],
+    10-5 = configs[4]) in the default fp32 MFMA arithmetic; 15-5 also in bf16x6 = the opt-in fp32-accurate arithmetic on the bf16
+    matrix cores (ABR_CONV_MATH=bf16x6): the SAME oracle comparisons at the SAME tolerances must hold for all of them."""
     import os
     import random
-    os.environ["ABR_CONV_MATH"] = request.param
+    from e2e_common import CONFIGS, clamp_targets, needs_source
+    name, math = request.param
+    task, dist_type, feat, alpha, beta, gamma, label_range, n_old = CONFIGS[name]
+    os.environ["ABR_CONV_MATH"] = math
 
     from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
     from abr_iod_amd.utils.checkpoint import reference_state_dict
 
     overrides = ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 600, "MODEL.RPN.POST_NMS_TOP_N_TRAIN", 100, "MODEL.RPN.PRE_NMS_TOP_N_TEST", 300,
                  "MODEL.RPN.POST_NMS_TOP_N_TEST", 150, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 48, "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 64]
-    cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, overrides=overrides)
+    cfg_s, cfg_t = make_cfgs(task, dist_type=dist_type, feat=feat, alpha=alpha, beta=beta, gamma=gamma, overrides=overrides)
     torch.manual_seed(0)
     random.seed(0)
-    ms, mt = build_models(cfg_s, cfg_t, seed=0)
+    ms, mt = build_models(cfg_s, cfg_t, seed=0, need_source=needs_source(name))
     with torch.no_grad():  # make target != source so that the ARD / ID gradients are non-trivial
         g = torch.Generator(device="cuda").manual_seed(5)
         n = mt.flat.n_trainable
         mt.flat.params[:n].mul_(1.0 + 0.05 * torch.randn(n, device="cuda", generator=g))
-    # full (7x7) pooled features in the detection pass too, so shapes match the reference tuple
-    images, targets = synthetic_batch(2, 160, 224, seed=3, max_boxes=3)
-    # keep GT inside the small image
-    for t in targets:
-        t.bbox[:, 0::2].clamp_(max=223); t.bbox[:, 1::2].clamp_(max=159)
-        t.bbox[:, 2] = torch.max(t.bbox[:, 2], t.bbox[:, 0] + 8).clamp(max=223); t.bbox[:, 3] = torch.max(t.bbox[:, 3], t.bbox[:, 1] + 8).clamp(max=159)
+    images, targets = synthetic_batch(2, 160, 224, seed=3, max_boxes=3, label_range=label_range)
+    clamp_targets(targets, 224, 160)   # keep GT inside the small image
     os.environ.pop("ABR_CONV_MATH", None)   # read at model construction only
     from abr_iod_amd import ops
-    want = ops.MATH_BF16X6 if request.param == "bf16x6" else ops.MATH_F32
+    want = ops.MATH_BF16X6 if math == "bf16x6" else ops.MATH_F32
     assert all(m.math == want for m in mt.modules() if hasattr(m, "math"))
-    return dict(cfg_s=cfg_s, cfg_t=cfg_t, ms=ms, mt=mt, images=images, targets=targets,
-                sd_s=reference_state_dict(ms), sd_t=reference_state_dict(mt))
+    return dict(name=name, cfg_s=cfg_s, cfg_t=cfg_t, ms=ms, mt=mt, images=images, targets=targets, n_old=n_old, dist_type=dist_type,
+                sd_s=reference_state_dict(ms) if ms is not None else None, sd_t=reference_state_dict(mt))
 
 
 def test_train_step_losses_and_grads_vs_oracle(step_state):
@@ -62,27 +65,35 @@ def test_train_step_losses_and_grads_vs_oracle(step_state):
 
     S = step_state
     ms, mt, images, targets, cfg = S["ms"], S["mt"], S["images"], S["targets"], S["cfg_t"]
+    n_old, dist_type = S["n_old"], S["dist_type"]
+    k_old, k_all = n_old + 1, mt.roi_heads.box.predictor.num_classes
+    distill = ms is not None
     mt.flat.zero_grad()
     # ---------------- GPU path (the trainer's sequence, train_incremental.py:82-128)
-    with torch.no_grad():
-        soften_result, _, soften_proposal, feat_s, _, _, _, raf_s = ms.generate_soften_proposal(images)
+    if distill:
+        with torch.no_grad():
+            soften_result, _, soften_proposal, feat_s, _, _, _, raf_s = ms.generate_soften_proposal(images)
     loss_dict, feat_t, _, anchors, rpn_out, props, raf_det, _ = mt(images, targets)
     feat_t[0].retain_grad()
-    target_result, _, raf_t = mt.forward(images, targets, features=feat_t, proposals=soften_proposal)
-    l_id = calculate_roi_distillation_losses(soften_result, target_result, dist="id")
-    l_ard = calculate_attentive_roi_feature_distillation(raf_s, raf_t, gamma=cfg.DIST.GAMMA)
-    total = sum(loss_dict.values()) + cfg.DIST.ALPHA * l_id + cfg.DIST.BETA * l_ard
+    total = sum(loss_dict.values())
+    gpu = {k: float(v) for k, v in loss_dict.items()}
+    if distill:
+        target_result, _, raf_t = mt.forward(images, targets, features=feat_t, proposals=soften_proposal)
+        l_id = calculate_roi_distillation_losses(soften_result, target_result, dist=dist_type)
+        l_ard = calculate_attentive_roi_feature_distillation(raf_s, raf_t, gamma=cfg.DIST.GAMMA)
+        total = total + cfg.DIST.ALPHA * l_id + cfg.DIST.BETA * l_ard
+        gpu["id"], gpu["ard"] = float(l_id), float(l_ard)
     total.backward()
     torch.cuda.synchronize()
-    gpu = {k: float(v) for k, v in loss_dict.items()}
-    gpu["id"], gpu["ard"] = float(l_id), float(l_ard)
 
     # ---------------- oracle on the same weights, same proposals / samples
-    ref_s, ref_t = RefModel(S["sd_s"], trainable_prefixes=()), RefModel(S["sd_t"])
+    ref_t = RefModel(S["sd_t"])
     img = images.cpu()
-    with torch.no_grad():
-        fs = ref_s.backbone(img)
-    np.testing.assert_allclose(feat_s[0].cpu().numpy(), fs.numpy(), rtol=0, atol=1e-4 * float(fs.abs().max()))
+    if distill:
+        ref_s = RefModel(S["sd_s"], trainable_prefixes=())
+        with torch.no_grad():
+            fs = ref_s.backbone(img)
+        np.testing.assert_allclose(feat_s[0].cpu().numpy(), fs.numpy(), rtol=0, atol=1e-4 * float(fs.abs().max()))
     ft = ref_t.backbone(img)
     ft.retain_grad()
     np.testing.assert_allclose(feat_t[0].detach().cpu().numpy(), ft.detach().numpy(), rtol=0, atol=1e-4 * float(ft.abs().max()))
@@ -109,22 +120,26 @@ def test_train_step_losses_and_grads_vs_oracle(step_state):
     labels_h = torch.cat([p.get_field("labels") for p in det_props]).cpu()
     rt_h = torch.cat([p.get_field("regression_targets") for p in det_props]).cpu()
     _, logits, boxreg = ref_t.box_head(ft, rois)
-    lc, lbox = R.box_head_loss(logits, boxreg, labels_h, rt_h, "id", 15)
-    # distillation pass on the source's 64 proposals
-    rois64 = convert_to_roi_format(soften_proposal).cpu()
-    with torch.no_grad():
-        pooled_s, zs, bs = ref_s.box_head(fs, rois64)
-    pooled_t, zt, bt = ref_t.box_head(ft, rois64)
-    l_id_r = R.roi_distillation_loss(zs, bs.view(-1, 16, 4), zt, bt.view(-1, 21, 4), "id")
-    l_ard_r = R.ard_loss(pooled_s, pooled_t, cfg.DIST.GAMMA)
-    total_r = lc + lbox + lo + lb + cfg.DIST.ALPHA * l_id_r + cfg.DIST.BETA * l_ard_r
+    assert logits.shape[1] == k_all
+    lc, lbox = R.box_head_loss(logits, boxreg, labels_h, rt_h, dist_type, n_old)   # inclusive CE only with dist_type 'id' (loss.py:151-163)
+    total_r = lc + lbox + lo + lb
+    ref = dict(loss_classifier=float(lc), loss_box_reg=float(lbox), loss_objectness=float(lo), loss_rpn_box_reg=float(lb))
+    if distill:   # distillation pass on the source's 64 proposals
+        rois64 = convert_to_roi_format(soften_proposal).cpu()
+        with torch.no_grad():
+            pooled_s, zs, bs = ref_s.box_head(fs, rois64)
+        pooled_t, zt, bt = ref_t.box_head(ft, rois64)
+        assert zs.shape[1] == k_old and zt.shape[1] == k_all
+        l_id_r = R.roi_distillation_loss(zs, bs.view(-1, k_old, 4), zt, bt.view(-1, k_all, 4), dist_type)
+        l_ard_r = R.ard_loss(pooled_s, pooled_t, cfg.DIST.GAMMA)
+        total_r = total_r + cfg.DIST.ALPHA * l_id_r + cfg.DIST.BETA * l_ard_r
+        ref["id"], ref["ard"] = float(l_id_r), float(l_ard_r)
     total_r.backward()
-    ref = dict(loss_classifier=float(lc), loss_box_reg=float(lbox), loss_objectness=float(lo), loss_rpn_box_reg=float(lb),
-               id=float(l_id_r), ard=float(l_ard_r))
     print("GPU   ", gpu)
     print("oracle", ref)
     for k in ref:
         assert _close(gpu[k], ref[k]), f"{k}: gpu {gpu[k]} vs oracle {ref[k]}"
+    assert _close(float(total), float(total_r)), (float(total), float(total_r))
 
     gf, rf = feat_t[0].grad.cpu(), ft.grad
     print("d(total)/d(features): max-rel", float((gf - rf).abs().max() / rf.abs().max()), "l2-rel", float((gf - rf).norm() / rf.norm()))
@@ -210,11 +225,14 @@ def test_joint_roi_pass_equals_two_calls(step_state):
     from abr_iod_amd.distillation.distillation import calculate_attentive_roi_feature_distillation, calculate_roi_distillation_losses
     S = step_state
     ms, mt, images, targets, cfg = S["ms"], S["mt"], S["images"], S["targets"], S["cfg_t"]
+    if ms is None:
+        pytest.skip("finetune: no source model, no second RoI pass")
+    dist_type = S["dist_type"]
     with torch.no_grad():
         soften_result, _, soften_proposal, _, _, _, _, raf_s = ms.generate_soften_proposal(images)
 
     def total_of(loss_dict, target_result, raf_t):
-        l_id = calculate_roi_distillation_losses(soften_result, target_result, dist="id")
+        l_id = calculate_roi_distillation_losses(soften_result, target_result, dist=dist_type)
         l_ard = calculate_attentive_roi_feature_distillation(raf_s, raf_t, gamma=cfg.DIST.GAMMA)
         return sum(loss_dict.values()) + cfg.DIST.ALPHA * l_id + cfg.DIST.BETA * l_ard, float(l_id), float(l_ard)
 

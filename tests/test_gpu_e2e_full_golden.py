@@ -1,0 +1,127 @@
+"""GPU, FULL SIZE: the HIP path against the reference ITSELF on BASELINE.json's geometry -- two 600x1000 images through the
+full-width R50-C4 (38x63 C4 map, 35 910 anchors, 12000 -> 2000 proposals, 512 RoIs + 64 distillation RoIs per image) for every
+BASELINE configuration (finetune = configs[1], 15-5 = configs[2], 10-10 = configs[3], 10-5 = configs[4]; the 2-image CPU run of
+the reference that produced the fixtures is configs[0]).
+
+Fixtures: tests/golden/e2e_full_<config>.npz, written in the build container by tests/golden/make_golden_e2e_full.py from
+/root/reference's own forward (train_incremental.py:82-116).  Weights are regenerated on both sides from the same seeded CPU
+initialisation; everything random the reference drew (sampler index lists, the 64 soften picks) is injected.
+
+Proposal lists are compared as sets (tests/e2e_common.py::match_fraction: a 1-ulp score tie re-orders a 2000-box list); the six
+losses are then computed on the REFERENCE's lists, so that they are comparable at the north-star tolerance 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, W = 600, 1000
+
+
+def _close(a, b, tol=1e-4):
+    return abs(a - b) <= tol * max(1.0, abs(b))
+
+
+@pytest.mark.parametrize("name", ["15-5", "10-10", "10-5", "finetune"])
+def test_full_size_step_matches_reference(gold, name):
+    from e2e_common import CONFIGS, match_fraction, needs_source, perturb_trainable
+    from abr_iod_amd.distillation.distillation import calculate_attentive_roi_feature_distillation, calculate_roi_distillation_losses
+    from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
+    from abr_iod_amd.structures.bounding_box import BoxList
+    from abr_iod_amd.utils.checkpoint import load_reference_state_dict, reference_state_dict
+
+    g = gold("e2e_full_" + name)
+    task, dist_type, feat, alpha, beta, gamma, label_range, n_old = CONFIGS[name]
+    cfg_s, cfg_t = make_cfgs(task, dist_type=dist_type, feat=feat, alpha=alpha, beta=beta, gamma=gamma)
+    ms, mt = build_models(cfg_s, cfg_t, seed=0, need_source=needs_source(name))
+    sd_t = {k: v.cpu() for k, v in reference_state_dict(mt).items()}
+    perturb_trainable(sd_t, [n for n, p in mt.named_parameters() if p.requires_grad])
+    assert load_reference_state_dict(mt, sd_t) == []
+    images, targets = synthetic_batch(2, H, W, seed=int(g["image_seed"]), label_range=label_range)
+    for i in range(2):
+        np.testing.assert_array_equal(targets[i].bbox.cpu().numpy(), g[f"gt{i}"])
+    mt.roi_heads.box.need_roi_features_in_training = True
+
+    # ---- source pass: its ranked top-128 vs the reference's, then the reference's 64 picks of the reference's list
+    if ms is not None:
+        with torch.no_grad():
+            state = ms.soften_begin(images, defer=False)
+            for i, p in enumerate(state["pending"]):
+                order = p.get_field("objectness").sort(descending=True)[1]
+                top = p.bbox[order][:128].cpu().numpy()
+                frac = match_fraction(g[f"src_top128_{i}"], top)
+                print(f"[{name}] source top-128, image {i}: {frac:.3f} of the reference's boxes present; list length {len(p)} vs {int(g[f'src_n_props{i}'])}")
+                assert frac >= 0.95
+            ref_lists = []
+            for i in range(2):
+                b = BoxList(torch.from_numpy(g[f"src_top128_{i}"]).cuda(), (W, H), mode="xyxy")
+                b.add_field("objectness", -torch.arange(128, dtype=torch.float32, device="cuda"))   # already ranked
+                ref_lists.append(b)
+            soften_result, _, soften_proposal, feat_s, _, _, _, raf_s = ms._soften_from_proposals(
+                ref_lists, state["features"], state["backbone_features"], state["anchors"], state["rpn_output"],
+                selected_indices=[g["soften_sel0"].tolist(), g["soften_sel1"].tolist()])
+        np.testing.assert_allclose(soften_result[0][:8].cpu().numpy(), g["soften_scores_head"], rtol=1e-4, atol=2e-5)
+
+    # ---- target pass: backbone + RPN (+ loss with the reference's draw) + proposal selection
+    n = 35910
+    pos = torch.cat([torch.from_numpy(g[f"rpn_pos{i}"].astype(np.int64)) + i * n for i in range(2)]).cuda()
+    neg = torch.cat([torch.from_numpy(g[f"rpn_neg{i}"].astype(np.int64)) + i * n for i in range(2)]).cuda()
+    mt.rpn.loss_evaluator.inject_sampled = (pos, torch.cat([pos, neg]))
+    try:
+        begun = mt.forward_begin(images, targets)
+        (boxes, rpn_losses), anchors, rpn_out = mt.rpn.forward_finish(begun["rpn"])
+    finally:
+        mt.rpn.loss_evaluator.inject_sampled = None
+    feat_t = begun["features"]
+    f = feat_t[0].detach()
+    np.testing.assert_allclose(f[:, ::97, ::7, ::11].cpu().numpy(), g["feat_t_spot"], rtol=0, atol=1e-4 * float(g["feat_t_absmax"]))
+    np.testing.assert_allclose(rpn_out[0][0].detach()[:, :, ::5, ::9].cpu().numpy(), g["rpn_obj_spot"], rtol=0, atol=1e-4 * float(g["rpn_obj_absmax"]))
+    assert anchors[0][0].bbox.shape[0] == n
+    for i in range(2):
+        mine, ref = boxes[i].bbox.cpu().numpy(), g[f"tgt_props{i}"]
+        frac = match_fraction(ref, mine)
+        print(f"[{name}] target proposals, image {i}: {len(mine)} vs {len(ref)} boxes, {frac:.4f} of the reference's present, "
+              f"identical positions: {np.mean(np.abs(mine[:min(len(mine), len(ref))] - ref[:min(len(mine), len(ref))]).max(1) < 1e-2):.4f}")
+        assert abs(len(mine) - len(ref)) <= 3 and frac >= 0.98
+        np.testing.assert_array_equal(mine[-len(g[f"gt{i}"]):], g[f"gt{i}"])     # GT appended last (inference.py:53-74)
+    for k in ("loss_objectness", "loss_rpn_box_reg"):
+        assert _close(float(rpn_losses[k]), float(g[k])), (k, float(rpn_losses[k]), float(g[k]))
+
+    # ---- box head on the reference's proposal lists with the reference's sampler draw
+    ref_props = []
+    for i in range(2):
+        b = BoxList(torch.from_numpy(g[f"tgt_props{i}"]).cuda(), (W, H), mode="xyxy")
+        b.add_field("objectness", torch.ones(len(b), device="cuda"))
+        ref_props.append(b)
+    ev = mt.roi_heads.box.loss_evaluator
+    ev.inject_sampled_inds = [torch.from_numpy(g[f"head_sel{i}"].astype(np.int64)).cuda() for i in range(2)]
+    try:
+        x, result, soft_res, det_losses, raf_det = mt.roi_heads(feat_t, ref_props, targets)
+    finally:
+        ev.inject_sampled_inds = None
+    for i in range(2):
+        assert np.array_equal(result[i].get_field("labels").cpu().numpy(), g[f"det_labels{i}"].astype(np.int64))
+    np.testing.assert_allclose(soft_res[0][:16].detach().cpu().numpy(), g["det_logits_head"], rtol=1e-4, atol=2e-5)
+    got = {k: float(v) for k, v in det_losses.items()}
+    got.update({k: float(v) for k, v in rpn_losses.items()})
+
+    # ---- second RoI pass + distillation losses
+    total = sum(det_losses.values()) + sum(rpn_losses.values())
+    if ms is not None:
+        target_result, _, raf_t = mt.forward(images, targets, features=feat_t, proposals=soften_proposal)
+        np.testing.assert_allclose(target_result[0][:8].detach().cpu().numpy(), g["target_scores_head"], rtol=1e-4, atol=2e-5)
+        l_id = calculate_roi_distillation_losses(soften_result, target_result, dist=dist_type)
+        l_ard = calculate_attentive_roi_feature_distillation(raf_s, raf_t, gamma=gamma)
+        got["loss_id"], got["loss_ard"] = float(l_id), float(l_ard)
+        total = total + alpha * l_id + beta * l_ard
+    want = {k: float(g[k]) for k in got}
+    print(f"[{name}] HIP      ", got)
+    print(f"[{name}] reference", want)
+    for k in got:
+        assert _close(got[k], want[k]), (k, got[k], want[k])
+    # and the full-size step is differentiable end to end on these weights
+    mt.flat.zero_grad()
+    total.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(mt.flat.grads).all() and float(mt.flat.grads.abs().sum()) > 0
