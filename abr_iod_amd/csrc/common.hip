@@ -18,7 +18,9 @@ struct ProfRec { hipEvent_t a, b; double work; int id; bool overlapped; };
 static bool g_prof = false;
 static bool g_overlap = false;
 static unsigned g_mask = 0xFFFFFFFFu;
-static unsigned g_every = 1, g_seen = 0;
+static unsigned g_every = 1;
+static unsigned g_seen[32] = {0};          // per kernel id: every shape of every kernel is sampled equally often
+static double g_all_launches[32] = {0}, g_all_work[32] = {0};   // every launch between begin and end, bracketed or not
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 bool prof_enabled() { return g_prof; }
@@ -29,8 +31,10 @@ static hipEvent_t get_event() {
     return e;
 }
 int prof_start(hipStream_t st, int id, double work) {
-    if (!g_prof || !((g_mask >> id) & 1u)) return -1;
-    if (g_every > 1 && (g_seen++ % g_every) != 0) return -1;  // sample every n-th eligible launch
+    if (!g_prof) return -1;
+    if (id >= 0 && id < 32) { g_all_launches[id] += 1.0; g_all_work[id] += work; }
+    if (!((g_mask >> id) & 1u)) return -1;
+    if (g_every > 1 && (g_seen[id & 31]++ % g_every) != 0) return -1;  // sample every n-th eligible launch of this kernel
     ProfRec r{get_event(), get_event(), work, id, g_overlap};
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
@@ -43,12 +47,18 @@ void prof_stop(hipStream_t st, int rec) {
 
 extern "C" int abr_prof_begin(void) {
     abr::g_prof = true;
+    for (int i = 0; i < 32; i++) abr::g_all_launches[i] = abr::g_all_work[i] = 0.0;
+    return ABR_OK;
+}
+// out[id*2 + {0,1}] = {launches, total work} of EVERY launch since abr_prof_begin (sampled or not): the executed flops of a step
+extern "C" int abr_prof_totals(double* out, int n_ids) {
+    for (int i = 0; i < n_ids && i < 32; i++) { out[2 * i] = abr::g_all_launches[i]; out[2 * i + 1] = abr::g_all_work[i]; }
     return ABR_OK;
 }
 extern "C" int abr_prof_set_mask(uint32_t mask, int every_nth) {
     abr::g_mask = mask;
     abr::g_every = every_nth > 1 ? (unsigned)every_nth : 1u;
-    abr::g_seen = 0;
+    for (int i = 0; i < 32; i++) abr::g_seen[i] = 0;
     return ABR_OK;
 }
 extern "C" int abr_prof_mark_overlap(int on) {

@@ -4,7 +4,9 @@ Distillation + inclusive distillation (BASELINE.json configs[2]: task 15-5, --fe
 synthetic 600x1000 images, fp32), data-parallel over N MI355X with one RCCL all-reduce of the flat gradient per step.
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N ...            (WORLD_SIZE unset: starts its own N rank processes, one per GPU, before touching the GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus 8 --task 10-10 --batch-per-gpu 2      (BASELINE.json configs[3])
 
 Rank 0 prints ONE JSON line (contract in the task description) plus the `roofline` and `cpu_baseline` objects.
 """
@@ -53,12 +55,59 @@ def cpu_baseline(model_target, images, targets, n_old):
             "seconds_per_image": {k: round(v / reps, 3) for k, v in acc.items()}}
 
 
+# BASELINE.json configurations as the reference's launch scripts spell them (scripts/run_SI.sh:24-32, scripts/run_MI.sh:11-21):
+#        task     dist_type feat  alpha beta gamma
+TASKS = {"15-5": ("id", "ard", 0.5, 1.0, 1.0),      # configs[2]
+         "10-10": ("id", "ard", 0.1, 0.5, 1.0),     # configs[3]
+         "10-5": ("id", "ard", 1.0, 1.0, 1.0),      # configs[4] (step 1 of the multi-step schedule)
+         "19-1": ("id", "ard", 1.0, 1.0, 5.0)}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without an outer launcher: start N fresh rank processes (one per GPU; the reference does the same
+    through torch.distributed.launch, scripts/run_SI.sh:6 + tools/train_incremental.py:406-409).  The parent has not imported
+    torch or touched the GPU; it only waits and exits with the children's status -- no exec of a GPU-initialised process."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            bad = [p for p in procs if p.poll() not in (None, 0)]
+            if bad:   # one rank died: the others would wait in a collective forever
+                rc = bad[0].returncode
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                break
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc or max((abs(p.returncode or 0) for p in procs), default=0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=4)
+    ap.add_argument("--task", choices=sorted(TASKS), default="15-5",
+                    help="15-5 = BASELINE configs[2] (the metric's configuration); 10-10 with --batch-per-gpu 2 = configs[3]; 10-5 = configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the short informational re-run in the bf16x6 (fp32-accurate) arithmetic")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -66,10 +115,31 @@ def main():
                     help="f32 (default, the BASELINE metric); bf16 = BASELINE.json configs[4]'s bf16 MFMA backbone (cfg.DTYPE bfloat16: operands "
                          "rounded in-kernel, fp32 accumulate, fp32 tensors); bf16-all = RPN head and layer4 as well.  Not the headline number.")
     ap.add_argument("--time-all-kernels", action="store_true", help="event-bracket every conv / ROIAlign launch, not only the dominant kernel")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher self-test: start the ranks, form the process group (gloo when there is no GPU), all-reduce a 1 per rank, print the count")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
 
     import torch
     import torch.distributed as dist
+
+    if a.rendezvous_only:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        assert world == a.gpus
+        gpu = torch.cuda.device_count() >= world   # (device_count does not initialise the GPU)
+        if gpu:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if world > 1:
+            dist.init_process_group(backend="nccl" if gpu else "gloo", init_method="env://")
+        one = torch.ones(1, device="cuda" if gpu else "cpu")
+        if world > 1:
+            dist.all_reduce(one)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"rendezvous_only": True, "ranks": int(one.item()), "backend": ("rccl" if gpu else "gloo") if world > 1 else None}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -91,12 +161,15 @@ def main():
         os.environ["ABR_BF16_SCOPE"] = "all"
     if a.math == "bf16x6":
         os.environ["ABR_CONV_MATH"] = "bf16x6"
-    cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, ims_per_batch=B * world,
+    dist_type, feat, alpha, beta, gamma = TASKS[a.task]
+    n_old_cls, n_new_cls = {"15-5": (15, 5), "10-10": (10, 10), "10-5": (10, 5), "19-1": (19, 1)}[a.task]
+    cfg_s, cfg_t = make_cfgs(a.task, dist_type=dist_type, feat=feat, alpha=alpha, beta=beta, gamma=gamma, ims_per_batch=B * world,
                              overrides=("DTYPE", "bfloat16") if a.math in ("bf16", "bf16-all") else ())
     model_source, model_target = build_models(cfg_s, cfg_t, seed=0)       # same seed on every rank = broadcast weights
     optimizer = make_optimizer(cfg_t, model_target)
     scheduler = make_lr_scheduler(cfg_t, optimizer)
-    images, targets = synthetic_batch(B, 600, 1000, seed=42 + rank)        # each rank its own shard of the global batch
+    images, targets = synthetic_batch(B, 600, 1000, seed=42 + rank,        # each rank its own shard of the global batch
+                                      label_range=(n_old_cls + 1, n_old_cls + n_new_cls + 1))
 
     def barrier():
         if world > 1:
@@ -127,10 +200,15 @@ def main():
         _lib.check(_lib.lib().abr_prof_end(ctypes.cast(buf, ctypes.c_void_p), len(PROF_NAMES)), "prof_end")
         # (name, exclusive launches / ms / flops, overlapped launches / ms / flops)  -- include/abr_iod_hip.h abr_prof_end
         prof = [(PROF_NAMES[i],) + tuple(buf[6 * i + j] for j in range(6)) for i in range(len(PROF_NAMES))]
+    rccl_ranks = 1
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        one = torch.ones(1, dtype=torch.float32, device="cuda")
+        dist.all_reduce(one)                      # every rank contributes 1 over RCCL: the sum is the number of ranks that really took part
+        rccl_ranks = int(round(float(one.item())))
+        assert rccl_ranks == dist.get_world_size() == world
 
     if rank == 0:
         total_imgs = B * world * a.steps
@@ -143,9 +221,12 @@ def main():
             "dtype": "f32" if a.math == "f32" else "f32 emulated on bf16 MFMA (exact 3-term split, 6 cross products, f32 accumulate); f32 elsewhere"
             if a.math == "bf16x6" else "bf16 MFMA operands / f32 accumulate / f32 tensors ({}); f32 elsewhere".format(
                 "backbone layer1-3" if a.math == "bf16" else "backbone, RPN head, layer4"),
-            "config": {"workload": "BASELINE.json configs[2]: task 15-5 ABR step, --feat ard --dist_type id (alpha .5, beta 1, gamma 1), "
-                                   "R50-C4, 600x1000, 512 RoIs/img + 64 distillation RoIs/img, source+target models, SGD step",
+            "config": {"workload": "BASELINE.json {}: task {} ABR step, --feat {} --dist_type {} (alpha {}, beta {}, gamma {}), "
+                                   "R50-C4, 600x1000, 512 RoIs/img + 64 distillation RoIs/img, source+target models, gradient all-reduce + SGD step".format(
+                                       {"15-5": "configs[2]", "10-10": "configs[3]", "10-5": "configs[4]"}.get(a.task, "(extra task)"), a.task, feat,
+                                       dist_type, alpha, beta, gamma),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "math": a.math,
+                       "rccl_ranks": rccl_ranks, "collective": "RCCL all-reduce of the flat gradient, 3 buckets, 2 under backward" if world > 1 else None,
                        "gflop_per_img_algorithmic": GFLOP_PER_IMG_ARD},
             "final_losses": {k: round(float(v), 5) for k, v in loss_dict.items()},
             "conv_roofline_frac_whole_step": round(value / world * GFLOP_PER_IMG_ARD / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -50,9 +50,13 @@ int abr_device_info(int32_t* out_host);
 int abr_prof_begin(void);
 int abr_prof_mark_overlap(int on);
 /* bit id set = time that kernel (default all); every_nth > 1 = bracket only every n-th eligible launch (an event pair costs a
- * ~6 us pipeline bubble per launch; with a per-step launch count coprime to n every shape is sampled equally often) */
+ * ~6 us pipeline bubble per launch; the counter is per kernel id, so with a per-step launch count coprime to n every shape of
+ * every kernel is sampled equally often) */
 int abr_prof_set_mask(uint32_t id_mask, int every_nth);
 int abr_prof_end(double* out_host, int n_ids);
+/* out[id*2+{0,1}] = {launches, total flops} of EVERY launch of kernel id since abr_prof_begin, event-bracketed or not (call before
+ * abr_prof_end or after: the totals survive until the next abr_prof_begin) */
+int abr_prof_totals(double* out_host, int n_ids);
 
 /* =====================================================================================================
  * 1. maskrcnn_benchmark._C  (csrc/vision.cpp:10-16)
