@@ -34,7 +34,13 @@ int prof_start(hipStream_t st, int id, double work) {
     if (!g_prof) return -1;
     if (id >= 0 && id < 32) { g_all_launches[id] += 1.0; g_all_work[id] += work; }
     if (!((g_mask >> id) & 1u)) return -1;
-    if (g_every > 1 && (g_seen[id & 31]++ % g_every) != 0) return -1;  // sample every n-th eligible launch of this kernel
+    if (g_every > 1) {
+        // one launch in n, chosen by a hash of the kernel's own launch counter: unbiased over the shapes of a step whatever the
+        // number of launches per step (a plain modulo samples only every gcd-th shape when that number shares a factor with n)
+        unsigned h = (g_seen[id & 31]++) * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        if (h % g_every != 0) return -1;
+    }
     ProfRec r{get_event(), get_event(), work, id, g_overlap};
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);

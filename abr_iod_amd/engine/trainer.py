@@ -153,8 +153,9 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
 
 
 def do_train(model_source, model_target, data_loader, optimizer, scheduler, checkpointer_target, device, checkpoint_period,
-             arguments_target, summary_writer, cfg):
-    """Same signature as tools/train_incremental.py:55-56.  data_loader yields (images, targets, _, idx)."""
+             arguments_target, summary_writer, cfg, faithful_rng=False):
+    """Same signature as tools/train_incremental.py:55-56.  data_loader yields (images, targets, _, idx).
+    `faithful_rng=True` also runs the reference's dead `subsample` call on the source model (:86), which consumes device RNG."""
     logger = logging.getLogger("abr_iod_amd.trainer")
     logger.info("Start training")
     max_iter = len(data_loader)
@@ -169,7 +170,8 @@ def do_train(model_source, model_target, data_loader, optimizer, scheduler, chec
         arguments_target["iteration"] = iteration
         images = images.to(device)
         targets = [t.to(device) for t in targets]
-        loss_dict_target, losses = train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg)
+        loss_dict_target, losses = train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg,
+                                              faithful_rng=faithful_rng)
         loss_dict_reduced = reduce_loss_dict(loss_dict_target)
         batch_time = time.time() - end
         end = time.time()

@@ -150,6 +150,8 @@ class GeneralizedRCNN(nn.Module):
         picks = []
         for k, props in enumerate(all_proposals):
             n = len(props)
+            if selected_indices is None and getattr(self, "inject_soften_indices", None) is not None:
+                selected_indices = self.inject_soften_indices     # parity tests pin python's random.sample here
             if selected_indices is not None:
                 sel = list(selected_indices[k])
             elif n < 64:
@@ -163,6 +165,7 @@ class GeneralizedRCNN(nn.Module):
         # host wait for everything queued on the stream -- here, the target's entire forward)
         dev = all_proposals[0].bbox.device if all_proposals else None
         flat_idx = ops.h2d([i for sel in picks for i in sel], torch.int64, dev) if picks else None
+        self.last_soften_indices = picks   # (tests replay a draw through inject_soften_indices)
         all_selected, off = [], 0
         for props, sel in zip(all_proposals, picks):
             order = props.get_field("objectness").sort(descending=True)[1]

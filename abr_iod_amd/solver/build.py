@@ -36,8 +36,12 @@ class FusedSGD(object):
         self._lr = torch.empty(len(self.param_groups), dtype=torch.float32, device=dev)
         self._lr_host = None
         self._steps = 0
-        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.reducer = GradReducer(self.flat.grads, self.flat.segments, side_streams=self._grad_writer_streams)
+
+    @property
+    def world_size(self):
+        """read when used (not snapshotted at construction): an optimizer built before init_process_group still averages over the ranks"""
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     @property
     def force_all_reduce(self):  # single-rank RCCL run in tests/test_gpu_dist.py

@@ -7,8 +7,13 @@ The flat buffer is cut into three buckets by the order their gradients become fi
     backbone   (layer2 + layer3, 8.3 M)             -> final at the end of backward
 `reduce_bucket_async(name)` is called from gradient hooks the trainer arms on those tensors (engine/trainer.py::_arm_overlap), so
 the first two exchanges (75 % of the bytes) run on RCCL's stream underneath the rest of the backward pass; `finish()` issues whatever
-is left and makes the current stream wait for all of them.  Every rank fires the hooks in the same order (same graph), so the
-collectives are issued in the same order everywhere.  The 1/world factor is folded into the SGD kernel."""
+is left and makes the current stream wait for all of them.
+
+Every rank must issue the SAME sequence of collectives whatever its local state (which hooks fired, whether overlap is enabled,
+whether any tensor of this rank's graph required a gradient): the sequence is therefore fixed -- always the per-range all-reduces
+of BUCKET_ORDER, in that order; sending a bucket first sends every earlier one that is still outstanding (their gradients are final
+by then: the RPN's become final after the RoI heads').  Hooks only move the issue POINT earlier, never the order or the sizes.
+The 1/world factor is folded into the SGD kernel."""
 import os
 
 import torch
@@ -64,11 +69,14 @@ class GradReducer(object):
             self._warm = True
 
     def _issue(self, name):
-        if name in self._done:
-            return
-        self._done.add(name)
-        for a, b in self.buckets[name]:
-            self._works.append(dist.all_reduce(self.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        """all-reduce bucket `name` and, before it, every earlier bucket of BUCKET_ORDER that has not gone out yet"""
+        for b_name in BUCKET_ORDER[: BUCKET_ORDER.index(name) + 1]:
+            if b_name in self._done:
+                continue
+            self._done.add(b_name)
+            for a, b in self.buckets[b_name]:
+                if b > a:
+                    self._works.append(dist.all_reduce(self.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def reduce_bucket_async(self, name):
         """Called when every kernel that writes bucket `name` has been ENQUEUED (on the current stream or a side stream)."""
@@ -89,11 +97,7 @@ class GradReducer(object):
     def finish(self):
         """Issue the buckets still outstanding (the caller has joined its side streams) and wait for all of them."""
         if self.active:
-            if not self._done and not self._works:   # nothing overlapped: ONE all-reduce of the whole buffer
-                self._works.append(dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, async_op=True))
-            else:
-                for name in BUCKET_ORDER:
-                    self._issue(name)
+            self._issue(BUCKET_ORDER[-1])    # everything still outstanding, in BUCKET_ORDER (the same collectives on every rank)
         for w in self._works:
             w.wait()                                  # GPU: the current stream waits on RCCL's; CPU (gloo): blocks
         self._works = []

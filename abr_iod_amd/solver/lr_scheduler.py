@@ -14,6 +14,8 @@ class WarmupMultiStepLR(object):
         self.warmup_factor, self.warmup_iters, self.warmup_method = warmup_factor, warmup_iters, warmup_method
         self.base_lrs = [g["initial_lr"] for g in optimizer.param_groups]
         self.last_epoch = last_epoch
+        self._step_count = 0          # torch's _LRScheduler bookkeeping: carried so that state_dict() round-trips with the reference's
+        self._last_lr = list(self.base_lrs)
         self.step()
 
     def get_lr(self):
@@ -29,14 +31,19 @@ class WarmupMultiStepLR(object):
 
     def step(self):
         self.last_epoch += 1
-        for g, lr in zip(self.optimizer.param_groups, self.get_lr()):
+        self._step_count += 1
+        self._last_lr = self.get_lr()
+        for g, lr in zip(self.optimizer.param_groups, self._last_lr):
             g["lr"] = lr
+
+    def get_last_lr(self):
+        return self._last_lr
 
     def state_dict(self):
         """torch's _LRScheduler.state_dict(): every attribute but the optimizer (what the reference checkpoints hold)."""
         return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
 
     def load_state_dict(self, sd):
-        for k in ("milestones", "gamma", "warmup_factor", "warmup_iters", "warmup_method", "base_lrs", "last_epoch"):
+        for k in ("milestones", "gamma", "warmup_factor", "warmup_iters", "warmup_method", "base_lrs", "last_epoch", "_step_count", "_last_lr"):
             if k in sd:
-                setattr(self, k, list(sd[k]) if k in ("milestones", "base_lrs") else sd[k])
+                setattr(self, k, list(sd[k]) if k in ("milestones", "base_lrs", "_last_lr") else sd[k])

@@ -1,6 +1,7 @@
 """Checkpoint boundary: convert between this package's storage (OHWI conv weights, padded stem, fused heads in flat
 buffers) and the reference's state_dict layout (OIHW, names of maskrcnn_benchmark/utils/checkpoint.py:32-74).
-Keys and shapes of `reference_state_dict(model)` equal those of the reference's `model.state_dict()` for the same cfg."""
+Keys and shapes of `reference_state_dict(model)` equal those of the reference's `model.state_dict()` for the same cfg
+(the anchor generator's `cell_anchors.0` buffer included)."""
 import torch
 
 from ..modeling.backbone.resnet import Conv2d, bump_param_version
@@ -14,6 +15,8 @@ def reference_state_dict(model):
         out[name] = m.oihw().clone() if m is not None else p.detach().clone()
     for name, b in model.named_buffers():
         if name.endswith("cell_anchors"):
+            # the reference registers its cell anchors through a BufferList (rpn/anchor_generator.py:13-31, 61): one buffer per level
+            out[name.replace("cell_anchors", "cell_anchors.0")] = b.detach().clone()
             continue
         out[name] = b.detach().clone()
     return out

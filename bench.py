@@ -39,20 +39,87 @@ def cpu_baseline(model_target, images, targets, n_old):
     cores = min(os.cpu_count() or 1, 32)  # oneDNN convs on this path stop scaling (and regress badly) beyond a few dozen threads
     torch.set_num_threads(cores)
     sd = reference_state_dict(model_target)
-    img = images[:1].cpu()
-    gtb = [targets[0].bbox.cpu().numpy()]
-    gtl = [targets[0].get_field("labels").cpu().numpy()]
+    n_img = min(2, images.shape[0])                     # BASELINE.json configs[0]: "2 synthetic 600x1000 images, CPU-only forward+loss"
+    img = images[:n_img].cpu()
+    gtb = [targets[i].bbox.cpu().numpy() for i in range(n_img)]
+    gtl = [targets[i].get_field("labels").cpu().numpy() for i in range(n_img)]
     cpu_forward_loss(sd, img, gtb, gtl, n_old, timings={})  # warm-up (thread pools, oneDNN primitive caches)
-    reps, acc = 12, {}     # ~10 s of host work: a bounded sample, the same image each time
+    reps, acc = 6, {}     # ~10 s of host work: a bounded sample, the same batch each time
     for _ in range(reps):
         tm = {}
         cpu_forward_loss(sd, img, gtb, gtl, n_old, timings=tm)
         for k, v in tm.items():
             acc[k] = acc.get(k, 0.0) + v
-    return {"value": round(reps / acc["total"], 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "{} passes over 1 synthetic 600x1000 image, target-model forward + 4 detector losses only (the reference has no "
-                      "CPU backward: csrc/ROIAlign.h:44), torch-CPU convs + oracle.c ROIAlign/NMS single-threaded as the reference".format(reps),
-            "seconds_per_image": {k: round(v / reps, 3) for k, v in acc.items()}}
+    return {"value": round(reps * n_img / acc["total"], 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "{} passes over a batch of {} synthetic 600x1000 images (BASELINE.json configs[0]), target-model forward + 4 detector losses "
+                      "only (the reference has no CPU backward: csrc/ROIAlign.h:44; no source model, no distillation), torch-CPU convs on {} threads + "
+                      "oracle.c ROIAlign/NMS single-threaded as the reference's".format(reps, n_img, cores),
+            "seconds_per_image": {k: round(v / (reps * n_img), 3) for k, v in acc.items()}}
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (separate rocprofv3 --pmc passes of this same command,
+    tools/pmc_traffic.sh: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), launch-weighted over its template
+    instances.  None when no summary names the kernel."""
+    import glob
+    prefix = {"conv_igemm_kernel<128,128>": "conv_igemm_kernel<128, 128,", "conv_wgrad_kernel": "conv_wgrad_kernel<",
+              "conv_igemm_kernel<64,64>": "conv_igemm_kernel<64, 64,", "conv_igemm_kernel<128,64>": "conv_igemm_kernel<128, 64, 4, 1, false"}.get(kernel)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        hits = [v for k, v in json.load(open(f))["kernels"].items() if prefix and k.startswith(prefix)]
+        n_l = sum(v["launches"] for v in hits)
+        if n_l:
+            return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n_l), os.path.relpath(f, ROOT)
+    return None, None
+
+
+def roofline(prof, totals, a, elapsed):
+    """The `roofline` object.  Per kernel: achieved = executed flops of the sampled launches / their summed HIP-event durations, over
+    ALL sampled launches (exclusive or overlapped with the other stream: what rocprofv3 --kernel-trace --stats averages too); the
+    two kernels with the most time per step are listed, the top one fills the contract's fields.  `whole_step` relates the step's
+    executed and algorithmic conv flops to the wall-clock step."""
+    bf16 = a.math != "f32"
+
+    def peak_of(name):
+        return (PEAK_BF16_MFMA_TFLOPS / (6.0 if a.math == "bf16x6" else 1.0)) if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
+
+    def tf(fl, ms):
+        return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0
+
+    rows = []
+    for name, n, ms, fl, n_o, ms_o, fl_o in prof:
+        launches_all, flops_all = totals[name]
+        if n + n_o == 0 or "roi_align" in name:
+            continue
+        avg_ms = (ms + ms_o) / (n + n_o)
+        rows.append({"kernel": name, "launches_per_step": round(launches_all / a.steps, 1), "sampled_launches": int(n + n_o),
+                     "avg_launch_ms": round(avg_ms, 4), "ms_per_step": round(avg_ms * launches_all / a.steps, 3),
+                     "gflop_per_launch": round(flops_all / max(launches_all, 1) / 1e9, 3),
+                     "gflop_per_launch_sampled": round((fl + fl_o) / (n + n_o) / 1e9, 3),
+                     "achieved": tf(fl + fl_o, ms + ms_o), "peak": peak_of(name), "frac": round(tf(fl + fl_o, ms + ms_o) / peak_of(name), 4),
+                     "exclusive": {"launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4), "tflops": tf(fl, ms)},
+                     "overlapped": {"launches": int(n_o), "avg_launch_ms": round(ms_o / max(n_o, 1), 4), "tflops": tf(fl_o, ms_o)}})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    top = rows[0]
+    traffic, traffic_src = _pmc_traffic(top["kernel"])
+    step_s = elapsed / a.steps
+    exec_flops_step = sum(v[1] for k, v in totals.items() if "roi_align" not in k) / a.steps
+    alg_flops_step = GFLOP_PER_IMG_ARD * 1e9 * a.batch_per_gpu
+    peak_step = PEAK_FP32_MFMA_TFLOPS if not bf16 else None
+    r = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": top["peak"], "unit": "TFLOP/s", "frac": top["frac"],
+         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+         "launches": "all sampled launches of the timed region (1 in {} of each kernel, hash-picked; exclusive and stream-overlapped alike)".format(
+             1 if a.time_all_kernels else 8),
+         "flops_counted": "executed multiply-adds x2 of each launch (a Winograd F(4x4,3x3) conv executes 1/4 of its algorithmic MACs)",
+         "avg_launch_ms": top["avg_launch_ms"], "avg_gflop_per_launch": top["gflop_per_launch_sampled"],
+         "kernels_by_time": rows[:2],
+         "all_conv_kernels": {x["kernel"]: {k: x[k] for k in ("launches_per_step", "avg_launch_ms", "ms_per_step", "achieved", "frac")} for x in rows},
+         "whole_step": {"executed_gflop": round(exec_flops_step / 1e9, 1), "executed_tflops": round(exec_flops_step / step_s / 1e12, 2),
+                        "algorithmic_gflop": round(alg_flops_step / 1e9, 1), "algorithmic_tflops": round(alg_flops_step / step_s / 1e12, 2),
+                        "note": "conv/linear flops of one rank's step / wall-clock step time (everything else in the step included)"}}
+    if peak_step:
+        r["whole_step"]["executed_frac"] = round(exec_flops_step / step_s / 1e12 / peak_step, 4)
+        r["whole_step"]["algorithmic_frac"] = round(alg_flops_step / step_s / 1e12 / peak_step, 4)
+    return r
 
 
 # BASELINE.json configurations as the reference's launch scripts spell them (scripts/run_SI.sh:24-32, scripts/run_MI.sh:11-21):
@@ -182,11 +249,10 @@ def main():
     time_kernels = (rank == 0) and not a.no_kernel_timing
     barrier()
     if time_kernels:
-        # default: only the dominant kernel (conv_igemm<128,128>, id 0) is event-bracketed, and only every 4th of its launches
-        # (73 per step, coprime to 4: every shape is sampled equally over 4 steps) -- an event pair costs a ~6 us bubble per
-        # launch, 1.6 ms/step if all ~250 conv/ROIAlign launches are timed.  --time-all-kernels fills the whole table.
-        dom_mask = 0x1 if a.math == "f32" else 0x81   # + id 7: the bf16 implicit GEMM
-        _lib.check(_lib.lib().abr_prof_set_mask(0xFFFFFFFF if a.time_all_kernels else dom_mask, 1 if a.time_all_kernels else 4), "prof_set_mask")
+        # Every conv / ROIAlign launch is COUNTED (flops per launch: abr_prof_totals); one launch in 8 of each kernel -- picked by a
+        # hash of the kernel's own launch counter, so every shape is sampled equally often -- is bracketed with a HIP event pair on its
+        # launch stream.  An event pair costs a ~6 us bubble: ~30 sampled launches = ~0.2 ms of a step.  --time-all-kernels brackets all.
+        _lib.check(_lib.lib().abr_prof_set_mask(0xFFFFFFFF, 1 if a.time_all_kernels else 8), "prof_set_mask")
         _lib.check(_lib.lib().abr_prof_begin(), "prof_begin")
     t0 = time.perf_counter()
     last = None
@@ -200,6 +266,9 @@ def main():
         _lib.check(_lib.lib().abr_prof_end(ctypes.cast(buf, ctypes.c_void_p), len(PROF_NAMES)), "prof_end")
         # (name, exclusive launches / ms / flops, overlapped launches / ms / flops)  -- include/abr_iod_hip.h abr_prof_end
         prof = [(PROF_NAMES[i],) + tuple(buf[6 * i + j] for j in range(6)) for i in range(len(PROF_NAMES))]
+        tot = (ctypes.c_double * (2 * len(PROF_NAMES)))()
+        _lib.check(_lib.lib().abr_prof_totals(ctypes.cast(tot, ctypes.c_void_p), len(PROF_NAMES)), "prof_totals")
+        prof_totals = {PROF_NAMES[i]: (tot[2 * i], tot[2 * i + 1]) for i in range(len(PROF_NAMES))}   # (launches, flops) of ALL launches
     rccl_ranks = 1
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -232,43 +301,7 @@ def main():
             "conv_roofline_frac_whole_step": round(value / world * GFLOP_PER_IMG_ARD / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
         }
         if prof:
-            traffic, traffic_src = None, None
-            pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            dom = max(prof, key=lambda r: r[2] + r[5])  # by total kernel time
-            if os.path.exists(pmc_file):  # HBM bytes/launch from separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.sh)
-                pk = json.load(open(pmc_file))["kernels"]
-                prefix = {"conv_igemm_kernel<128,128>": "conv_igemm_kernel<128, 128,", "conv_wgrad_kernel": "conv_wgrad_kernel",
-                          "conv_igemm_kernel<64,64>": "conv_igemm_kernel<64, 64,", "conv_igemm_kernel<128,64>": "conv_igemm_kernel<128, 64, 4, 1, false"}.get(dom[0])
-                # the kernel has single-/double-buffered template instances: launch-weighted mean over all of them
-                hits = [v for k, v in pk.items() if prefix and k.startswith(prefix)]
-                if hits:
-                    n_l = sum(v["launches"] for v in hits)
-                    traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / max(n_l, 1))
-                    traffic_src = "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
-
-            def tf(fl, ms):
-                return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0
-            name, n, ms, flops, n_o, ms_o, flops_o = dom
-            # Launches that had the device to themselves define the kernel's achieved rate (forward passes: nothing else is
-            # queued).  During backward the weight-gradient kernels run on a second stream NEXT to the dgrad launches; those
-            # launches share CUs, so their event-bracketed durations are reported separately ("overlapped"), not as kernel quality.
-            if n == 0:
-                n, ms, flops, n_o, ms_o, flops_o = n_o, ms_o, flops_o, 0, 0.0, 0.0
-            achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            peak = (PEAK_BF16_MFMA_TFLOPS / (6.0 if a.math == "bf16x6" else 1.0)) if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
-                               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                               "flops_counted": "executed multiply-adds of each launch (a Winograd F(4x4,3x3) conv executes 1/4 of its algorithmic "
-                                                "MACs, so conv_roofline_frac_whole_step -- algorithmic -- can exceed this kernel fraction)",
-                               "launches": int(n), "sampling": "every launch" if a.time_all_kernels else "every 4th launch of this kernel",
-                               "avg_launch_ms": round(ms / max(n, 1), 4),
-                               "avg_gflop_per_launch": round(flops / max(n, 1) / 1e9, 3),
-                               "overlapped": {"launches": int(n_o), "avg_launch_ms": round(ms_o / max(n_o, 1), 4), "tflops": tf(flops_o, ms_o),
-                                              "note": "dgrad launches issued while wgrad kernels run on the side stream (ABR_WGRAD_STREAM=0 serialises them)"},
-                               "avg_launch_ms_all": round((ms + ms_o) / max(n + n_o, 1), 4),
-                               "all_conv_kernels": {r[0]: {"launches": int(r[1]), "ms": round(r[2], 3), "tflops": tf(r[3], r[2]),
-                                                           "overlapped_launches": int(r[4]), "overlapped_ms": round(r[5], 3),
-                                                           "overlapped_tflops": tf(r[6], r[5])} for r in prof if r[1] + r[4] > 0}}
+            out["roofline"] = roofline(prof, prof_totals, a, elapsed)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_target, images, targets, len(cfg_t.MODEL.ROI_BOX_HEAD.NAME_OLD_CLASSES))
         if world == 1 and a.math == "f32" and not a.no_alt_math:

@@ -49,9 +49,9 @@ int abr_device_info(int32_t* out_host);
  * fwd/bwd, 7 igemm bf16, 8 wgrad bf16.  Synchronises on the recorded events and stops profiling. */
 int abr_prof_begin(void);
 int abr_prof_mark_overlap(int on);
-/* bit id set = time that kernel (default all); every_nth > 1 = bracket only every n-th eligible launch (an event pair costs a
- * ~6 us pipeline bubble per launch; the counter is per kernel id, so with a per-step launch count coprime to n every shape of
- * every kernel is sampled equally often) */
+/* bit id set = time that kernel (default all); every_nth > 1 = bracket one eligible launch in n (an event pair costs a ~6 us
+ * pipeline bubble per launch), picked by a hash of the kernel's own launch counter so that every shape of a step is sampled
+ * equally often whatever the number of launches per step */
 int abr_prof_set_mask(uint32_t id_mask, int every_nth);
 int abr_prof_end(double* out_host, int n_ids);
 /* out[id*2+{0,1}] = {launches, total flops} of EVERY launch of kernel id since abr_prof_begin, event-bracketed or not (call before

@@ -54,9 +54,9 @@ def test_model_file_round_trip_and_grown_head(gold, tmp_path):
     extra = Checkpointer(ms).load(f)
     assert extra == {"iteration": 7}
     back = reference_state_dict(ms)
+    assert set(back) == set(sd_s)            # every key of the reference's state_dict, cell-anchor buffers included
     for k, v in sd_s.items():
-        if "anchor_generator" not in k:
-            assert torch.equal(back[k], v), k
+        assert torch.equal(back[k], v), k
     # weight surgery: the 16-class source file into the 21-class target -> first 16 / 64 rows copied, the rest untouched
     before = reference_state_dict(mt)
     Checkpointer(mt).load(f)
@@ -74,7 +74,7 @@ def test_model_file_round_trip_and_grown_head(gold, tmp_path):
     assert sorted(os.listdir(d)) == ["model_trimmed.pth"]
     data = torch.load(os.path.join(d, "model_trimmed.pth"), weights_only=False)
     assert list(data.keys()) == ["model"]
-    assert set(k for k in sd_t if "anchor_generator" not in k) == set(data["model"].keys())
+    assert set(sd_t) == set(data["model"].keys())
     for k, v in data["model"].items():
         assert v.shape == sd_t[k].shape and v.device.type == "cpu", k
 
@@ -191,6 +191,6 @@ def test_reference_checkpointer_reads_our_file(tmp_path):
     #  Checkpointer._load_file/_load_model do: torch.load + utils/model_serialization.py:72 load_state_dict)
     ref_load_state_dict(rm, torch.load(os.path.join(d, "model_final.pth"), weights_only=False)["model"])
     ours = reference_state_dict(mt)
+    assert set(rm.state_dict()) == set(ours)
     for k, v in rm.state_dict().items():
-        if "anchor_generator" not in k:
-            assert torch.equal(v, ours[k]), k
+        assert torch.equal(v, ours[k]), k

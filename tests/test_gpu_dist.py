@@ -74,19 +74,48 @@ def _two_rank_worker(rank, world, port, out):
     tiny = ["MODEL.RESNETS.STEM_OUT_CHANNELS", 16, "MODEL.RESNETS.RES2_OUT_CHANNELS", 32, "MODEL.RESNETS.WIDTH_PER_GROUP", 8,
             "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 128]
     cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, overrides=tiny)
+    images, targets = synthetic_batch(1, 160, 224, seed=10 + rank)  # each rank its own image
+
+    # (a) this rank's LOCAL, un-reduced gradient of the first step: same weights, same draws (recorded), exchange switched off
+    ms, mt = build_models(cfg_s, cfg_t, seed=0)
+    opt = make_optimizer(cfg_t, mt); sch = make_lr_scheduler(cfg_t, opt)
+    opt.reducer.reduce_bucket_async = lambda name: None
+    opt.reducer.finish = lambda: None
+    torch.manual_seed(3 + rank); random.seed(3 + rank)
+    train_step(ms, mt, images, targets, opt, sch, cfg_t)
+    torch.cuda.synchronize()
+    g_local = mt.flat.grads.clone().cpu().numpy()
+    ev_rpn, ev_box = mt.rpn.loss_evaluator, mt.roi_heads.box.loss_evaluator
+    pos, samp = ev_rpn.last_sampled
+    draws = ((pos[pos >= 0].clone(), samp[samp >= 0].clone()), [t.clone() for t in ev_box.last_sampled_inds], [list(s) for s in ms.last_soften_indices])
+
+    # (b) the real thing: two steps with the hook-issued exchange; the first replays the draws of (a)
     ms, mt = build_models(cfg_s, cfg_t, seed=0)                     # same weights on both ranks
     opt = make_optimizer(cfg_t, mt); sch = make_lr_scheduler(cfg_t, opt)
     assert opt.reducer.active and opt.world_size == 2
     sent, inner = [], opt.reducer.reduce_bucket_async
     opt.reducer.reduce_bucket_async = lambda name: (sent.append(name), inner(name))
-    images, targets = synthetic_batch(1, 160, 224, seed=10 + rank)  # each rank its own image
-    torch.manual_seed(3 + rank); random.seed(3 + rank)
+    p_before = mt.flat.params.detach().clone()
+    n = mt.flat.n_trainable
+    lr = torch.zeros(n, device="cuda"); wd = torch.zeros(n, device="cuda")   # per element, at iteration 0 (warm-up factor included)
+    for g_ in opt.param_groups:
+        a, b = g_["range"]
+        lr[a:b] = g_["lr"]; wd[a:b] = g_["weight_decay"]
     grads = []
-    for _ in range(2):
+    for it in range(2):
+        if it == 0:
+            mt.rpn.loss_evaluator.inject_sampled, mt.roi_heads.box.loss_evaluator.inject_sampled_inds, ms.inject_soften_indices = draws
+        else:
+            mt.rpn.loss_evaluator.inject_sampled = mt.roi_heads.box.loss_evaluator.inject_sampled_inds = ms.inject_soften_indices = None
         train_step(ms, mt, images, targets, opt, sch, cfg_t)
         torch.cuda.synchronize()
         grads.append(mt.flat.grads.clone().cpu().numpy())           # after step(): the all-reduced (summed) gradient
-    out.put((rank, mt.flat.params.detach().cpu().numpy(), grads, sent))   # (numpy: nothing shared by file descriptor)
+        if it == 0:
+            p_after1 = mt.flat.params.detach().clone()
+    # SGD's first step on the AVERAGED gradient (solver/build.py:7-21 groups: weights lr/wd, biases 2*lr / 0), restated in torch
+    expect = p_before[:n] - lr * (torch.from_numpy(grads[0]).cuda() / world + wd * p_before[:n])
+    upd_err = float((p_after1[:n] - expect).norm() / (p_after1[:n] - p_before[:n]).norm())
+    out.put((rank, mt.flat.params.detach().cpu().numpy(), grads, sent, g_local, upd_err))   # (numpy: nothing shared by file descriptor)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -94,7 +123,9 @@ def _two_rank_worker(rank, world, port, out):
 @pytest.mark.timeout(600)
 def test_two_ranks_exchange_gradients_through_the_hooks():
     """Two processes, one image each, a real exchange (gloo over CUDA tensors, both ranks on this GPU): the hook-issued bucket
-    all-reduces plus the one in step() must leave both ranks with the SAME summed gradient and the same parameters."""
+    all-reduces plus the one in step() must leave both ranks with the SAME gradient, that gradient must be g_rank0 + g_rank1 (each
+    element reduced exactly once: a bucket sent twice or a wrong range would be identical on both ranks and still wrong), and the
+    update must be SGD on the gradient averaged over the ranks."""
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -106,11 +137,123 @@ def test_two_ranks_exchange_gradients_through_the_hooks():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, p0, g0, s0), (_, p1, g1, s1) = got
+    (_, p0, g0, s0, l0, u0), (_, p1, g1, s1, l1, u1) = got
     # the hooks fired during backward on both ranks: pooled-input hook -> roi_heads; feature-map hook -> roi_heads (already sent), rpn
     assert s0[:3] == ["roi_heads", "roi_heads", "rpn"] and s1 == s0
     import numpy as np
     for a, b in zip(g0, g1):
         assert np.isfinite(a).all() and float(np.abs(a).max()) > 0
-        assert np.array_equal(a, b)                                               # every element reduced exactly once, same sum everywhere
+        assert np.array_equal(a, b)                                               # the same sum everywhere
     assert np.array_equal(p0, p1)
+    want = l0 + l1                                                                # every element reduced exactly ONCE
+    rel = float(np.linalg.norm(g0[0] - want) / np.linalg.norm(want))
+    assert rel < 1e-5, rel                                                        # (atomic accumulation order is the only difference)
+    assert float(np.abs(g0[0] - want).max()) <= 1e-4 * float(np.abs(want).max())
+    assert u0 < 1e-4 and u1 < 1e-4, (u0, u1)                                      # update == SGD on the averaged gradient
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# 1 rank x 2 images  ==  2 ranks x 1 image  on the REAL (full-width) model -- SURVEY.md §4: "distributed correctness = same loss /
+# gradients for 1 vs N ranks with a fixed sampler".  Every random draw of the single-process run (RPN sampler, box-head sampler, the 64
+# soften picks) is replayed on the rank that owns the image.  Reference: DistributedDataParallel averages the per-rank gradients
+# (tools/train_incremental.py:231-235); here: sum all-reduce of the flat gradient + 1/world in the SGD kernel.
+EQ_OVERRIDES = ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 600, "MODEL.RPN.POST_NMS_TOP_N_TRAIN", 100, "MODEL.RPN.PRE_NMS_TOP_N_TEST", 300,
+                "MODEL.RPN.POST_NMS_TOP_N_TEST", 150, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 48, "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 64]
+EQ_H, EQ_W = 160, 224
+
+
+def _eq_setup(image_ids):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from e2e_common import clamp_targets
+    from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
+    from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer
+    cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, overrides=EQ_OVERRIDES)   # full width
+    ms, mt = build_models(cfg_s, cfg_t, seed=0)
+    with torch.no_grad():   # target != source, identically in every process (same device generator, same seed)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        n = mt.flat.n_trainable
+        mt.flat.params[:n].mul_(1.0 + 0.05 * torch.randn(n, device="cuda", generator=g))
+    from abr_iod_amd.modeling.backbone.resnet import bump_param_version
+    bump_param_version()
+    images, targets = synthetic_batch(2, EQ_H, EQ_W, seed=3, max_boxes=3)
+    clamp_targets(targets, EQ_W, EQ_H)
+    images, targets = images[image_ids], [targets[i] for i in image_ids]
+    opt = make_optimizer(cfg_t, mt)
+    return cfg_t, ms, mt, images, targets, opt, make_lr_scheduler(cfg_t, opt)
+
+
+def _eq_rank_worker(rank, world, port, draws, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # a real 2-rank exchange (gloo moves CUDA tensors) on the one GPU
+    torch.cuda.set_device(0)
+    from abr_iod_amd.engine import train_step
+    cfg_t, ms, mt, images, targets, opt, sch = _eq_setup([rank])
+    assert opt.reducer.active and opt.world_size == world
+    pos, samp, head, soften = draws[rank]
+    mt.rpn.loss_evaluator.inject_sampled = (torch.tensor(pos).cuda(), torch.tensor(samp).cuda())
+    mt.roi_heads.box.loss_evaluator.inject_sampled_inds = [torch.tensor(head).cuda()]
+    ms.inject_soften_indices = [soften]
+    ld, total = train_step(ms, mt, images, targets, opt, sch, cfg_t)
+    torch.cuda.synchronize()
+    props = mt.roi_heads.box.loss_evaluator.last_input_proposals[0].bbox.cpu().numpy()
+    out.put((rank, mt.flat.grads.cpu().numpy(), mt.flat.params.detach().cpu().numpy(), {k: float(v) for k, v in ld.items()}, props))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_one_image_each_equal_one_rank_two_images():
+    import numpy as np
+    import torch.multiprocessing as mp
+    from abr_iod_amd.engine import train_step
+    # ---- one process, both images; the samplers draw freely and the draws are recorded
+    cfg_t, ms, mt, images, targets, opt, sch = _eq_setup([0, 1])
+    assert not opt.reducer.active
+    p_before = mt.flat.params.detach().clone()
+    ld, total = train_step(ms, mt, images, targets, opt, sch, cfg_t)
+    torch.cuda.synchronize()
+    g_single = mt.flat.grads.cpu().numpy()
+    p_single = mt.flat.params.detach().cpu().numpy()
+    assert float((mt.flat.params - p_before).abs().max()) > 0
+    ev_rpn, ev_box = mt.rpn.loss_evaluator, mt.roi_heads.box.loss_evaluator
+    n = ev_rpn.last_targets[0][0].numel()                      # anchors per image
+    pos_all, samp_all = (t.cpu() for t in ev_rpn.last_sampled)
+    pos_all, samp_all = pos_all[pos_all >= 0], samp_all[samp_all >= 0]
+    draws, single_props = [], []
+    for i in range(2):
+        sel = lambda t: (t[(t >= i * n) & (t < (i + 1) * n)] - i * n).tolist()
+        draws.append((sel(pos_all), sel(samp_all), ev_box.last_sampled_inds[i].cpu().tolist(), list(ms.last_soften_indices[i])))
+        single_props.append(ev_box.last_input_proposals[i].bbox.cpu().numpy())
+        assert len(draws[i][1]) == 64 and len(draws[i][2]) == 48 and len(draws[i][3]) == 64   # equal shares: mean of means == global mean
+    ld_single = {k: float(v) for k, v in ld.items()}
+
+    # ---- two ranks, one image each, the same draws
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eq_rank_worker, args=(r, world, port, draws, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=800) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, p0, ld0, props0), (_, g1, p1, ld1, props1) = got
+    # the per-image proposal lists the injected indices refer to are the same lists
+    assert np.array_equal(props0, single_props[0]) and np.array_equal(props1, single_props[1])
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1)              # both ranks hold the same sum and the same parameters
+    # losses: mean over ranks of the per-rank losses == the 2-image losses (engine/trainer.py:15-37 reduce_loss_dict semantics)
+    for k in ld_single:
+        assert abs(0.5 * (ld0[k] + ld1[k]) - ld_single[k]) <= 1e-5 * max(1.0, abs(ld_single[k])), (k, ld0[k], ld1[k], ld_single[k])
+    # gradients: (g_rank0 + g_rank1) / world == gradient of the 2-image batch, to fp32 reduction order
+    g_mean = 0.5 * g0
+    rel = float(np.linalg.norm(g_mean - g_single) / np.linalg.norm(g_single))
+    print("1x2 vs 2x1: gradient rel-L2", rel, " max-abs", float(np.abs(g_mean - g_single).max()), " |g|max", float(np.abs(g_single).max()))
+    assert rel < 2e-5, rel
+    # and the SGD update (1/world folded into the kernel) lands on the same parameters
+    relp = float(np.linalg.norm(p0 - p_single) / np.linalg.norm(p_single - p_before.cpu().numpy()))
+    print("parameter update rel-L2 difference", relp)
+    assert relp < 2e-5, relp
