@@ -19,7 +19,8 @@ static bool g_prof = false;
 static bool g_overlap = false;
 static unsigned g_mask = 0xFFFFFFFFu;
 static unsigned g_every = 1;
-static unsigned g_seen[32] = {0};          // per kernel id: every shape of every kernel is sampled equally often
+static unsigned g_seen[32] = {0};          // per kernel id: launches since the last abr_prof_step_begin
+static unsigned g_step = 0;                // steps begun since abr_prof_begin
 static double g_all_launches[32] = {0}, g_all_work[32] = {0};   // every launch between begin and end, bracketed or not
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -35,11 +36,10 @@ int prof_start(hipStream_t st, int id, double work) {
     if (id >= 0 && id < 32) { g_all_launches[id] += 1.0; g_all_work[id] += work; }
     if (!((g_mask >> id) & 1u)) return -1;
     if (g_every > 1) {
-        // one launch in n, chosen by a hash of the kernel's own launch counter: unbiased over the shapes of a step whatever the
-        // number of launches per step (a plain modulo samples only every gcd-th shape when that number shares a factor with n)
-        unsigned h = (g_seen[id & 31]++) * 2654435761u;
-        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-        if (h % g_every != 0) return -1;
+        // systematic sample: launch i of this kernel in step s is bracketed iff (i + s) % n == 0 -- over n consecutive steps every
+        // launch position (= every shape of the step's fixed launch sequence) is sampled exactly once, so sampled averages equal
+        // population averages when the number of steps is a multiple of n
+        if ((g_seen[id & 31]++ + g_step) % g_every != 0) return -1;
     }
     ProfRec r{get_event(), get_event(), work, id, g_overlap};
     (void)hipEventRecord(r.a, st);
@@ -51,8 +51,14 @@ void prof_stop(hipStream_t st, int rec) {
 }
 }  // namespace abr
 
+extern "C" int abr_prof_step_begin(void) {
+    abr::g_step++;
+    for (int i = 0; i < 32; i++) abr::g_seen[i] = 0;
+    return ABR_OK;
+}
 extern "C" int abr_prof_begin(void) {
     abr::g_prof = true;
+    abr::g_step = 0;
     for (int i = 0; i < 32; i++) abr::g_all_launches[i] = abr::g_all_work[i] = 0.0;
     return ABR_OK;
 }

@@ -509,8 +509,10 @@ def sample_pos_neg(labels, batch_size, max_pos, index_offset_per_image=0, seed=N
     neg = torch.empty((N, batch_size), dtype=torch.int64, device=dev)
     counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
     if seed is None:
+        # one draw from torch's default CPU generator per launch (host-side, no device sync): torch.manual_seed() therefore replays the
+        # sampler's choices, as it replays torch.randperm in the reference (balanced_positive_negative_sampler.py:44-49)
         _sample_calls[0] += 1
-        seed = (torch.initial_seed() * 0x9E3779B1 + _sample_calls[0] * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+        seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
     is64 = labels.dtype == torch.int64
     if not is64 and labels.dtype != _f32:
         raise RuntimeError("sample_pos_neg: labels must be float32 or int64")

@@ -107,8 +107,8 @@ def roofline(prof, totals, a, elapsed):
     peak_step = PEAK_FP32_MFMA_TFLOPS if not bf16 else None
     r = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": top["peak"], "unit": "TFLOP/s", "frac": top["frac"],
          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-         "launches": "all sampled launches of the timed region (1 in {} of each kernel, hash-picked; exclusive and stream-overlapped alike)".format(
-             1 if a.time_all_kernels else 8),
+         "launches": "every launch position of the step sampled equally often over the timed region (1 launch in {} per step, rotating; "
+                     "exclusive and stream-overlapped launches alike)".format(1 if a.time_all_kernels else max(d for d in range(1, 11) if a.steps % d == 0)),
          "flops_counted": "executed multiply-adds x2 of each launch (a Winograd F(4x4,3x3) conv executes 1/4 of its algorithmic MACs)",
          "avg_launch_ms": top["avg_launch_ms"], "avg_gflop_per_launch": top["gflop_per_launch_sampled"],
          "kernels_by_time": rows[:2],
@@ -249,14 +249,18 @@ def main():
     time_kernels = (rank == 0) and not a.no_kernel_timing
     barrier()
     if time_kernels:
-        # Every conv / ROIAlign launch is COUNTED (flops per launch: abr_prof_totals); one launch in 8 of each kernel -- picked by a
-        # hash of the kernel's own launch counter, so every shape is sampled equally often -- is bracketed with a HIP event pair on its
-        # launch stream.  An event pair costs a ~6 us bubble: ~30 sampled launches = ~0.2 ms of a step.  --time-all-kernels brackets all.
-        _lib.check(_lib.lib().abr_prof_set_mask(0xFFFFFFFF, 1 if a.time_all_kernels else 8), "prof_set_mask")
+        # Every conv / ROIAlign launch is COUNTED (flops per launch: abr_prof_totals); launch i of a kernel in step s is bracketed with
+        # a HIP event pair on its launch stream iff (i + s) % n == 0, n = the largest divisor of --steps that is <= 10: every launch
+        # position of the step is sampled exactly steps/n times, so the sampled averages ARE the population averages rocprofv3 reports.
+        # An event pair costs a ~6 us bubble: ~25 sampled launches = ~0.15 ms of a step at n = 10.  --time-all-kernels brackets all.
+        sample_n = 1 if a.time_all_kernels else max(d for d in range(1, 11) if a.steps % d == 0)
+        _lib.check(_lib.lib().abr_prof_set_mask(0xFFFFFFFF, sample_n), "prof_set_mask")
         _lib.check(_lib.lib().abr_prof_begin(), "prof_begin")
     t0 = time.perf_counter()
     last = None
     for _ in range(a.steps):
+        if time_kernels:
+            _lib.lib().abr_prof_step_begin()
         last = train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t)
     barrier()
     elapsed = time.perf_counter() - t0

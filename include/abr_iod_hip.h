@@ -49,10 +49,11 @@ int abr_device_info(int32_t* out_host);
  * fwd/bwd, 7 igemm bf16, 8 wgrad bf16.  Synchronises on the recorded events and stops profiling. */
 int abr_prof_begin(void);
 int abr_prof_mark_overlap(int on);
-/* bit id set = time that kernel (default all); every_nth > 1 = bracket one eligible launch in n (an event pair costs a ~6 us
- * pipeline bubble per launch), picked by a hash of the kernel's own launch counter so that every shape of a step is sampled
- * equally often whatever the number of launches per step */
+/* bit id set = time that kernel (default all); every_nth = n > 1: bracket launch i of a kernel in step s iff (i + s) % n == 0 (an
+ * event pair costs a ~6 us pipeline bubble per launch).  The caller marks step boundaries with abr_prof_step_begin(); over n
+ * consecutive steps every launch position of the step's fixed launch sequence is sampled exactly once. */
 int abr_prof_set_mask(uint32_t id_mask, int every_nth);
+int abr_prof_step_begin(void);
 int abr_prof_end(double* out_host, int n_ids);
 /* out[id*2+{0,1}] = {launches, total flops} of EVERY launch of kernel id since abr_prof_begin, event-bracketed or not (call before
  * abr_prof_end or after: the totals survive until the next abr_prof_begin) */
