@@ -76,6 +76,16 @@ int wino_outgrad_transform(const float* gy, int B, int H, int W, int N, float* M
 int wino_wgrad_inverse(const float* dU, int N, int C, const float* scale, float* dw, hipStream_t st);
 float* wino_ws(hipStream_t st, size_t floats);
 
+// bf16x6 range guard (see abr_x6_range_flags in include/abr_iod_hip.h).  The flag word lives in device memory owned by common.hip.
+unsigned* x6_flags_ptr();
+constexpr unsigned kX6TinyB = (17u << 24) - 1u;   // (bits << 1) - 1 of the smallest in-domain magnitude 2^-110 (biased exponent 17)
+__device__ __forceinline__ void x6_report(unsigned bmin, float nonfin, unsigned* flags) {
+    unsigned f = 0;
+    if (bmin < kX6TinyB) f |= ABR_X6_FLAG_TINY;       // a non-zero operand below 2^-110: its low bf16 planes leave the normal range
+    if (nonfin != nonfin) f |= ABR_X6_FLAG_NONFINITE;  // inf / nan operand: inf - inf poisons the low planes (NaN where fp32 gives inf)
+    if (f) atomicOr(flags, f);
+}
+
 bool prof_enabled();
 int prof_start(hipStream_t st, int id, double work);  // returns record index (or -1)
 void prof_stop(hipStream_t st, int rec);

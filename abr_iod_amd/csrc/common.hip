@@ -96,6 +96,40 @@ extern "C" int abr_prof_end(double* out, int n_ids) {
     return ABR_OK;
 }
 
+namespace abr {
+unsigned* x6_flags_ptr() {
+    static unsigned* p = nullptr;
+    if (!p) {
+        if (hipMalloc(&p, sizeof(unsigned)) != hipSuccess) return nullptr;
+        (void)hipMemset(p, 0, sizeof(unsigned));
+    }
+    return p;
+}
+}  // namespace abr
+extern "C" int abr_x6_range_flags(uint32_t* out_host, int reset, void* stream) {
+    ABR_REQUIRE(out_host, "x6_range_flags: null pointer");
+    unsigned* p = abr::x6_flags_ptr();
+    ABR_REQUIRE(p, "x6_range_flags: no device memory");
+    hipStream_t st = abr::as_stream(stream);
+    if (hipMemcpyAsync(out_host, p, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        abr::set_error("x6_range_flags: read-back failed");
+        return ABR_E_LAUNCH;
+    }
+    if (reset && *out_host) (void)hipMemsetAsync(p, 0, sizeof(unsigned), st);
+    return ABR_OK;
+}
+
+extern "C" int abr_x6_range_flags_async(uint32_t* out_pinned_host, void* stream) {
+    ABR_REQUIRE(out_pinned_host, "x6_range_flags_async: null pointer");
+    unsigned* p = abr::x6_flags_ptr();
+    ABR_REQUIRE(p, "x6_range_flags_async: no device memory");
+    if (hipMemcpyAsync(out_pinned_host, p, sizeof(unsigned), hipMemcpyDeviceToHost, abr::as_stream(stream)) != hipSuccess) {
+        abr::set_error("x6_range_flags_async: copy failed");
+        return ABR_E_LAUNCH;
+    }
+    return ABR_OK;
+}
+
 extern "C" const char* abr_last_error(void) { return abr::g_err; }
 extern "C" int abr_version(void) { return 100; }
 extern "C" int abr_device_info(int32_t* out) {

@@ -80,6 +80,7 @@ struct ConvP {
     float* v_out;  // Winograd path: keep the transformed input here (abr_conv_desc::wino_v)
     const void* w_planes;  // bf16x6: pre-split weight planes (abr_conv_desc::w_planes), or NULL
     unsigned w_plane_bytes;  // distance between two planes
+    unsigned* x6_flags;      // bf16x6: device word of the range guard (abr::x6_flags_ptr)
 };
 
 
@@ -670,6 +671,19 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
             rb[i] = PB ? __builtin_amdgcn_raw_buffer_load_b128(rwp, (int)(valid ? b_off0[i] : kOOB), k0 * 2, 0)
                        : __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(valid ? b_off0[i] : kOOB), k0 * 4, 0);
     };
+    // Range guard of the exact split (abr_x6_range_flags, include/abr_iod_hip.h): every operand element is inspected ONCE per GEMM --
+    // the A rows by the workgroups of the first n-tile column, the weights by those of the first m-tile row (a workgroup-uniform
+    // branch; the other workgroups pay nothing).  bmin: smallest (bits << 1) - 1 seen (zero wraps to 0xFFFFFFFF and never wins);
+    // nonfin: x * 0 summed (NaN as soon as any element is inf or NaN).
+    const bool chk_a = tile_n == 0, chk_b = tile_m == 0 && !PB;
+    unsigned bmin = 0xFFFFFFFFu;
+    float nonfin = 0.f;
+    auto inspect = [&](const u32x4 v) {
+        const unsigned b0 = (v.x << 1) - 1u, b1 = (v.y << 1) - 1u, b2 = (v.z << 1) - 1u, b3 = (v.w << 1) - 1u;
+        bmin = min(min(bmin, min(b0, b1)), min(b2, b3));
+        nonfin = fmaf(__uint_as_float(v.x), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.y), 0.f, nonfin);
+        nonfin = fmaf(__uint_as_float(v.z), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.w), 0.f, nonfin);
+    };
     // exact three-way split of four fp32 values into bf16 planes
     auto split_store = [](const u32x4 v, __bf16* dst, int plane_stride) {
         const f32x4v f = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
@@ -683,6 +697,14 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
         *reinterpret_cast<uint2*>(dst + 2 * plane_stride) = *reinterpret_cast<const uint2*>(&h2);
     };
     auto store_tile = [&](u32x4 (&ra)[NA], u32x4 (&rb)[NB]) {
+        if (chk_a) {
+#pragma unroll
+            for (int i = 0; i < NA; i++) inspect(ra[i]);
+        }
+        if (chk_b) {
+#pragma unroll
+            for (int i = 0; i < NB; i++) inspect(rb[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NA; i++) split_store(ra[i], As + (srow + 32 * i) * LDX + kq * 4, BM * LDX);
 #pragma unroll
@@ -770,6 +792,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
         }
     }
     compute_tile();
+    if (chk_a | chk_b) abr::x6_report(bmin, nonfin, p.x6_flags);
     __syncthreads();  // the epilogue reuses the operand LDS
     epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
 }
@@ -782,6 +805,8 @@ int launch_x6(const ConvP& p, const float* x, const float* w, float* out, hipStr
     q.tiles_pb = q.tiles_m * q.tiles_n;
     if (q.nbatch < 1) q.nbatch = 1;
     q.n_full = q.tiles_pb * q.nbatch; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
+    q.x6_flags = abr::x6_flags_ptr();
+    if (!q.x6_flags) return 1;
     constexpr size_t lds_op = sizeof(__bf16) * 3 * (BM + BN) * LDX;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
     const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
@@ -977,188 +1002,6 @@ static void dispatch_igemm_bf16(const ConvP& p, const float* x, const float* w, 
     }
 }
 
-// Second bf16x6 loop, opt-in (ABR_X6_V2=1; tools/x6lab/lab2.hip is its stand-alone form): k-stage 16, DOUBLE-buffered three-plane LDS
-// (73.7 KB: still two workgroups per CU), four fp32 stages in flight in a register ring (a stage is only 24 MFMAs per wave), and
-// the split + LDS store of stage kt+1 in the same basic block as the MFMAs of stage kt, interleaved with sched_group_barrier so
-// that the VALU / DS work issues in the shadow of the matrix pipe: 0.85 -> 0.68 ms on a 32768x2048x1024 GEMM with random
-// operands (at the 1.8 GHz the chip sustains under bf16 MFMA load: 65 % of the 1847 / 6 = 308 TFLOP/s the pipe can deliver).
-constexpr int BKS = 16;
-constexpr int LDSP = BKS + 8;   // LDS row pitch in bf16 (48 B: conflict-free ds_read_b128)
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_x6v2_kernel(const ConvP p, const float* __restrict__ x_, const float* __restrict__ w_,
-                                                               float* __restrict__ out_) {
-    const float* x = x_;
-    const float* w = w_;
-    float* out = out_;
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int NA = BM / 64, NB = BN / 64;
-    constexpr int NR = NA + NB;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* As = reinterpret_cast<__bf16*>(smem);   // [2][3][BM][LDSP]
-    __bf16* Bs = As + 2 * 3 * BM * LDSP;            // [2][3][BN][LDSP]
-
-    int tile = (int)abr::xcd_remap(blockIdx.x, gridDim.x);
-    if (p.nbatch > 1) {
-        const int bt = tile / p.tiles_pb;
-        tile -= bt * p.tiles_pb;
-        x += bt * p.a_bs; w += bt * p.w_bs; out += bt * p.o_bs;
-    }
-    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int kq = tid & 3, srow = tid >> 2;   // 16 B slot of the 64 B row segment; rows srow + 64 i
-
-    constexpr unsigned kOOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, p.w_bytes, 0x00020000);
-    int a_hi0[NA], a_wi0[NA], a_off0[NA];
-    bool a_ok[NA];
-#pragma unroll
-    for (int i = 0; i < NA; i++) {
-        const int m = m0 + srow + 64 * i;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
-        unsigned b, rem, ho, wo;
-        p.d_howo.divmod((unsigned)mm, b, rem);
-        p.d_wo.divmod(rem, ho, wo);
-        a_hi0[i] = (int)ho * p.stride - p.pad;
-        a_wi0[i] = (int)wo * p.stride - p.pad;
-        a_off0[i] = (((int)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + kq * 4;
-    }
-    unsigned b_off0[NB];
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        const int n = n0 + srow + 64 * i;
-        b_off0[i] = n < p.Cout ? (unsigned)(n * p.K + kq * 4) * 4u : kOOB;
-    }
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 ring[4][NR];   // [stage & 3][A rows..., B rows...]
-    auto load_stage = [&](int kt, u32x4 (&r)[NR], bool valid) {
-        const int k0 = kt * BKS;
-        unsigned rs, c0, rr, ss;
-        p.d_cin.divmod((unsigned)k0, rs, c0);
-        p.d_s.divmod(rs, rr, ss);
-        const int delta = ((int)rr * p.W + (int)ss) * p.Cin + (int)c0;
-#pragma unroll
-        for (int i = 0; i < NA; i++) {
-            const int hi = a_hi0[i] + (int)rr, wi = a_wi0[i] + (int)ss;
-            const bool ok = valid & a_ok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-            r[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB), 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; i++) r[NA + i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(valid ? b_off0[i] : kOOB), k0 * 4, 0);
-    };
-    auto split_store = [](const u32x4 v, __bf16* dst, int plane_stride) {
-        const f32x4v f = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-        const bf16x4 h0 = __builtin_convertvector(f, bf16x4);
-        const f32x4v r1 = f - __builtin_convertvector(h0, f32x4v);
-        const bf16x4 h1 = __builtin_convertvector(r1, bf16x4);
-        const f32x4v r2 = r1 - __builtin_convertvector(h1, f32x4v);
-        const bf16x4 h2 = __builtin_convertvector(r2, bf16x4);
-        *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(&h0);
-        *reinterpret_cast<uint2*>(dst + plane_stride) = *reinterpret_cast<const uint2*>(&h1);
-        *reinterpret_cast<uint2*>(dst + 2 * plane_stride) = *reinterpret_cast<const uint2*>(&h2);
-    };
-    auto store_stage = [&](int buf, u32x4 (&r)[NR]) {
-        __bf16* a = As + buf * 3 * BM * LDSP;
-        __bf16* b = Bs + buf * 3 * BN * LDSP;
-#pragma unroll
-        for (int i = 0; i < NA; i++) split_store(r[i], a + (srow + 64 * i) * LDSP + kq * 4, BM * LDSP);
-#pragma unroll
-        for (int i = 0; i < NB; i++) split_store(r[NA + i], b + (srow + 64 * i) * LDSP + kq * 4, BN * LDSP);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    const int l31 = lane & 31, lh = lane >> 5;
-    const __bf16* a_frag = As + (wm * (TM * 32) + l31) * LDSP + lh * 8;
-    const __bf16* b_frag = Bs + (wn * (TN * 32) + l31) * LDSP + lh * 8;
-    auto compute_stage = [&](int buf) {
-        bf16x8 fa[TM][3], fb[TN][3];
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + (buf * 3 + pl) * BM * LDSP + i * 32 * LDSP);
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) fb[j][pl] = *reinterpret_cast<const bf16x8*>(b_frag + (buf * 3 + pl) * BN * LDSP + j * 32 * LDSP);
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++) {   // smallest terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-            }
-    };
-
-    const int nk = p.K / BKS;
-    load_stage(0, ring[0], true);
-    load_stage(1, ring[1], 1 < nk);
-    load_stage(2, ring[2], 2 < nk);
-    load_stage(3, ring[3], 3 < nk);
-    store_stage(0, ring[0]);
-    __syncthreads();
-    // iteration kt: LDS[kt & 1] holds stage kt; stage kt+1 (ring set (kt+1) & 3) is split into the other buffer while stage kt is
-    // multiplied; set kt & 3 (split one iteration ago) is refilled with stage kt+4
-#define ABR_X6_ITER(KT, S_SPLIT, S_LOAD)                                                        \
-    if ((KT) < nk) {                                                                            \
-        compute_stage((KT) & 1);                                                                \
-        if ((KT) + 1 < nk) store_stage(((KT) + 1) & 1, ring[S_SPLIT]);                          \
-        load_stage((KT) + 4, ring[S_LOAD], (KT) + 4 < nk);                                      \
-        _Pragma("unroll") for (int q = 0; q < TM * TN * 6; q++) {                               \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA ...              */  \
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); /* ... four VALU of the split */ \
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); /* ... one LDS store          */ \
-        }                                                                                       \
-        __syncthreads();                                                                        \
-    }
-    for (int kt = 0; kt < nk; kt += 4) {
-        ABR_X6_ITER(kt, 1, 0)
-        ABR_X6_ITER(kt + 1, 2, 1)
-        ABR_X6_ITER(kt + 2, 3, 2)
-        ABR_X6_ITER(kt + 3, 0, 3)
-    }
-#undef ABR_X6_ITER
-    // (the last iteration ended with a barrier: the epilogue may reuse the operand LDS)
-    epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
-}
-
-template <int BM, int BN, int WM, int WN>
-int launch_x6v2(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
-    ConvP q = p;
-    q.tiles_m = (p.M + BM - 1) / BM;
-    q.tiles_n = (p.Cout + BN - 1) / BN;
-    q.tiles_pb = q.tiles_m * q.tiles_n;
-    if (q.nbatch < 1) q.nbatch = 1;
-    q.n_full = q.tiles_pb * q.nbatch; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
-    constexpr size_t lds_op = sizeof(__bf16) * 2 * 3 * (BM + BN) * LDSP;
-    constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
-    const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
-    auto kern = conv_igemm_x6v2_kernel<BM, BN, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    const int rec = abr::prof_start(st, abr::PROF_IGEMM_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
-    kern<<<(unsigned)(q.tiles_pb * q.nbatch), 256, lds, st>>>(q, x, w, out);
-    abr::prof_stop(st, rec);
-    return 0;
-}
-
 // bf16x6 math mode (fp32-accurate): same tile rules as the bf16 mode
 static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
     const int cus = num_cus();
@@ -1166,21 +1009,15 @@ static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, fl
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * nb;
     const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64) * nb;
     const bool pb = p.w_planes != nullptr && nb == 1;
-    // the double-buffered k-16 loop (conv_igemm_x6v2_kernel) wins 20 % in its stand-alone form but not inside the conv kernel yet
-    // (layer4 downsample 0.81 vs 0.78 ms, step 32.8 vs 31.8 ms): ABR_X6_V2=1 selects it for further work
-    static const bool v1 = !(getenv("ABR_X6_V2") && atoi(getenv("ABR_X6_V2")) != 0);
     if (p.Cout > 64 && t128 >= 2 * cus) {
         if (pb) launch_x6<128, 128, 2, 2, true>(p, x, w, out, st);
-        else if (v1) launch_x6<128, 128, 2, 2, false>(p, x, w, out, st);
-        else launch_x6v2<128, 128, 2, 2>(p, x, w, out, st);
+        else launch_x6<128, 128, 2, 2, false>(p, x, w, out, st);
     } else if (t12864 >= 2 * cus || p.Cout <= 64) {
         if (pb) launch_x6<128, 64, 4, 1, true>(p, x, w, out, st);
-        else if (v1) launch_x6<128, 64, 4, 1, false>(p, x, w, out, st);
-        else launch_x6v2<128, 64, 4, 1>(p, x, w, out, st);
+        else launch_x6<128, 64, 4, 1, false>(p, x, w, out, st);
     } else {
         if (pb) launch_x6<64, 64, 2, 2, true>(p, x, w, out, st);
-        else if (v1) launch_x6<64, 64, 2, 2, false>(p, x, w, out, st);
-        else launch_x6v2<64, 64, 2, 2>(p, x, w, out, st);
+        else launch_x6<64, 64, 2, 2, false>(p, x, w, out, st);
     }
 }
 

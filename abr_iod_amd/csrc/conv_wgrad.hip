@@ -58,6 +58,7 @@ struct WgP {
     int nbatch, tiles_pb;        // batched mode (the 36 Winograd-domain gradients): tile -> (batch, tile inside the batch)
     long x_bs, gy_bs, dw_bs;
     int math;                    // ABR_MATH_F32 or ABR_MATH_BF16X6 (the bf16 mode has its own launch)
+    unsigned* x6_flags;          // bf16x6: device word of the range guard (abr::x6_flags_ptr)
 };
 
 // SB: single-buffered operand LDS (two barriers per stage, 32 KB instead of 64 KB -> a third resident workgroup per CU)
@@ -449,6 +450,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const f
                 }
             }
     };
+    // range guard of the exact split (abr_x6_range_flags): gy is inspected by the workgroups of the first k-tile column, x by those of
+    // the first n-tile row -- every operand element once per GEMM, workgroup-uniform branches (see conv_igemm_x6_kernel)
+    const bool chk_g = tile_k == 0, chk_x = tile_n == 0;
+    unsigned bmin = 0xFFFFFFFFu;
+    float nonfin = 0.f;
+    auto inspect = [&](const u32x4 v) {
+        const unsigned b0 = (v.x << 1) - 1u, b1 = (v.y << 1) - 1u, b2 = (v.z << 1) - 1u, b3 = (v.w << 1) - 1u;
+        bmin = min(min(bmin, min(b0, b1)), min(b2, b3));
+        nonfin = fmaf(__uint_as_float(v.x), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.y), 0.f, nonfin);
+        nonfin = fmaf(__uint_as_float(v.z), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.w), 0.f, nonfin);
+    };
     // rows (m, m+1) of one 16 B column group -> three planes of four bf16x2 dwords
     auto split_store = [](const u32x4 lo, const u32x4 hi, unsigned* dst, int plane) {
         u32x4 o0, o1, o2;
@@ -469,6 +481,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const f
         *reinterpret_cast<u32x4*>(dst + 2 * plane) = o2;
     };
     auto store_tile = [&]() {
+        if (chk_g) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) { inspect(rg[i][0]); inspect(rg[i][1]); }
+        }
+        if (chk_x) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) { inspect(ra[i][0]); inspect(ra[i][1]); }
+        }
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             split_store(rg[i][0], rg[i][1], Gs + (rp + 8 * i) * TN_ + q * 4, PL);
@@ -532,6 +552,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const f
         }
         compute_tile();
     }
+    if (chk_g | chk_x) abr::x6_report(bmin, nonfin, p.x6_flags);
 
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
@@ -603,6 +624,7 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
             attr6 = true;
         }
+        p.x6_flags = abr::x6_flags_ptr();
         const int rec6 = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
         conv_wgrad_x6_kernel<<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
         abr::prof_stop(abr::as_stream(stream), rec6);
@@ -661,6 +683,7 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     p.tiles_k = (p.K + TK_ - 1) / TK_;
     if (p.M == 0) return ABR_OK;
     p.nbatch = 1; p.tiles_pb = 0; p.x_bs = p.gy_bs = p.dw_bs = 0; p.overwrite = 0;
+    p.x6_flags = nullptr;
     p.math = d->math == ABR_MATH_BF16X6 ? ABR_MATH_BF16X6 : ABR_MATH_F32;   // (x6 handles any Cin % 4 == 0: no k-tile constraint here)
     hipStream_t st = abr::as_stream(stream);
     ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16 || d->math == ABR_MATH_BF16X6, "conv_wgrad: unknown math mode");

@@ -33,6 +33,29 @@ SOURCE_OVERLAP = os.environ.get("ABR_SOURCE_OVERLAP", "1") != "0"
 JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "0") != "0"
 
 
+_x6_watch = [None]
+
+
+def _x6_guard(model_source, model_target, log=None):
+    """bf16x6 arithmetic only: poll the kernels' range guard (ops.X6RangeWatch -- asynchronous, one step behind, no host stall).  When
+    an operand has left the domain in which the three-way bf16 split is exact (a non-zero magnitude below 2^-110, inf or nan) both
+    models switch to the fp32 MFMA kernels for the rest of the run."""
+    if getattr(model_target, "conv_math", "f32") != "bf16x6":
+        return
+    from .. import ops
+    if _x6_watch[0] is None:
+        _x6_watch[0] = ops.X6RangeWatch()
+    flags = _x6_watch[0].poll()
+    if flags:
+        what = " + ".join(n for b, n in ((ops.X6_FLAG_TINY, "non-zero operand below 2^-110"), (ops.X6_FLAG_NONFINITE, "inf/nan operand")) if flags & b)
+        (log or logging.getLogger("abr_iod_amd.trainer")).warning(
+            "bf16x6 range guard tripped ({}): switching both models to the fp32 MFMA kernels".format(what))
+        for m in (model_source, model_target):
+            if m is not None and hasattr(m, "set_conv_math"):
+                m.set_conv_math("f32")
+        ops.x6_range_flags(reset=True)
+
+
 def reduce_loss_dict(loss_dict):
     """engine/trainer.py:15-37: sum the loss scalars to rank 0 and average there (logging only)."""
     world_size = get_world_size()
@@ -149,6 +172,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
     losses.backward()                                                                                      # :144-145 (amp O0 = identity)
     optimizer.step()                                                                                       # :146 (+ RCCL all-reduce)
     scheduler.step()                                                                                       # :147
+    _x6_guard(model_source, model_target, log)
     return loss_dict_target, losses
 
 

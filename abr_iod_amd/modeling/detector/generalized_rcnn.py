@@ -28,6 +28,9 @@ from ..rpn.rpn import build_rpn
 from .._flat import flatten_parameters
 
 
+DEFAULT_CONV_MATH = "f32"
+
+
 class GeneralizedRCNN(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -44,13 +47,22 @@ class GeneralizedRCNN(nn.Module):
             from ..backbone.resnet import set_conv_math
             set_conv_math(self.rpn, ops.MATH_BF16)
             set_conv_math(self.roi_heads, ops.MATH_BF16)
-        # ABR_CONV_MATH=bf16x6 (opt-in): fp32-ACCURATE contractions on the bf16 matrix cores for every bottleneck / RPN conv -- each
-        # operand split exactly into three bf16 terms, six cross products, fp32 accumulate (csrc/conv_igemm.hip); cfg.DTYPE stays float32
-        if cfg.DTYPE == "float32" and os.environ.get("ABR_CONV_MATH", "f32") == "bf16x6":
-            from ..backbone.resnet import set_conv_math
-            for m in (self.backbone, self.rpn, self.roi_heads):
-                set_conv_math(m, ops.MATH_BF16X6)
+        # Contraction arithmetic of every bottleneck / RPN conv (cfg.DTYPE float32): "bf16x6" = fp32-ACCURATE contractions on the bf16
+        # matrix cores -- each operand split exactly into three bf16 terms, six cross products, fp32 accumulate (csrc/conv_igemm.hip),
+        # guarded by a hardware range check (ops.x6_range_flags; engine/trainer.py falls back to "f32" when it trips) -- or "f32" =
+        # v_mfma_f32_32x32x2_f32.  ABR_CONV_MATH overrides the default.
+        self.conv_math = "f32"
+        if cfg.DTYPE == "float32" and os.environ.get("ABR_CONV_MATH", DEFAULT_CONV_MATH) == "bf16x6":
+            self.set_conv_math("bf16x6")
         self.flat = None
+
+    def set_conv_math(self, name):
+        """'f32' or 'bf16x6' for every conv of the backbone, RPN head and layer4 head (takes effect at the next call)"""
+        from ..backbone.resnet import set_conv_math
+        math = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6}[name]
+        for m in (self.backbone, self.rpn, self.roi_heads):
+            set_conv_math(m, math)
+        self.conv_math = name
 
     # --- storage: one flat fp32 buffer for parameters, one for gradients (RCCL all-reduce + fused SGD work on them)
     def flatten_parameters(self):

@@ -199,6 +199,37 @@ def bce_logits_gather(x, y, idx, gscale=1.0, want_grad=False, yidx=None, denom_d
 
 # ----------------------------------------------------------------------------------------------- conv
 MATH_F32, MATH_BF16, MATH_BF16X6 = 0, 1, 2   # abr_conv_desc::math (include/abr_iod_hip.h)
+X6_FLAG_TINY, X6_FLAG_NONFINITE = 1, 2       # ABR_X6_FLAG_*
+
+
+def x6_range_flags(reset=True):
+    """Range guard of the bf16x6 arithmetic (include/abr_iod_hip.h, abr_x6_range_flags): OR of X6_FLAG_* raised by any bf16x6 kernel
+    since the last reset -- an operand left the domain in which the three-way bf16 split is exact (non-zero |x| < 2^-110, inf, nan).
+    Synchronises the current stream."""
+    import ctypes
+    v = ctypes.c_uint32(0)
+    L.check(L.lib().abr_x6_range_flags(ctypes.cast(ctypes.pointer(v), ctypes.c_void_p), int(bool(reset)), L.stream()), "x6_range_flags")
+    return int(v.value)
+
+
+class X6RangeWatch(object):
+    """Non-blocking poll of the range guard for a training loop: `poll()` at the end of every step enqueues an asynchronous copy of the
+    flag word into pinned host memory and returns the value of the PREVIOUS copy once its event has completed (no host stall)."""
+
+    def __init__(self):
+        self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._event = None
+
+    def poll(self):
+        seen = 0
+        if self._event is not None and self._event.query():
+            seen = int(self._host[0].item()) & 0xFFFFFFFF
+            self._event = None
+        if self._event is None:
+            L.check(L.lib().abr_x6_range_flags_async(self._host.data_ptr(), L.stream()), "x6_range_flags_async")
+            self._event = torch.cuda.Event()
+            self._event.record()
+        return seen
 
 
 def conv_desc(x_shape, w_shape, stride, pad, scale=None, bias=None, residual=None, mask=None, relu=False,

@@ -59,6 +59,19 @@ int abr_prof_end(double* out_host, int n_ids);
  * abr_prof_end or after: the totals survive until the next abr_prof_begin) */
 int abr_prof_totals(double* out_host, int n_ids);
 
+/* Range guard of the bf16x6 arithmetic (abr_conv_desc::math == ABR_MATH_BF16X6).  The three-way bf16 split x = x0 + x1 + x2 is
+ * EXACT -- and the contraction then meets the fp32 error bound -- for operands that are zero or have 2^-110 <= |x| < 2^128 (finite);
+ * below 2^-110 the low planes leave bf16's normal range and precision decays towards bf16's, and an inf operand yields NaN
+ * (inf - inf in the split) where an fp32 multiply-add chain yields inf.  Every bf16x6 kernel inspects each operand element once per
+ * GEMM and ORs ABR_X6_FLAG_* into a device word; abr_x6_range_flags copies it to *out_host (synchronising `stream`) and, if `reset`,
+ * clears it.  A caller that needs the fp32 result for out-of-domain data re-runs the operation with ABR_MATH_F32 when a flag is up
+ * (the Python host does: ops.x6_range_flags, engine/trainer.py). */
+#define ABR_X6_FLAG_TINY 1u
+#define ABR_X6_FLAG_NONFINITE 2u
+int abr_x6_range_flags(uint32_t* out_host, int reset, void* stream);
+/* the same word copied to PINNED host memory on `stream` without synchronising (the trainer polls it one step later) */
+int abr_x6_range_flags_async(uint32_t* out_pinned_host, void* stream);
+
 /* =====================================================================================================
  * 1. maskrcnn_benchmark._C  (csrc/vision.cpp:10-16)
  * ===================================================================================================== */

@@ -18,7 +18,16 @@ TINY = ["MODEL.RESNETS.STEM_OUT_CHANNELS", 16, "MODEL.RESNETS.RES2_OUT_CHANNELS"
 
 
 class _Loader(list):
-    """a data loader is anything with __len__ that yields (images, targets, _, idx) -- train_incremental.py:71,77"""
+    """a data loader is anything with __len__ that yields (images, targets, _, idx) -- train_incremental.py:71,77.  `total`: the
+    reference's iteration-based batch sampler reports the TOTAL number of iterations as its length also when it starts at
+    `start_iter` (data/samplers/iteration_based_batch_sampler.py:28-31), which is what `max_iter = len(data_loader)` relies on."""
+
+    def __init__(self, items=(), total=None):
+        super().__init__(items)
+        self.total = total
+
+    def __len__(self):
+        return self.total if self.total is not None else super().__len__()
 
 
 def _fresh(tmp, name):
@@ -94,7 +103,7 @@ def test_do_train_loop_checkpoints_and_equals_manual_steps(tmp_path, faithful):
     for i, st in last["optimizer"]["state"].items():              # and the momentum buffers
         assert torch.equal(st3[i]["momentum_buffer"].cpu(), st["momentum_buffer"].cpu()), i
     args3 = {"iteration": extra["iteration"]}
-    do_train(ms3, mt3, _Loader(loader[2:]), opt3, sch3, ckpt3, torch.device("cuda"), 2, args3, None, cfg_t, faithful_rng=faithful)
+    do_train(ms3, mt3, _Loader(list(loader)[2:], total=3), opt3, sch3, ckpt3, torch.device("cuda"), 2, args3, None, cfg_t, faithful_rng=faithful)
     torch.cuda.synchronize()
     assert args3["iteration"] == 3 and os.path.exists(os.path.join(d3, "model_final.pth"))
     assert [g["lr"] for g in opt3.param_groups] == [g["lr"] for g in opt.param_groups]
