@@ -78,6 +78,7 @@ float* wino_ws(hipStream_t st, size_t floats);
 
 // bf16x6 range guard (see abr_x6_range_flags in include/abr_iod_hip.h).  The flag word lives in device memory owned by common.hip.
 unsigned* x6_flags_ptr();
+bool x6_guard_enabled();   // ABR_X6_GUARD=0 switches the inspection off (A/B measurements of its cost only)
 constexpr unsigned kX6TinyB = (17u << 24) - 1u;   // (bits << 1) - 1 of the smallest in-domain magnitude 2^-110 (biased exponent 17)
 __device__ __forceinline__ void x6_report(unsigned bmin, float nonfin, unsigned* flags) {
     unsigned f = 0;

@@ -1,4 +1,5 @@
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -97,6 +98,10 @@ extern "C" int abr_prof_end(double* out, int n_ids) {
 }
 
 namespace abr {
+bool x6_guard_enabled() {
+    static const bool on = !(getenv("ABR_X6_GUARD") && atoi(getenv("ABR_X6_GUARD")) == 0);
+    return on;
+}
 unsigned* x6_flags_ptr() {
     static unsigned* p = nullptr;
     if (!p) {

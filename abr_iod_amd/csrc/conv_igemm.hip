@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
     // the A rows by the workgroups of the first n-tile column, the weights by those of the first m-tile row (a workgroup-uniform
     // branch; the other workgroups pay nothing).  bmin: smallest (bits << 1) - 1 seen (zero wraps to 0xFFFFFFFF and never wins);
     // nonfin: x * 0 summed (NaN as soon as any element is inf or NaN).
-    const bool chk_a = tile_n == 0, chk_b = tile_m == 0 && !PB;
+    const bool chk_a = p.x6_flags && tile_n == 0, chk_b = p.x6_flags && tile_m == 0 && !PB;
     unsigned bmin = 0xFFFFFFFFu;
     float nonfin = 0.f;
     auto inspect = [&](const u32x4 v) {
@@ -805,8 +805,7 @@ int launch_x6(const ConvP& p, const float* x, const float* w, float* out, hipStr
     q.tiles_pb = q.tiles_m * q.tiles_n;
     if (q.nbatch < 1) q.nbatch = 1;
     q.n_full = q.tiles_pb * q.nbatch; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
-    q.x6_flags = abr::x6_flags_ptr();
-    if (!q.x6_flags) return 1;
+    q.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
     constexpr size_t lds_op = sizeof(__bf16) * 3 * (BM + BN) * LDX;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
     const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const f
     };
     // range guard of the exact split (abr_x6_range_flags): gy is inspected by the workgroups of the first k-tile column, x by those of
     // the first n-tile row -- every operand element once per GEMM, workgroup-uniform branches (see conv_igemm_x6_kernel)
-    const bool chk_g = tile_k == 0, chk_x = tile_n == 0;
+    const bool chk_g = p.x6_flags && tile_k == 0, chk_x = p.x6_flags && tile_n == 0;
     unsigned bmin = 0xFFFFFFFFu;
     float nonfin = 0.f;
     auto inspect = [&](const u32x4 v) {
@@ -624,7 +624,7 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
             attr6 = true;
         }
-        p.x6_flags = abr::x6_flags_ptr();
+        p.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
         const int rec6 = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
         conv_wgrad_x6_kernel<<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
         abr::prof_stop(abr::as_stream(stream), rec6);

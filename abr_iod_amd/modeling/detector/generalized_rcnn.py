@@ -28,7 +28,9 @@ from ..rpn.rpn import build_rpn
 from .._flat import flatten_parameters
 
 
-DEFAULT_CONV_MATH = "f32"
+# Default contraction arithmetic: fp32-accurate on the bf16 matrix cores (admitted by tests/test_gpu_x6_admission.py; range-guarded with
+# an automatic fall-back to the fp32 MFMA kernels, engine/trainer.py::_x6_guard).  ABR_CONV_MATH=f32 selects the fp32 MFMA kernels.
+DEFAULT_CONV_MATH = "bf16x6"
 
 
 class GeneralizedRCNN(nn.Module):

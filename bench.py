@@ -28,6 +28,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense
 PROF_NAMES = ["conv_igemm_kernel<128,128>", "conv_igemm_kernel<128,64>", "conv_igemm_kernel<64,64>", "conv_igemm_kernel<128,64,small_c>",
               "conv_wgrad_kernel", "roi_align_fwd", "roi_align_bwd", "conv_igemm_bf16_kernel", "conv_wgrad_bf16_kernel"]
+# (ids 7 / 8 are the bf16-MFMA kernels of the chosen arithmetic: conv_igemm_x6_kernel / conv_wgrad_x6_kernel -- all tile instances
+#  together -- under --math bf16x6, conv_igemm_bf16_kernel / conv_wgrad_bf16_kernel under --math bf16)
 
 
 def cpu_baseline(model_target, images, targets, n_old):
@@ -63,6 +65,7 @@ def _pmc_traffic(kernel):
     instances.  None when no summary names the kernel."""
     import glob
     prefix = {"conv_igemm_kernel<128,128>": "conv_igemm_kernel<128, 128,", "conv_wgrad_kernel": "conv_wgrad_kernel<",
+              "conv_igemm_x6_kernel": "conv_igemm_x6_kernel<", "conv_wgrad_x6_kernel": "conv_wgrad_x6_kernel",
               "conv_igemm_kernel<64,64>": "conv_igemm_kernel<64, 64,", "conv_igemm_kernel<128,64>": "conv_igemm_kernel<128, 64, 4, 1, false"}.get(kernel)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         hits = [v for k, v in json.load(open(f))["kernels"].items() if prefix and k.startswith(prefix)]
@@ -77,15 +80,18 @@ def roofline(prof, totals, a, elapsed):
     ALL sampled launches (exclusive or overlapped with the other stream: what rocprofv3 --kernel-trace --stats averages too); the
     two kernels with the most time per step are listed, the top one fills the contract's fields.  `whole_step` relates the step's
     executed and algorithmic conv flops to the wall-clock step."""
-    bf16 = a.math != "f32"
-
     def peak_of(name):
-        return (PEAK_BF16_MFMA_TFLOPS / (6.0 if a.math == "bf16x6" else 1.0)) if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
+        if "_x6_" in name:
+            return round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)   # six bf16 MFMA products per fp32 multiply-add
+        return PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
 
     def tf(fl, ms):
         return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0
 
     rows = []
+    if a.math == "bf16x6":
+        prof = [(nm.replace("_bf16_kernel", "_x6_kernel"),) + tuple(rest) for nm, *rest in prof]
+        totals = {k.replace("_bf16_kernel", "_x6_kernel"): v for k, v in totals.items()}
     for name, n, ms, fl, n_o, ms_o, fl_o in prof:
         launches_all, flops_all = totals[name]
         if n + n_o == 0 or "roi_align" in name:
@@ -104,7 +110,7 @@ def roofline(prof, totals, a, elapsed):
     step_s = elapsed / a.steps
     exec_flops_step = sum(v[1] for k, v in totals.items() if "roi_align" not in k) / a.steps
     alg_flops_step = GFLOP_PER_IMG_ARD * 1e9 * a.batch_per_gpu
-    peak_step = PEAK_FP32_MFMA_TFLOPS if not bf16 else None
+    peak_step = PEAK_FP32_MFMA_TFLOPS if a.math == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if a.math == "bf16x6" else None
     r = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": top["peak"], "unit": "TFLOP/s", "frac": top["frac"],
          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
          "launches": "every launch position of the step sampled equally often over the timed region (1 launch in {} per step, rotating; "
@@ -176,11 +182,14 @@ def main():
     ap.add_argument("--task", choices=sorted(TASKS), default="15-5",
                     help="15-5 = BASELINE configs[2] (the metric's configuration); 10-10 with --batch-per-gpu 2 = configs[3]; 10-5 = configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt-math", action="store_true", help="skip the short informational re-run in the bf16x6 (fp32-accurate) arithmetic")
+    ap.add_argument("--no-alt-math", action="store_true", help="skip the short informational re-run on the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--math", choices=["f32", "bf16", "bf16-all", "bf16x6"], default="f32",
-                    help="f32 (default, the BASELINE metric); bf16 = BASELINE.json configs[4]'s bf16 MFMA backbone (cfg.DTYPE bfloat16: operands "
-                         "rounded in-kernel, fp32 accumulate, fp32 tensors); bf16-all = RPN head and layer4 as well.  Not the headline number.")
+    ap.add_argument("--math", choices=["f32", "bf16", "bf16-all", "bf16x6"], default="bf16x6",
+                    help="bf16x6 (default): fp32 tensors, fp32 accumulation, fp32 error bound -- every contraction operand is split EXACTLY into "
+                         "three bf16 terms and the six leading cross products run on the bf16 matrix cores (range-guarded; admitted by "
+                         "tests/test_gpu_x6_admission.py).  f32 = the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32).  bf16 = BASELINE.json "
+                         "configs[4]'s bf16 MFMA backbone (cfg.DTYPE bfloat16: operands ROUNDED to bf16 in-kernel -- reduced precision, never "
+                         "the headline); bf16-all = RPN head and layer4 as well.")
     ap.add_argument("--time-all-kernels", action="store_true", help="event-bracket every conv / ROIAlign launch, not only the dominant kernel")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher self-test: start the ranks, form the process group (gloo when there is no GPU), all-reduce a 1 per rank, print the count")
@@ -226,8 +235,7 @@ def main():
     B = a.batch_per_gpu
     if a.math == "bf16-all":
         os.environ["ABR_BF16_SCOPE"] = "all"
-    if a.math == "bf16x6":
-        os.environ["ABR_CONV_MATH"] = "bf16x6"
+    os.environ["ABR_CONV_MATH"] = "bf16x6" if a.math == "bf16x6" else "f32"
     dist_type, feat, alpha, beta, gamma = TASKS[a.task]
     n_old_cls, n_new_cls = {"15-5": (15, 5), "10-10": (10, 10), "10-5": (10, 5), "19-1": (19, 1)}[a.task]
     cfg_s, cfg_t = make_cfgs(a.task, dist_type=dist_type, feat=feat, alpha=alpha, beta=beta, gamma=gamma, ims_per_batch=B * world,
@@ -291,7 +299,8 @@ def main():
             "metric": "training images/sec (R50-C4 Faster R-CNN + ARD)", "value": round(value, 3), "unit": "img/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-            "dtype": "f32" if a.math == "f32" else "f32 emulated on bf16 MFMA (exact 3-term split, 6 cross products, f32 accumulate); f32 elsewhere"
+            "dtype": "f32" if a.math == "f32" else "f32 (tensors, accumulation and error bound; contractions via an exact 3-term bf16 split of both "
+                                                   "operands, 6 cross products on the bf16 matrix cores, range-guarded)"
             if a.math == "bf16x6" else "bf16 MFMA operands / f32 accumulate / f32 tensors ({}); f32 elsewhere".format(
                 "backbone layer1-3" if a.math == "bf16" else "backbone, RPN head, layer4"),
             "config": {"workload": "BASELINE.json {}: task {} ABR step, --feat {} --dist_type {} (alpha {}, beta {}, gamma {}), "
@@ -302,34 +311,29 @@ def main():
                        "rccl_ranks": rccl_ranks, "collective": "RCCL all-reduce of the flat gradient, 3 buckets, 2 under backward" if world > 1 else None,
                        "gflop_per_img_algorithmic": GFLOP_PER_IMG_ARD},
             "final_losses": {k: round(float(v), 5) for k, v in loss_dict.items()},
-            "conv_roofline_frac_whole_step": round(value / world * GFLOP_PER_IMG_ARD / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
         }
         if prof:
             out["roofline"] = roofline(prof, prof_totals, a, elapsed)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_target, images, targets, len(cfg_t.MODEL.ROI_BOX_HEAD.NAME_OLD_CLASSES))
-        if world == 1 and a.math == "f32" and not a.no_alt_math:
-            # Informational only, AFTER the timed region above and never part of `value`: the same workload in the opt-in bf16x6
-            # arithmetic (fp32 operands split exactly into three bf16 terms, six cross products, fp32 accumulate: DESIGN.md section 5),
-            # which meets every fp32 parity criterion of the test-suite.
-            os.environ["ABR_CONV_MATH"] = "bf16x6"
-            try:
-                ms6, mt6 = build_models(cfg_s, cfg_t, seed=0)
-                opt6 = make_optimizer(cfg_t, mt6)
-                sch6 = make_lr_scheduler(cfg_t, opt6)
-                for _ in range(3):
-                    train_step(ms6, mt6, images, targets, opt6, sch6, cfg_t)
-                torch.cuda.synchronize()
-                t6 = time.perf_counter()
-                for _ in range(10):
-                    l6 = train_step(ms6, mt6, images, targets, opt6, sch6, cfg_t)
-                torch.cuda.synchronize()
-                e6 = time.perf_counter() - t6
-                out["alt_math_bf16x6"] = {"value": round(B * 10 / e6, 3), "unit": "img/s", "ms_per_step": round(1e3 * e6 / 10, 3), "steps": 10,
-                                          "note": "informational: fp32-accurate arithmetic on the bf16 matrix cores (opt-in, ABR_CONV_MATH=bf16x6); "
-                                                  "not the reported value", "final_total_loss": round(float(l6[1].detach()), 5)}
-            finally:
-                os.environ.pop("ABR_CONV_MATH", None)
+        if world == 1 and a.math == "bf16x6" and not a.no_alt_math:
+            # Informational only, AFTER the timed region above and never part of `value`: the same workload on the fp32 MFMA kernels
+            # (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) -- the arithmetic of round 1's headline, for comparison.
+            os.environ["ABR_CONV_MATH"] = "f32"
+            ms6, mt6 = build_models(cfg_s, cfg_t, seed=0)
+            opt6 = make_optimizer(cfg_t, mt6)
+            sch6 = make_lr_scheduler(cfg_t, opt6)
+            for _ in range(3):
+                train_step(ms6, mt6, images, targets, opt6, sch6, cfg_t)
+            torch.cuda.synchronize()
+            t6 = time.perf_counter()
+            for _ in range(10):
+                l6 = train_step(ms6, mt6, images, targets, opt6, sch6, cfg_t)
+            torch.cuda.synchronize()
+            e6 = time.perf_counter() - t6
+            out["alt_math_f32_mfma"] = {"value": round(B * 10 / e6, 3), "unit": "img/s", "ms_per_step": round(1e3 * e6 / 10, 3), "steps": 10,
+                                        "note": "informational: the same step on the fp32 MFMA kernels (ABR_CONV_MATH=f32); not the reported value",
+                                        "final_total_loss": round(float(l6[1].detach()), 5)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

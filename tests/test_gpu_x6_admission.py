@@ -54,11 +54,11 @@ def _case(name):
     if name.startswith("exponent spread"):   # exponents spread over 2^+-sp INSIDE every reduction, both operands
         sp = int(name.split("+-")[1])
         return rn(M, K) * torch.exp2((ru(M, K) * 2 - 1) * sp), rn(N, K) * torch.exp2((ru(N, K) * 2 - 1) * sp)
-    if name.startswith("x ~ 2^"):
+    if name.startswith("x ~ 2^"):             # magnitudes in [0.5, 1.5) * 2^e, random signs: every element inside the domain
         e = int(name.split("^")[1])
-        return rn(M, K) * 2.0 ** e, rn(N, K) * (2.0 ** -10 if e > 0 else 1.0)
+        return torch.sign(rn(M, K)) * (0.5 + ru(M, K)) * 2.0 ** e, rn(N, K) * (2.0 ** -10 if e > 0 else 1.0)
     if name == "x, w ~ 2^-60":
-        return rn(M, K) * 2.0 ** -60, rn(N, K) * 2.0 ** -60
+        return torch.sign(rn(M, K)) * (0.5 + ru(M, K)) * 2.0 ** -60, torch.sign(rn(N, K)) * (0.5 + ru(N, K)) * 2.0 ** -60
     if name == "cancellation to 2^-12":       # pairs (u, -u(1 + 2^-12 r)) against equal x
         v, u = rn(M, K // 2), rn(N, K // 2)
         return torch.stack([v, v], 2).reshape(M, K), torch.stack([u, -u * (1 + 2.0 ** -12 * rn(N, K // 2))], 2).reshape(N, K)
@@ -144,7 +144,7 @@ def test_out_of_domain_magnitudes_raise_the_flag(which):
     assert ops.x6_range_flags(reset=True) == ops.X6_FLAG_TINY
     assert ops.x6_range_flags(reset=True) == 0             # reset worked
     if which != "tiny weight":
-        _wgrad(x[:, :N].contiguous(), rn(M, N), ops.MATH_BF16X6)
+        _wgrad(x[:, K - N:].contiguous(), rn(M, N), ops.MATH_BF16X6)
         assert ops.x6_range_flags(reset=True) == ops.X6_FLAG_TINY
         _wgrad(rn(M, N), x[:, K - N:].contiguous(), ops.MATH_BF16X6)   # the tiny operand in the OTHER role (gy)
         assert ops.x6_range_flags(reset=True) == ops.X6_FLAG_TINY
@@ -162,7 +162,7 @@ def test_non_finite_operands_propagate_and_raise_the_flag():
     bad = ~torch.isfinite(y32)
     assert bad.any(dim=1).nonzero().flatten().tolist() == [3, 7, 11]
     assert torch.equal(~torch.isfinite(y6), bad)                       # non-finiteness reaches exactly the same outputs
-    assert torch.allclose(y6[~bad], y32[~bad], rtol=1e-5, atol=1e-5)    # and nothing else is disturbed
+    assert torch.allclose(y6[~bad], y32[~bad], rtol=1e-5, atol=2e-4)    # and nothing else is disturbed (|y| ~ 32, K = 1024)
     w2 = w.clone(); w2[5, 7] = float("nan")
     y6 = _gemm(rn(M, K), w2, ops.MATH_BF16X6)
     assert ops.x6_range_flags(reset=True) == ops.X6_FLAG_NONFINITE
