@@ -31,6 +31,7 @@ class ConvDesc(C.Structure):
         ("wino_v", _vp),
         ("w_planes", _vp),
         ("w_plane_stride", _i64),
+        ("w_version", _i64),
     ]
 
 

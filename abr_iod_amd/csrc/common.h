@@ -75,6 +75,9 @@ int wino_output_transform(const float* M, int B, int H, int W, int N, const floa
 int wino_outgrad_transform(const float* gy, int B, int H, int W, int N, float* Mg, hipStream_t st);
 int wino_wgrad_inverse(const float* dU, int N, int C, const float* scale, float* dw, hipStream_t st);
 float* wino_ws(hipStream_t st, size_t floats);
+// cached Winograd-domain weights U [36][N][C] of the tensor at `w` (abr_conv_desc::w_version != 0), transformed on `st` when (w, version)
+// has not been seen; nullptr = no memory (transform into scratch instead)
+float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t st);
 
 // bf16x6 range guard (see abr_x6_range_flags in include/abr_iod_hip.h).  The flag word lives in device memory owned by common.hip.
 unsigned* x6_flags_ptr();

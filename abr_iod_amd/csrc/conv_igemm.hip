@@ -81,6 +81,7 @@ struct ConvP {
     const void* w_planes;  // bf16x6: pre-split weight planes (abr_conv_desc::w_planes), or NULL
     unsigned w_plane_bytes;  // distance between two planes
     unsigned* x6_flags;      // bf16x6: device word of the range guard (abr::x6_flags_ptr)
+    int64_t w_version;       // abr_conv_desc::w_version (0 = nothing derived from w may be cached)
 };
 
 
@@ -1026,11 +1027,14 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
     const int64_t T = (int64_t)p.B * th_n * tw_n;
     const size_t nV = (size_t)36 * T * p.Cin, nU = (size_t)36 * p.Cout * p.Cin, nM = (size_t)36 * T * p.Cout;
     if (T * (int64_t)std::max(p.Cin, p.Cout) * 4 >= (int64_t)0x7FFFFFF0) return false;
-    float* ws = abr::wino_ws(st, (p.v_out ? 0 : nV) + nU + nM);
+    // Winograd-domain weights: from the per-weight cache when the caller vouches for (w, w_version), else transformed into scratch
+    float* Uc = p.w_version ? abr::wino_u_cached(w, p.Cout, p.Cin, p.w_version, st) : nullptr;
+    float* ws = abr::wino_ws(st, (p.v_out ? 0 : nV) + (Uc ? 0 : nU) + nM);
     if (!ws) return false;
     float* V = p.v_out ? p.v_out : ws;
-    float *U = ws + (p.v_out ? 0 : nV), *Mm = U + nU;
-    if (abr::wino_weight_transform(w, p.Cout, p.Cin, U, st)) return false;
+    float* U = Uc ? Uc : ws + (p.v_out ? 0 : nV);
+    float* Mm = ws + (p.v_out ? 0 : nV) + (Uc ? 0 : nU);
+    if (!Uc && abr::wino_weight_transform(w, p.Cout, p.Cin, U, st)) return false;
     if (abr::wino_input_transform(x, p.B, p.H, p.W, p.Cin, V, st)) return false;
     ConvP g = p;
     g.B = (int)T; g.H = g.W = 1; g.R = g.S = 1; g.stride = 1; g.pad = 0; g.Ho = g.Wo = 1;
@@ -1086,6 +1090,7 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     p.tiles_m = p.tiles_n = 0;
     p.nbatch = 1; p.tiles_pb = 0; p.a_bs = p.w_bs = p.o_bs = 0;
     p.v_out = d->wino_v;
+    p.w_version = d->w_version;
     p.w_planes = d->math == ABR_MATH_BF16X6 ? d->w_planes : nullptr;
     const int64_t wps = d->w_plane_stride > 0 ? d->w_plane_stride : (int64_t)d->Cout * d->R * d->S * d->Cin;
     ABR_REQUIRE(!p.w_planes || (wps >= (int64_t)d->Cout * d->R * d->S * d->Cin && wps * 4 + (int64_t)d->Cout * d->R * d->S * d->Cin * 2 < (int64_t)0xFFFFFFF0),

@@ -19,17 +19,56 @@
 
 namespace {
 
-// The transforms work on TWO adjacent channels per thread (8 B loads / stores, half the memory instructions of a scalar version;
-// four channels would need > 200 VGPRs for the 6x6 tile).
-struct f2 {
-    float x, y;
+// The transforms work on V adjacent channels per thread: V = 4 (16 B loads / stores per lane, the width at which the memory pipe
+// reaches its peak -- cdna_hip_programming.md) whenever the channel count allows, V = 2 otherwise.  A 6x6 tile of float4 is 144
+// live VGPRs: two waves per SIMD, each with 36 independent 16 B loads in flight, which is plenty for a streaming kernel.
+template <int V>
+struct vf {
+    float v[V];
 };
-__device__ __forceinline__ f2 operator+(f2 a, f2 b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ f2 operator-(f2 a, f2 b) { return {a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ f2 operator-(f2 a) { return {-a.x, -a.y}; }
-__device__ __forceinline__ f2 operator*(float s, f2 a) { return {s * a.x, s * a.y}; }
-__device__ __forceinline__ f2 ld2(const float* p) { const float2 v = *reinterpret_cast<const float2*>(p); return {v.x, v.y}; }
-__device__ __forceinline__ void st2(float* p, f2 v) { *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y); }
+template <int V>
+__device__ __forceinline__ vf<V> operator+(vf<V> a, vf<V> b) {
+    vf<V> r;
+#pragma unroll
+    for (int i = 0; i < V; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+template <int V>
+__device__ __forceinline__ vf<V> operator-(vf<V> a, vf<V> b) {
+    vf<V> r;
+#pragma unroll
+    for (int i = 0; i < V; i++) r.v[i] = a.v[i] - b.v[i];
+    return r;
+}
+template <int V>
+__device__ __forceinline__ vf<V> operator-(vf<V> a) {
+    vf<V> r;
+#pragma unroll
+    for (int i = 0; i < V; i++) r.v[i] = -a.v[i];
+    return r;
+}
+template <int V>
+__device__ __forceinline__ vf<V> operator*(float s, vf<V> a) {
+    vf<V> r;
+#pragma unroll
+    for (int i = 0; i < V; i++) r.v[i] = s * a.v[i];
+    return r;
+}
+template <int V>
+__device__ __forceinline__ vf<V> vzero() {
+    vf<V> r;
+#pragma unroll
+    for (int i = 0; i < V; i++) r.v[i] = 0.f;
+    return r;
+}
+template <int V>
+__device__ __forceinline__ vf<V> vld(const float* p);
+template <>
+__device__ __forceinline__ vf<2> vld<2>(const float* p) { const float2 t = *reinterpret_cast<const float2*>(p); return {{t.x, t.y}}; }
+template <>
+__device__ __forceinline__ vf<4> vld<4>(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); return {{t.x, t.y, t.z, t.w}}; }
+__device__ __forceinline__ void vst(float* p, vf<2> a) { *reinterpret_cast<float2*>(p) = make_float2(a.v[0], a.v[1]); }
+__device__ __forceinline__ void vst(float* p, vf<4> a) { *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]); }
 
 // B^T (6x6), applied to columns then rows
 template <typename T>
@@ -43,15 +82,17 @@ __device__ __forceinline__ void bt6(const T d0, const T d1, const T d2, const T 
     o5 = 4.f * d1 - 5.f * d3 + d5;
 }
 
-// grid-stride over (tile, channel pair); consecutive threads = consecutive channel pairs (coalesced 512 B per wave)
+// grid-stride over (tile, channel group); consecutive threads = consecutive channel groups (coalesced 1 KB per wave at V = 4)
+template <int V>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int B, int H, int W, int C, int th_n, int tw_n,
-                                                         float* __restrict__ V) {
+                                                         float* __restrict__ Vo) {
+    typedef vf<V> f2;
     const int64_t T = (int64_t)B * th_n * tw_n;
-    const int C2 = C / 2;
+    const int C2 = C / V;
     const int64_t total = T * C2;
     const int64_t ps = T * C;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = 2 * (int)(idx % C2);
+        const int c = V * (int)(idx % C2);
         const int64_t t = idx / C2;
         const int tw = (int)(t % tw_n), th = (int)((t / tw_n) % th_n), b = (int)(t / ((int64_t)tw_n * th_n));
         const int y0 = 4 * th - 1, x0 = 4 * tw - 1;
@@ -64,7 +105,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 const int y = y0 + i;
-                d[i] = (xin && (unsigned)y < (unsigned)H) ? ld2(x + (((int64_t)b * H + y) * W + xx) * C + c) : f2{0.f, 0.f};
+                d[i] = (xin && (unsigned)y < (unsigned)H) ? vld<V>(x + (((int64_t)b * H + y) * W + xx) * C + c) : vzero<V>();
             }
             bt6(d[0], d[1], d[2], d[3], d[4], d[5], tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j], tcol[4][j], tcol[5][j]);
         }
@@ -72,15 +113,15 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         for (int i = 0; i < 6; i++) {  // (B^T d) B : the same combination along the row
             f2 v0, v1, v2, v3, v4, v5;
             bt6(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], tcol[i][4], tcol[i][5], v0, v1, v2, v3, v4, v5);
-            float* o = V + ((int64_t)(6 * i) * T + t) * C + c;
-            st2(o, v0); st2(o + ps, v1); st2(o + 2 * ps, v2); st2(o + 3 * ps, v3); st2(o + 4 * ps, v4); st2(o + 5 * ps, v5);
+            float* o = Vo + ((int64_t)(6 * i) * T + t) * C + c;
+            vst(o, v0); vst(o + ps, v1); vst(o + 2 * ps, v2); vst(o + 3 * ps, v3); vst(o + 4 * ps, v4); vst(o + 5 * ps, v5);
         }
     }
 }
 
 // G (6x3) on a 3-vector
-__device__ __forceinline__ void g6(const float g0, const float g1, const float g2, float& o0, float& o1, float& o2, float& o3, float& o4,
-                                   float& o5) {
+template <typename T>
+__device__ __forceinline__ void g6(const T g0, const T g1, const T g2, T& o0, T& o1, T& o2, T& o3, T& o4, T& o5) {
     o0 = 0.25f * g0;
     o1 = (-1.f / 6.f) * (g0 + g1 + g2);
     o2 = (-1.f / 6.f) * (g0 - g1 + g2);
@@ -89,27 +130,30 @@ __device__ __forceinline__ void g6(const float g0, const float g1, const float g
     o5 = g2;
 }
 
-// w [N][3][3][C] (OHWI) -> U [36][N][C]
+// w [N][3][3][C] (OHWI) -> U [36][N][C]; V input channels per thread
+template <int V>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int N, int C, float* __restrict__ U) {
-    const int64_t total = (int64_t)N * C;
+    typedef vf<V> fv;
+    const int Cv = C / V;
+    const int64_t total = (int64_t)N * Cv;
+    const int64_t ps = (int64_t)N * C;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const int64_t n = idx / C;
-        float g[3][3];
+        const int c = V * (int)(idx % Cv);
+        const int64_t n = idx / Cv;
+        fv g[3][3];
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int s = 0; s < 3; s++) g[r][s] = w[((n * 3 + r) * 3 + s) * C + c];
-        float t[6][3];  // G g
+            for (int q = 0; q < 3; q++) g[r][q] = vld<V>(w + ((n * 3 + r) * 3 + q) * C + c);
+        fv t[6][3];  // G g
 #pragma unroll
-        for (int s = 0; s < 3; s++) g6(g[0][s], g[1][s], g[2][s], t[0][s], t[1][s], t[2][s], t[3][s], t[4][s], t[5][s]);
+        for (int q = 0; q < 3; q++) g6(g[0][q], g[1][q], g[2][q], t[0][q], t[1][q], t[2][q], t[3][q], t[4][q], t[5][q]);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            float u0, u1, u2, u3, u4, u5;
+            fv u0, u1, u2, u3, u4, u5;
             g6(t[i][0], t[i][1], t[i][2], u0, u1, u2, u3, u4, u5);
             float* o = U + ((int64_t)(6 * i) * N + n) * C + c;
-            const int64_t ps = (int64_t)N * C;
-            o[0] = u0; o[ps] = u1; o[2 * ps] = u2; o[3 * ps] = u3; o[4 * ps] = u4; o[5 * ps] = u5;
+            vst(o, u0); vst(o + ps, u1); vst(o + 2 * ps, u2); vst(o + 3 * ps, u3); vst(o + 4 * ps, u4); vst(o + 5 * ps, u5);
         }
     }
 }
@@ -124,25 +168,29 @@ __device__ __forceinline__ void at4(const T m0, const T m1, const T m2, const T 
     o3 = d12 + 8.f * d34 + m5;
 }
 
-// M [36][T][N] -> out [B,H,W,N] with the conv epilogue (scale, bias, ReLU, ReLU mask of the producer); two channels per thread
+// M [36][T][N] -> out [B,H,W,N] with the conv epilogue (scale, bias, ReLU, ReLU mask of the producer); V channels per thread
+template <int V>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mm, int B, int H, int W, int N, int th_n, int tw_n,
                                                           const float* __restrict__ scale, const float* __restrict__ bias, int relu,
                                                           const float* __restrict__ mask, float* __restrict__ out) {
+    typedef vf<V> f2;
     const int64_t T = (int64_t)B * th_n * tw_n;
-    const int N2 = N / 2;
+    const int N2 = N / V;
     const int64_t total = T * N2;
     const int64_t ps = T * N;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int n = 2 * (int)(idx % N2);
+        const int n = V * (int)(idx % N2);
         const int64_t t = idx / N2;
         const int tw = (int)(t % tw_n), th = (int)((t / tw_n) % th_n), b = (int)(t / ((int64_t)tw_n * th_n));
         const float* m = Mm + t * N + n;
         f2 tcol[4][6];  // A^T M
 #pragma unroll
         for (int j = 0; j < 6; j++)
-            at4(ld2(m + (0 + j) * ps), ld2(m + (6 + j) * ps), ld2(m + (12 + j) * ps), ld2(m + (18 + j) * ps), ld2(m + (24 + j) * ps),
-                ld2(m + (30 + j) * ps), tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j]);
-        const f2 sc = scale ? ld2(scale + n) : f2{1.f, 1.f}, bi = bias ? ld2(bias + n) : f2{0.f, 0.f};
+            at4(vld<V>(m + (0 + j) * ps), vld<V>(m + (6 + j) * ps), vld<V>(m + (12 + j) * ps), vld<V>(m + (18 + j) * ps), vld<V>(m + (24 + j) * ps),
+                vld<V>(m + (30 + j) * ps), tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j]);
+        f2 sc, bi;
+#pragma unroll
+        for (int e = 0; e < V; e++) { sc.v[e] = scale ? scale[n + e] : 1.f; bi.v[e] = bias ? bias[n + e] : 0.f; }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             f2 y[4];
@@ -154,13 +202,18 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                 const int ox = 4 * tw + j;
                 if (ox >= W) continue;
                 const int64_t o = (((int64_t)b * H + oy) * W + ox) * N + n;
-                f2 v = {y[j].x * sc.x + bi.x, y[j].y * sc.y + bi.y};
-                if (relu) v = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)};
-                if (mask) {
-                    const f2 mk = ld2(mask + o);
-                    v = {mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f};
+                f2 v;
+#pragma unroll
+                for (int e = 0; e < V; e++) {
+                    v.v[e] = y[j].v[e] * sc.v[e] + bi.v[e];
+                    if (relu) v.v[e] = fmaxf(v.v[e], 0.f);
                 }
-                st2(out + o, v);
+                if (mask) {
+                    const f2 mk = vld<V>(mask + o);
+#pragma unroll
+                    for (int e = 0; e < V; e++) v.v[e] = mk.v[e] > 0.f ? v.v[e] : 0.f;
+                }
+                vst(out + o, v);
             }
         }
     }
@@ -178,14 +231,16 @@ __device__ __forceinline__ void a6(const T y0, const T y1, const T y2, const T y
 }
 
 // weight gradient, step 1: gy [B,H,W,N] -> Mg [36][T][N] = A dY A^T per 4x4 output tile (zeros beyond the image)
+template <int V>
 __global__ __launch_bounds__(256) void wino_outgrad_kernel(const float* __restrict__ gy, int B, int H, int W, int N, int th_n, int tw_n,
                                                            float* __restrict__ Mg) {
+    typedef vf<V> f2;
     const int64_t T = (int64_t)B * th_n * tw_n;
-    const int N2 = N / 2;
+    const int N2 = N / V;
     const int64_t total = T * N2;
     const int64_t ps = T * N;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int n = 2 * (int)(idx % N2);
+        const int n = V * (int)(idx % N2);
         const int64_t t = idx / N2;
         const int tw = (int)(t % tw_n), th = (int)((t / tw_n) % th_n), b = (int)(t / ((int64_t)tw_n * th_n));
         f2 tcol[6][4];  // A dY
@@ -196,7 +251,7 @@ __global__ __launch_bounds__(256) void wino_outgrad_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int oy = 4 * th + i;
-                y[i] = (oy < H && ox < W) ? ld2(gy + (((int64_t)b * H + oy) * W + ox) * N + n) : f2{0.f, 0.f};
+                y[i] = (oy < H && ox < W) ? vld<V>(gy + (((int64_t)b * H + oy) * W + ox) * N + n) : vzero<V>();
             }
             a6(y[0], y[1], y[2], y[3], tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j], tcol[4][j], tcol[5][j]);
         }
@@ -205,40 +260,43 @@ __global__ __launch_bounds__(256) void wino_outgrad_kernel(const float* __restri
             f2 v0, v1, v2, v3, v4, v5;
             a6(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], v0, v1, v2, v3, v4, v5);
             float* o = Mg + ((int64_t)(6 * i) * T + t) * N + n;
-            st2(o, v0); st2(o + ps, v1); st2(o + 2 * ps, v2); st2(o + 3 * ps, v3); st2(o + 4 * ps, v4); st2(o + 5 * ps, v5);
+            vst(o, v0); vst(o + ps, v1); vst(o + 2 * ps, v2); vst(o + 3 * ps, v3); vst(o + 4 * ps, v4); vst(o + 5 * ps, v5);
         }
     }
 }
 
 // G^T (3x6) on a 6-vector
-__device__ __forceinline__ void gt3(const float u0, const float u1, const float u2, const float u3, const float u4, const float u5, float& o0,
-                                    float& o1, float& o2) {
+template <typename T>
+__device__ __forceinline__ void gt3(const T u0, const T u1, const T u2, const T u3, const T u4, const T u5, T& o0, T& o1, T& o2) {
     o0 = 0.25f * u0 - (1.f / 6.f) * (u1 + u2) + (1.f / 24.f) * (u3 + u4);
     o1 = (1.f / 6.f) * (u2 - u1) + (1.f / 12.f) * (u3 - u4);
     o2 = (1.f / 6.f) * (u3 + u4 - u1 - u2) + u5;
 }
 
-// weight gradient, step 3: dU [36][N][C] -> dw [N][3][3][C] += scale[n] * G^T dU G
+// weight gradient, step 3: dU [36][N][C] -> dw [N][3][3][C] += scale[n] * G^T dU G; V input channels per thread
+template <int V>
 __global__ __launch_bounds__(256) void wino_wgrad_inverse_kernel(const float* __restrict__ dU, int N, int C, const float* __restrict__ scale,
                                                                  float* __restrict__ dw) {
-    const int64_t total = (int64_t)N * C;
-    const int64_t ps = total;
+    typedef vf<V> fv;
+    const int Cv = C / V;
+    const int64_t total = (int64_t)N * Cv;
+    const int64_t ps = (int64_t)N * C;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const int64_t n = idx / C;
-        const float* u = dU + idx;
-        float tcol[3][6];  // G^T dU
+        const int c = V * (int)(idx % Cv);
+        const int64_t n = idx / Cv;
+        const float* u = dU + n * C + c;
+        fv tcol[3][6];  // G^T dU
 #pragma unroll
         for (int j = 0; j < 6; j++)
-            gt3(u[(0 + j) * ps], u[(6 + j) * ps], u[(12 + j) * ps], u[(18 + j) * ps], u[(24 + j) * ps], u[(30 + j) * ps], tcol[0][j], tcol[1][j],
-                tcol[2][j]);
+            gt3(vld<V>(u + (0 + j) * ps), vld<V>(u + (6 + j) * ps), vld<V>(u + (12 + j) * ps), vld<V>(u + (18 + j) * ps), vld<V>(u + (24 + j) * ps),
+                vld<V>(u + (30 + j) * ps), tcol[0][j], tcol[1][j], tcol[2][j]);
         const float sc = scale ? scale[n] : 1.f;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            float g0, g1, g2;
+            fv g0, g1, g2;
             gt3(tcol[r][0], tcol[r][1], tcol[r][2], tcol[r][3], tcol[r][4], tcol[r][5], g0, g1, g2);
             float* o = dw + ((n * 3 + r) * 3) * C + c;
-            o[0] += sc * g0; o[C] += sc * g1; o[2 * C] += sc * g2;
+            vst(o, vld<V>(o) + sc * g0); vst(o + C, vld<V>(o + C) + sc * g1); vst(o + 2 * C, vld<V>(o + 2 * C) + sc * g2);
         }
     }
 }
@@ -249,32 +307,40 @@ inline unsigned grid_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 25
 
 namespace abr {
 
+// V = 4 needs C % 4 == 0 (16 B alignment of every row of every tensor involved: all of them have C as their innermost pitch)
 int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, hipStream_t st) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
-    wino_input_kernel<<<grid_for((int64_t)B * th_n * tw_n * (C / 2)), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V);
+    if (C % 4 == 0) wino_input_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (C / 4)), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V);
+    else wino_input_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (C / 2)), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st) {
-    wino_weight_kernel<<<grid_for((int64_t)N * C), 256, 0, st>>>(w, N, C, U);
+    if (C % 4 == 0) wino_weight_kernel<4><<<grid_for((int64_t)N * (C / 4)), 256, 0, st>>>(w, N, C, U);
+    else wino_weight_kernel<2><<<grid_for((int64_t)N * (C / 2)), 256, 0, st>>>(w, N, C, U);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int wino_output_transform(const float* Mm, int B, int H, int W, int N, const float* scale, const float* bias, int relu, const float* mask,
                           float* out, hipStream_t st) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
-    wino_output_kernel<<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out);
+    if (N % 4 == 0)
+        wino_output_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (N / 4)), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out);
+    else
+        wino_output_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int wino_outgrad_transform(const float* gy, int B, int H, int W, int N, float* Mg, hipStream_t st) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
-    wino_outgrad_kernel<<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg);
+    if (N % 4 == 0) wino_outgrad_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (N / 4)), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg);
+    else wino_outgrad_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int wino_wgrad_inverse(const float* dU, int N, int C, const float* scale, float* dw, hipStream_t st) {
-    wino_wgrad_inverse_kernel<<<grid_for((int64_t)N * C), 256, 0, st>>>(dU, N, C, scale, dw);
+    if (C % 4 == 0) wino_wgrad_inverse_kernel<4><<<grid_for((int64_t)N * (C / 4)), 256, 0, st>>>(dU, N, C, scale, dw);
+    else wino_wgrad_inverse_kernel<2><<<grid_for((int64_t)N * (C / 2)), 256, 0, st>>>(dU, N, C, scale, dw);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -289,6 +355,36 @@ float* wino_ws(hipStream_t st, size_t floats) {
         w.floats = floats;
     }
     return w.buf;
+}
+
+// Winograd-domain weights U kept per weight tensor (abr_conv_desc::w_version).  One entry per weight address; a new version refills the
+// same buffer.  The users of one entry are expected on one stream (forward / dgrad convs run on the caller's main stream); a hit
+// from another stream is ordered behind the fill through an event.  Returns nullptr when there is no memory (caller uses scratch).
+float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t st) {
+    struct Entry { float* buf = nullptr; size_t floats = 0; int64_t version = 0; hipStream_t stream = nullptr; hipEvent_t filled = nullptr; };
+    static std::map<const float*, Entry> cache;
+    const size_t floats = (size_t)36 * N * C;
+    Entry& e = cache[w];
+    if (e.buf && e.floats != floats) {   // the address now holds a different weight tensor
+        (void)hipStreamSynchronize(e.stream);
+        (void)hipFree(e.buf);
+        e.buf = nullptr; e.version = 0;
+    }
+    if (!e.buf) {
+        if (hipMalloc(&e.buf, floats * sizeof(float)) != hipSuccess) { e.buf = nullptr; return nullptr; }
+        e.floats = floats;
+        if (!e.filled) (void)hipEventCreateWithFlags(&e.filled, hipEventDisableTiming);
+    }
+    if (e.version == version) {
+        if (st != e.stream) (void)hipStreamWaitEvent(st, e.filled, 0);
+        return e.buf;
+    }
+    if (e.stream && st != e.stream) (void)hipStreamSynchronize(e.stream);   // readers of the previous version on another stream
+    if (wino_weight_transform(w, N, C, e.buf, st)) return nullptr;
+    (void)hipEventRecord(e.filled, st);
+    e.version = version;
+    e.stream = st;
+    return e.buf;
 }
 
 }  // namespace abr

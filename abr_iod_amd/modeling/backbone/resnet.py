@@ -33,11 +33,22 @@ ResNet50StagesTo5 = tuple(StageSpec(index=i, block_count=c, return_features=r) f
 # launches): under real data the x6 loop is bound by the matrix pipe's sustained clock, not by the split's VALU work -- off by default.
 X6_WEIGHT_PLANES = os.environ.get("ABR_X6_WEIGHT_PLANES", "0") != "0"
 
-# bumped by the optimiser after every step: cached dgrad weight copies are rebuilt lazily when stale
+# Weight versions: data derived from a weight tensor (the flipped dgrad copies, the library's Winograd-domain weights: abr_conv_desc::
+# w_version) is rebuilt lazily when its version is stale.  _PARAM_VERSION moves with EVERY change (optimiser steps, loads, in-place
+# surgery), _STATIC_VERSION only with changes that can touch weights no optimiser owns (loads, surgery, model construction): the
+# frozen source model's derived data therefore survives the target's optimiser steps.  Code that writes weights in place must call
+# bump_param_version().
 _PARAM_VERSION = [0]
+_STATIC_VERSION = [0]
 
 
 def bump_param_version():
+    _PARAM_VERSION[0] += 1
+    _STATIC_VERSION[0] += 1
+
+
+def bump_trained_version():
+    """after an optimiser step: only tensors an optimiser owns (Conv2d._optimised) have changed"""
     _PARAM_VERSION[0] += 1
 
 
@@ -55,6 +66,7 @@ class Conv2d(nn.Module):
         self._wt = None
         self._wt_version = -1
         self._wtp = None          # bf16x3 planes of the dgrad copy (bf16x6 arithmetic)
+        self._optimised = False   # set by FusedSGD for the convs it updates: their version moves with every optimiser step
         self._flat = None         # the model's FlatParams (set by GeneralizedRCNN.flatten_parameters): source of weight planes
 
     def kaiming_uniform_(self, a=1):
@@ -86,6 +98,10 @@ class Conv2d(nn.Module):
             self._wt = ops.conv_dgrad_weights(self.weight.detach(), scale, out=self._wt if same else None, planes=self._wtp if planes else None)
             self._wt_version = _PARAM_VERSION[0]
         return self._wt
+
+    def version(self):
+        """abr_conv_desc::w_version for this conv's weight and for its dgrad copy: non-zero, changes whenever the values may have"""
+        return 2 * _PARAM_VERSION[0] + 1 if self._optimised else 2 * _STATIC_VERSION[0] + 2
 
     def weight_planes(self):
         """(plane-0 view of this weight inside the model's split parameter buffer, elements between planes) or (None, 0)"""
@@ -129,14 +145,14 @@ class Bottleneck(nn.Module):
             pl, st = conv.weight_planes()
             if pl is not None:
                 kw.update(w_planes=pl, w_plane_stride=st)
-        return ops.conv_forward(x, conv.weight, stride, pad, math=self.math, **kw)
+        return ops.conv_forward(x, conv.weight, stride, pad, math=self.math, w_version=conv.version(), **kw)
 
     def _dgrad(self, g, conv, scale, pad, **kw):
         x6 = X6_WEIGHT_PLANES and self.math == ops.MATH_BF16X6
         wt = conv.dgrad_weight(scale, planes=x6)
         if x6:
             kw.update(w_planes=conv._wtp)
-        return ops.conv_forward(g, wt, 1, pad, math=self.math, **kw)
+        return ops.conv_forward(g, wt, 1, pad, math=self.math, w_version=conv.version(), **kw)
 
     # x, returns NHWC tensors.  `stride` may be overridden to 1 when the caller already sub-sampled (bin_step=2 ROIAlign)
     def fwd(self, x, save, stride=None):

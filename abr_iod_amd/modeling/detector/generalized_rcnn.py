@@ -69,7 +69,8 @@ class GeneralizedRCNN(nn.Module):
     # --- storage: one flat fp32 buffer for parameters, one for gradients (RCCL all-reduce + fused SGD work on them)
     def flatten_parameters(self):
         self.flat = flatten_parameters(self)
-        from ..backbone.resnet import Conv2d
+        from ..backbone.resnet import Conv2d, bump_param_version
+        bump_param_version()   # new weight storage: nothing derived from an earlier tensor at the same address may be reused
         for m in self.modules():
             if isinstance(m, Conv2d):
                 m._flat = self.flat
@@ -78,7 +79,8 @@ class GeneralizedRCNN(nn.Module):
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         if self.flat is not None and next(self.parameters()).device != self.flat.params.device:
-            self.flat = flatten_parameters(self)
+            # a device move: NEW flat buffers (an optimiser built on the old ones refuses to step: FusedSGD.step), convs re-pointed
+            self.flatten_parameters()
         return out
 
     def forward(self, images, targets=None, rpn_output_source=None, features=None, proposals=None):

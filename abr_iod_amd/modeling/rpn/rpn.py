@@ -103,7 +103,7 @@ class _RPNHeadFn(Function):
     def forward(ctx, x, head, *params):
         xh = as_nhwc(x)
         v = ops.wino_v_alloc(xh, head.conv.weight, 1, 1, head.math) if head.conv.weight.requires_grad else None
-        t = ops.conv_forward(xh, head.conv.weight, 1, 1, bias=head.conv.bias, relu=True, math=head.math, wino_v=v)
+        t = ops.conv_forward(xh, head.conv.weight, 1, 1, bias=head.conv.bias, relu=True, math=head.math, wino_v=v, w_version=head.conv.version())
         y = ops.conv_forward(t, head.fused_weight, 1, 0, bias=head.fused_bias, math=head.math)
         ctx.head, ctx.saved = head, (xh, t, v)
         ctx.need_dx = x.requires_grad
@@ -121,7 +121,7 @@ class _RPNHeadFn(Function):
         gt = ops.conv_forward(g, head.fused_dgrad_weight(), 1, 0, mask=t, math=head.math)   # (reduction width 76: exact fp32 either way)
         ops.conv_wgrad_async(xh, gt, _grad_buf(head.conv.weight), 1, 1, math=head.math, wino_v=v)
         ops.bias_grad(gt, _grad_buf(head.conv.bias))
-        gx = from_nhwc(ops.conv_forward(gt, head.conv.dgrad_weight(), 1, 1, math=head.math)) if ctx.need_dx else None
+        gx = from_nhwc(ops.conv_forward(gt, head.conv.dgrad_weight(), 1, 1, math=head.math, w_version=head.conv.version())) if ctx.need_dx else None
         ctx.saved = None
         return (gx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
@@ -205,7 +205,7 @@ class RPNHead(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
             return _RPNHeadFn.apply(x, self, *params)
         xh = as_nhwc(x)
-        t = ops.conv_forward(xh, self.conv.weight, 1, 1, bias=self.conv.bias, relu=True, math=self.math)
+        t = ops.conv_forward(xh, self.conv.weight, 1, 1, bias=self.conv.bias, relu=True, math=self.math, w_version=self.conv.version())
         return from_nhwc(ops.conv_forward(t, self.fused_weight, 1, 0, bias=self.fused_bias, math=self.math))
 
     def forward(self, x):

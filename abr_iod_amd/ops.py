@@ -269,7 +269,7 @@ def wino_v_alloc(x, w, stride, pad, math=MATH_F32):
 
 
 def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, mask=None, relu=False,
-                 out=None, out_hw=None, out_stride=(1, 1), math=MATH_F32, wino_v=None, w_planes=None, w_plane_stride=0):
+                 out=None, out_hw=None, out_stride=(1, 1), math=MATH_F32, wino_v=None, w_planes=None, w_plane_stride=0, w_version=0):
     """x [B,H,W,Cin] NHWC, w [Cout,R,S,Cin] OHWI -> [B,Ho,Wo,Cout] (or scattered into `out` [B,out_H,out_W,Cout]).
     math=MATH_BF16: operands rounded to bf16 inside the kernel, bf16 MFMA, fp32 accumulate (fp32 tensors in and out)."""
     L.require_cuda(x, w)
@@ -277,6 +277,7 @@ def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, ma
     d = conv_desc(x.shape, w.shape, stride, pad, scale, bias, residual, mask, relu, out_hw, out_stride, math)
     d.wino_v = L.ptr(wino_v)
     d.w_planes, d.w_plane_stride = L.ptr(w_planes), int(w_plane_stride)
+    d.w_version = int(w_version)   # non-zero: the library may keep data derived from (w, w_version) -- the Winograd-domain weights
     if out is None:
         if out_hw is not None:
             out = torch.zeros((d.B, d.out_H, d.out_W, d.Cout), dtype=_f32, device=x.device)

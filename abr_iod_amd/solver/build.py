@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 
 from .. import ops
-from ..modeling.backbone.resnet import bump_param_version
+from ..modeling.backbone.resnet import Conv2d, bump_trained_version
 from .grad_reducer import GradReducer
 from .lr_scheduler import WarmupMultiStepLR
 
@@ -23,6 +23,9 @@ class FusedSGD(object):
             model.flatten_parameters()
         self.model = model
         self.flat = model.flat
+        for m in model.modules():   # these convs' weights change with every step() (modeling/backbone/resnet.py: weight versions)
+            if isinstance(m, Conv2d) and m.weight.requires_grad:
+                m._optimised = True
         self.momentum = momentum
         self.param_groups = []
         for name, a, b, is_bias in self.flat.segments:
@@ -65,6 +68,9 @@ class FusedSGD(object):
         self.reducer.finish()
 
     def step(self):
+        if self.flat is not self.model.flat:
+            raise RuntimeError("the model's flat parameter storage was rebuilt (model.to(device) after the optimizer was made): "
+                               "build the optimizer after moving the model")
         ops.join_side_stream()  # weight gradients queued on the side stream (no-op when already joined after backward)
         self.all_reduce_grads()
         lrs = [g["lr"] for g in self.param_groups]
@@ -76,7 +82,7 @@ class FusedSGD(object):
         ops.sgd_momentum_(self.flat.params[:n], self.flat.grads, self.momentum_buffer, self._seg_end, self._lr, self._wd,
                           self.momentum, gscale=1.0 / self.world_size, first_step=(self._steps == 0))
         self._steps += 1
-        bump_param_version()  # cached dgrad weight copies are stale now
+        bump_trained_version()  # data derived from the optimised weights (dgrad copies, Winograd-domain weights) is stale now
 
     def _reference_params(self):
         """(name, parameter, offset into the flat buffer, Conv2d module or None) for every trainable tensor, in the

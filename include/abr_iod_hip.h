@@ -233,6 +233,11 @@ typedef struct {
     const void* w_planes;
     int64_t w_plane_stride;  /* elements between two planes (0 = Cout*R*S*Cin: a stand-alone abr_split_bf16x3 of w); larger when
                                 the planes are a slice of a bigger split buffer, e.g. the whole flat parameter buffer split at once */
+    /* abr_conv_forward: non-zero = "the weight tensor at address w has not changed since the last call that passed this same
+       (w, w_version) pair": the library then keeps data derived from it -- the Winograd-domain weights U = G g G^T, 36*Cout*Cin
+       floats -- and skips the weight transform on later calls (the frozen source model: once; a trainable conv: once per optimiser
+       step, shared by its forward passes).  0 = derive it again on every call. */
+    int64_t w_version;
 } abr_conv_desc;
 
 int abr_conv_forward(const abr_conv_desc* d_host, const float* x, const float* w, float* out, void* stream);

@@ -688,3 +688,27 @@ def test_bf16x6_optional_loops_pass_the_same_parity_tests():
         r = subprocess.run([sys.executable, "-m", "pytest", target, "-x", "-q", "-p", "no:cacheprovider"], cwd=root,
                            env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_winograd_weight_cache_follows_w_version():
+    """abr_conv_desc::w_version: the Winograd-domain weights are derived once per (weight address, version) -- the second call with
+    the same pair must not depend on the weight transform running again, a new version must pick up new weight values, and
+    w_version = 0 never caches."""
+    from abr_iod_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(2, 20, 24, 128, device="cuda", generator=g)
+    w = torch.randn(128, 3, 3, 128, device="cuda", generator=g) / (9 * 128) ** 0.5
+    ref = lambda ww: torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), ww.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+    close = lambda y, r: (y.double() - r).abs().max().item() <= 5e-5 * r.abs().max().item()
+    for math in (ops.MATH_F32, ops.MATH_BF16X6):
+        w1 = w.clone()
+        r1 = ref(w1)
+        y_a = ops.conv_forward(x, w1, 1, 1, math=math, w_version=7)
+        y_b = ops.conv_forward(x, w1, 1, 1, math=math, w_version=7)          # cache hit
+        assert close(y_a, r1) and torch.equal(y_a, y_b)
+        assert torch.equal(y_a, ops.conv_forward(x, w1, 1, 1, math=math))     # same arithmetic as the uncached path
+        w1.mul_(-2.0)                                                         # in-place change of the weights ...
+        y_c = ops.conv_forward(x, w1, 1, 1, math=math, w_version=9)          # ... announced by a new version
+        assert close(y_c, ref(w1))
+        y_d = ops.conv_forward(x, w1, 1, 1, math=math, w_version=0)          # and never cached with version 0
+        assert torch.equal(y_c, y_d)

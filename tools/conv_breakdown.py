@@ -45,7 +45,7 @@ def _timed(kind, fn, key_fn):
 
 
 def _fwd_key(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, mask=None, relu=False, out=None, out_hw=None,
-             out_stride=(1, 1)):
+             out_stride=(1, 1), *_a, **_):
     Cout, R, S, Cin = w.shape
     B, H, W, _ = x.shape
     Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
@@ -54,7 +54,7 @@ def _fwd_key(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, mask=N
     return (tag, M, Cout, R * S * Cin, f"{R}x{S}s{stride} {H}x{W}"), 2.0 * M * Cout * R * S * Cin
 
 
-def _wg_key(x, gy, dw, stride=1, pad=0, scale=None):
+def _wg_key(x, gy, dw, stride=1, pad=0, scale=None, *_a, **_):
     Cout, R, S, Cin = dw.shape
     M = gy.numel() // Cout
     return ("wgrad", M, Cout, R * S * Cin, f"{R}x{S}s{stride} {x.shape[1]}x{x.shape[2]}"), 2.0 * M * Cout * R * S * Cin
