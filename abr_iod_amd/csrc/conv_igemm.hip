@@ -1009,6 +1009,14 @@ static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, fl
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * nb;
     const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64) * nb;
     const bool pb = p.w_planes != nullptr && nb == 1;
+    static const int force = getenv("ABR_X6_TILE") ? atoi(getenv("ABR_X6_TILE")) : 0;   // experiments: 1 = 128x128, 2 = 128x64, 3 = 64x64
+    static const int force_maxk = getenv("ABR_X6_TILE_MAXK") ? atoi(getenv("ABR_X6_TILE_MAXK")) : 1 << 30;
+    if (force && p.K <= force_maxk && nb == 1 && !pb) {
+        if (force == 1) launch_x6<128, 128, 2, 2, false>(p, x, w, out, st);
+        else if (force == 2) launch_x6<128, 64, 4, 1, false>(p, x, w, out, st);
+        else launch_x6<64, 64, 2, 2, false>(p, x, w, out, st);
+        return;
+    }
     if (p.Cout > 64 && t128 >= 2 * cus) {
         if (pb) launch_x6<128, 128, 2, 2, true>(p, x, w, out, st);
         else launch_x6<128, 128, 2, 2, false>(p, x, w, out, st);
@@ -1122,6 +1130,18 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     if (p.math == ABR_MATH_BF16X6) dispatch_igemm_x6(p, x, w, out, st);
     else dispatch_igemm(p, x, w, out, st);
     ABR_CHECK_LAUNCH("conv_forward");
+    return ABR_OK;
+}
+
+extern "C" int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, int Cin, int stride, int pad, int math, int64_t w_version,
+                                        void* stream) {
+    ABR_REQUIRE(w && w_version != 0, "conv_prepare_weights: needs a weight pointer and a non-zero w_version");
+    // the same predicate as abr_conv_forward's Winograd branch (residual / scatter never occur on the convs that prepare)
+    if (wino_min_c() > 0 && math != ABR_MATH_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && Cin % BK == 0 && Cout % 4 == 0 &&
+        Cin >= wino_min_c() && Cout >= 128) {
+        ABR_REQUIRE(abr::wino_u_cached(w, Cout, Cin, w_version, abr::as_stream(stream)) != nullptr, "conv_prepare_weights: no memory for the Winograd-domain weights");
+        ABR_CHECK_LAUNCH("conv_prepare_weights");
+    }
     return ABR_OK;
 }
 

@@ -90,6 +90,7 @@ class Conv2d(nn.Module):
     def dgrad_weight(self, scale=None, planes=False):
         """[Cin,R,S,Cout] flipped copy with the FrozenBN scale folded in; rebuilt only after an optimiser step.
         planes=True (bf16x6 arithmetic) also keeps its exact bf16x3 split in self._wtp, made by the same launch."""
+        ops.prep_wait()
         if (self._wt is None or self._wt_version != _PARAM_VERSION[0] or self._wt.device != self.weight.device
                 or (planes and self._wtp is None)):
             same = self._wt is not None and self._wt.device == self.weight.device
@@ -153,6 +154,22 @@ class Bottleneck(nn.Module):
         if x6:
             kw.update(w_planes=conv._wtp)
         return ops.conv_forward(g, wt, 1, pad, math=self.math, w_version=conv.version(), **kw)
+
+    def prepare_derived(self):
+        """Rebuild, on the current stream, everything this block derives from its trainable weights: the flipped / BN-scaled dgrad
+        copies and, for the 3x3 conv, the Winograd-domain weights of the weight and of its dgrad copy (FusedSGD.step runs this on the
+        weight-preparation stream right after the update)."""
+        x6 = X6_WEIGHT_PLANES and self.math == ops.MATH_BF16X6
+        pairs = [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+        if self.downsample is not None:
+            pairs.append((self.downsample[0], self.downsample[1]))
+        for conv, bn in pairs:
+            if not (conv.weight.requires_grad and conv.weight.is_cuda):
+                continue
+            wt = conv.dgrad_weight(bn.scale_bias()[0], planes=x6)
+            if conv.kernel_size == 3 and conv.stride == 1 and conv.padding == 1:
+                ops.conv_prepare_weights(conv.weight, 1, 1, self.math, conv.version())
+                ops.conv_prepare_weights(wt, 1, 1, self.math, conv.version())
 
     # x, returns NHWC tensors.  `stride` may be overridden to 1 when the caller already sub-sampled (bin_step=2 ROIAlign)
     def fwd(self, x, save, stride=None):

@@ -179,7 +179,13 @@ class FastRCNNPredictor(nn.Module):
         else:
             self._set_fused(self._fw2d, view, self._gw2d, grad_view)
 
+    def prepare_derived(self):
+        """see Bottleneck.prepare_derived"""
+        if self.fused_weight.is_cuda and self.cls_score.weight.requires_grad:
+            self.fused_dgrad_weight()
+
     def fused_dgrad_weight(self):
+        ops.prep_wait()
         if self._wt is None or self._wt_version != _PARAM_VERSION[0]:
             self._wt = ops.conv_dgrad_weights(self.fused_weight, None, out=self._wt)
             self._wt_version = _PARAM_VERSION[0]

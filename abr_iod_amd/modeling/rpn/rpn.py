@@ -192,8 +192,20 @@ class RPNHead(nn.Module):
         return [("weight", [self.cls_logits.weight, self.bbox_pred.weight], self.n_out_pad - self.n_out),
                 ("bias", [self.cls_logits.bias, self.bbox_pred.bias], self.n_out_pad - self.n_out)]
 
+    def prepare_derived(self):
+        """see Bottleneck.prepare_derived"""
+        if not self.fused_weight.is_cuda:
+            return
+        if self.fused_weight_grad is not None and (self.cls_logits.weight.requires_grad or self.bbox_pred.weight.requires_grad):
+            self.fused_dgrad_weight()
+        if self.conv.weight.requires_grad:
+            wt = self.conv.dgrad_weight()
+            ops.conv_prepare_weights(self.conv.weight, 1, 1, self.math, self.conv.version())
+            ops.conv_prepare_weights(wt, 1, 1, self.math, self.conv.version())
+
     def fused_dgrad_weight(self):
         from ..backbone.resnet import _PARAM_VERSION
+        ops.prep_wait()
         if self._wt is None or self._wt_version != _PARAM_VERSION[0]:
             self._wt = ops.conv_dgrad_weights(self.fused_weight, None, out=self._wt)
             self._wt_version = _PARAM_VERSION[0]

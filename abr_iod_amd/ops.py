@@ -287,6 +287,13 @@ def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, ma
     return out
 
 
+def conv_prepare_weights(w, stride, pad, math, w_version):
+    """Derive on the CURRENT stream what conv_forward(.., w, stride, pad, math=, w_version=) would derive from w (the Winograd-domain
+    weights of a wide 3x3 conv) so that the call itself finds it cached; consumers on other streams are ordered behind it."""
+    Cout, R, S, Cin = w.shape
+    L.check(L.lib().abr_conv_prepare_weights(L.ptr(w), Cout, R, S, Cin, stride, pad, int(math), int(w_version), L.stream()), "conv_prepare_weights")
+
+
 def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino_v=None):
     """dw [Cout,R,S,Cin] += scale * gy^T im2col(x) (fp32 atomics; caller zeroes dw once per step)"""
     L.require_cuda(x, gy, dw)
@@ -313,6 +320,28 @@ def h2d(values, dtype, device):
     if torch.device(device).type != "cuda":
         return t.to(device)
     return t.pin_memory().to(device, non_blocking=True)
+
+
+# Weight preparation off the critical stream (solver/build.py::FusedSGD.step): after the SGD kernel the data derived from the new weights
+# (flipped dgrad copies, Winograd-domain weights) is rebuilt on its own stream, next to the following step's source-model forward; the
+# first consumer on another stream waits for the event recorded behind it.
+_prep = {"event": None, "waited": set()}
+
+
+def prep_done(stream):
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    _prep["event"], _prep["waited"] = ev, set()
+
+
+def prep_wait():
+    """make the current stream see the last weight preparation (no-op once per stream and preparation)"""
+    ev = _prep["event"]
+    if ev is not None:
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream not in _prep["waited"]:
+            cur.wait_event(ev)
+            _prep["waited"].add(cur.cuda_stream)
 
 
 def side_stream(key):

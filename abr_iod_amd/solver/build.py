@@ -5,6 +5,8 @@ The reference builds one torch.optim.SGD param group PER TENSOR (weights: lr=BAS
 hyper-parameters but applies the whole update as ONE kernel over the model's flat parameter buffer, and owns the
 data-parallel gradient exchange (a few large RCCL all-reduces of the flat gradient buffer over xGMI, the first ones issued during
 the backward pass: solver/grad_reducer.py)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -26,6 +28,10 @@ class FusedSGD(object):
         for m in model.modules():   # these convs' weights change with every step() (modeling/backbone/resnet.py: weight versions)
             if isinstance(m, Conv2d) and m.weight.requires_grad:
                 m._optimised = True
+        # modules that keep data derived from trainable weights (flipped dgrad copies, Winograd-domain weights): rebuilt right after
+        # the update on a stream of their own, off the next step's critical path (ABR_WEIGHT_PREP_STREAM=0: lazily, at first use)
+        self._derived = [m for m in model.modules() if hasattr(m, "prepare_derived") and any(p.requires_grad for p in m.parameters())]
+        self._prep_stream = os.environ.get("ABR_WEIGHT_PREP_STREAM", "1") != "0"
         self.momentum = momentum
         self.param_groups = []
         for name, a, b, is_bias in self.flat.segments:
@@ -83,6 +89,14 @@ class FusedSGD(object):
                           self.momentum, gscale=1.0 / self.world_size, first_step=(self._steps == 0))
         self._steps += 1
         bump_trained_version()  # data derived from the optimised weights (dgrad copies, Winograd-domain weights) is stale now
+        if self._prep_stream and self.flat.params.is_cuda and self._derived:
+            cur = torch.cuda.current_stream()
+            prep = ops.side_stream((self.flat.params.device.index, "weight-prep"))
+            prep.wait_stream(cur)            # behind the SGD kernel and every reader of the previous copies
+            with torch.cuda.stream(prep), torch.no_grad():
+                for m in self._derived:
+                    m.prepare_derived()
+            ops.prep_done(prep)
 
     def _reference_params(self):
         """(name, parameter, offset into the flat buffer, Conv2d module or None) for every trainable tensor, in the

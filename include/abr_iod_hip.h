@@ -241,6 +241,11 @@ typedef struct {
 } abr_conv_desc;
 
 int abr_conv_forward(const abr_conv_desc* d_host, const float* x, const float* w, float* out, void* stream);
+/* Derive, on `stream`, whatever abr_conv_forward would derive from the weight tensor (w, w_version != 0) of a conv with this geometry and
+ * arithmetic -- today: the Winograd-domain weights of a wide stride-1 3x3 conv -- so that the next abr_conv_forward with the same
+ * (w, w_version) finds it ready (a consumer on another stream is ordered behind it by the library).  A no-op for other convs.  Lets a
+ * caller move the per-step weight preparation of its trainable convs off the critical stream (solver/build.py). */
+int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, int Cin, int stride, int pad, int math, int64_t w_version, void* stream);
 /* floats of the Winograd-domain input V = 36 * B*ceil(H/4)*ceil(W/4) * Cin if BOTH abr_conv_forward and abr_conv_wgrad take the
  * Winograd F(4x4,3x3) path for this descriptor (wide stride-1 pad-1 3x3, no residual / scatter, fp32 or bf16x6 math), else 0 */
 int64_t abr_conv_wino_v_floats(const abr_conv_desc* d_host);
