@@ -45,6 +45,9 @@ _SIGS = {
     "abr_prof_totals": (_i, [_vp, _i]),
     "abr_prof_step_begin": (_i, []),
     "abr_conv_prepare_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp]),
+    "abr_roi_head_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _i, _i, C.c_uint64,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "abr_gather_proposals": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "abr_x6_range_flags": (_i, [_vp, _i, _vp]),
     "abr_x6_range_flags_async": (_i, [_vp, _vp]),
     "abr_roi_align_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -122,6 +122,142 @@ __global__ void match_encode_kernel(const float* __restrict__ boxes, int n, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Box-head training targets for the whole batch without leaving the device (abr_roi_head_targets):
+//   candidate list of image i = its post-NMS proposals (rows keep[i, :n_keep[i]] of the decoded, score-sorted boxes) followed by
+//   its ground-truth boxes (rpn/inference.py:53-74 add_gt_proposals); every candidate is matched against the image's GT
+//   (Matcher 0.5 / 0.5, no low-quality rule), labelled and encoded (box_head/loss.py:56-84) -- the same arithmetic, in the same
+//   order, as match_encode_kernel above.
+#pragma clang fp contract(off)
+__global__ void cand_match_kernel(const float* __restrict__ props, const float* __restrict__ scores, const int32_t* __restrict__ keep,
+                                  const int32_t* __restrict__ n_keep, int k_pre, int post, const float* const* __restrict__ gt_ptrs,
+                                  const int64_t* const* __restrict__ gt_label_ptrs, const int32_t* __restrict__ n_gt, int Pmax, float hi,
+                                  float lo, float wx, float wy, float ww, float wh, float* __restrict__ cand,
+                                  int64_t* __restrict__ labels_all, float* __restrict__ regt_all, float* __restrict__ obj_all,
+                                  int32_t* __restrict__ n_cand, float* __restrict__ n_valid) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nk = min(n_keep[i], post), G = n_gt[i];
+    const int nc = nk + G;
+    if (j == 0) {
+        n_cand[i] = nc;
+        if (i == 0) *n_valid = 0.f;   // (accumulated by roi_merge_gather_kernel, a later launch on the same stream)
+    }
+    if (j >= Pmax) return;
+    const float* gt = gt_ptrs[i];
+    const int64_t* gt_labels = gt_label_ptrs[i];
+    const int64_t o = (int64_t)i * Pmax + j;
+    if (j >= nc) {
+        labels_all[o] = -1;   // never sampled
+        obj_all[o] = 0.f;
+        reinterpret_cast<float4*>(cand)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(regt_all)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int src = j < nk ? keep[(int64_t)i * post + j] : 0;
+    const float4 b = j < nk ? reinterpret_cast<const float4*>(props)[(int64_t)i * k_pre + src] : reinterpret_cast<const float4*>(gt)[j - nk];
+    obj_all[o] = j < nk ? scores[(int64_t)i * k_pre + src] : 1.f;               // GT boxes join with objectness 1 (inference.py:66-68)
+    float best = -1.f;
+    int bi = 0;
+    for (int g = 0; g < G; g++) {
+        const float v = box_iou(reinterpret_cast<const float4*>(gt)[g], b);
+        if (v > best) { best = v; bi = g; }                                    // first max wins (torch.max)
+    }
+    const int64_t m = best < lo ? -1 : (best < hi ? -2 : bi);                   // matcher.py:68-75
+    const int gi = m < 0 ? 0 : (int)m;                                          // clamp(min=0)
+    int64_t l = gt_labels[gi];                                                  // box_head/loss.py:66-75
+    if (m == -1) l = 0;
+    if (m == -2) l = -1;
+    labels_all[o] = l;
+    const float4 r = reinterpret_cast<const float4*>(gt)[gi];                   // box_coder.py:22-50
+    const float ew = b.z - b.x + 1, eh = b.w - b.y + 1;
+    const float ecx = b.x + 0.5f * ew, ecy = b.y + 0.5f * eh;
+    const float gw = r.z - r.x + 1, gh = r.w - r.y + 1;
+    const float gcx = r.x + 0.5f * gw, gcy = r.y + 0.5f * gh;
+    float4 t;
+    t.x = wx * (gcx - ecx) / ew;
+    t.y = wy * (gcy - ecy) / eh;
+    t.z = ww * logf(gw / ew);
+    t.w = wh * logf(gh / eh);
+    reinterpret_cast<float4*>(cand)[o] = b;
+    reinterpret_cast<float4*>(regt_all)[o] = t;
+}
+
+__device__ __forceinline__ int lower_bound_i64(const int64_t* a, int n, int64_t v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// The sampler's two ascending index lists of image i merged into ONE ascending list (box_head/loss.py:108-114 takes
+// nonzero(pos_mask | neg_mask), i.e. ascending candidate order) and the sampled rows gathered: rois (batch index, box), labels,
+// regression targets.  Rows past the number drawn are padding: label -1 (ignored by the loss kernels), a zero box of image i.
+__global__ __launch_bounds__(256) void roi_merge_gather_kernel(const float* __restrict__ cand, const int64_t* __restrict__ labels_all,
+                                                               const float* __restrict__ regt_all, const float* __restrict__ obj_all, int Pmax,
+                                                               const int64_t* __restrict__ pos_idx, int max_pos,
+                                                               const int64_t* __restrict__ neg_idx, int batch,
+                                                               const int32_t* __restrict__ counts, float* __restrict__ rois,
+                                                               int64_t* __restrict__ labels, float* __restrict__ reg_targets,
+                                                               int64_t* __restrict__ sampled_idx, float* __restrict__ obj,
+                                                               int64_t* __restrict__ pos_rows, int64_t* __restrict__ col0, int num_classes,
+                                                               int cls_agnostic, float* __restrict__ n_valid) {
+    const int i = blockIdx.x;
+    const int cp = counts[2 * i], cn = counts[2 * i + 1];
+    const int64_t* pos = pos_idx + (int64_t)i * max_pos;
+    const int64_t* neg = neg_idx + (int64_t)i * batch;
+    for (int e = threadIdx.x; e < batch; e += blockDim.x) {
+        int64_t v = -1;
+        int rank;
+        if (e < cp) {
+            v = pos[e];
+            rank = e + lower_bound_i64(neg, cn, v);
+        } else if (e < cp + cn) {
+            v = neg[e - cp];
+            rank = (e - cp) + lower_bound_i64(pos, cp, v);
+        } else {
+            rank = e;   // padding rows keep their place behind the drawn ones
+        }
+        const int64_t row = (int64_t)i * batch + rank;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f), t = b;
+        int64_t l = -1;
+        float ob = 0.f;
+        if (v >= 0) {
+            const int64_t o = (int64_t)i * Pmax + v;
+            b = reinterpret_cast<const float4*>(cand)[o];
+            t = reinterpret_cast<const float4*>(regt_all)[o];
+            l = labels_all[o];
+            ob = obj_all[o];
+        }
+        obj[row] = ob;
+        pos_rows[row] = l > 0 ? row : -1;                                      // rows entering the box-regression loss (loss.py:166)
+        col0[row] = num_classes + (cls_agnostic ? 4 : 4 * (l > 0 ? l : 0));    // their 4 columns of the fused predictor output (:168-171)
+        float* r = rois + row * 5;
+        r[0] = (float)i; r[1] = b.x; r[2] = b.y; r[3] = b.z; r[4] = b.w;
+        labels[row] = l;
+        reinterpret_cast<float4*>(reg_targets)[row] = t;
+        sampled_idx[row] = v;
+    }
+    if (threadIdx.x == 0) atomicAdd(n_valid, (float)(cp + cn));
+}
+
+// rows picks[i*P + j] of image i's post-NMS list -> rois [N*P, 5] = (i, box), obj [N*P] (the 64 distillation proposals of the source
+// model: generalized_rcnn.py:140-158; the post-NMS list is already in descending objectness order)
+__global__ void gather_proposals_kernel(const float* __restrict__ props, const float* __restrict__ scores, const int32_t* __restrict__ keep,
+                                        int k_pre, int post, const int64_t* __restrict__ picks, int N, int P, float* __restrict__ rois,
+                                        float* __restrict__ obj) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * P) return;
+    const int i = t / P;
+    const int src = keep[(int64_t)i * post + picks[t]];
+    const float4 b = reinterpret_cast<const float4*>(props)[(int64_t)i * k_pre + src];
+    float* r = rois + (int64_t)t * 5;
+    r[0] = (float)i; r[1] = b.x; r[2] = b.y; r[3] = b.z; r[4] = b.w;
+    if (obj) obj[t] = scores[(int64_t)i * k_pre + src];
+}
+
 // BoxCoder.encode row-wise (box_coder.py:22-50): out[i] = encode(gt[i], ex[i])
 #pragma clang fp contract(off)
 __global__ void box_encode_kernel(const float* __restrict__ gt, const float* __restrict__ ex, int n, float wx, float wy,
@@ -191,5 +327,44 @@ extern "C" int abr_match_encode(const float* boxes, int n, const float* gt, cons
     match_encode_kernel<<<abr::cdiv(n, 256), 256, 0, st>>>(boxes, n, gt, gt_labels, G, vis, hi, lo, allow_low_quality, rowmax,
                                                            wx, wy, ww, wh, matched, labels_f32, labels_i64, reg_targets);
     ABR_CHECK_LAUNCH("match_encode");
+    return ABR_OK;
+}
+
+extern "C" int abr_sample_pos_neg(const void* labels, int labels_are_int64, int N, int n, int64_t stride, int batch_size, int max_pos,
+                                  uint64_t seed, int first_image, int64_t index_offset_per_image, int64_t* pos_idx,
+                                  int64_t* neg_idx, int32_t* counts, void* stream);
+
+extern "C" int abr_roi_head_targets(const float* props, const int32_t* keep, const int32_t* n_keep, int N, int k_pre, int post,
+                                    const float* const* gt_ptrs, const int64_t* const* gt_label_ptrs, const int32_t* n_gt, int g_max,
+                                    float hi, float lo, float wx, float wy, float ww, float wh, int batch_size, int max_pos,
+                                    uint64_t seed, float* cand, int64_t* labels_all, float* regt_all, int32_t* n_cand, int64_t* pos_idx,
+                                    int64_t* neg_idx, int32_t* counts, float* rois, int64_t* labels, float* reg_targets,
+                                    int64_t* sampled_idx, float* n_valid, const float* scores, float* obj_all, float* obj,
+                                    int64_t* pos_rows, int64_t* col0, int num_classes, int cls_agnostic, void* stream) {
+    ABR_REQUIRE(N > 0 && k_pre > 0 && post > 0 && g_max > 0 && batch_size > 0 && max_pos >= 0 && max_pos <= batch_size,
+                "roi_head_targets: bad sizes");
+    ABR_REQUIRE(props && keep && n_keep && gt_ptrs && gt_label_ptrs && n_gt && cand && labels_all && regt_all && n_cand && pos_idx && neg_idx &&
+                counts && rois && labels && reg_targets && sampled_idx && n_valid && scores && obj_all && obj && pos_rows && col0,
+                "roi_head_targets: null pointer");
+    hipStream_t st = abr::as_stream(stream);
+    const int Pmax = post + g_max;
+    cand_match_kernel<<<dim3(abr::cdiv(Pmax, 256), N), 256, 0, st>>>(props, scores, keep, n_keep, k_pre, post, gt_ptrs, gt_label_ptrs, n_gt, Pmax,
+                                                                     hi, lo, wx, wy, ww, wh, cand, labels_all, regt_all, obj_all, n_cand, n_valid);
+    ABR_CHECK_LAUNCH("roi_head_targets (match)");
+    const int rc = abr_sample_pos_neg(labels_all, 1, N, Pmax, Pmax, batch_size, max_pos, seed, 0, 0, pos_idx, neg_idx, counts, stream);
+    if (rc != ABR_OK) return rc;
+    roi_merge_gather_kernel<<<N, 256, 0, st>>>(cand, labels_all, regt_all, obj_all, Pmax, pos_idx, max_pos, neg_idx, batch_size, counts, rois, labels,
+                                               reg_targets, sampled_idx, obj, pos_rows, col0, num_classes, cls_agnostic, n_valid);
+    ABR_CHECK_LAUNCH("roi_head_targets (gather)");
+    return ABR_OK;
+}
+
+extern "C" int abr_gather_proposals(const float* props, const float* scores, const int32_t* keep, int N, int k_pre, int post,
+                                    const int64_t* picks, int P, float* rois, float* obj, void* stream) {
+    ABR_REQUIRE(N >= 0 && P >= 0 && k_pre > 0 && post > 0, "gather_proposals: bad sizes");
+    if (N * P == 0) return ABR_OK;
+    ABR_REQUIRE(props && keep && picks && rois && (!obj || scores), "gather_proposals: null pointer");
+    gather_proposals_kernel<<<abr::cdiv((int64_t)N * P, 256), 256, 0, abr::as_stream(stream)>>>(props, scores, keep, k_pre, post, picks, N, P, rois, obj);
+    ABR_CHECK_LAUNCH("gather_proposals");
     return ABR_OK;
 }

@@ -31,6 +31,8 @@ from .._flat import flatten_parameters
 # Default contraction arithmetic: fp32-accurate on the bf16 matrix cores (admitted by tests/test_gpu_x6_admission.py; range-guarded with
 # an automatic fall-back to the fp32 MFMA kernels, engine/trainer.py::_x6_guard).  ABR_CONV_MATH=f32 selects the fp32 MFMA kernels.
 DEFAULT_CONV_MATH = "bf16x6"
+# source model's distillation proposals gathered from the selector's raw output by one kernel (GeneralizedRCNN._soften_fused)
+FUSED_SOFTEN = os.environ.get("ABR_FUSED_SOFTEN", "1") != "0"
 
 
 class GeneralizedRCNN(nn.Module):
@@ -156,27 +158,58 @@ class GeneralizedRCNN(nn.Module):
 
     def soften_finish(self, state, selected_indices=None):
         pending = state["pending"]
-        if isinstance(pending, dict):   # deferred: join the side stream, read the keep counts, cut the BoxLists
+        if isinstance(pending, dict):   # deferred: join the side stream, read the keep counts
             sel = self.rpn.box_selector_test
+            if FUSED_SOFTEN and pending["props"].is_cuda:
+                return self._soften_fused(sel, pending, state, selected_indices)
             pending = sel.collect(pending)
         return self._soften_from_proposals(pending, state["features"], state["backbone_features"], state["anchors"],
                                            state["rpn_output"], selected_indices)
 
+    def _pick_soften(self, n, k, selected_indices):
+        """generalized_rcnn.py:140-149: python's random.sample over the top-128 (or all n < 128) of the ranked list"""
+        if selected_indices is None and getattr(self, "inject_soften_indices", None) is not None:
+            selected_indices = self.inject_soften_indices     # parity tests pin python's random.sample here
+        if selected_indices is not None:
+            return list(selected_indices[k])
+        if n < 64:
+            return random.sample(range(0, n, 1), n)
+        if n < 128:
+            return random.sample(range(0, n, 1), 64)
+        return random.sample(range(0, 128, 1), 64)
+
+    def _soften_fused(self, sel, pending, state, selected_indices):
+        """The 64 distillation proposals per image straight from the selector's raw output: the keep counts are read on the selection's
+        own stream (it finished long ago: the target's backbone ran in between), the picks go up in one pinned asynchronous copy and ONE
+        gather kernel builds the RoI table -- instead of cutting per-image BoxLists, sorting them (the post-NMS list already is in
+        descending objectness order) and indexing them field by field.  Falls back to the BoxList path for ragged pick counts."""
+        side = pending.get("stream")
+        if side is not None:
+            with torch.cuda.stream(side):
+                nk = pending["n_keep"].tolist()
+        else:
+            nk = pending["n_keep"].tolist()
+        picks = [self._pick_soften(n, k, selected_indices) for k, n in enumerate(nk)]
+        P = len(picks[0]) if picks else 0
+        if not picks or any(len(p) != P for p in picks) or P == 0:
+            return self._soften_from_proposals(sel.collect(pending), state["features"], state["backbone_features"], state["anchors"],
+                                               state["rpn_output"], picks)
+        sel.join(pending)
+        self.last_soften_indices = picks
+        dev = pending["props"].device
+        rois, obj = ops.gather_proposals(pending["props"], pending["scores"], pending["keep"], ops.h2d([i for p in picks for i in p], torch.int64, dev), P)
+        all_selected = []
+        for k, size in enumerate(pending["sizes"]):
+            b = BoxList(rois[k * P:(k + 1) * P, 1:5], size, mode="xyxy")
+            b.add_field("objectness", obj[k * P:(k + 1) * P])
+            b._roi_table = (rois, k)     # lets Pooler.convert_to_roi_format hand the table back instead of re-assembling it
+            all_selected.append(b)
+        soften_scores, soften_bboxes, mask_logits, roi_align_features = self.roi_heads.calculate_soften_label(state["features"], rois)
+        return ((soften_scores, soften_bboxes), mask_logits, all_selected, state["features"], state["backbone_features"], state["anchors"],
+                state["rpn_output"], roi_align_features)
+
     def _soften_from_proposals(self, all_proposals, features, backbone_features, anchors, rpn_output, selected_indices=None):
-        picks = []
-        for k, props in enumerate(all_proposals):
-            n = len(props)
-            if selected_indices is None and getattr(self, "inject_soften_indices", None) is not None:
-                selected_indices = self.inject_soften_indices     # parity tests pin python's random.sample here
-            if selected_indices is not None:
-                sel = list(selected_indices[k])
-            elif n < 64:
-                sel = random.sample(range(0, n, 1), n)
-            elif n < 128:
-                sel = random.sample(range(0, n, 1), 64)
-            else:
-                sel = random.sample(range(0, 128, 1), 64)
-            picks.append(sel)
+        picks = [self._pick_soften(len(props), k, selected_indices) for k, props in enumerate(all_proposals)]
         # one pinned, asynchronous upload for the whole batch's picks (a pageable torch.tensor(..., device=) per image would make the
         # host wait for everything queued on the stream -- here, the target's entire forward)
         dev = all_proposals[0].bbox.device if all_proposals else None

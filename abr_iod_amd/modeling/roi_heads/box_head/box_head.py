@@ -37,6 +37,10 @@ def convert_to_roi_format(boxes):
     """poolers.py:73-86: [K,5] = (batch index, x1, y1, x2, y2).  The batch-index column only depends on the per-image box counts,
     which repeat from step to step (512 sampled RoIs / 64 distillation RoIs per image): it is cached instead of being rebuilt from
     2N tiny kernels each time."""
+    tab = getattr(boxes[0], "_roi_table", None) if len(boxes) else None
+    if tab is not None and all(getattr(b, "_roi_table", (None, -1))[0] is tab[0] and b._roi_table[1] == i for i, b in enumerate(boxes)) \
+            and tab[0].shape[0] == sum(len(b) for b in boxes):
+        return tab[0]   # these BoxLists ARE consecutive views of one ready-made [K,5] table (fused proposal paths)
     concat = torch.cat([b.bbox for b in boxes], dim=0)
     key = (tuple(len(b) for b in boxes), concat.device, concat.dtype)
     ids = _roi_id_cache.get(key)
@@ -55,7 +59,9 @@ class Pooler(nn.Module):
         self.output_size = output_size
 
     def forward(self, x, boxes, bin_step=1):
-        return self.poolers[0](x[0], convert_to_roi_format(boxes), bin_step)
+        """boxes: list of BoxLists (poolers.py:88-105) or an [K,5] RoI table (batch index, x1, y1, x2, y2) already on the device"""
+        rois = boxes if torch.is_tensor(boxes) else convert_to_roi_format(boxes)
+        return self.poolers[0](x[0], rois, bin_step)
 
 
 class ResNet50Conv5ROIFeatureExtractor(nn.Module):
@@ -212,16 +218,22 @@ class _BoxHeadLossFn(Function):
     the fused predictor output and writing ONE fused gradient buffer (box_head/loss.py:151-179)."""
 
     @staticmethod
-    def forward(ctx, fused, K, labels, regression_targets, inclusive, n_old, cls_agnostic):
+    def forward(ctx, fused, K, labels, regression_targets, inclusive, n_old, cls_agnostic, prepared=None):
+        """prepared = (pos_rows, col0, n_valid) from ops.roi_head_targets: the regression rows / columns and the device-resident
+        number of sampled RoIs (rows with label -1 are padding: both loss kernels skip them)"""
         n = fused.shape[0]
         want = fused.requires_grad
         grad = torch.zeros_like(fused) if want else None
         lc, _ = ops.softmax_ce(fused[:, :K], labels, inclusive, n_old, want_grad=want, grad_out=grad[:, :K] if want else None)
-        # rows with label > 0 (:166) as a fixed-size list: non-positive rows become -1 and are skipped by the kernel (no nonzero() sync)
-        ar = torch.arange(n, device=labels.device)
-        pos = torch.where(labels > 0, ar, torch.full_like(ar, -1))
-        col0 = K + (4 * labels.clamp(min=0) if not cls_agnostic else torch.full_like(ar, 4))  # :168-171
-        lb, gb = ops.smooth_l1_rows(fused, regression_targets, pos, col0, 1.0, scale=1.0 / max(n, 1), want_grad=want)
+        if prepared is not None:
+            pos, col0, n_valid = prepared
+            lb, gb = ops.smooth_l1_rows(fused, regression_targets, pos, col0, 1.0, scale=1.0, want_grad=want, denom_dev=n_valid)
+        else:
+            # rows with label > 0 (:166) as a fixed-size list: non-positive rows become -1 and are skipped by the kernel (no nonzero() sync)
+            ar = torch.arange(n, device=labels.device)
+            pos = torch.where(labels > 0, ar, torch.full_like(ar, -1))
+            col0 = K + (4 * labels.clamp(min=0) if not cls_agnostic else torch.full_like(ar, 4))  # :168-171
+            lb, gb = ops.smooth_l1_rows(fused, regression_targets, pos, col0, 1.0, scale=1.0 / max(n, 1), want_grad=want)
         if want:
             ops.add_(grad, gb)
         ctx.save_for_backward(grad)
@@ -238,7 +250,7 @@ class _BoxHeadLossFn(Function):
         ops.scale_(gc, 1.0, g_lc.contiguous())
         gr = grad[:, K:].contiguous()
         ops.scale_(gr, 1.0, g_lb.contiguous())
-        return torch.cat((gc, gr), 1), None, None, None, None, None, None
+        return torch.cat((gc, gr), 1), None, None, None, None, None, None, None
 
 
 class FastRCNNLossComputation(object):
@@ -258,6 +270,38 @@ class FastRCNNLossComputation(object):
             regression_targets.append(tgt)
         return labels, regression_targets
 
+    def subsample_fused(self, lazy, targets, num_classes):
+        """`subsample` for the training selector's raw output (rpn.LazyProposals): GT append, matching, labels, encoding, sampling and
+        the RoI table for the whole batch in three launches without a host round trip (ops.roi_head_targets).  Every image gets
+        BATCH_SIZE_PER_IMAGE rows; rows past the number actually drawn (only when an image has fewer candidates than that) are
+        padding with label -1, which the loss kernels skip.  Returns the dict of device tensors; `self._proposals` are BoxList VIEWS of it."""
+        props, scores, keep, n_keep, sizes = lazy.raw()
+        R = self.fg_bg_sampler.batch_size_per_image
+        t = ops.roi_head_targets(props, scores, keep, n_keep, [g.bbox for g in targets], [g.get_field("labels") for g in targets],
+                                 self.proposal_matcher.high_threshold, self.proposal_matcher.low_threshold, self.box_coder.weights, R,
+                                 int(R * self.fg_bg_sampler.positive_fraction), num_classes, self.cls_agnostic_bbox_reg)
+        out = []
+        for i, size in enumerate(sizes):
+            lo, hi = i * R, (i + 1) * R
+            b = BoxList(t["rois"][lo:hi, 1:5], size, mode="xyxy")
+            b.add_field("objectness", t["obj"][lo:hi])
+            b.add_field("labels", t["labels"][lo:hi])
+            b.add_field("regression_targets", t["reg_targets"][lo:hi])
+            out.append(b)
+        self._proposals, self._fused_targets, self._lazy = out, t, lazy
+        self.last_sampled_inds = [t["sampled_idx"][i] for i in range(len(sizes))]
+        return t
+
+    @property
+    def last_input_proposals(self):
+        """the post-NMS + GT lists the last `subsample` drew from (introspection for parity tests; reads counts back)"""
+        lazy = getattr(self, "_lazy", None)
+        return lazy.materialize() if lazy is not None else getattr(self, "_last_input_proposals", None)
+
+    @last_input_proposals.setter
+    def last_input_proposals(self, v):
+        self._last_input_proposals, self._lazy = v, None
+
     def subsample(self, proposals, targets, sampled_inds=None):
         """:86-120.  Keeps state (self._proposals).  `sampled_inds` (list of index tensors) injects the sampler's choice."""
         labels, regression_targets = self.prepare_targets(proposals, targets)
@@ -275,21 +319,27 @@ class FastRCNNLossComputation(object):
             p.add_field("labels", lab)
             p.add_field("regression_targets", tgt)
             proposals[i] = p[sampled_inds[i]]
-        self._proposals = proposals
+        self._proposals, self._fused_targets = proposals, None
         return proposals
 
     def __call__(self, class_logits, box_regression, fused=None):
         if not hasattr(self, "_proposals"):
             raise RuntimeError("subsample needs to be called before")
-        proposals = self._proposals
-        labels = torch.cat([p.get_field("labels") for p in proposals], dim=0)
-        regression_targets = torch.cat([p.get_field("regression_targets") for p in proposals], dim=0)
+        t = getattr(self, "_fused_targets", None)
+        if t is not None:    # subsample_fused: the batch's labels / targets / loss rows already are single tensors
+            labels, regression_targets, prepared = t["labels"], t["reg_targets"], (t["pos_rows"], t["col0"], t["n_valid"])
+        else:
+            proposals = self._proposals
+            labels = torch.cat([p.get_field("labels") for p in proposals], dim=0)
+            regression_targets = torch.cat([p.get_field("regression_targets") for p in proposals], dim=0)
+            prepared = None
         if fused is None:
             fused = torch.cat((torch.cat(class_logits, 0), torch.cat(box_regression, 0)), 1)
             K = class_logits[0].shape[1]
         else:
             K = class_logits
-        return _BoxHeadLossFn.apply(fused, K, labels, regression_targets, self.dist_type == "id", self.n_old_cl, self.cls_agnostic_bbox_reg)
+        return _BoxHeadLossFn.apply(fused, K, labels, regression_targets, self.dist_type == "id", self.n_old_cl, self.cls_agnostic_bbox_reg,
+                                    prepared)
 
 
 def make_roi_box_loss_evaluator(cfg):
@@ -323,11 +373,18 @@ class ROIBoxHead(nn.Module):
             result, results_background = self.post_processor(
                 (fused[:, :K], fused[:, K:K + 4 * self.predictor.num_bbox_reg_classes]), proposals)
             return x, result, results_background
-        with torch.no_grad():
-            proposals = self.loss_evaluator.subsample(proposals, targets)
-        x, roi_align_features = self.feature_extractor(features, proposals, need_roi_features=self.need_roi_features_in_training)
-        fused = self.predictor.forward_fused(x)
         K = self.predictor.num_classes
+        ev = self.loss_evaluator
+        with torch.no_grad():
+            if hasattr(proposals, "raw") and getattr(ev, "inject_sampled_inds", None) is None:
+                # the training selector's raw output: everything between NMS and ROIAlign stays on the device
+                rois = ev.subsample_fused(proposals, targets, K)["rois"]
+                proposals = ev._proposals
+            else:
+                proposals = ev.subsample(proposals, targets)
+                rois = proposals
+        x, roi_align_features = self.feature_extractor(features, rois, need_roi_features=self.need_roi_features_in_training)
+        fused = self.predictor.forward_fused(x)
         loss_classifier, loss_box_reg = self.loss_evaluator(K, None, fused=fused)
         class_logits, box_regression = fused[:, :K], fused[:, K:K + 4 * self.predictor.num_bbox_reg_classes]
         return (x, proposals, (class_logits, box_regression.reshape(-1, K, 4)),

@@ -55,6 +55,39 @@ def generate_anchors(stride=16, sizes=(32, 64, 128, 256, 512), aspect_ratios=(0.
 
 
 PROPOSALS_SIDE_STREAM = os.environ.get("ABR_PROPOSAL_STREAM", "1") != "0"
+# training: hand the box head the selector's RAW device output (LazyProposals) instead of per-image BoxLists cut on the host
+FUSED_ROI_TARGETS = os.environ.get("ABR_FUSED_ROI_TARGETS", "1") != "0"
+
+
+class LazyProposals(object):
+    """The training selector's output before anything has been read back: the decoded score-sorted boxes, the NMS keep lists and
+    their device-resident counts (RPNPostProcessor.launch).  The box head consumes it as is (ROIBoxHead.forward ->
+    ops.roi_head_targets: GT append, matching, sampling and the RoI table in three launches, no host round trip).  Any other use --
+    indexing, iteration, len() -- materialises the reference's list of per-image BoxLists (RPNPostProcessor.collect: one read-back
+    of the counts), so it can stand wherever that list is expected."""
+
+    def __init__(self, selector, pending, targets):
+        self.selector, self.pending, self.targets = selector, pending, targets
+        self._list = None
+
+    def raw(self):
+        """(props [N,k,4], scores [N,k], keep [N,post] int32, n_keep [N] int32, image sizes) visible to the current stream"""
+        p = self.selector.join(self.pending)
+        return p["props"], p["scores"], p["keep"], p["n_keep"], p["sizes"]
+
+    def materialize(self):
+        if self._list is None:
+            self._list = self.selector.collect(self.pending, self.targets)
+        return self._list
+
+    def __len__(self):
+        return len(self.pending["sizes"])
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
 
 
 class AnchorGenerator(nn.Module):
@@ -476,7 +509,10 @@ class RPNModule(nn.Module):
 
     def forward_finish(self, state):
         with torch.no_grad():
-            boxes = self.box_selector_train.collect(state["pending"], state["targets"])
+            if FUSED_ROI_TARGETS and state["pending"]["props"].is_cuda and state["targets"] is not None:
+                boxes = LazyProposals(self.box_selector_train, state["pending"], state["targets"])
+            else:
+                boxes = self.box_selector_train.collect(state["pending"], state["targets"])
         return (boxes, state["losses"]), state["anchors"], state["rpn_output"]
 
 

@@ -557,6 +557,68 @@ def match_encode(boxes, gt, gt_labels, vis, hi, lo, allow_low_quality, weights, 
 
 
 _sample_calls = [0]
+_ptr_tables = {}
+
+
+def _pointer_table(tensors, dev):
+    """device int64 array of the tensors' device addresses (one pinned asynchronous upload; cached while the addresses repeat)"""
+    key = (tuple(t.data_ptr() for t in tensors), torch.device(dev))
+    tab = _ptr_tables.get(key)
+    if tab is None:
+        if len(_ptr_tables) > 64:
+            _ptr_tables.clear()
+        tab = _ptr_tables[key] = h2d(list(key[0]), torch.int64, dev)
+    return tab
+
+
+def roi_head_targets(props, scores, keep, n_keep, gt_boxes, gt_labels, hi, lo, weights, batch_size, max_pos, num_classes, cls_agnostic=False,
+                     seed=None):
+    """Box-head training targets for the whole batch, on device, no host round trip (include/abr_iod_hip.h, abr_roi_head_targets).
+    props [N,k,4] / scores [N,k] / keep [N,post] int32 / n_keep [N] int32: the RPN selector's raw output; gt_boxes / gt_labels: per-image
+    tensors.  Returns a dict of fixed-size tensors (batch_size rows per image)."""
+    N, k_pre, _ = props.shape
+    post = keep.shape[1]
+    dev = props.device
+    gtb = [L.f32c(b) for b in gt_boxes]
+    gtl = [l.to(torch.int64).contiguous() for l in gt_labels]
+    n_gt = [int(b.shape[0]) for b in gtb]
+    if min(n_gt) == 0:   # matcher.py:53-57
+        raise ValueError("No ground-truth boxes available for one of the images during training")
+    g_max = max(n_gt)
+    Pmax = post + g_max
+    R = batch_size
+    i64, i32 = torch.int64, torch.int32
+    out = dict(
+        cand=torch.empty((N, Pmax, 4), dtype=_f32, device=dev), labels_all=torch.empty((N, Pmax), dtype=i64, device=dev),
+        regt_all=torch.empty((N, Pmax, 4), dtype=_f32, device=dev), obj_all=torch.empty((N, Pmax), dtype=_f32, device=dev),
+        n_cand=torch.empty((N,), dtype=i32, device=dev), pos_idx=torch.empty((N, max(max_pos, 1)), dtype=i64, device=dev),
+        neg_idx=torch.empty((N, R), dtype=i64, device=dev), counts=torch.empty((N, 2), dtype=i32, device=dev),
+        rois=torch.empty((N * R, 5), dtype=_f32, device=dev), labels=torch.empty((N * R,), dtype=i64, device=dev),
+        reg_targets=torch.empty((N * R, 4), dtype=_f32, device=dev), sampled_idx=torch.empty((N, R), dtype=i64, device=dev),
+        n_valid=torch.empty((1,), dtype=_f32, device=dev), obj=torch.empty((N * R,), dtype=_f32, device=dev),
+        pos_rows=torch.empty((N * R,), dtype=i64, device=dev), col0=torch.empty((N * R,), dtype=i64, device=dev),
+        n_gt=n_gt, g_max=g_max, keepalive=(gtb, gtl))
+    if seed is None:
+        _sample_calls[0] += 1
+        seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
+    ngt_dev = h2d(n_gt, i32, dev)
+    L.check(L.lib().abr_roi_head_targets(
+        L.ptr(props), L.ptr(keep), L.ptr(n_keep), N, k_pre, post, L.ptr(_pointer_table(gtb, dev)), L.ptr(_pointer_table(gtl, dev)), L.ptr(ngt_dev),
+        g_max, float(hi), float(lo), *[float(v) for v in weights], R, max_pos, seed, L.ptr(out["cand"]), L.ptr(out["labels_all"]),
+        L.ptr(out["regt_all"]), L.ptr(out["n_cand"]), L.ptr(out["pos_idx"]), L.ptr(out["neg_idx"]), L.ptr(out["counts"]), L.ptr(out["rois"]),
+        L.ptr(out["labels"]), L.ptr(out["reg_targets"]), L.ptr(out["sampled_idx"]), L.ptr(out["n_valid"]), L.ptr(scores), L.ptr(out["obj_all"]),
+        L.ptr(out["obj"]), L.ptr(out["pos_rows"]), L.ptr(out["col0"]), int(num_classes), int(bool(cls_agnostic)), L.stream()), "roi_head_targets")
+    return out
+
+
+def gather_proposals(props, scores, keep, picks, P):
+    """rois [N*P,5] = (i, props[i, keep[i, picks[i*P+j]]]), obj [N*P]: P picked rows per image of the post-NMS lists"""
+    N, k_pre, _ = props.shape
+    rois = torch.empty((N * P, 5), dtype=_f32, device=props.device)
+    obj = torch.empty((N * P,), dtype=_f32, device=props.device)
+    L.check(L.lib().abr_gather_proposals(L.ptr(props), L.ptr(scores), L.ptr(keep), N, k_pre, keep.shape[1], L.ptr(picks), P, L.ptr(rois), L.ptr(obj),
+                                         L.stream()), "gather_proposals")
+    return rois, obj
 
 
 def sample_pos_neg(labels, batch_size, max_pos, index_offset_per_image=0, seed=None):

@@ -344,6 +344,31 @@ int abr_sample_pos_neg(const void* labels, int labels_are_int64, int N, int n, i
                        int max_pos, uint64_t seed, int first_image, int64_t index_offset_per_image,
                        int64_t* pos_idx, int64_t* neg_idx, int32_t* counts, void* stream);
 
+/* Box-head training targets of a whole batch in three launches and NO host round trip -- what RPNPostProcessor.add_gt_proposals
+ * (rpn/inference.py:53-74) + FastRCNNLossComputation.subsample (box_head/loss.py:56-120: match, label, encode, sample, cut) +
+ * Pooler.convert_to_roi_format (poolers.py:73-86) do per image with a dozen small ops and two device synchronisations each:
+ *   props [N,k_pre,4] decoded score-sorted boxes, keep [N,post] / n_keep [N] = abr_nms_sorted_batched's output (device);
+ *   gt_ptrs / gt_label_ptrs [N] device arrays of device pointers to each image's GT boxes [G_i,4] / labels [G_i] int64, n_gt [N];
+ *   candidates of image i = kept proposals then GT (Pmax = post + g_max rows per image):
+ *     cand [N,Pmax,4], labels_all [N,Pmax] int64 (rows past the count = -1), regt_all [N,Pmax,4], n_cand [N];
+ *   sampler (abr_sample_pos_neg on labels_all): pos_idx [N,max_pos], neg_idx [N,batch_size], counts [N,2];
+ *   sampled rows, ascending candidate order per image, batch_size rows per image (rows past the number drawn: label -1, zero box):
+ *     rois [N*batch_size,5] = (image, x1,y1,x2,y2), labels [N*batch_size], reg_targets [N*batch_size,4], sampled_idx [N,batch_size];
+ *   obj [N*batch_size] the rows' objectness (scores [N,k_pre] for proposals, 1 for GT; obj_all [N,Pmax] scratch);
+ *   pos_rows [N*batch_size] = row index where label > 0 else -1, col0 = num_classes + 4*label (or + 4 when cls_agnostic): the rows
+ *   and columns of the fused predictor output that enter the box-regression loss (box_head/loss.py:166-171);
+ *   n_valid [1] fp32 = total number of drawn rows (the denominator of the box-regression loss, box_head/loss.py:179). */
+int abr_roi_head_targets(const float* props, const int32_t* keep, const int32_t* n_keep, int N, int k_pre, int post,
+                         const float* const* gt_ptrs, const int64_t* const* gt_label_ptrs, const int32_t* n_gt, int g_max, float hi,
+                         float lo, float wx, float wy, float ww, float wh, int batch_size, int max_pos, uint64_t seed, float* cand,
+                         int64_t* labels_all, float* regt_all, int32_t* n_cand, int64_t* pos_idx, int64_t* neg_idx, int32_t* counts,
+                         float* rois, int64_t* labels, float* reg_targets, int64_t* sampled_idx, float* n_valid, const float* scores,
+                         float* obj_all, float* obj, int64_t* pos_rows, int64_t* col0, int num_classes, int cls_agnostic, void* stream);
+/* rois [N*P,5] = (i, props[i, keep[i, picks[i*P+j]]]), obj [N*P] (or NULL) = the matching scores: the P picked distillation
+ * proposals per image of the source model (generalized_rcnn.py:140-158) straight from the NMS output */
+int abr_gather_proposals(const float* props, const float* scores, const int32_t* keep, int N, int k_pre, int post,
+                         const int64_t* picks, int P, float* rois, float* obj, void* stream);
+
 /* =====================================================================================================
  * 6. Optimiser (solver/build.py:7-21, torch.optim.SGD semantics, one fused launch over all tensors)
  *    p,g,m flat fp32 buffers of `total` elements; seg_end[i] = exclusive end offset of tensor i;
