@@ -308,7 +308,7 @@ class FastRCNNLossComputation(object):
         if sampled_inds is None:
             sampled_inds = getattr(self, "inject_sampled_inds", None)  # parity tests pin the sampler's draw here
         proposals = list(proposals)
-        self.last_input_proposals = proposals   # introspection for parity tests (the post-NMS + GT lists, before sampling)
+        self.last_input_proposals = list(proposals)   # introspection for parity tests (the post-NMS + GT lists, before sampling)
         if sampled_inds is None:
             # fused sampler: one launch per image (ragged proposal counts), all counts fetched with ONE host sync
             drawn = [self.fg_bg_sampler.sample_padded(lab) for lab in labels]

@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """every GPU test gets a 15-minute ceiling (pytest-timeout) unless it sets its own: a wedged worker process or collective must
+    fail the test, not hang the run"""
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

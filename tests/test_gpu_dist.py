@@ -243,7 +243,9 @@ def test_two_ranks_one_image_each_equal_one_rank_two_images():
         assert p.exitcode == 0
     (_, g0, p0, ld0, props0), (_, g1, p1, ld1, props1) = got
     # the per-image proposal lists the injected indices refer to are the same lists
-    assert np.array_equal(props0, single_props[0]) and np.array_equal(props1, single_props[1])
+    for w, sgl in ((props0, single_props[0]), (props1, single_props[1])):
+        assert w.shape == sgl.shape, (w.shape, sgl.shape)
+        assert np.array_equal(w, sgl), (float(np.abs(w - sgl).max()), np.nonzero(np.abs(w - sgl).max(1))[0][:10])
     assert np.array_equal(g0, g1) and np.array_equal(p0, p1)              # both ranks hold the same sum and the same parameters
     # losses: mean over ranks of the per-rank losses == the 2-image losses (engine/trainer.py:15-37 reduce_loss_dict semantics)
     for k in ld_single:

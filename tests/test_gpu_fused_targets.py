@@ -19,12 +19,12 @@ TINY = ["MODEL.RESNETS.STEM_OUT_CHANNELS", 16, "MODEL.RESNETS.RES2_OUT_CHANNELS"
         "MODEL.RPN.POST_NMS_TOP_N_TEST", 150, "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 64]
 
 
-def _setup(post_nms, rois_per_image):
+def _setup(post_nms, rois_per_image, extra=()):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from e2e_common import clamp_targets
     from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
-    cfg_s, cfg_t = make_cfgs("15-5", overrides=TINY + ["MODEL.RPN.POST_NMS_TOP_N_TRAIN", post_nms, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", rois_per_image])
+    cfg_s, cfg_t = make_cfgs("15-5", overrides=TINY + ["MODEL.RPN.POST_NMS_TOP_N_TRAIN", post_nms, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", rois_per_image] + list(extra))
     ms, mt = build_models(cfg_s, cfg_t, seed=0)
     images, targets = synthetic_batch(3, 160, 224, seed=5, max_boxes=3)
     clamp_targets(targets, 224, 160)
@@ -105,12 +105,13 @@ def test_fused_box_head_targets_equal_generic_path(post_nms, R):
 
 
 def test_fused_soften_gather_equals_boxlist_path():
-    cfg, ms, mt, images, targets = _setup(100, 48)
+    cfg, ms, mt, images, targets = _setup(100, 48, ["MODEL.RPN.PRE_NMS_TOP_N_TEST", 2000, "MODEL.RPN.POST_NMS_TOP_N_TEST", 400])
     import random
     random.seed(7)
     with torch.no_grad():
         fused = ms.soften_finish(ms.soften_begin(images))                       # deferred selection + one gather kernel
         picks = ms.last_soften_indices
+        assert all(len(p) == 64 for p in picks) and all(hasattr(b, "_roi_table") for b in fused[2])   # the fused path really ran
         generic = ms.generate_soften_proposal(images, selected_indices=picks)   # reference-shaped: cut, sort, index per image
     (zs, bs), _, sel, _, _, _, _, raf = fused
     (zs2, bs2), _, sel2, _, _, _, _, raf2 = generic
