@@ -59,6 +59,7 @@ struct WgP {
     long x_bs, gy_bs, dw_bs;
     int math;                    // ABR_MATH_F32 or ABR_MATH_BF16X6 (the bf16 mode has its own launch)
     unsigned* x6_flags;          // bf16x6: device word of the range guard (abr::x6_flags_ptr)
+    int tile_fast;               // workgroup order: output tile fastest (1, default) or row slice fastest (0)
 };
 
 // SB: single-buffered operand LDS (two barriers per stage, 32 KB instead of 64 KB -> a third resident workgroup per CU)
@@ -74,8 +75,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
     float* As = smem + NBUF * MR * TN_;     // [NBUF][MR][TK_]
 
     const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
-    const int split = bid % p.splits;
-    int tile = bid / p.splits;
+    // workgroup -> (row slice, output tile): the output tile is the FAST index, so the workgroups one XCD runs side by side (a
+    // contiguous bid range, abr::xcd_remap) cover ALL output tiles of a few row slices.  They stream the same rows of gy and x in
+    // lockstep: every operand element is then fetched from HBM once per XCD and served to the other tiles from that XCD's L2,
+    // instead of being re-fetched by each of the N/128 (resp. K/128) tiles that need it (slice-fast order: ~3x the HBM traffic on the
+    // 9576 x {1024 x 256} gradients, which made them bandwidth-bound).  ABR_WGRAD_TILE_FAST=0 restores the old order.
+    const int total_tiles = p.tiles_pb * (p.nbatch > 1 ? p.nbatch : 1);
+    const int split = p.tile_fast ? bid / total_tiles : bid % p.splits;
+    int tile = p.tile_fast ? bid % total_tiles : bid / p.splits;
     if (p.nbatch > 1) {
         const int bt = tile / p.tiles_pb;
         tile -= bt * p.tiles_pb;
@@ -245,8 +252,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgP p, const
     unsigned* As = Gs + (MRH / 2) * TN_;                // [MRH/2][TK_]
 
     const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
-    const int split = bid % p.splits;
-    const int tile = bid / p.splits;
+    const int total_tiles = p.tiles_n * p.tiles_k;   // tile-fast order: see conv_wgrad_kernel
+    const int split = p.tile_fast ? bid / total_tiles : bid % p.splits;
+    const int tile = p.tile_fast ? bid % total_tiles : bid / p.splits;
     const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
     const int n0 = tile_n * TN_, k0 = tile_k * TK_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -395,8 +403,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const f
     unsigned* As = Gs + 3 * PL;                          // [3][MRX/2][TK_]
 
     const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
-    const int split = bid % p.splits;
-    int tile = bid / p.splits;
+    // workgroup -> (row slice, output tile): the output tile is the FAST index, so the workgroups one XCD runs side by side (a
+    // contiguous bid range, abr::xcd_remap) cover ALL output tiles of a few row slices.  They stream the same rows of gy and x in
+    // lockstep: every operand element is then fetched from HBM once per XCD and served to the other tiles from that XCD's L2,
+    // instead of being re-fetched by each of the N/128 (resp. K/128) tiles that need it (slice-fast order: ~3x the HBM traffic on the
+    // 9576 x {1024 x 256} gradients, which made them bandwidth-bound).  ABR_WGRAD_TILE_FAST=0 restores the old order.
+    const int total_tiles = p.tiles_pb * (p.nbatch > 1 ? p.nbatch : 1);
+    const int split = p.tile_fast ? bid / total_tiles : bid % p.splits;
+    int tile = p.tile_fast ? bid % total_tiles : bid / p.splits;
     if (p.nbatch > 1) {
         const int bt = tile / p.tiles_pb;
         tile -= bt * p.tiles_pb;
@@ -589,6 +603,10 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
     // Prefer two workgroups per CU when each still gets >= 64 stages: a lone workgroup cannot hide its own prologue / atomics
     // epilogue (head 1x1 gradients: 113 -> 126..134 TF alone; -1.0 ms per training step).  ABR_WGRAD_OCC2=0 turns it off.
     static const bool occ2 = !(getenv("ABR_WGRAD_OCC2") && atoi(getenv("ABR_WGRAD_OCC2")) == 0);
+    // ABR_WGRAD_WGS_PER_CU = k > 1: small-output gradients (few tiles, long M) are split until k workgroups per CU are resident
+    // (never below 6 stages = 192 rows per workgroup): a lone 256-thread workgroup per CU leaves three quarters of the wave slots
+    // empty and cannot overlap its own fetch / split / MFMA / atomic phases
+    static const int per_cu = getenv("ABR_WGRAD_WGS_PER_CU") ? atoi(getenv("ABR_WGRAD_WGS_PER_CU")) : 1;
     const int max_splits = std::max(1, (m_tiles + 7) / 8);
     int splits = 1;
     double best = -1.0;
@@ -602,6 +620,11 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
                                                    // atomics epilogue: take two when each still gets >= 64 stages (head 1x1s: +11..15 %)
         eff -= 0.0002 * sp;                        // tie-break: fewer partial sums
         if (eff > best) { best = eff; splits = sp; }
+    }
+    if (per_cu > 1 && (long)tiles * splits < (long)per_cu * cus) {
+        const int want = (int)(((long)per_cu * cus + tiles - 1) / tiles);
+        const int cap = std::max(1, m_tiles / 6);
+        splits = std::max(splits, std::min(want, cap));
     }
     if (p.overwrite) splits = 1;  // one workgroup per output tile owns it: no zero-fill, no atomics
     p.splits = splits;
@@ -684,6 +707,8 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     if (p.M == 0) return ABR_OK;
     p.nbatch = 1; p.tiles_pb = 0; p.x_bs = p.gy_bs = p.dw_bs = 0; p.overwrite = 0;
     p.x6_flags = nullptr;
+    static const int tile_fast = !(getenv("ABR_WGRAD_TILE_FAST") && atoi(getenv("ABR_WGRAD_TILE_FAST")) == 0);
+    p.tile_fast = tile_fast;
     p.math = d->math == ABR_MATH_BF16X6 ? ABR_MATH_BF16X6 : ABR_MATH_F32;   // (x6 handles any Cin % 4 == 0: no k-tile constraint here)
     hipStream_t st = abr::as_stream(stream);
     ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16 || d->math == ABR_MATH_BF16X6, "conv_wgrad: unknown math mode");
