@@ -429,10 +429,39 @@ __global__ __launch_bounds__(64) void roi_bwd_tables_kernel(const float* __restr
 
 constexpr int kXT = 8;  // pixels per workgroup along x
 
+// Pass 1b: for every feature row y, the ORDERED list of RoIs (of any image, ascending index) whose footprint covers that row.  The
+// gather workgroups of row y then walk ~K*h/H entries instead of all K rectangles (2048 scalar tests each at B = 4, most of them
+// misses).  Ordered block compaction (ballot + prefix), so the summation order of the gather stays the fixed ascending-RoI order.
+__global__ __launch_bounds__(256) void roi_row_lists_kernel(const RoiRect* __restrict__ rect, int K, int32_t* __restrict__ lists,
+                                                            int32_t* __restrict__ counts) {
+    __shared__ int wave_cnt[4];
+    const int y = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int r0 = 0; r0 < K; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        bool hit = false;
+        if (r < K) {
+            const RoiRect rc = rect[r];
+            hit = y >= rc.ymin && y <= rc.ymax && rc.xmax >= rc.xmin;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; w++) off += wave_cnt[w];
+        if (hit) lists[(size_t)y * K + off + __popcll(m & ((1ull << lane) - 1ull))] = r;
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[y] = base;
+}
+
 template <int PO>  // PO = compile-time bound on PHo and PWo (4 for bin_step=2 on 7x7, 8 otherwise)
 __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* __restrict__ grad, int K, int C, int H, int W, int Wp,
                                                                     int PHo, int PWo, const float* __restrict__ Wy,
                                                                     const float* __restrict__ Wx, const RoiRect* __restrict__ rect,
+                                                                    const int32_t* __restrict__ lists, const int32_t* __restrict__ counts,
                                                                     int cchunks, int accumulate, float* __restrict__ gfeat) {
     const int xt = blockIdx.x / cchunks, chunk = blockIdx.x % cchunks;
     const int y = blockIdx.y, b = blockIdx.z;
@@ -442,9 +471,12 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
     float4 acc[kXT];
 #pragma unroll
     for (int i = 0; i < kXT; i++) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < K; r++) {
-        const RoiRect rc = rect[r];  // wave-uniform: scalar loads
-        if (rc.b != b || y < rc.ymin || y > rc.ymax || rc.xmax < x0 || rc.xmin >= x0 + kXT) continue;
+    const int32_t* row_list = lists + (size_t)y * K;
+    const int n_row = counts[y];
+    for (int e = 0; e < n_row; e++) {
+        const int r = row_list[e];   // wave-uniform: scalar loads
+        const RoiRect rc = rect[r];
+        if (rc.b != b || rc.xmax < x0 || rc.xmin >= x0 + kXT) continue;
         const float* wyr = Wy + (size_t)r * PHo * H + y;
         const float* g = grad + (size_t)r * PHo * PWo * C + cv * 4;
         float4 T[PO];
@@ -664,7 +696,8 @@ static inline int round8(int w) { return (w + 7) / 8 * 8; }
 
 extern "C" int64_t abr_roi_align_backward_ws_bytes(int K, int H, int W, int PH, int PW, int bin_step) {
     const int PHo = (PH + bin_step - 1) / bin_step, PWo = (PW + bin_step - 1) / bin_step;
-    return (int64_t)K * ((int64_t)PHo * H + (int64_t)PWo * round8(W)) * 4 + (int64_t)K * sizeof(RoiRect) + 256;
+    return (int64_t)K * ((int64_t)PHo * H + (int64_t)PWo * round8(W)) * 4 + (int64_t)K * sizeof(RoiRect) + 256 +
+           ((int64_t)H * K + H) * 4 + 64;   // + per-row RoI lists and their lengths
 }
 
 extern "C" int abr_roi_align_backward_gather(const float* grad, const float* rois, int K, int B, int C, int H, int W, float scale,
@@ -689,13 +722,16 @@ extern "C" int abr_roi_align_backward_gather(const float* grad, const float* roi
     const size_t lds = sizeof(float) * ((size_t)PHo * H + (size_t)PWo * Wp) + 16;
     ABR_REQUIRE(lds <= 60 * 1024, "roi_align_backward_gather: feature map too large for the table builder");
     roi_bwd_tables_kernel<<<K, 64, lds, st>>>(rois, K, H, W, Wp, scale, PH, PW, sr, bin_step, PHo, PWo, Wy, Wx, rect);
+    int32_t* lists = (int32_t*)(((uintptr_t)(rect + K) + 63) & ~(uintptr_t)63);
+    int32_t* counts = lists + (size_t)H * K;
+    roi_row_lists_kernel<<<H, 256, 0, st>>>(rect, K, lists, counts);
     const int cchunks = (C / 4 + 255) / 256;
     dim3 grid((unsigned)(((W + kXT - 1) / kXT) * cchunks), (unsigned)H, (unsigned)B);
     const int rec = abr::prof_start(st, abr::PROF_ROIALIGN_BWD, 0.0);
     if (PHo <= 4 && PWo <= 4)
-        roi_align_bwd_gather_kernel<4><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, cchunks, accumulate, gfeat);
+        roi_align_bwd_gather_kernel<4><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
     else
-        roi_align_bwd_gather_kernel<8><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, cchunks, accumulate, gfeat);
+        roi_align_bwd_gather_kernel<8><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
     abr::prof_stop(st, rec);
     ABR_CHECK_LAUNCH("roi_align_backward_gather");
     return ABR_OK;
