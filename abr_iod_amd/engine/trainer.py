@@ -30,6 +30,11 @@ from ..utils.comm import get_world_size
 # (1152 tiles -> 5 rounds) and the step gets 0.5 ms SLOWER than two separate passes whose small GEMMs overlap with the side-stream
 # weight gradients anyway; it pays when RoI counts are not already multiples of the CU count.
 SOURCE_OVERLAP = os.environ.get("ABR_SOURCE_OVERLAP", "1") != "0"
+# the frozen source model's backbone + RPN head on a stream of their own, NEXT to the target's forward (its many small layer1-3 kernels
+# leave CUs idle that the other model's kernels fill, as the dgrad / wgrad pair does in the backward pass)
+SOURCE_STREAM = os.environ.get("ABR_SOURCE_STREAM", "1") != "0"
+# ... and its 64-RoI head pass too (next to the target's 2048-RoI pass); 0: on the main stream between the target's two forward halves
+SOURCE_HEAD_STREAM = os.environ.get("ABR_SOURCE_HEAD_STREAM", "1") != "0"
 JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "0") != "0"
 
 
@@ -96,6 +101,18 @@ def _arm_overlap(optimizer, head_inputs, features):
         f.register_hook(features_done)
 
 
+def _join_source_stream(deferred):
+    """make the current stream (and the caching allocator) see what the source model's stream produced"""
+    src = deferred.pop("_stream", None)
+    if src is None:
+        return
+    cur = torch.cuda.current_stream()
+    cur.wait_stream(src)
+    for t in list(deferred["features"]) + [x for pair in deferred["rpn_output"] for x in pair]:
+        if torch.is_tensor(t):
+            t.record_stream(cur)
+
+
 def train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg, faithful_rng=False, log=None):
     """One iteration of tools/train_incremental.py:77-147.  Returns (loss_dict_target incl. 'distillation_loss', total loss)."""
     dist_type = cfg.DIST.TYPE
@@ -110,7 +127,16 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
             on_gpu = (images.tensors if hasattr(images, "tensors") else images).is_cuda
             if SOURCE_OVERLAP and not faithful_rng and on_gpu and hasattr(model_source, "soften_begin") and not model_source.training:
                 # source backbone + RPN head now, its proposal selection on a side stream; finished after the target's forward
-                deferred = model_source.soften_begin(images)
+                if SOURCE_STREAM:
+                    from .. import ops
+                    cur = torch.cuda.current_stream()
+                    src = ops.side_stream((cur.device.index, "source-model"))
+                    src.wait_stream(cur)          # the images, and everything of the previous step that read this stream's buffers
+                    with torch.cuda.stream(src):
+                        deferred = model_source.soften_begin(images)
+                    deferred["_stream"] = src
+                else:
+                    deferred = model_source.soften_begin(images)
                 rpn_output_source = deferred["rpn_output"]
             else:
                 soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
@@ -128,17 +154,37 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         # model's selection finished long ago, so its head pass (a few ms of small GEMMs) goes in NOW: the device has work while
         # the target's top-k / NMS run and while the host waits for their counts
         begun = model_target.forward_begin(images, targets, rpn_output_source=rpn_output_source)               # :89-90 (first half)
-        with torch.no_grad():
-            soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
-                model_source.soften_finish(deferred)
+        src = deferred.get("_stream") if SOURCE_HEAD_STREAM else None
+        if src is not None:       # the source's head pass stays on its stream, next to the target's big RoI pass below
+            deferred.pop("_stream")
+            with torch.no_grad(), torch.cuda.stream(src):
+                soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
+                    model_source.soften_finish(deferred)
+        else:
+            _join_source_stream(deferred)
+            with torch.no_grad():
+                soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
+                    model_source.soften_finish(deferred)
         deferred = None
         loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results = \
             model_target.forward_finish(begun)                                                             # :89-90 (second half)
+        if src is not None:       # everything the source stream produced becomes visible to the main stream here
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(src)
+            outs = [soften_result[0], soften_result[1], roi_align_features_source] + list(feature_source) + [p.bbox for p in soften_proposal] + \
+                   [x for pair in rpn_output_source for x in pair]
+            tab = getattr(soften_proposal[0], "_roi_table", None) if soften_proposal else None
+            if tab is not None:
+                outs.append(tab[0])
+            for t in outs:
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
     else:
         loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results = \
             model_target(images, targets, rpn_output_source=rpn_output_source)                             # :89-90
     faster_rcnn_losses = sum(loss for loss in loss_dict_target.values())                                   # :91
     if deferred is not None:
+        _join_source_stream(deferred)
         with torch.no_grad():
             soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
                 model_source.soften_finish(deferred)

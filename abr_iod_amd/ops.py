@@ -357,16 +357,25 @@ def mark_overlap(on):
     L.lib().abr_prof_mark_overlap(1 if on else 0)
 
 
+WGRAD_STREAMS = max(1, int(os.environ.get("ABR_WGRAD_STREAMS", "1")))   # weight gradients round-robin over this many side streams
+
+
+def _wgrad_stream(dev, i):
+    return side_stream(dev if i == 0 else (dev, "wgrad%d" % i))
+
+
 def join_side_stream():
-    """Make the current stream wait for everything queued on the side stream (queued automatically as an end-of-backward
+    """Make the current stream wait for everything queued on the side stream(s) (queued automatically as an end-of-backward
     callback by conv_wgrad_async; FusedSGD.step calls it again before touching the gradients)."""
     if _join_pending[0]:
         L.lib().abr_prof_mark_overlap(0)
     _join_pending[0] = False
     if torch.cuda.is_available():
-        s = _side_streams.get(torch.cuda.current_device())
-        if s is not None:
-            torch.cuda.current_stream().wait_stream(s)
+        dev = torch.cuda.current_device()
+        for i in range(WGRAD_STREAMS):
+            s = _side_streams.get(dev if i == 0 else (dev, "wgrad%d" % i))
+            if s is not None:
+                torch.cuda.current_stream().wait_stream(s)
 
 
 # The side stream ends a backward pass behind the main one (the dgrad chain of the last stage is short, its weight gradients are not):
@@ -381,7 +390,7 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino
     if not WGRAD_SIDE_STREAM:
         return conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v)
     cur = torch.cuda.current_stream()
-    side = side_stream(x.device.index)
+    side = _wgrad_stream(x.device.index, _wg_seq["n"] % WGRAD_STREAMS)
     if not _join_pending[0]:
         _join_pending[0] = True
         _wg_seq["last_total"], _wg_seq["n"] = _wg_seq["n"], 0

@@ -61,8 +61,11 @@ class FusedSGD(object):
         self.reducer.force = bool(on)
 
     def _grad_writer_streams(self):
-        s = ops._side_streams.get(self.flat.grads.device.index) if self.flat.grads.is_cuda else None
-        return [s] if s is not None else []
+        if not self.flat.grads.is_cuda:
+            return []
+        dev = self.flat.grads.device.index
+        keys = [dev] + [(dev, "wgrad%d" % i) for i in range(1, ops.WGRAD_STREAMS)]
+        return [ops._side_streams[k] for k in keys if k in ops._side_streams]
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
