@@ -63,11 +63,16 @@ class FusedSGD(object):
     def _grad_writer_streams(self):
         if not self.flat.grads.is_cuda:
             return []
+        # every side stream of this device may hold kernels that write the gradient buffer (weight gradients, a head pass that ran on
+        # its own stream: engine/trainer.py), and so may the stream the step was started on
         dev = self.flat.grads.device.index
-        keys = [dev] + [(dev, "wgrad%d" % i) for i in range(1, ops.WGRAD_STREAMS)]
-        return [ops._side_streams[k] for k in keys if k in ops._side_streams]
+        out = [s for k, s in ops._side_streams.items() if (k[0] if isinstance(k, tuple) else k) == dev]
+        if getattr(self, "_main_stream", None) is not None:
+            out.append(self._main_stream)
+        return out
 
     def zero_grad(self, set_to_none=False):
+        self._main_stream = torch.cuda.current_stream() if self.flat.grads.is_cuda else None
         self.flat.zero_grad()
         self.reducer.begin()
 
