@@ -307,10 +307,21 @@ inline unsigned grid_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 25
 
 namespace abr {
 
-// V = 4 needs C % 4 == 0 (16 B alignment of every row of every tensor involved: all of them have C as their innermost pitch)
+// V = 4 needs C % 4 == 0 (16 B alignment of every row of every tensor involved: all of them have C as their innermost pitch) and is
+// only taken when it still leaves >= 4 workgroups per CU: the small layers (layer3: 640 tiles x 256 channels) are bound by launch
+// latency / parallelism, not by access width, and run better with twice the threads
+static inline bool wide(int64_t tiles, int C) {
+    static const int force = getenv("ABR_WINO_VEC") ? atoi(getenv("ABR_WINO_VEC")) : 0;
+    if (force == 2) return false;
+    if (force == 4) return C % 4 == 0;
+    return C % 4 == 0 && tiles * (C / 4) >= (int64_t)256 * 4 * 256;
+}
+
 int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, hipStream_t st) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
-    if (C % 4 == 0) wino_input_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (C / 4)), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V);
+    // (measured: the input transform is never faster with 16 B accesses -- 0.95 ms / step at V = 2 against 1.07 mixed and 1.13 at V = 4)
+    static const bool in4 = getenv("ABR_WINO_VEC") && atoi(getenv("ABR_WINO_VEC")) == 4;
+    if (in4 && C % 4 == 0) wino_input_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (C / 4)), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V);
     else wino_input_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (C / 2)), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -324,7 +335,7 @@ int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st
 int wino_output_transform(const float* Mm, int B, int H, int W, int N, const float* scale, const float* bias, int relu, const float* mask,
                           float* out, hipStream_t st) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
-    if (N % 4 == 0)
+    if (wide((int64_t)B * th_n * tw_n, N))
         wino_output_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (N / 4)), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out);
     else
         wino_output_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out);
@@ -333,7 +344,7 @@ int wino_output_transform(const float* Mm, int B, int H, int W, int N, const flo
 
 int wino_outgrad_transform(const float* gy, int B, int H, int W, int N, float* Mg, hipStream_t st) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
-    if (N % 4 == 0) wino_outgrad_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (N / 4)), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg);
+    if (wide((int64_t)B * th_n * tw_n, N)) wino_outgrad_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (N / 4)), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg);
     else wino_outgrad_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
