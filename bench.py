@@ -123,8 +123,14 @@ def roofline(prof, totals, a, elapsed):
                         "algorithmic_gflop": round(alg_flops_step / 1e9, 1), "algorithmic_tflops": round(alg_flops_step / step_s / 1e12, 2),
                         "note": "conv/linear flops of one rank's step / wall-clock step time (everything else in the step included)"}}
     if peak_step:
+        r["whole_step"]["peak"] = peak_step
         r["whole_step"]["executed_frac"] = round(exec_flops_step / step_s / 1e12 / peak_step, 4)
         r["whole_step"]["algorithmic_frac"] = round(alg_flops_step / step_s / 1e12 / peak_step, 4)
+    if a.math == "bf16x6":   # for orientation: the same flops against what the fp32 matrix pipe (round 1's arithmetic) could ever deliver
+        r["whole_step"]["vs_fp32_mfma_peak"] = {"peak": PEAK_FP32_MFMA_TFLOPS, "executed_frac": round(exec_flops_step / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                                "algorithmic_frac": round(alg_flops_step / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    r["note"] = ("per-launch durations inside the step are stretched by the kernels of the other HIP streams sharing the CUs (3 streams in the "
+                 "forward pass, 2 in the backward pass); they shrink when the streams are serialised or when a profiler slows the host")
     return r
 
 
