@@ -35,6 +35,11 @@ SOURCE_OVERLAP = os.environ.get("ABR_SOURCE_OVERLAP", "1") != "0"
 SOURCE_STREAM = os.environ.get("ABR_SOURCE_STREAM", "1") != "0"
 # ... and its 64-RoI head pass too (next to the target's 2048-RoI pass); 0: on the main stream between the target's two forward halves
 SOURCE_HEAD_STREAM = os.environ.get("ABR_SOURCE_HEAD_STREAM", "1") != "0"
+# software pipelining across steps: when the caller names the NEXT batch (`train_step(..., next_images=)`; `do_train` looks one batch ahead),
+# the frozen source model's backbone + RPN head for it are enqueued on the source stream before this step's backward pass and run next to it
+# -- their result does not depend on this step's update.  Same work per step, same results; 0 = off.
+PIPELINE_SOURCE = os.environ.get("ABR_PIPELINE_SOURCE", "1") != "0"
+_PREFETCHED = {}
 JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "0") != "0"
 
 
@@ -113,7 +118,7 @@ def _join_source_stream(deferred):
             t.record_stream(cur)
 
 
-def train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg, faithful_rng=False, log=None):
+def train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg, faithful_rng=False, log=None, next_images=None):
     """One iteration of tools/train_incremental.py:77-147.  Returns (loss_dict_target incl. 'distillation_loss', total loss)."""
     dist_type = cfg.DIST.TYPE
     use_id = cfg.DIST.ALPHA > 0
@@ -127,7 +132,13 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
             on_gpu = (images.tensors if hasattr(images, "tensors") else images).is_cuda
             if SOURCE_OVERLAP and not faithful_rng and on_gpu and hasattr(model_source, "soften_begin") and not model_source.training:
                 # source backbone + RPN head now, its proposal selection on a side stream; finished after the target's forward
-                if SOURCE_STREAM:
+                pre = None
+                if _PREFETCHED.get("images") is images and _PREFETCHED.get("model") is model_source:
+                    pre = _PREFETCHED["state"]        # enqueued during the previous step's backward pass
+                _PREFETCHED.clear()
+                if pre is not None:
+                    deferred = pre
+                elif SOURCE_STREAM:
                     from .. import ops
                     cur = torch.cuda.current_stream()
                     src = ops.side_stream((cur.device.index, "source-model"))
@@ -213,6 +224,19 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
     loss_dict_target["distillation_loss"] = distillation_losses.clone().detach()                           # :124-126
     losses = faster_rcnn_losses + distillation_losses                                                      # :128
 
+    if (PIPELINE_SOURCE and need_source and next_images is not None and SOURCE_STREAM and SOURCE_OVERLAP and not faithful_rng
+            and hasattr(model_source, "soften_begin") and not model_source.training
+            and (next_images.tensors if hasattr(next_images, "tensors") else next_images).is_cuda):
+        # software pipelining: the frozen source model's backbone + RPN head for the NEXT batch go onto the source stream now, where they
+        # run next to this step's backward pass (their result does not depend on this step's update)
+        from .. import ops
+        cur = torch.cuda.current_stream()
+        src = ops.side_stream((cur.device.index, "source-model"))
+        with torch.no_grad(), torch.cuda.stream(src):
+            nxt = model_source.soften_begin(next_images)
+        nxt["_stream"] = src
+        _PREFETCHED.clear()
+        _PREFETCHED.update(images=next_images, model=model_source, state=nxt)   # (holds the batch object: identity, not id(), is the key)
     optimizer.zero_grad()                                                                                  # :142
     _arm_overlap(optimizer, [det_pooled, roi_align_features_target if need_source else None], feature_target)
     losses.backward()                                                                                      # :144-145 (amp O0 = identity)
@@ -234,14 +258,23 @@ def do_train(model_source, model_target, data_loader, optimizer, scheduler, chec
     model_source.eval()
     start_training_time = time.time()
     end = time.time()
-    for iteration, (images, targets, _, idx) in enumerate(data_loader, start_iter):
+    def on_device(batch):
+        images, targets, _, idx = batch
+        return images.to(device), [t.to(device) for t in targets], idx
+
+    it = iter(data_loader)
+    nxt = next(it, None)
+    nxt = on_device(nxt) if nxt is not None else None
+    iteration = start_iter
+    while nxt is not None:
         data_time = time.time() - end
+        images, targets, idx = nxt
+        nxt = next(it, None)                      # one batch of lookahead: the source model's forward for it is pipelined into this step
+        nxt = on_device(nxt) if nxt is not None else None
         iteration = iteration + 1
         arguments_target["iteration"] = iteration
-        images = images.to(device)
-        targets = [t.to(device) for t in targets]
         loss_dict_target, losses = train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg,
-                                              faithful_rng=faithful_rng)
+                                              faithful_rng=faithful_rng, next_images=nxt[0] if nxt is not None else None)
         loss_dict_reduced = reduce_loss_dict(loss_dict_target)
         batch_time = time.time() - end
         end = time.time()

@@ -258,7 +258,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t)
+        train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t, next_images=images)
 
     time_kernels = (rank == 0) and not a.no_kernel_timing
     barrier()
@@ -275,7 +275,7 @@ def main():
     for _ in range(a.steps):
         if time_kernels:
             _lib.lib().abr_prof_step_begin()
-        last = train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t)
+        last = train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t, next_images=images)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = None

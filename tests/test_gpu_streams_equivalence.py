@@ -1,5 +1,5 @@
 """GPU: every stream-level overlap of the training step -- weight gradients on a side stream, proposal selections on side streams, the
-source model's forward and head pass on a stream of their own, weight preparation (dgrad copies, Winograd-domain weights) on its own
+source model's forward and head pass on a stream of their own (for the NEXT batch pipelined into the current backward pass), weight preparation (dgrad copies, Winograd-domain weights) on its own
 stream after the SGD kernel -- changes WHEN kernels run, never what they compute: four training steps with all of them on must
 leave the same parameters as four steps with all of them off (same seeds, so the same sampler draws and soften picks; fp32 atomic
 accumulation order is the only difference).  A missing stream dependency (a kernel reading a buffer another stream has not finished
@@ -36,7 +36,9 @@ def _run(overlap, width_overrides, steps=4):
         losses = []
         for it in range(steps):
             images, targets = batches[it % 2]
-            ld, total = trainer.train_step(ms, mt, images, targets, opt, sch, cfg_t)
+            # overlap mode also names the NEXT batch: the source model's forward for it is pipelined into this step's backward pass
+            nxt = batches[(it + 1) % 2][0] if (overlap and it + 1 < steps) else None
+            ld, total = trainer.train_step(ms, mt, images, targets, opt, sch, cfg_t, next_images=nxt)
             losses.append(float(total.detach()))
         torch.cuda.synchronize()
         return mt.flat.params.detach().clone(), losses
