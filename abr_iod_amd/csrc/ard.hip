@@ -25,7 +25,7 @@ __device__ __forceinline__ float sumsq4(float acc, const float4 v) {
 
 // element (n, hw, c) at base + hw*sHW + c*sC
 template <bool VEC4>
-__global__ __launch_bounds__(256) void ard_fwd_kernel(const float* __restrict__ f_src, const float* __restrict__ f_tgt,
+__global__ __launch_bounds__(1024) void ard_fwd_kernel(const float* __restrict__ f_src, const float* __restrict__ f_tgt,
                                                        int N, int C, int HW, int sHW, int sC, float gamma,
                                                        float* __restrict__ coef, float* __restrict__ loss_out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // ms[HW], mt[HW], d2[HW], red[8]
@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void ard_fwd_kernel(const float* __restrict__ 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* ps = f_src + (size_t)n * HW * C;
     const float* pt = f_tgt + (size_t)n * HW * C;
-    for (int hw = wave; hw < HW; hw += 4) {
+    const int nwaves = blockDim.x >> 6;   // 16 waves per RoI: one workgroup per CU needs them to keep enough 16 B loads in flight
+    for (int hw = wave; hw < HW; hw += nwaves) {
         float a = 0.f, b = 0.f, d = 0.f;
         if (VEC4) {
             const float4* rs = reinterpret_cast<const float4*>(ps + (size_t)hw * sHW);
@@ -155,11 +156,11 @@ extern "C" int abr_ard_forward(const float* f_src, const float* f_tgt, int N, in
     ABR_REQUIRE(f_src && f_tgt && coef, "ard_forward: null pointer");
     const size_t lds = sizeof(float) * (3 * (size_t)HW + 8);
     if (layout == ABR_NHWC && C % 4 == 0)
-        ard_fwd_kernel<true><<<N, 256, lds, st>>>(f_src, f_tgt, N, C, HW, C, 1, gamma, coef, loss_out);
+        ard_fwd_kernel<true><<<N, 1024, lds, st>>>(f_src, f_tgt, N, C, HW, C, 1, gamma, coef, loss_out);
     else if (layout == ABR_NHWC)
-        ard_fwd_kernel<false><<<N, 256, lds, st>>>(f_src, f_tgt, N, C, HW, C, 1, gamma, coef, loss_out);
+        ard_fwd_kernel<false><<<N, 1024, lds, st>>>(f_src, f_tgt, N, C, HW, C, 1, gamma, coef, loss_out);
     else
-        ard_fwd_kernel<false><<<N, 256, lds, st>>>(f_src, f_tgt, N, C, HW, 1, HW, gamma, coef, loss_out);
+        ard_fwd_kernel<false><<<N, 1024, lds, st>>>(f_src, f_tgt, N, C, HW, 1, HW, gamma, coef, loss_out);
     ABR_CHECK_LAUNCH("ard_forward");
     return ABR_OK;
 }

@@ -57,3 +57,25 @@ def match_fraction(a, b, atol=1e-2):
         d = np.abs(a[lo:lo + 256, None, :] - b[None, :, :]).max(-1)
         hit += int((d.min(1) <= atol).sum())
     return hit / len(a)
+
+
+def run_ranks(ctx, target, argsets, timeout):
+    """start one process per argument tuple, collect one queue item per rank, and ALWAYS reap the children: a rank that died or wedged in
+    a collective must fail the test, not leave orphans that block the interpreter's exit (daemonic + terminate/kill in `finally`)"""
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=tuple(a) + (q,), daemon=True) for a in argsets]
+    for p in procs:
+        p.start()
+    try:
+        got = [q.get(timeout=timeout) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0, p.exitcode
+        return got
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(5)
+                if p.is_alive():
+                    p.kill()

@@ -68,14 +68,9 @@ def _worker(rank, world, port, out):
 def test_flat_allreduce_matches_single_process():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=150) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=30)
-        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from e2e_common import run_ranks
+    got = run_ranks(ctx, _worker, [(r, world, port) for r in range(world)], timeout=150)
     params0, red, _ = next(g for g in got if g[0] is not None)
     per_rank_losses = [g[2] for g in got]
 
@@ -123,14 +118,9 @@ def test_eval_predictions_merge_across_ranks():
     ranks with None (engine/inference.py:143-160)."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = dict(q.get(timeout=150) for _ in range(world))
-    for p in procs:
-        p.join(timeout=30)
-        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from e2e_common import run_ranks
+    got = dict(x for x in run_ranks(ctx, _eval_worker, [(r, world, port) for r in range(world)], timeout=150))
     assert got[1] is None
     assert got[0] == [(i + 1, (100 + i, 50), float(i), [float(v) for v in range(i + 1)]) for i in range(6)]
 
@@ -178,14 +168,9 @@ def _reducer_worker(rank, world, port, out):
 def test_bucketed_overlapped_allreduce_equals_one_allreduce():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=150) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=30)
-        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from e2e_common import run_ranks
+    got = run_ranks(ctx, _reducer_worker, [(r, world, port) for r in range(world)], timeout=150)
     want = torch.arange(2048, dtype=torch.float32) * 3   # rank 0 holds 1x, rank 1 holds 2x: every element summed exactly once
     for rank, results in got:
         for r in results:

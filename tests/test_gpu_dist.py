@@ -87,7 +87,7 @@ def _two_rank_worker(rank, world, port, out):
     g_local = mt.flat.grads.clone().cpu().numpy()
     ev_rpn, ev_box = mt.rpn.loss_evaluator, mt.roi_heads.box.loss_evaluator
     pos, samp = ev_rpn.last_sampled
-    draws = ((pos[pos >= 0].clone(), samp[samp >= 0].clone()), [t.clone() for t in ev_box.last_sampled_inds], [list(s) for s in ms.last_soften_indices])
+    draws = ((pos[pos >= 0].clone(), samp[samp >= 0].clone()), [t[t >= 0].clone() for t in ev_box.last_sampled_inds], [list(s) for s in ms.last_soften_indices])
 
     # (b) the real thing: two steps with the hook-issued exchange; the first replays the draws of (a)
     ms, mt = build_models(cfg_s, cfg_t, seed=0)                     # same weights on both ranks
@@ -129,14 +129,10 @@ def test_two_ranks_exchange_gradients_through_the_hooks():
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from e2e_common import run_ranks
+    got = sorted(run_ranks(ctx, _two_rank_worker, [(r, world, port) for r in range(world)], timeout=500), key=lambda t: t[0])
     (_, p0, g0, s0, l0, u0), (_, p1, g1, s1, l1, u1) = got
     # the hooks fired during backward on both ranks: pooled-input hook -> roi_heads; feature-map hook -> roi_heads (already sent), rpn
     assert s0[:3] == ["roi_heads", "roi_heads", "rpn"] and s1 == s0
@@ -225,7 +221,7 @@ def test_two_ranks_one_image_each_equal_one_rank_two_images():
     draws, single_props = [], []
     for i in range(2):
         sel = lambda t: (t[(t >= i * n) & (t < (i + 1) * n)] - i * n).tolist()
-        draws.append((sel(pos_all), sel(samp_all), ev_box.last_sampled_inds[i].cpu().tolist(), list(ms.last_soften_indices[i])))
+        draws.append((sel(pos_all), sel(samp_all), [v for v in ev_box.last_sampled_inds[i].cpu().tolist() if v >= 0], list(ms.last_soften_indices[i])))
         single_props.append(ev_box.last_input_proposals[i].bbox.cpu().numpy())
         assert len(draws[i][1]) == 64 and len(draws[i][2]) == 48 and len(draws[i][3]) == 64   # equal shares: mean of means == global mean
     ld_single = {k: float(v) for k, v in ld.items()}
@@ -233,14 +229,8 @@ def test_two_ranks_one_image_each_equal_one_rank_two_images():
     # ---- two ranks, one image each, the same draws
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_eq_rank_worker, args=(r, world, port, draws, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = sorted([q.get(timeout=800) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    from e2e_common import run_ranks
+    got = sorted(run_ranks(ctx, _eq_rank_worker, [(r, world, port, draws) for r in range(world)], timeout=700), key=lambda t: t[0])
     (_, g0, p0, ld0, props0), (_, g1, p1, ld1, props1) = got
     # the per-image proposal lists the injected indices refer to are the same lists
     for w, sgl in ((props0, single_props[0]), (props1, single_props[1])):

@@ -248,7 +248,7 @@ def test_joint_roi_pass_equals_two_calls(step_state):
     pos_idx, samp_idx = ev_rpn.last_sampled
     # run 2: the joint pass with the same draws
     ev_rpn.inject_sampled = (pos_idx[pos_idx >= 0], samp_idx[samp_idx >= 0])
-    ev_box.inject_sampled_inds = ev_box.last_sampled_inds
+    ev_box.inject_sampled_inds = [t[t >= 0] for t in ev_box.last_sampled_inds]   # (the fused sampler pads short lists with -1)
     try:
         mt.flat.zero_grad()
         (loss_dict2, _, _, _, _, props2, _, soft_res2), (target_result2, _, raf_t2) = mt.forward_joint(images, targets, soften_proposal)
