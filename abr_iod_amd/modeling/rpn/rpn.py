@@ -110,16 +110,17 @@ class AnchorGenerator(nn.Module):
             a, vis = ops.grid_anchors(self.cell_anchors, H, W, self.strides[0], int(image_hw[0]), int(image_hw[1]), self.straddle_thresh)
             # the boxes depend on (H, W) only, the visibility also on the image size: share ONE box tensor per grid
             a = self._cache.setdefault((H, W, self.cell_anchors.device), a)
-            hit = self._cache[key] = (a, vis)
+            hit = self._cache[key] = (a, vis, vis.bool())   # uint8 for the kernels, bool for the reference-typed BoxList field: made once
         return hit
 
     def forward(self, image_list, feature_maps):
         H, W = feature_maps[0].shape[-2:]
         anchors = []
         for (ih, iw) in image_list.image_sizes:
-            a, vis = self.grid(H, W, (ih, iw))
+            a, vis, vis_bool = self.grid(H, W, (ih, iw))
             bl = BoxList(a, (iw, ih), mode="xyxy")
-            bl.add_field("visibility", vis.bool())
+            bl.add_field("visibility", vis_bool)
+            bl._visibility_u8 = vis                   # the same mask as the kernels read it (no per-step dtype round trip)
             anchors.append([bl])
         return anchors
 
@@ -418,9 +419,11 @@ class RPNLossComputation(object):
         """rpn/loss.py:66-102 per image -> labels fp32 {1,0,-1}, regression targets, matched idxs"""
         labels, regression_targets, matched = [], [], []
         for a, t in zip(anchors, targets):
-            vis = a.get_field("visibility")
-            m, lab, tgt = self.proposal_matcher.match_boxes(t.bbox, a.bbox, None, vis.to(torch.uint8) if vis.dtype != torch.uint8 else vis,
-                                                            self.box_coder.weights, rpn_labels=True)
+            vis = getattr(a, "_visibility_u8", None)
+            if vis is None:
+                vis = a.get_field("visibility")
+                vis = vis.to(torch.uint8) if vis.dtype != torch.uint8 else vis
+            m, lab, tgt = self.proposal_matcher.match_boxes(t.bbox, a.bbox, None, vis, self.box_coder.weights, rpn_labels=True)
             labels.append(lab)
             regression_targets.append(tgt)
             matched.append(m)
