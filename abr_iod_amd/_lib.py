@@ -47,6 +47,10 @@ _SIGS = {
     "abr_conv_prepare_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "abr_roi_head_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _i, _i, C.c_uint64,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "abr_rpn_targets_batched": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i64, _vp]),
+    "abr_rpn_loss_indices": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "abr_loss_sum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "abr_loss_sum_backward": (_i, [_vp, _i, _vp, _vp, _vp]),
     "abr_gather_proposals": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "abr_x6_range_flags": (_i, [_vp, _i, _vp]),
     "abr_x6_range_flags_async": (_i, [_vp, _vp]),

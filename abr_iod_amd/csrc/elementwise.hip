@@ -307,6 +307,46 @@ extern "C" int abr_add_inplace(float* a, const float* b, int64_t n, void* stream
     return ABR_OK;
 }
 
+namespace {
+struct LossTerms { const float* p[8]; float w[8]; int group[8]; };
+// out[0] = sum_i w_i * *p_i ; out[1 + g] = the same restricted to group g (0 / 1): the trainer's total loss and its two logged parts
+__global__ void loss_sum_kernel(const LossTerms t, int n, float* __restrict__ total, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float tot = 0.f, g0 = 0.f, g1 = 0.f;
+        for (int i = 0; i < n; i++) {
+            const float v = t.w[i] * *t.p[i];
+            tot += v;
+            if (t.group[i] == 0) g0 += v; else g1 += v;
+        }
+        *total = tot;
+        out[0] = tot; out[1] = g0; out[2] = g1;
+    }
+}
+// grads[i] = w_i * *g (the upstream gradient of the total, a device scalar)
+__global__ void loss_sum_bwd_kernel(const LossTerms t, int n, const float* __restrict__ g, float* __restrict__ grads) {
+    if (threadIdx.x < n && blockIdx.x == 0) grads[threadIdx.x] = t.w[threadIdx.x] * *g;
+}
+}  // namespace
+
+extern "C" int abr_loss_sum(const float* const* terms_host, const float* weights_host, const int32_t* groups_host, int n, float* total, float* out,
+                            void* stream) {
+    ABR_REQUIRE(n >= 1 && n <= 8 && terms_host && weights_host && groups_host && total && out, "loss_sum: 1..8 terms");
+    LossTerms t;
+    for (int i = 0; i < 8; i++) { t.p[i] = i < n ? terms_host[i] : nullptr; t.w[i] = i < n ? weights_host[i] : 0.f; t.group[i] = i < n ? groups_host[i] : 0; }
+    for (int i = 0; i < n; i++) ABR_REQUIRE(t.p[i], "loss_sum: null term");
+    loss_sum_kernel<<<1, 64, 0, abr::as_stream(stream)>>>(t, n, total, out);
+    ABR_CHECK_LAUNCH("loss_sum");
+    return ABR_OK;
+}
+extern "C" int abr_loss_sum_backward(const float* weights_host, int n, const float* g, float* grads, void* stream) {
+    ABR_REQUIRE(n >= 1 && n <= 8 && weights_host && g && grads, "loss_sum_backward: 1..8 terms");
+    LossTerms t;
+    for (int i = 0; i < 8; i++) { t.p[i] = nullptr; t.w[i] = i < n ? weights_host[i] : 0.f; t.group[i] = 0; }
+    loss_sum_bwd_kernel<<<1, 64, 0, abr::as_stream(stream)>>>(t, n, g, grads);
+    ABR_CHECK_LAUNCH("loss_sum_backward");
+    return ABR_OK;
+}
+
 extern "C" int abr_scale_inplace(float* x, int64_t n, float s, const float* s_dev, void* stream) {
     if (n == 0) return ABR_OK;
     ABR_REQUIRE(x && n > 0, "scale_inplace: bad args");

@@ -258,6 +258,90 @@ __global__ void gather_proposals_kernel(const float* __restrict__ props, const f
     if (obj) obj[t] = scores[(int64_t)i * k_pre + src];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// RPN training targets for the whole batch (abr_rpn_targets_batched): the anchors are shared by the images (same feature-map size), the
+// GT boxes and the visibility masks are per image.  Same arithmetic as gt_max_iou_kernel / match_encode_kernel, blockIdx.y = image.
+__global__ void gt_max_iou_batched_kernel(const float* __restrict__ boxes, int n, const float* const* __restrict__ gt_ptrs,
+                                          const int32_t* __restrict__ n_gt, int g_max, unsigned* __restrict__ rowmax) {
+    const int i = blockIdx.y;
+    const float* gt = gt_ptrs[i];
+    const int G = n_gt[i];
+    for (int g = 0; g < G; g++) {
+        const float4 gb = reinterpret_cast<const float4*>(gt)[g];
+        float m = 0.f;
+        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+            m = fmaxf(m, box_iou(gb, reinterpret_cast<const float4*>(boxes)[j]));
+        m = abr::wave_max(m);
+        if ((threadIdx.x & 63) == 0) atomicMax(rowmax + (size_t)i * g_max + g, __float_as_uint(m));
+    }
+}
+
+#pragma clang fp contract(off)
+__global__ void rpn_match_batched_kernel(const float* __restrict__ boxes, int n, const float* const* __restrict__ gt_ptrs,
+                                         const int32_t* __restrict__ n_gt, int g_max, const uint8_t* const* __restrict__ vis_ptrs, float hi,
+                                         float lo, const unsigned* __restrict__ rowmax, float wx, float wy, float ww, float wh,
+                                         float* __restrict__ labels, float* __restrict__ reg_targets) {
+    const int i = blockIdx.y;
+    const float* gt = gt_ptrs[i];
+    const uint8_t* vis = vis_ptrs[i];
+    const int G = n_gt[i];
+    const unsigned* rm = rowmax + (size_t)i * g_max;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const float4 b = reinterpret_cast<const float4*>(boxes)[j];
+        float best = -1.f;
+        int bi = 0;
+        bool lq = false;
+        for (int g = 0; g < G; g++) {
+            const float v = box_iou(reinterpret_cast<const float4*>(gt)[g], b);
+            if (v > best) { best = v; bi = g; }
+            if (v == __uint_as_float(rm[g])) lq = true;                            // allow_low_quality_matches (matcher.py:83-112)
+        }
+        int64_t m = best < lo ? -1 : (best < hi ? -2 : bi);
+        if (lq) m = bi;
+        const int gi = m < 0 ? 0 : (int)m;
+        float l = m >= 0 ? 1.f : 0.f;                                               // rpn/loss.py:78-92
+        if (vis && !vis[j]) l = -1.f;
+        if (m == -2) l = -1.f;
+        labels[(size_t)i * n + j] = l;
+        const float4 r = reinterpret_cast<const float4*>(gt)[gi];
+        const float ew = b.z - b.x + 1, eh = b.w - b.y + 1;
+        const float ecx = b.x + 0.5f * ew, ecy = b.y + 0.5f * eh;
+        const float gw = r.z - r.x + 1, gh = r.w - r.y + 1;
+        const float gcx = r.x + 0.5f * gw, gcy = r.y + 0.5f * gh;
+        float4 o;
+        o.x = wx * (gcx - ecx) / ew;
+        o.y = wy * (gcy - ecy) / eh;
+        o.z = ww * logf(gw / ew);
+        o.w = wh * logf(gh / eh);
+        reinterpret_cast<float4*>(reg_targets)[(size_t)i * n + j] = o;
+    }
+}
+
+// RPN loss bookkeeping in one launch: the sampler's two padded lists -> the concatenated "all sampled" list, the flat positions of their
+// objectness logits and box deltas inside the fused NHWC head output (anchor j of the flattened batch: row j / A, columns j % A and
+// A + 4 (j % A) of a row of Cf columns), and the number of sampled anchors as a float (the losses' normaliser, rpn/loss.py:136,146).
+__global__ void rpn_loss_indices_kernel(const int64_t* __restrict__ pos, int n_pos, const int64_t* __restrict__ neg, int n_neg,
+                                        const int32_t* __restrict__ counts, int n_img, int A, int Cf, int64_t* __restrict__ samp,
+                                        int64_t* __restrict__ obj_flat, int64_t* __restrict__ pos_row, int64_t* __restrict__ pos_col,
+                                        float* __restrict__ denom) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_pos + n_neg) {
+        const int64_t v = t < n_pos ? pos[t] : neg[t - n_pos];
+        samp[t] = v;
+        const int64_t row = v >= 0 ? v / A : -1;
+        obj_flat[t] = v >= 0 ? row * Cf + (v - row * A) : -1;
+        if (t < n_pos) {
+            pos_row[t] = row;
+            pos_col[t] = v >= 0 ? A + 4 * (v - row * A) : 0;
+        }
+    }
+    if (t == 0) {
+        int c = 0;
+        for (int i = 0; i < 2 * n_img; i++) c += counts[i];
+        *denom = (float)c;
+    }
+}
+
 // BoxCoder.encode row-wise (box_coder.py:22-50): out[i] = encode(gt[i], ex[i])
 #pragma clang fp contract(off)
 __global__ void box_encode_kernel(const float* __restrict__ gt, const float* __restrict__ ex, int n, float wx, float wy,
@@ -366,5 +450,32 @@ extern "C" int abr_gather_proposals(const float* props, const float* scores, con
     ABR_REQUIRE(props && keep && picks && rois && (!obj || scores), "gather_proposals: null pointer");
     gather_proposals_kernel<<<abr::cdiv((int64_t)N * P, 256), 256, 0, abr::as_stream(stream)>>>(props, scores, keep, k_pre, post, picks, N, P, rois, obj);
     ABR_CHECK_LAUNCH("gather_proposals");
+    return ABR_OK;
+}
+
+extern "C" int abr_rpn_targets_batched(const float* anchors, int n, int N, const float* const* gt_ptrs, const int32_t* n_gt, int g_max,
+                                       const uint8_t* const* vis_ptrs, float hi, float lo, float wx, float wy, float ww, float wh,
+                                       float* labels, float* reg_targets, void* workspace, int64_t workspace_bytes, void* stream) {
+    ABR_REQUIRE(n >= 0 && N > 0 && g_max > 0, "rpn_targets_batched: bad sizes");
+    if (n == 0) return ABR_OK;
+    ABR_REQUIRE(anchors && gt_ptrs && n_gt && vis_ptrs && labels && reg_targets && workspace, "rpn_targets_batched: null pointer");
+    ABR_REQUIRE(workspace_bytes >= (int64_t)N * g_max * 4, "rpn_targets_batched: workspace too small");
+    hipStream_t st = abr::as_stream(stream);
+    unsigned* rowmax = (unsigned*)workspace;
+    if (hipMemsetAsync(rowmax, 0, 4 * (size_t)N * g_max, st) != hipSuccess) return ABR_E_LAUNCH;
+    gt_max_iou_batched_kernel<<<dim3(std::min(abr::cdiv(n, 256), 256u), N), 256, 0, st>>>(anchors, n, gt_ptrs, n_gt, g_max, rowmax);
+    rpn_match_batched_kernel<<<dim3(abr::cdiv(n, 256), N), 256, 0, st>>>(anchors, n, gt_ptrs, n_gt, g_max, vis_ptrs, hi, lo, rowmax, wx, wy, ww, wh,
+                                                                          labels, reg_targets);
+    ABR_CHECK_LAUNCH("rpn_targets_batched");
+    return ABR_OK;
+}
+
+extern "C" int abr_rpn_loss_indices(const int64_t* pos, int n_pos, const int64_t* neg, int n_neg, const int32_t* counts, int n_img, int A,
+                                    int Cf, int64_t* samp, int64_t* obj_flat, int64_t* pos_row, int64_t* pos_col, float* denom, void* stream) {
+    ABR_REQUIRE(n_pos >= 0 && n_neg >= 0 && n_img > 0 && A > 0 && Cf >= 5 * A, "rpn_loss_indices: bad sizes");
+    ABR_REQUIRE(pos && neg && counts && samp && obj_flat && pos_row && pos_col && denom, "rpn_loss_indices: null pointer");
+    rpn_loss_indices_kernel<<<abr::cdiv(std::max(n_pos + n_neg, 1), 256), 256, 0, abr::as_stream(stream)>>>(pos, n_pos, neg, n_neg, counts, n_img, A, Cf,
+                                                                                                             samp, obj_flat, pos_row, pos_col, denom);
+    ABR_CHECK_LAUNCH("rpn_loss_indices");
     return ABR_OK;
 }

@@ -193,36 +193,40 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
     else:
         loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results = \
             model_target(images, targets, rpn_output_source=rpn_output_source)                             # :89-90
-    faster_rcnn_losses = sum(loss for loss in loss_dict_target.values())                                   # :91
     if deferred is not None:
         _join_source_stream(deferred)
         with torch.no_grad():
             soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
                 model_source.soften_finish(deferred)
 
-    distillation_losses = torch.zeros((), device=faster_rcnn_losses.device)
+    # the loss arithmetic of train_incremental.py:91,101-128 -- sum of the detector losses, alpha * ID (+ std) + beta * ARD (+ RPN), their
+    # sum -- gathered as (term, weight, group) and evaluated by ONE kernel (ops.loss_sum) instead of a chain of scalar adds / muls
+    terms = [(v, 1.0, 0) for v in loss_dict_target.values()]                                               # :91
     if need_source:
         if not joint:
             target_result, _, roi_align_features_target = model_target.forward(images, targets, features=feature_target,
                                                                                proposals=soften_proposal)  # :93-95
         if use_id:                                                                                         # :101-103
-            distillation_losses = cfg.DIST.ALPHA * calculate_roi_distillation_losses(soften_result, target_result, dist=dist_type,
-                                                                                     soften_proposal=None)
+            terms.append((calculate_roi_distillation_losses(soften_result, target_result, dist=dist_type, soften_proposal=None),
+                          cfg.DIST.ALPHA, 1))
         if cfg.DIST.FEAT == "std":                                                                         # :108-112 (ablation)
-            distillation_losses = distillation_losses + calculate_feature_distillation_loss(feature_source, feature_target,
-                                                                                          loss="normalized_filtered_l1")
+            terms.append((calculate_feature_distillation_loss(feature_source, feature_target, loss="normalized_filtered_l1"), 1.0, 1))
         elif use_ard:                                                                                      # :113-116
-            feature_distillation_losses = calculate_attentive_roi_feature_distillation(roi_align_features_source,
-                                                                                       roi_align_features_target, gamma=cfg.DIST.GAMMA)
-            distillation_losses = distillation_losses + cfg.DIST.BETA * feature_distillation_losses
+            terms.append((calculate_attentive_roi_feature_distillation(roi_align_features_source, roi_align_features_target,
+                                                                       gamma=cfg.DIST.GAMMA), cfg.DIST.BETA, 1))
         if cfg.DIST.RPN:                                                                                   # :120-122 (ablation)
-            distillation_losses = distillation_losses + calculate_rpn_distillation_loss(rpn_output_source, rpn_output_target,
-                                                                                        cls_loss="filtered_l2", bbox_loss="l2",
-                                                                                        bbox_threshold=0.1)
-
+            terms.append((calculate_rpn_distillation_loss(rpn_output_source, rpn_output_target, cls_loss="filtered_l2", bbox_loss="l2",
+                                                          bbox_threshold=0.1), 1.0, 1))
     loss_dict_target = dict(loss_dict_target)
-    loss_dict_target["distillation_loss"] = distillation_losses.clone().detach()                           # :124-126
-    losses = faster_rcnn_losses + distillation_losses                                                      # :128
+    if terms[0][0].is_cuda and len(terms) <= 8:
+        from .. import ops
+        losses, parts = ops.loss_sum([t for t, _, _ in terms], [w for _, w, _ in terms], [g for _, _, g in terms])
+        loss_dict_target["distillation_loss"] = parts[2]                                                   # :124-126
+    else:
+        faster_rcnn_losses = sum(t for t, _, g in terms if g == 0)
+        distillation_losses = sum((w * t for t, w, g in terms if g == 1), torch.zeros((), device=faster_rcnn_losses.device))
+        loss_dict_target["distillation_loss"] = distillation_losses.clone().detach()
+        losses = faster_rcnn_losses + distillation_losses                                                  # :128
 
     if (PIPELINE_SOURCE and need_source and next_images is not None and SOURCE_STREAM and SOURCE_OVERLAP and not faithful_rng
             and hasattr(model_source, "soften_begin") and not model_source.training

@@ -381,7 +381,7 @@ class _RPNLossFn(Function):
     (rpn/loss.py:136,145-146), reading objectness and deltas straight out of the fused NHWC head output."""
 
     @staticmethod
-    def forward(ctx, fused, A, labels, reg_targets, pos_idx, samp_idx, denom=None):
+    def forward(ctx, fused, A, labels, reg_targets, pos_idx, samp_idx, denom=None, prepared=None):
         y = as_nhwc(fused)
         N, H, W, Cf = y.shape
         y2 = y.reshape(N * H * W, Cf)
@@ -389,12 +389,16 @@ class _RPNLossFn(Function):
         # by the kernels; `denom` is then the device-resident number of sampled anchors
         n_samp = samp_idx.numel()
         # anchor j of the flattened batch lives in row j // A; objectness at column j % A, deltas at A + 4*(j % A)
-        row = torch.div(samp_idx, A, rounding_mode="floor")
-        obj_flat_idx = row * Cf + (samp_idx - row * A)
-        prow = torch.div(pos_idx, A, rounding_mode="floor")
+        if prepared is not None:   # (obj_flat_idx, pos rows, pos columns) straight from ops.rpn_loss_indices
+            obj_flat_idx, prow, pcol = prepared
+        else:
+            row = torch.div(samp_idx, A, rounding_mode="floor")
+            obj_flat_idx = row * Cf + (samp_idx - row * A)
+            prow = torch.div(pos_idx, A, rounding_mode="floor")
+            pcol = A + 4 * (pos_idx - prow * A)
         want = fused.requires_grad
         lo, g_obj = ops.bce_logits_gather(y2, labels, obj_flat_idx, want_grad=want, yidx=samp_idx, denom_dev=denom)
-        lb, g_reg = ops.smooth_l1_rows(y2, reg_targets, prow, A + 4 * (pos_idx - prow * A), 1.0 / 9,
+        lb, g_reg = ops.smooth_l1_rows(y2, reg_targets, prow, pcol, 1.0 / 9,
                                        scale=1.0 if denom is not None else 1.0 / max(n_samp, 1), want_grad=want, trows=pos_idx,
                                        denom_dev=denom)
         ctx.shape = (N, H, W, Cf)
@@ -407,7 +411,7 @@ class _RPNLossFn(Function):
         ops.scale_(g_obj, 1.0, g_lo.contiguous())
         ops.scale_(g_reg, 1.0, g_lb.contiguous())
         ops.add_(g_obj, g_reg)  # disjoint columns of the same [N*H*W, Cf] buffer
-        return from_nhwc(g_obj.view(ctx.shape)), None, None, None, None, None, None
+        return from_nhwc(g_obj.view(ctx.shape)), None, None, None, None, None, None, None
 
 
 class RPNLossComputation(object):
@@ -443,21 +447,38 @@ class RPNLossComputation(object):
         """Returns (objectness_loss, box_loss).  `rpn_output_source` is accepted and ignored as in the reference (:129-143).
         `sampled=(pos_idx, samp_idx)` injects the sampler's choice (parity tests)."""
         anchors = [a[0] if isinstance(a, (list, tuple)) else a for a in anchors]
-        labels, regression_targets, _ = self.prepare_targets(anchors, targets)
         if sampled is None:
             sampled = getattr(self, "inject_sampled", None)  # parity tests pin the sampler's draw here
-        denom = None
-        if sampled is not None:
-            pos_idx, samp_idx = sampled
-        else:
-            pos_idx, samp_idx, denom = self.sample(labels)
-        self.last_sampled, self.last_targets = (pos_idx, samp_idx), (labels, regression_targets)  # introspection for parity tests
         if fused is None:
             fused = torch.cat((objectness[0], box_regression[0]), 1)
             A = objectness[0].shape[1]
         else:
             A = anchors[0].bbox.shape[0] // (fused.shape[-1] * fused.shape[-2])
-        return _RPNLossFn.apply(fused, A, torch.cat(labels), torch.cat(regression_targets), pos_idx, samp_idx, denom)
+        shared = fused.is_cuda and all(a.bbox.data_ptr() == anchors[0].bbox.data_ptr() and getattr(a, "_visibility_u8", None) is not None for a in anchors)
+        if shared:
+            # the batch's targets in two launches (one anchor grid for all images), the sampler in one, the loss bookkeeping in one
+            lab2d, tgt3d, _keep = ops.rpn_targets_batched(anchors[0].bbox, [a._visibility_u8 for a in anchors], [t.bbox for t in targets],
+                                                          self.proposal_matcher.high_threshold, self.proposal_matcher.low_threshold,
+                                                          self.box_coder.weights)
+            labels, regression_targets = list(lab2d.unbind(0)), list(tgt3d.unbind(0))      # views (introspection, API)
+            lab_flat, tgt_flat = lab2d.view(-1), tgt3d.view(-1, 4)
+        else:
+            labels, regression_targets, _ = self.prepare_targets(anchors, targets)
+            lab2d = None
+            lab_flat, tgt_flat = torch.cat(labels), torch.cat(regression_targets)
+        denom = prepared = None
+        if sampled is not None:
+            pos_idx, samp_idx = sampled
+        elif lab2d is not None:
+            n = lab2d.shape[1]
+            pos, neg, counts = self.fg_bg_sampler.sample_padded(lab2d, index_offset_per_image=n)
+            samp_idx, obj_flat, prow, pcol, denom = ops.rpn_loss_indices(pos, neg, counts, A, fused.shape[1])
+            pos_idx = pos.reshape(-1)
+            prepared = (obj_flat, prow, pcol)
+        else:
+            pos_idx, samp_idx, denom = self.sample(labels)
+        self.last_sampled, self.last_targets = (pos_idx, samp_idx), (labels, regression_targets)  # introspection for parity tests
+        return _RPNLossFn.apply(fused, A, lab_flat, tgt_flat, pos_idx, samp_idx, denom, prepared)
 
 
 def make_rpn_loss_evaluator(cfg, box_coder):

@@ -512,6 +512,39 @@ def add_(a, b):
     return a
 
 
+class _LossSum(torch.autograd.Function):
+    """total = sum_i w_i * loss_i (plus the two group sums, detached) in ONE launch, and one launch for all the terms' gradients: the
+    reference's chain of python adds / muls on device scalars (train_incremental.py:91,101-128) is ~10 tiny kernels forward and as many
+    autograd nodes backward"""
+
+    @staticmethod
+    def forward(ctx, weights, groups, *terms):
+        n = len(terms)
+        ts = [t.detach().reshape(()).contiguous() for t in terms]
+        total = torch.empty((), dtype=_f32, device=ts[0].device)
+        out = torch.empty((3,), dtype=_f32, device=ts[0].device)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        w = (C.c_float * n)(*[float(v) for v in weights])
+        g = (C.c_int32 * n)(*[int(v) for v in groups])
+        L.check(L.lib().abr_loss_sum(C.cast(ptrs, C.c_void_p), C.cast(w, C.c_void_p), C.cast(g, C.c_void_p), n, L.ptr(total), L.ptr(out), L.stream()), "loss_sum")
+        ctx.weights, ctx.n = [float(v) for v in weights], n
+        ctx.mark_non_differentiable(out)
+        return total, out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        n = ctx.n
+        grads = torch.empty((n,), dtype=_f32, device=g_total.device)
+        w = (C.c_float * n)(*ctx.weights)
+        L.check(L.lib().abr_loss_sum_backward(C.cast(w, C.c_void_p), n, L.ptr(g_total.contiguous()), L.ptr(grads), L.stream()), "loss_sum_backward")
+        return (None, None) + tuple(grads[i] for i in range(n))
+
+
+def loss_sum(terms, weights, groups):
+    """-> (total (differentiable 0-dim), parts [3] = (total, group-0 sum, group-1 sum), detached)"""
+    return _LossSum.apply(tuple(weights), tuple(groups), *terms)
+
+
 def scale_(x, s=1.0, s_dev=None):
     """x *= s * s_dev[0] (s_dev: device scalar, e.g. the upstream gradient of a loss) -- no host sync"""
     if x is None:
@@ -580,6 +613,20 @@ _sample_calls = [0]
 _ptr_tables = {}
 
 
+_small_tables = {}
+
+
+def _small_table(values, dtype, dev):
+    """device copy of a short list of host integers, cached while the same list repeats (per-image GT counts, ...)"""
+    key = (tuple(values), dtype, torch.device(dev))
+    t = _small_tables.get(key)
+    if t is None:
+        if len(_small_tables) > 256:
+            _small_tables.clear()
+        t = _small_tables[key] = h2d(list(values), dtype, dev)
+    return t
+
+
 def _pointer_table(tensors, dev):
     """device int64 array of the tensors' device addresses (one pinned asynchronous upload; cached while the addresses repeat)"""
     key = (tuple(t.data_ptr() for t in tensors), torch.device(dev))
@@ -621,7 +668,7 @@ def roi_head_targets(props, scores, keep, n_keep, gt_boxes, gt_labels, hi, lo, w
     if seed is None:
         _sample_calls[0] += 1
         seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
-    ngt_dev = h2d(n_gt, i32, dev)
+    ngt_dev = _small_table(n_gt, i32, dev)
     L.check(L.lib().abr_roi_head_targets(
         L.ptr(props), L.ptr(keep), L.ptr(n_keep), N, k_pre, post, L.ptr(_pointer_table(gtb, dev)), L.ptr(_pointer_table(gtl, dev)), L.ptr(ngt_dev),
         g_max, float(hi), float(lo), *[float(v) for v in weights], R, max_pos, seed, L.ptr(out["cand"]), L.ptr(out["labels_all"]),
@@ -629,6 +676,38 @@ def roi_head_targets(props, scores, keep, n_keep, gt_boxes, gt_labels, hi, lo, w
         L.ptr(out["labels"]), L.ptr(out["reg_targets"]), L.ptr(out["sampled_idx"]), L.ptr(out["n_valid"]), L.ptr(scores), L.ptr(out["obj_all"]),
         L.ptr(out["obj"]), L.ptr(out["pos_rows"]), L.ptr(out["col0"]), int(num_classes), int(bool(cls_agnostic)), L.stream()), "roi_head_targets")
     return out
+
+
+def rpn_targets_batched(anchors, vis_list, gt_boxes, hi, lo, weights):
+    """RPN labels [N,n] (fp32 1 / 0 / -1) and regression targets [N,n,4] for the whole batch in two launches (abr_rpn_targets_batched);
+    anchors [n,4] shared, vis_list / gt_boxes per image"""
+    n, N, dev = anchors.shape[0], len(gt_boxes), anchors.device
+    gtb = [L.f32c(b) for b in gt_boxes]
+    n_gt = [int(b.shape[0]) for b in gtb]
+    if min(n_gt) == 0:   # matcher.py:53-57
+        raise ValueError("No ground-truth boxes available for one of the images during training")
+    g_max = max(n_gt)
+    labels = torch.empty((N, n), dtype=_f32, device=dev)
+    tgt = torch.empty((N, n, 4), dtype=_f32, device=dev)
+    ws = torch.empty((N * g_max,), dtype=torch.int32, device=dev)
+    L.check(L.lib().abr_rpn_targets_batched(L.ptr(anchors), n, N, L.ptr(_pointer_table(gtb, dev)), L.ptr(_small_table(n_gt, torch.int32, dev)), g_max,
+                                            L.ptr(_pointer_table(vis_list, dev)), float(hi), float(lo), *[float(v) for v in weights], L.ptr(labels),
+                                            L.ptr(tgt), L.ptr(ws), ws.numel() * 4, L.stream()), "rpn_targets_batched")
+    return labels, tgt, (gtb,)
+
+
+def rpn_loss_indices(pos, neg, counts, A, Cf):
+    """-> (samp [n_pos+n_neg], obj_flat, pos_row [n_pos], pos_col [n_pos], denom [1] fp32) from the sampler's padded lists (one launch)"""
+    pos, neg = pos.reshape(-1), neg.reshape(-1)
+    n_pos, n_neg, dev = pos.numel(), neg.numel(), pos.device
+    samp = torch.empty((n_pos + n_neg,), dtype=torch.int64, device=dev)
+    obj_flat = torch.empty_like(samp)
+    pos_row = torch.empty((n_pos,), dtype=torch.int64, device=dev)
+    pos_col = torch.empty_like(pos_row)
+    denom = torch.empty((1,), dtype=_f32, device=dev)
+    L.check(L.lib().abr_rpn_loss_indices(L.ptr(pos), n_pos, L.ptr(neg), n_neg, L.ptr(counts), counts.shape[0], int(A), int(Cf), L.ptr(samp),
+                                         L.ptr(obj_flat), L.ptr(pos_row), L.ptr(pos_col), L.ptr(denom), L.stream()), "rpn_loss_indices")
+    return samp, obj_flat, pos_row, pos_col, denom
 
 
 def gather_proposals(props, scores, keep, picks, P):

@@ -283,6 +283,13 @@ int abr_channel_mean(const float* x, int64_t rows, int C, float* out, void* stre
 /* out = g * (y > 0)  (ReLU backward); out == g is allowed (in place) */
 int abr_relu_backward(const float* g, const float* y, int64_t n, float* out, void* stream);
 int abr_add_inplace(float* a, const float* b, int64_t n, void* stream);
+/* The training loop's loss arithmetic (tools/train_incremental.py:91,101-128: sum of the detector losses, alpha * ID + beta * ARD, their sum)
+ * in one launch: terms_host [n <= 8] HOST array of DEVICE pointers to the scalar losses, weights_host / groups_host [n] host arrays
+ * (group 0 = detector losses, 1 = distillation); *total = out[0] = sum w_i l_i, out[1] / out[2] = the two groups' sums.  The backward hands
+ * every term its gradient w_i * *g (g: device scalar) in one launch. */
+int abr_loss_sum(const float* const* terms_host, const float* weights_host, const int32_t* groups_host, int n, float* total, float* out,
+                 void* stream);
+int abr_loss_sum_backward(const float* weights_host, int n, const float* g, float* grads, void* stream);
 /* x *= s * (s_dev ? *s_dev : 1): applies an upstream (device-resident) loss gradient without a host sync */
 int abr_scale_inplace(float* x, int64_t n, float s, const float* s_dev, void* stream);
 
@@ -364,6 +371,19 @@ int abr_roi_head_targets(const float* props, const int32_t* keep, const int32_t*
                          int64_t* labels_all, float* regt_all, int32_t* n_cand, int64_t* pos_idx, int64_t* neg_idx, int32_t* counts,
                          float* rois, int64_t* labels, float* reg_targets, int64_t* sampled_idx, float* n_valid, const float* scores,
                          float* obj_all, float* obj, int64_t* pos_rows, int64_t* col0, int num_classes, int cls_agnostic, void* stream);
+/* RPN training targets of a whole batch (rpn/loss.py:66-102 per image: boxlist_iou, Matcher with low-quality matches, labels with the
+ * visibility / between-thresholds discards, BoxCoder.encode) in two launches: anchors [n,4] shared by the images, gt_ptrs / vis_ptrs [N]
+ * device arrays of device pointers ([G_i,4] fp32 / [n] uint8), n_gt [N]; labels [N,n] fp32 (1 / 0 / -1), reg_targets [N,n,4];
+ * workspace >= N*g_max*4 bytes. */
+int abr_rpn_targets_batched(const float* anchors, int n, int N, const float* const* gt_ptrs, const int32_t* n_gt, int g_max,
+                            const uint8_t* const* vis_ptrs, float hi, float lo, float wx, float wy, float ww, float wh, float* labels,
+                            float* reg_targets, void* workspace, int64_t workspace_bytes, void* stream);
+/* RPN loss bookkeeping in one launch: pos [n_pos] / neg [n_neg] = abr_sample_pos_neg's batch-flattened, -1 padded lists, counts [n_img,2];
+ * samp [n_pos+n_neg] = their concatenation, obj_flat = position of each sampled anchor's objectness logit in the fused NHWC head output
+ * ([rows, Cf], anchor j -> row j / A, column j % A), pos_row / pos_col [n_pos] = row and first delta column (A + 4 (j % A)) of the
+ * positives, denom [1] fp32 = number of sampled anchors (rpn/loss.py:136,146). */
+int abr_rpn_loss_indices(const int64_t* pos, int n_pos, const int64_t* neg, int n_neg, const int32_t* counts, int n_img, int A, int Cf,
+                         int64_t* samp, int64_t* obj_flat, int64_t* pos_row, int64_t* pos_col, float* denom, void* stream);
 /* rois [N*P,5] = (i, props[i, keep[i, picks[i*P+j]]]), obj [N*P] (or NULL) = the matching scores: the P picked distillation
  * proposals per image of the source model (generalized_rcnn.py:140-158) straight from the NMS output */
 int abr_gather_proposals(const float* props, const float* scores, const int32_t* keep, int N, int k_pre, int post,
