@@ -442,10 +442,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const f
     const unsigned g_voff = g_ok ? (unsigned)(2 * rp * p.Cout + gn) * 4u : kOOB;
     const unsigned a_voff_plain = k_ok ? (unsigned)(2 * rp * p.Cin + fc) * 4u : kOOB;
     const int a_const = ((fr - p.pad) * p.W + (fs - p.pad)) * p.Cin + fc;
-    // TWO stages in flight (as conv_igemm_x6_kernel): a stage is only 48 MFMAs per wave, far less than the latency of its loads, and
-    // these gradients run with one workgroup per CU -- stage mt+2 is requested before stage mt is multiplied (register sets alternate)
-    u32x4 rg0[2][2], ra0[2][2], rg1[2][2], ra1[2][2];
-    auto load_tile = [&](int mt, u32x4 (&rg)[2][2], u32x4 (&ra)[2][2]) {
+    u32x4 rg[2][2], ra[2][2];
+    auto load_tile = [&](int mt) {
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -496,7 +494,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const f
         *reinterpret_cast<u32x4*>(dst + plane) = o1;
         *reinterpret_cast<u32x4*>(dst + 2 * plane) = o2;
     };
-    auto store_tile = [&](u32x4 (&rg)[2][2], u32x4 (&ra)[2][2]) {
+    auto store_tile = [&]() {
         if (chk_g) {
 #pragma unroll
             for (int i = 0; i < 2; i++) { inspect(rg[i][0]); inspect(rg[i][1]); }
@@ -554,29 +552,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const f
         }
     };
     if (mt0 < mt1) {
-        load_tile(mt0, rg0, ra0);
-        if (mt0 + 1 < mt1) load_tile(mt0 + 1, rg1, ra1);
-        store_tile(rg0, ra0);
+        load_tile(mt0);
+        store_tile();
         __syncthreads();
         int mt = mt0;
-        for (; mt + 2 < mt1; mt += 2) {   // LDS holds stage mt, set 1 holds stage mt+1 (possibly still in flight), set 0 is free
-            load_tile(mt + 2, rg0, ra0);
+        for (; mt + 1 < mt1; mt++) {
+            load_tile(mt + 1);
             __builtin_amdgcn_sched_barrier(0);
             compute_tile();
             __syncthreads();
-            store_tile(rg1, ra1);
-            __syncthreads();
-            if (mt + 3 < mt1) load_tile(mt + 3, rg1, ra1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_tile();
-            __syncthreads();
-            store_tile(rg0, ra0);
-            __syncthreads();
-        }
-        if (mt + 1 < mt1) {   // one more stage, waiting in set 1
-            compute_tile();
-            __syncthreads();
-            store_tile(rg1, ra1);
+            store_tile();
             __syncthreads();
         }
         compute_tile();
@@ -658,18 +643,13 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
     if (p.math == ABR_MATH_BF16X6) {   // same split plan (MRX == MR), three-plane LDS
         static bool attr6 = false;
         const size_t lds6 = sizeof(unsigned) * 3 * (MRX / 2) * (TN_ + TK_);
-        // ABR_WGRAD_SPREAD=1: a grid of at most one workgroup per CU asks for more than half of the CU's LDS, so that the dispatcher
-        // cannot put two of its workgroups on one CU while another CU idles (experiment knob)
-        static const bool spread = getenv("ABR_WGRAD_SPREAD") && atoi(getenv("ABR_WGRAD_SPREAD")) != 0;
-        const size_t lds_wide = 84 * 1024;
         if (!attr6) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
             attr6 = true;
         }
         p.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
         const int rec6 = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
-        const size_t lds_req = (spread && (long)tiles * splits <= cus) ? lds_wide : lds6;
-        conv_wgrad_x6_kernel<<<(unsigned)(tiles * splits), 256, lds_req, abr::as_stream(stream)>>>(p, x, gy, dw);
+        conv_wgrad_x6_kernel<<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
         abr::prof_stop(abr::as_stream(stream), rec6);
         return;
     }
