@@ -43,6 +43,7 @@ _SIGS = {
     "abr_prof_set_mask": (_i, [C.c_uint32, _i]),
     "abr_prof_end": (_i, [_vp, _i]),
     "abr_prof_totals": (_i, [_vp, _i]),
+    "abr_prof_event_overhead_ms": (_i, [_vp, _vp]),
     "abr_prof_step_begin": (_i, []),
     "abr_conv_prepare_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "abr_roi_head_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _i, _i, C.c_uint64,

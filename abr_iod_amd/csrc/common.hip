@@ -2,6 +2,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -94,6 +95,33 @@ extern "C" int abr_prof_end(double* out, int n_ids) {
         abr::g_pool.push_back(r.b);
     }
     abr::g_recs.clear();
+    return ABR_OK;
+}
+
+namespace {
+__global__ void prof_empty_kernel() {}
+}
+// What an event pair costs around a kernel on a busy stream: n back-to-back [record, empty kernel, record] brackets; the median elapsed
+// time is the part of an event-bracketed duration that is not the kernel (the dispatch gap the start event exposes), less the ~1 us an
+// empty kernel runs.  bench.py subtracts it so that its live per-launch durations agree with rocprofv3's kernel durations.
+extern "C" int abr_prof_event_overhead_ms(double* out_host, void* stream) {
+    ABR_REQUIRE(out_host, "prof_event_overhead_ms: null pointer");
+    hipStream_t st = abr::as_stream(stream);
+    const int n = 33;
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto& e : ev) ABR_REQUIRE(hipEventCreate(&e) == hipSuccess, "prof_event_overhead_ms: no event");
+    for (int i = 0; i < n; i++) {
+        (void)hipEventRecord(ev[2 * i], st);
+        prof_empty_kernel<<<1, 64, 0, st>>>();
+        (void)hipEventRecord(ev[2 * i + 1], st);
+    }
+    std::vector<float> ms(n, 0.f);
+    bool ok = hipStreamSynchronize(st) == hipSuccess;
+    for (int i = 0; i < n && ok; i++) ok = hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]) == hipSuccess;
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    ABR_REQUIRE(ok, "prof_event_overhead_ms: event timing failed");
+    std::sort(ms.begin(), ms.end());
+    *out_host = ms[n / 2];
     return ABR_OK;
 }
 

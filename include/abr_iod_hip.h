@@ -58,6 +58,9 @@ int abr_prof_end(double* out_host, int n_ids);
 /* out[id*2+{0,1}] = {launches, total flops} of EVERY launch of kernel id since abr_prof_begin, event-bracketed or not (call before
  * abr_prof_end or after: the totals survive until the next abr_prof_begin) */
 int abr_prof_totals(double* out_host, int n_ids);
+/* median duration (ms) of an event pair around an EMPTY kernel on a busy stream: the share of an event-bracketed duration that is
+ * dispatch gap, not kernel; bench.py subtracts it from its live per-launch durations (synchronises the stream) */
+int abr_prof_event_overhead_ms(double* out_host, void* stream);
 
 /* Range guard of the bf16x6 arithmetic (abr_conv_desc::math == ABR_MATH_BF16X6).  The three-way bf16 split x = x0 + x1 + x2 is
  * EXACT -- and the contraction then meets the fp32 error bound -- for operands that are zero or have 2^-110 <= |x| < 2^128 (finite);
