@@ -20,6 +20,8 @@
 // stride-1 3x3 convs go through the Winograd domain instead (36 batched plain GEMMs over the tile axis, conv_winograd.hip).
 #include <algorithm>
 
+#include <map>
+
 #include "common.h"
 
 namespace {
@@ -60,7 +62,90 @@ struct WgP {
     int math;                    // ABR_MATH_F32 or ABR_MATH_BF16X6 (the bf16 mode has its own launch)
     unsigned* x6_flags;          // bf16x6: device word of the range guard (abr::x6_flags_ptr)
     int tile_fast;               // workgroup order: output tile fastest (1, default) or row slice fastest (0)
+    // split-M partial sums (splits > 1): parked in `ws` (one 64 KB unit per workgroup, plain coalesced stores) and summed in split order by
+    // wgrad_reduce_kernel right behind this launch -- deterministic, and one write per output element instead of `splits` fp32 atomics
+    // (256 workgroups x 16 K atomics = 4 M per launch cost ~30 us whatever the shape).  nullptr: atomics into dw
+    float* ws;
+    int final_store;             // the reduction stores (dw = sum: the Winograd-domain dU, never zero-filled) instead of dw += sum
 };
+
+typedef f32x16 wg_f32x16;
+
+// Epilogue shared by the three weight-gradient kernels: tile (tm,tn) element (row i, col j) of a wave is
+// dW[n0 + wm*64 + 2i + tm][k0 + wn*64 + 2j + tn].  unit = global tile index * splits + split.
+constexpr unsigned kPartBytes = 16u * 256u * 16u;   // one partial tile (128 x 128 fp32), thread-major: quad (t,c) of thread tid at (t*4+c)*4096 + tid*16
+
+__device__ __forceinline__ void wgrad_store_tile(const WgP& p, const float (&v)[4], int tm, int tn, int c, int n0, int k0, int wm, int wn, int l31, int lh,
+                                                 bool store, float* __restrict__ dw) {
+    const int k = k0 + wn * 64 + 2 * l31 + tn;
+    if (k >= p.K) return;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int r = 4 * c + e;
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int n = n0 + wm * 64 + 2 * i + tm;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        if (store) dw[(size_t)n * p.K + k] = v[e] * sc;
+        else unsafeAtomicAdd(dw + (size_t)n * p.K + k, v[e] * sc);   // dw += (other launches may add to the same dw)
+    }
+}
+
+__device__ __forceinline__ void wgrad_finish(const WgP& p, f32x16 (&acc)[2][2], int n0, int k0, int wm, int wn, int l31, int lh, int tid,
+                                             int gtile, int split, float* __restrict__ dw) {
+    if (p.ws) {   // park the partial sums; wgrad_reduce_kernel adds them up
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<char*>(p.ws) + ((size_t)gtile * p.splits + split) * kPartBytes) + tid;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const f32x16& a = acc[t >> 1][t & 1];
+                dst[(t * 4 + c) * 256] = make_float4(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+            }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const f32x16& a = acc[t >> 1][t & 1];
+            const float v[4] = {a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]};
+            wgrad_store_tile(p, v, t >> 1, t & 1, c, n0, k0, wm, wn, l31, lh, p.overwrite != 0, dw);
+        }
+}
+
+// One workgroup per (output tile, accumulator quad): thread tid sums quad (t,c) of the tile's `splits` partials in split order and
+// writes the four elements the producing thread tid of conv_wgrad*_kernel would have written.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgP p, float* __restrict__ dw_) {
+    const int gtile = blockIdx.x >> 4, quad = blockIdx.x & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.ws) + (size_t)gtile * p.splits * kPartBytes) + quad * 256 + tid;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int q = 0;
+    for (; q + 4 <= p.splits; q += 4) {   // four loads in flight; the additions stay in split order
+        const float4 v0 = src[(size_t)q * (kPartBytes / 16)], v1 = src[(size_t)(q + 1) * (kPartBytes / 16)];
+        const float4 v2 = src[(size_t)(q + 2) * (kPartBytes / 16)], v3 = src[(size_t)(q + 3) * (kPartBytes / 16)];
+        sum.x += v0.x; sum.y += v0.y; sum.z += v0.z; sum.w += v0.w;
+        sum.x += v1.x; sum.y += v1.y; sum.z += v1.z; sum.w += v1.w;
+        sum.x += v2.x; sum.y += v2.y; sum.z += v2.z; sum.w += v2.w;
+        sum.x += v3.x; sum.y += v3.y; sum.z += v3.z; sum.w += v3.w;
+    }
+    for (; q < p.splits; q++) {
+        const float4 v = src[(size_t)q * (kPartBytes / 16)];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    float* dw = dw_;
+    int tile = gtile;
+    if (p.nbatch > 1) {
+        const int bt = tile / p.tiles_pb;
+        tile -= bt * p.tiles_pb;
+        dw += bt * p.dw_bs;
+    }
+    const int n0 = (tile % p.tiles_n) * TN_, k0 = (tile / p.tiles_n) * TK_;
+    const float v[4] = {sum.x, sum.y, sum.z, sum.w};
+    const int t = quad >> 2, c = quad & 3;
+    wgrad_store_tile(p, v, t >> 1, t & 1, c, n0, k0, wave >> 1, wave & 1, lane & 31, lane >> 5, p.final_store != 0, dw);
+}
 
 // SB: single-buffered operand LDS (two barriers per stage, 32 KB instead of 64 KB -> a third resident workgroup per CU)
 template <bool SB>
@@ -83,6 +168,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
     const int total_tiles = p.tiles_pb * (p.nbatch > 1 ? p.nbatch : 1);
     const int split = p.tile_fast ? bid / total_tiles : bid % p.splits;
     int tile = p.tile_fast ? bid % total_tiles : bid / p.splits;
+    const int gtile = tile;
     if (p.nbatch > 1) {
         const int bt = tile / p.tiles_pb;
         tile -= bt * p.tiles_pb;
@@ -210,23 +296,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p, const floa
     }
 
     // epilogue: tile (tm,tn) element (row i, col j) is dW[n0 + wm*64 + 2i + tm][k0 + wn*64 + 2j + tn]
-#pragma unroll
-    for (int tm = 0; tm < 2; tm++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int n = n0 + wm * 64 + 2 * i + tm;
-            if (n >= p.Cout) continue;
-            const float sc = p.scale ? p.scale[n] : 1.f;
-#pragma unroll
-            for (int tn = 0; tn < 2; tn++) {
-                const int k = k0 + wn * 64 + 2 * l31 + tn;
-                if (k < p.K) {
-                    if (p.overwrite) dw[(size_t)n * p.K + k] = acc[tm][tn][r] * sc;
-                    else unsafeAtomicAdd(dw + (size_t)n * p.K + k, acc[tm][tn][r] * sc);
-                }
-            }
-        }
+    wgrad_finish(p, acc, n0, k0, wm, wn, l31, lh, tid, gtile, split, dw);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -255,6 +325,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgP p, const
     const int total_tiles = p.tiles_n * p.tiles_k;   // tile-fast order: see conv_wgrad_kernel
     const int split = p.tile_fast ? bid / total_tiles : bid % p.splits;
     const int tile = p.tile_fast ? bid % total_tiles : bid / p.splits;
+    const int gtile = tile;
     const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
     const int n0 = tile_n * TN_, k0 = tile_k * TK_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -369,20 +440,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgP p, const
     }
 
     // epilogue: same interleave as the fp32 kernel -- tile (tm,tn) element (row i, col j) is dW[n0 + wm*64 + 2i + tm][k0 + wn*64 + 2j + tn]
-#pragma unroll
-    for (int tm = 0; tm < 2; tm++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int n = n0 + wm * 64 + 2 * i + tm;
-            if (n >= p.Cout) continue;
-            const float sc = p.scale ? p.scale[n] : 1.f;
-#pragma unroll
-            for (int tn = 0; tn < 2; tn++) {
-                const int k = k0 + wn * 64 + 2 * l31 + tn;
-                if (k < p.K) unsafeAtomicAdd(dw + (size_t)n * p.K + k, acc[tm][tn][r] * sc);
-            }
-        }
+    wgrad_finish(p, acc, n0, k0, wm, wn, l31, lh, tid, gtile, split, dw);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -411,6 +469,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const f
     const int total_tiles = p.tiles_pb * (p.nbatch > 1 ? p.nbatch : 1);
     const int split = p.tile_fast ? bid / total_tiles : bid % p.splits;
     int tile = p.tile_fast ? bid % total_tiles : bid / p.splits;
+    const int gtile = tile;
     if (p.nbatch > 1) {
         const int bt = tile / p.tiles_pb;
         tile -= bt * p.tiles_pb;
@@ -568,26 +627,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const f
     }
     if (chk_g | chk_x) abr::x6_report(bmin, nonfin, p.x6_flags);
 
-#pragma unroll
-    for (int tm = 0; tm < 2; tm++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int n = n0 + wm * 64 + 2 * i + tm;
-            if (n >= p.Cout) continue;
-            const float sc = p.scale ? p.scale[n] : 1.f;
-#pragma unroll
-            for (int tn = 0; tn < 2; tn++) {
-                const int k = k0 + wn * 64 + 2 * l31 + tn;
-                if (k < p.K) {
-                    if (p.overwrite) dw[(size_t)n * p.K + k] = acc[tm][tn][r] * sc;
-                    else unsafeAtomicAdd(dw + (size_t)n * p.K + k, acc[tm][tn][r] * sc);
-                }
-            }
-        }
+    wgrad_finish(p, acc, n0, k0, wm, wn, l31, lh, tid, gtile, split, dw);
 }
 
 }  // namespace
+
+// ABR_WGRAD_REDUCE=0: fp32 atomics into dw for the split-M partial sums (the round-1 scheme) instead of parked partials + reduction kernel
+static bool wgrad_ticket_enabled() {
+    static const bool on = !(getenv("ABR_WGRAD_REDUCE") && atoi(getenv("ABR_WGRAD_REDUCE")) == 0);
+    return on;
+}
+
+// scratch of the partial-sum reduction: `units` partial tiles of 64 KB, grow-only, one buffer per stream (launches on a stream are ordered)
+static float* wgrad_scratch(hipStream_t st, size_t units) {
+    struct Ws { float* ws = nullptr; size_t units = 0; };
+    static std::map<hipStream_t, Ws> pool;
+    Ws& w = pool[st];
+    if (w.units < units) {
+        if (w.ws) { (void)hipStreamSynchronize(st); (void)hipFree(w.ws); w.ws = nullptr; w.units = 0; }
+        if (hipMalloc(&w.ws, units * 65536) != hipSuccess) return nullptr;
+        w.units = units;
+    }
+    return w.ws;
+}
+
+// fills p.ws for a split launch (left null -> the kernel falls back to atomics; the caller must then have zeroed a final_store dw)
+static void wgrad_plan_reduction(WgP& p, int tiles, hipStream_t st) {
+    p.ws = nullptr;
+    if (p.splits <= 1) { if (p.final_store) p.overwrite = 1; return; }
+    if (wgrad_ticket_enabled()) p.ws = wgrad_scratch(st, (size_t)tiles * p.splits);
+}
+
+static void wgrad_reduce(const WgP& p, int tiles, float* dw, hipStream_t st) {
+    if (p.ws) wgrad_reduce_kernel<<<(unsigned)tiles * 16u, 256, 0, st>>>(p, dw);
+}
 
 // split choice + launch for one (possibly batched) weight-gradient GEMM described by p (tiles_n / tiles_k / M / K filled in)
 static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void* stream) {
@@ -629,6 +702,11 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
     if (p.overwrite) splits = 1;  // one workgroup per output tile owns it: no zero-fill, no atomics
     p.splits = splits;
     p.mt_per_split = (m_tiles + splits - 1) / splits;
+    wgrad_plan_reduction(p, tiles, abr::as_stream(stream));
+    if (p.final_store && splits > 1 && !p.ws) {   // no scratch: atomics into a zeroed dw after all
+        (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)nb * p.Cout * p.K, abr::as_stream(stream));
+        p.final_store = 0;
+    }
     // single-buffered by default: every shape of the step is as fast or faster with three resident workgroups per CU (RPN 3x3
     // 101 -> 109 TF, layer2 3x3 50 -> 62 TF, layer4 +2..3 %); ABR_WGRAD_SB=0 selects the double-buffered variant for comparison
     static const int sb_mode = getenv("ABR_WGRAD_SB") ? atoi(getenv("ABR_WGRAD_SB")) : 1;
@@ -651,12 +729,14 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
         const int rec6 = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
         conv_wgrad_x6_kernel<<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
         abr::prof_stop(abr::as_stream(stream), rec6);
+        wgrad_reduce(p, tiles, dw, abr::as_stream(stream));
         return;
     }
     const int rec = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
     if (sb) conv_wgrad_kernel<true><<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
     else conv_wgrad_kernel<false><<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
     abr::prof_stop(abr::as_stream(stream), rec);
+    wgrad_reduce(p, tiles, dw, abr::as_stream(stream));
 }
 
 
@@ -680,10 +760,12 @@ static void launch_wgrad_bf16(WgP p, const float* x, const float* gy, float* dw,
     }
     p.splits = splits;
     p.mt_per_split = (m_tiles + splits - 1) / splits;
+    wgrad_plan_reduction(p, tiles, abr::as_stream(stream));
     const size_t lds = sizeof(unsigned) * (MRH / 2) * (TN_ + TK_);
     const int rec = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
     conv_wgrad_bf16_kernel<<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
     abr::prof_stop(abr::as_stream(stream), rec);
+    wgrad_reduce(p, tiles, dw, abr::as_stream(stream));
 }
 
 extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const float* gy, float* dw, void* stream) {
@@ -706,6 +788,7 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     p.tiles_k = (p.K + TK_ - 1) / TK_;
     if (p.M == 0) return ABR_OK;
     p.nbatch = 1; p.tiles_pb = 0; p.x_bs = p.gy_bs = p.dw_bs = 0; p.overwrite = 0;
+    p.ws = nullptr; p.final_store = 0;
     p.x6_flags = nullptr;
     static const int tile_fast = !(getenv("ABR_WGRAD_TILE_FAST") && atoi(getenv("ABR_WGRAD_TILE_FAST")) == 0);
     p.tile_fast = tile_fast;
@@ -739,10 +822,14 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
             const int cus_ = abr_device_info(info) == ABR_OK ? info[0] : 256;
             const long out_tiles = 36L * ((d->Cout + TN_ - 1) / TN_) * ((d->Cin + TK_ - 1) / TK_);
             const int own = out_tiles >= 2L * cus_;
-            if (!own) bad |= hipMemsetAsync(dU, 0, nU * sizeof(float), st) != hipSuccess;
+            // split-M partial sums of dU go through the reduction kernel, which STORES the tile: no zero-fill of dU
+            // (launch_wgrad zero-fills dU itself when it has to fall back to atomics)
+            const bool ticket = wgrad_ticket_enabled();
+            if (!own && !ticket) bad |= hipMemsetAsync(dU, 0, nU * sizeof(float), st) != hipSuccess;
             if (!bad) {
                 WgP g = p;
                 g.overwrite = own;
+                g.final_store = (!own && ticket) ? 1 : 0;
                 g.B = (int)T; g.H = g.W = 1; g.R = g.S = 1; g.stride = 1; g.pad = 0; g.Ho = g.Wo = 1;
                 g.M = (int)T; g.K = d->Cin; g.plain = 1; g.scale = nullptr;
                 g.d_howo.init(1u); g.d_wo.init(1u);
