@@ -59,55 +59,82 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 // Column formulation: when the sweep reaches 64-box block bi, the boxes of that block already suppressed are
 //   removed(bi) = OR over every box i kept so far of mask[i][bi]
 // -- one 8-byte load per kept box, independent of each other, spread over the 256 threads and OR-reduced (<= max_keep/256
-// loads per thread).  Only then does wave 0 run the 64-step greedy chain on the diagonal word with lane broadcasts.
-// (The earlier row formulation OR-ed each kept row into all later words: ~188x more loads; 0.85 ms -> see DESIGN.md.)
+// loads per thread).  (The earlier row formulation OR-ed each kept row into all later words: ~188x more loads.)
+// The sweep is a chain of dependent steps, so its time is latency per block x blocks; two things keep that latency short:
+//   * the loads for block bi+1 are issued BEFORE block bi's greedy chain runs: the gather over the boxes kept before bi does not
+//     depend on it, and what block bi itself will add is fetched unconditionally (lane b of wave 0 loads mask[bi*64+b][bi+1], and
+//     the diagonal word of block bi+1) and selected by the keep bits afterwards;
+//   * the greedy chain visits only the boxes it keeps (count-trailing-zeros over the not-yet-suppressed bits, one lane broadcast of
+//     the kept box's diagonal row each) instead of stepping through all 64 -- at most max_keep + blocks iterations per image.
 __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t* __restrict__ mask, const int32_t* __restrict__ counts,
                                                          int n_max, int words, int max_keep, int32_t* __restrict__ keep,
                                                          int32_t* __restrict__ n_keep) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* kept = reinterpret_cast<int*>(smem);                                  // [max_keep]
-    uint64_t* s_red = reinterpret_cast<uint64_t*>(smem + (((size_t)max_keep * 4 + 15) & ~(size_t)15));  // [4] + [1]
-    int* s_cnt = reinterpret_cast<int*>(s_red + 5);
+    uint64_t* s_red = reinterpret_cast<uint64_t*>(smem + (((size_t)max_keep * 4 + 15) & ~(size_t)15));  // [2][4] gathered words (double-buffered) + [1]
+    int* s_cnt = reinterpret_cast<int*>(s_red + 9);
     const int img = blockIdx.x;
     const int n = counts[img];
     const uint64_t* m = mask + (size_t)img * n_max * words;
     int32_t* kp = keep + (size_t)img * max_keep;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) *s_cnt = 0;
+    if (threadIdx.x < 8) s_red[threadIdx.x] = 0ull;
     __syncthreads();
     const int nblk = (n + 63) / 64;
-    for (int bi = 0; bi < nblk; bi++) {
-        const int cnt = *s_cnt;
-        if (cnt >= max_keep) break;
-        uint64_t acc = 0;
-        for (int k = threadIdx.x; k < cnt; k += 256) acc |= m[(size_t)kept[k] * words + bi];
+    auto or_reduce = [&](uint64_t v) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const unsigned lo = __shfl_xor((unsigned)(acc & 0xffffffffu), o, 64);
-            const unsigned hi = __shfl_xor((unsigned)(acc >> 32), o, 64);
-            acc |= ((uint64_t)hi << 32) | lo;
+            const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), o, 64);
+            const unsigned hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+            v |= ((uint64_t)hi << 32) | lo;
         }
-        if (lane == 0) s_red[wave] = acc;
-        __syncthreads();
+        return v;
+    };
+    // wave 0 state: the diagonal word of the current block (bits j > lane) and what its own kept boxes add to the next block's word
+    uint64_t diag = 0ull, own_next = 0ull;
+    if (wave == 0 && nblk > 0) { const int i = lane; diag = i < n ? m[(size_t)i * words] : 0ull; }
+    for (int bi = 0; bi < nblk; bi++) {
+        const int cnt = *s_cnt;                    // boxes kept before block bi
+        if (cnt >= max_keep) break;
+        const bool more = bi + 1 < nblk;
+        // ---- loads for block bi+1, independent of block bi's chain
+        uint64_t acc = 0ull;
+        if (more)
+            for (int k = threadIdx.x; k < cnt; k += 256) acc |= m[(size_t)kept[k] * words + bi + 1];
+        uint64_t nxt = 0ull, diag_next = 0ull;
+        if (wave == 0 && more) {
+            const int i = bi * 64 + lane, i2 = i + 64;
+            nxt = i < n ? m[(size_t)i * words + bi + 1] : 0ull;          // what box i adds to block bi+1 IF it is kept
+            diag_next = i2 < n ? m[(size_t)i2 * words + bi + 1] : 0ull;
+        }
         if (wave == 0) {
-            uint64_t cur = s_red[0] | s_red[1] | s_red[2] | s_red[3];
-            const int i = bi * 64 + lane;
-            const uint64_t diag = i < n ? m[(size_t)i * words + bi] : 0ull;  // bits j > lane of this block
+            // ---- greedy chain on block bi: registers and lane broadcasts only
+            const uint64_t* red = s_red + (bi & 1) * 4;
+            uint64_t cur = red[0] | red[1] | red[2] | red[3] | own_next;      // removed(bi)
             const int valid = min(64, n - bi * 64);
             if (valid < 64) cur |= ~0ull << valid;
+            uint64_t avail = ~cur, keepm = 0ull;
             int c = cnt;
-            for (int b = 0; b < valid; b++) {  // serial greedy chain: registers + lane broadcasts only
-                if (!((cur >> b) & 1ull)) {
-                    if (c >= max_keep) break;
-                    if (lane == 0) { kept[c] = bi * 64 + b; kp[c] = bi * 64 + b; }
-                    c++;
-                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(diag & 0xffffffffu), b);
-                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), b);
-                    cur |= ((uint64_t)hi << 32) | lo;
-                }
+            while (avail != 0ull && c < max_keep) {
+                const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(avail));
+                keepm |= 1ull << b;
+                c++;
+                const unsigned lo = __builtin_amdgcn_readlane((unsigned)(diag & 0xffffffffu), b);
+                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), b);
+                avail &= ~((((uint64_t)hi << 32) | lo) | (1ull << b));
+            }
+            if ((keepm >> lane) & 1ull) {           // kept boxes of this block, in index order
+                const int pos = cnt + __popcll(keepm & ((1ull << lane) - 1ull));
+                kept[pos] = bi * 64 + lane;
+                kp[pos] = bi * 64 + lane;
             }
             if (lane == 0) *s_cnt = c;
+            own_next = or_reduce(((keepm >> lane) & 1ull) ? nxt : 0ull);
+            diag = diag_next;
         }
+        acc = or_reduce(acc);
+        if (lane == 0) s_red[((bi + 1) & 1) * 4 + wave] = acc;
         __syncthreads();
     }
     if (threadIdx.x == 0) n_keep[img] = *s_cnt;
@@ -139,7 +166,7 @@ extern "C" int abr_nms_sorted_batched(const float* boxes, const int32_t* counts,
     dim3 grid(words, words, N);
     nms_mask_kernel<<<grid, 64, 0, st>>>(boxes, counts, n_max, words, thr, strict_gt, (uint64_t*)workspace);
     ABR_CHECK_LAUNCH("nms_mask");
-    const size_t lds = (((size_t)max_keep * 4 + 15) & ~(size_t)15) + 5 * 8 + 16;
+    const size_t lds = (((size_t)max_keep * 4 + 15) & ~(size_t)15) + 9 * 8 + 16;
     ABR_REQUIRE(lds <= 150 * 1024, "nms: max_keep too large for the LDS keep list");
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
