@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libabr_iod_hip.so")
+# ABR_IOD_HIP_LIB: another build of the same C ABI (A/B measurements of two library versions inside one GPU session)
+LIB_PATH = os.environ.get("ABR_IOD_HIP_LIB") or os.path.join(_HERE, "libabr_iod_hip.so")
 
 NCHW, NHWC = 0, 1
 
