@@ -102,26 +102,35 @@ __global__ __launch_bounds__(256) void smooth_l1_rows_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxK = 128;
 
+// 8 lanes per row (a 256-thread workgroup takes 32 rows): a lane owns the classes c = lane, lane + 8, ...; row maximum and sums are
+// xor-shuffle reductions inside the 8-lane group.
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                           int n, int K, int ldz, int ldg, int inclusive, int n_old, const int* __restrict__ n_valid,
                                                           float* __restrict__ loss_out, float gscale, float* __restrict__ dz) {
     __shared__ float sm[4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int G = 8;
+    const int i = blockIdx.x * (256 / G) + threadIdx.x / G, l = threadIdx.x % G;
+    const bool live = i < n;
+    const int ii = live ? i : 0;           // (idle groups run the shuffles on row 0 and contribute nothing)
     float li = 0.f;
-    if (i < n) {
-        const float* z = logits + (size_t)i * ldz;
-        const int64_t lab = labels[i];
-        float mx = z[0];
-        for (int c = 1; c < K; c++) mx = fmaxf(mx, z[c]);
+    {
+        const float* z = logits + (size_t)ii * ldz;
+        const int64_t lab = labels[ii];
+        float mx = -INFINITY;
+        for (int c = l; c < K; c += G) mx = fmaxf(mx, z[c]);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, G));
         float se = 0.f, se_old = 0.f;
-        for (int c = 0; c < K; c++) {
+        for (int c = l; c < K; c += G) {
             const float e = expf(z[c] - mx);
             se += e;
             if (c <= n_old) se_old += e;
         }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) { se += __shfl_xor(se, o, G); se_old += __shfl_xor(se_old, o, G); }
         const float lse = logf(se) + mx;
         const float inv_n = 1.f / (float)(*n_valid);
-        if (lab >= 0) {
+        if (lab >= 0 && l == 0) {
             if (!inclusive) {
                 li = -(z[lab] - lse);
             } else if (lab == 0) {
@@ -132,10 +141,10 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
                 li = 0.f;                               // columns 1..n_old stay 0 (quirk 4)
             }
         }
-        if (dz) {
+        if (dz && live) {
             float* g = dz + (size_t)i * ldg;
             const float s = gscale * inv_n;
-            for (int c = 0; c < K; c++) {
+            for (int c = l; c < K; c += G) {
                 float v = 0.f;
                 if (lab >= 0) {
                     const float p = expf(z[c] - lse);
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
         }
         li *= inv_n;
     }
+    if (!live) li = 0.f;
     li = abr::block_sum<4>(li, sm);
     if (threadIdx.x == 0) atomicAdd(loss_out, li);
 }
@@ -163,39 +173,60 @@ __global__ void count_valid_kernel(const int64_t* __restrict__ labels, int n, in
 // ------------------------------------------------------------------------------------------------
 // RoI distillation -- distillation/distillation.py:164-240
 // ------------------------------------------------------------------------------------------------
+// 16 lanes per RoI (a 256-thread workgroup takes 16 RoIs): a lane owns the classes / box coordinates c = lane, lane + 16, ... and the
+// per-RoI maxima and sums are xor-shuffle reductions inside the 16-lane group -- the kernel sits between the last forward GEMM and the
+// first backward one, where one thread per RoI walking ~190 strided floats cost 130 us.
 __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restrict__ z_s, const float* __restrict__ b_s,
                                                            const float* __restrict__ z_t, const float* __restrict__ b_t, int n,
                                                            int ld_zs, int ld_bs, int ld_zt, int ld_bt, int ld_dzt, int ld_dbt,
                                                            int K_old, int K_all, int dist_id, float* __restrict__ loss_out,
                                                            float gscale, float* __restrict__ d_zt, float* __restrict__ d_bt) {
     __shared__ float sm[4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int G = 16;
+    const int i = blockIdx.x * (256 / G) + threadIdx.x / G, l = threadIdx.x % G;
+    auto gsum = [](float v) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+        return v;
+    };
+    auto gmax = [](float v) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, G));
+        return v;
+    };
     float li = 0.f;
-    if (i < n) {
-        const float* zs = z_s + (size_t)i * ld_zs;
-        const float* zt = z_t + (size_t)i * ld_zt;
+    const bool live = i < n;
+    const int ii = live ? i : 0;           // (idle groups run the shuffles on RoI 0 and contribute nothing)
+    {
+        const float* zs = z_s + (size_t)ii * ld_zs;
+        const float* zt = z_t + (size_t)ii * ld_zt;
         const float inv_n = 1.f / (float)n;
         if (dist_id) {
-            float mt = zt[0], ms = zs[0];
-            for (int c = 1; c < K_all; c++) mt = fmaxf(mt, zt[c]);
-            for (int c = 1; c < K_old; c++) ms = fmaxf(ms, zs[c]);
+            float mt = -INFINITY, ms = -INFINITY;
+            for (int c = l; c < K_all; c += G) mt = fmaxf(mt, zt[c]);
+            for (int c = l; c < K_old; c += G) ms = fmaxf(ms, zs[c]);
+            mt = gmax(mt);
+            ms = gmax(ms);
             float set = 0.f, sebg = 0.f, ses = 0.f;
-            for (int c = 0; c < K_all; c++) {
+            for (int c = l; c < K_all; c += G) {
                 const float e = expf(zt[c] - mt);
                 set += e;
                 if (c == 0 || c >= K_old) sebg += e;
             }
-            for (int c = 0; c < K_old; c++) ses += expf(zs[c] - ms);
+            for (int c = l; c < K_old; c += G) ses += expf(zs[c] - ms);
+            set = gsum(set); sebg = gsum(sebg); ses = gsum(ses);
             const float den = logf(set) + mt;
             const float out_bg = (logf(sebg) + mt) - den;                       // :196
             const float lab0 = expf(zs[0] - ms) / ses;
-            float acc = lab0 * out_bg;
-            for (int c = 1; c < K_old; c++) acc += (expf(zs[c] - ms) / ses) * (zt[c] - den);   // :195,:198
-            li = -(acc / (float)K_old) * inv_n;                                 // :198-199
-            if (d_zt) {
+            float acc = l == 0 ? lab0 * out_bg : 0.f;
+            for (int c = l; c < K_old; c += G)
+                if (c >= 1) acc += (expf(zs[c] - ms) / ses) * (zt[c] - den);    // :195,:198
+            acc = gsum(acc);
+            if (l == 0) li = -(acc / (float)K_old) * inv_n;                     // :198-199
+            if (d_zt && live) {
                 float* g = d_zt + (size_t)i * ld_dzt;
                 const float s = -gscale * inv_n / (float)K_old;
-                for (int c = 0; c < K_all; c++) {
+                for (int c = l; c < K_all; c += G) {
                     const float e = expf(zt[c] - mt);
                     float v = -e / set;
                     if (c == 0 || c >= K_old) v += lab0 * e / sebg;
@@ -205,21 +236,23 @@ __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restric
             }
         } else {
             float mean_s = 0.f, mean_t = 0.f;
-            for (int c = 0; c < K_old; c++) mean_s += zs[c];
-            for (int c = 0; c < K_all; c++) mean_t += zt[c];
-            mean_s /= (float)K_old;
-            mean_t /= (float)K_all;
+            for (int c = l; c < K_old; c += G) mean_s += zs[c];
+            for (int c = l; c < K_all; c += G) mean_t += zt[c];
+            mean_s = gsum(mean_s) / (float)K_old;
+            mean_t = gsum(mean_t) / (float)K_all;
             float acc = 0.f, dsum = 0.f;
-            for (int c = 0; c < K_old; c++) {
+            for (int c = l; c < K_old; c += G) {
                 const float d = (zt[c] - mean_t) - (zs[c] - mean_s);
                 acc += d * d;
                 dsum += d;
             }
-            li = acc / (float)K_old * inv_n;                                    // :185-188
-            if (d_zt) {
+            acc = gsum(acc);
+            dsum = gsum(dsum);
+            if (l == 0) li = acc / (float)K_old * inv_n;                        // :185-188
+            if (d_zt && live) {
                 float* g = d_zt + (size_t)i * ld_dzt;
                 const float s = gscale * inv_n / (float)K_old;
-                for (int c = 0; c < K_all; c++) {
+                for (int c = l; c < K_all; c += G) {
                     float v = -2.f * dsum / (float)K_all;
                     if (c < K_old) v += 2.f * ((zt[c] - mean_t) - (zs[c] - mean_s));
                     g[c] = v * s;
@@ -227,22 +260,24 @@ __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restric
             }
         }
         // boxes: mean_n mean_k sum_4 (b_t[:,1:K_old] - b_s[:,1:])^2       :204-209
-        const float* bs = b_s + (size_t)i * ld_bs;
-        const float* bt = b_t + (size_t)i * ld_bt;
+        const float* bs = b_s + (size_t)ii * ld_bs;
+        const float* bt = b_t + (size_t)ii * ld_bt;
         const int kk = K_old - 1;
         float bacc = 0.f;
         const float bsc = kk > 0 ? inv_n / (float)kk : 0.f;
-        for (int c = 4; c < K_old * 4; c++) {
+        for (int c = 4 + l; c < K_old * 4; c += G) {
             const float d = bt[c] - bs[c];
             bacc += d * d;
         }
-        li += bacc * bsc;
-        if (d_bt) {
+        bacc = gsum(bacc);
+        if (l == 0) li += bacc * bsc;
+        if (d_bt && live) {
             float* g = d_bt + (size_t)i * ld_dbt;
-            for (int c = 0; c < K_all * 4; c++)
+            for (int c = l; c < K_all * 4; c += G)
                 g[c] = (c >= 4 && c < K_old * 4) ? 2.f * (bt[c] - bs[c]) * bsc * gscale : 0.f;
         }
     }
+    if (!live) li = 0.f;
     li = abr::block_sum<4>(li, sm);
     if (threadIdx.x == 0) atomicAdd(loss_out, li);
 }
@@ -417,7 +452,7 @@ extern "C" int abr_softmax_ce(const float* logits, int ld_logits, const int64_t*
     ABR_REQUIRE(logits && labels, "softmax_ce: null pointer");
     int* cnt = reinterpret_cast<int*>(loss_out + 1);
     count_valid_kernel<<<1, 256, 0, st>>>(labels, n, cnt);
-    softmax_ce_kernel<<<abr::cdiv(n, 256), 256, 0, st>>>(logits, labels, n, K, ld_logits, ld_dlogits, inclusive, n_old, cnt, loss_out, gscale,
+    softmax_ce_kernel<<<abr::cdiv(n, 32), 256, 0, st>>>(logits, labels, n, K, ld_logits, ld_dlogits, inclusive, n_old, cnt, loss_out, gscale,
                                                           d_logits);
     ABR_CHECK_LAUNCH("softmax_ce");
     return ABR_OK;
@@ -436,7 +471,7 @@ extern "C" int abr_roi_distill(const float* z_s, const float* b_s, const float* 
     if (int e = zero_loss(loss_out, 1, st, "roi_distill")) return e;
     if (n == 0) return ABR_OK;
     ABR_REQUIRE(z_s && b_s && z_t && b_t, "roi_distill: null pointer");
-    roi_distill_kernel<<<abr::cdiv(n, 256), 256, 0, st>>>(z_s, b_s, z_t, b_t, n, ld[0], ld[1], ld[2], ld[3], ld[4], ld[5], K_old, K_all, dist_id, loss_out,
+    roi_distill_kernel<<<abr::cdiv(n, 16), 256, 0, st>>>(z_s, b_s, z_t, b_t, n, ld[0], ld[1], ld[2], ld[3], ld[4], ld[5], K_old, K_all, dist_id, loss_out,
                                                            gscale,
                                                            d_zt, d_bt);
     ABR_CHECK_LAUNCH("roi_distill");
