@@ -38,6 +38,7 @@ SOURCE_HEAD_STREAM = os.environ.get("ABR_SOURCE_HEAD_STREAM", "1") != "0"
 # software pipelining across steps: when the caller names the NEXT batch (`train_step(..., next_images=)`; `do_train` looks one batch ahead),
 # the frozen source model's backbone + RPN head for it are enqueued on the source stream before this step's backward pass and run next to it
 # -- their result does not depend on this step's update.  Same work per step, same results; 0 = off.
+EARLY_SECOND_PASS = os.environ.get("ABR_EARLY_SECOND_PASS", "1") != "0"
 PIPELINE_SOURCE = os.environ.get("ABR_PIPELINE_SOURCE", "1") != "0"
 _PREFETCHED = {}
 JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "0") != "0"
@@ -127,6 +128,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
 
     soften_result = soften_proposal = roi_align_features_source = rpn_output_source = roi_align_features_target = None
     deferred = None
+    second_done = False
     if need_source:
         with torch.no_grad():                                                                              # :82-86
             on_gpu = (images.tensors if hasattr(images, "tensors") else images).is_cuda
@@ -177,6 +179,19 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
                 soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
                     model_source.soften_finish(deferred)
         deferred = None
+        ready = getattr(soften_proposal[0], "_roi_ready", None) if (EARLY_SECOND_PASS and src is not None and soften_proposal) else None
+        if ready is not None:
+            # :93-95 ahead of the second half of :89-90.  The target's pass over the distillation RoIs needs its backbone features and the
+            # SOURCE's proposals -- not the target's own proposals, whose selection (top-k, NMS) the main stream would otherwise sit and
+            # wait for: ~1 ms of layer4 work over 256 RoIs fills that wait.  Same values; the two passes only swap places in the queue.
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ready)
+            tab = getattr(soften_proposal[0], "_roi_table", None)
+            if tab is not None:
+                tab[0].record_stream(cur)
+            target_result, _, roi_align_features_target = model_target.forward(images, targets, features=begun["features"],
+                                                                               proposals=soften_proposal)  # :93-95
+            second_done = True
         loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results = \
             model_target.forward_finish(begun)                                                             # :89-90 (second half)
         if src is not None:       # everything the source stream produced becomes visible to the main stream here
@@ -203,7 +218,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
     # sum -- gathered as (term, weight, group) and evaluated by ONE kernel (ops.loss_sum) instead of a chain of scalar adds / muls
     terms = [(v, 1.0, 0) for v in loss_dict_target.values()]                                               # :91
     if need_source:
-        if not joint:
+        if not joint and not second_done:
             target_result, _, roi_align_features_target = model_target.forward(images, targets, features=feature_target,
                                                                                proposals=soften_proposal)  # :93-95
         if use_id:                                                                                         # :101-103

@@ -198,11 +198,14 @@ class GeneralizedRCNN(nn.Module):
         self.last_soften_indices = picks
         dev = pending["props"].device
         rois, obj = ops.gather_proposals(pending["props"], pending["scores"], pending["keep"], ops.h2d([i for p in picks for i in p], torch.int64, dev), P)
-        all_selected = []
+        ready = torch.cuda.Event()
+        ready.record()          # the RoI table exists from here on: the trainer starts the target's distillation pass behind this event,
+        all_selected = []       # not behind the source model's whole head pass
         for k, size in enumerate(pending["sizes"]):
             b = BoxList(rois[k * P:(k + 1) * P, 1:5], size, mode="xyxy")
             b.add_field("objectness", obj[k * P:(k + 1) * P])
             b._roi_table = (rois, k)     # lets Pooler.convert_to_roi_format hand the table back instead of re-assembling it
+            b._roi_ready = ready
             all_selected.append(b)
         soften_scores, soften_bboxes, mask_logits, roi_align_features = self.roi_heads.calculate_soften_label(state["features"], rois)
         return ((soften_scores, soften_bboxes), mask_logits, all_selected, state["features"], state["backbone_features"], state["anchors"],
