@@ -357,7 +357,12 @@ def mark_overlap(on):
     L.lib().abr_prof_mark_overlap(1 if on else 0)
 
 
-WGRAD_STREAMS = max(1, int(os.environ.get("ABR_WGRAD_STREAMS", "1")))   # weight gradients round-robin over this many side streams
+# Weight gradients go to this many side streams.  Two are worth 0.7 ms per step now that the small gradients are short (three: +0.5, four:
+# +0.8 ms over two).  A weight's gradient always goes to the SAME stream (first-seen round-robin over the gradient buffers): a weight
+# that is used twice in a step (layer4 serves the detection RoIs and the distillation RoIs) gets `dw +=` from two launches, and the
+# Winograd inverse transform adds with a plain read-modify-write -- stream order keeps those two apart.
+WGRAD_STREAMS = max(1, int(os.environ.get("ABR_WGRAD_STREAMS", "2")))
+_wg_owner = {}
 
 
 def _wgrad_stream(dev, i):
@@ -390,7 +395,10 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino
     if not WGRAD_SIDE_STREAM:
         return conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v)
     cur = torch.cuda.current_stream()
-    side = _wgrad_stream(x.device.index, _wg_seq["n"] % WGRAD_STREAMS)
+    owner = _wg_owner.get(dw.data_ptr())
+    if owner is None:
+        owner = _wg_owner[dw.data_ptr()] = len(_wg_owner) % WGRAD_STREAMS
+    side = _wgrad_stream(x.device.index, owner)
     if not _join_pending[0]:
         _join_pending[0] = True
         _wg_seq["last_total"], _wg_seq["n"] = _wg_seq["n"], 0
