@@ -675,7 +675,9 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
     // workgroup keeps at least 8 stages (256 rows) of work.
     // Prefer two workgroups per CU when each still gets >= 64 stages: a lone workgroup cannot hide its own prologue / atomics
     // epilogue (head 1x1 gradients: 113 -> 126..134 TF alone; -1.0 ms per training step).  ABR_WGRAD_OCC2=0 turns it off.
-    static const bool occ2 = !(getenv("ABR_WGRAD_OCC2") && atoi(getenv("ABR_WGRAD_OCC2")) == 0);
+    // Since the step runs TWO weight-gradient streams next to the dgrad chain, the preference is off by default: alone the layer4 gradients are
+    // 20 % faster with it (0.43 vs 0.53 ms), in the step two concurrent 512-workgroup grids oversubscribe the CUs (step +0.13 ms).
+    static const bool occ2 = getenv("ABR_WGRAD_OCC2") && atoi(getenv("ABR_WGRAD_OCC2")) != 0;
     // ABR_WGRAD_WGS_PER_CU = k > 1: small-output gradients (few tiles, long M) are split until k workgroups per CU are resident
     // (never below 6 stages = 192 rows per workgroup): a lone 256-thread workgroup per CU leaves three quarters of the wave slots
     // empty and cannot overlap its own fetch / split / MFMA / atomic phases
