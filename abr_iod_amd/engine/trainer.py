@@ -39,6 +39,7 @@ SOURCE_HEAD_STREAM = os.environ.get("ABR_SOURCE_HEAD_STREAM", "1") != "0"
 # the frozen source model's backbone + RPN head for it are enqueued on the source stream before this step's backward pass and run next to it
 # -- their result does not depend on this step's update.  Same work per step, same results; 0 = off.
 EARLY_SECOND_PASS = os.environ.get("ABR_EARLY_SECOND_PASS", "1") != "0"
+PIPELINE_TARGET_FROZEN = os.environ.get("ABR_PIPELINE_TARGET_FROZEN", "1") != "0"
 PIPELINE_SOURCE = os.environ.get("ABR_PIPELINE_SOURCE", "1") != "0"
 _PREFETCHED = {}
 JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "0") != "0"
@@ -129,6 +130,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
     soften_result = soften_proposal = roi_align_features_source = rpn_output_source = roi_align_features_target = None
     deferred = None
     second_done = False
+    target_prefix = None      # (event, frozen_prefix result) of the target's frozen stem / layer1 for THIS batch, computed during the previous step
     if need_source:
         with torch.no_grad():                                                                              # :82-86
             on_gpu = (images.tensors if hasattr(images, "tensors") else images).is_cuda
@@ -137,6 +139,8 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
                 pre = None
                 if _PREFETCHED.get("images") is images and _PREFETCHED.get("model") is model_source:
                     pre = _PREFETCHED["state"]        # enqueued during the previous step's backward pass
+                    if _PREFETCHED.get("target_model") is model_target:
+                        target_prefix = _PREFETCHED.get("target_prefix")
                 _PREFETCHED.clear()
                 if pre is not None:
                     deferred = pre
@@ -166,7 +170,14 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         # the target's backbone / RPN head / RPN loss are queued and its proposal selection is in flight on a side stream; the source
         # model's selection finished long ago, so its head pass (a few ms of small GEMMs) goes in NOW: the device has work while
         # the target's top-k / NMS run and while the host waits for their counts
-        begun = model_target.forward_begin(images, targets, rpn_output_source=rpn_output_source)               # :89-90 (first half)
+        prefix = None
+        if target_prefix is not None:
+            ev, prefix = target_prefix
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for t in [prefix[0]] + list(prefix[1]):
+                t.record_stream(cur)
+        begun = model_target.forward_begin(images, targets, rpn_output_source=rpn_output_source, prefix=prefix)   # :89-90 (first half)
         src = deferred.get("_stream") if SOURCE_HEAD_STREAM else None
         if src is not None:       # the source's head pass stays on its stream, next to the target's big RoI pass below
             deferred.pop("_stream")
@@ -256,6 +267,16 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         nxt["_stream"] = src
         _PREFETCHED.clear()
         _PREFETCHED.update(images=next_images, model=model_source, state=nxt)   # (holds the batch object: identity, not id(), is the key)
+        if PIPELINE_TARGET_FROZEN and hasattr(model_target, "prefetch_frozen"):
+            # the TARGET's frozen stem + layer1 (FREEZE_CONV_BODY_AT = 2) for the next batch too: their output does not depend on this step's
+            # update either, and these bandwidth-bound convolutions overlap better with the backward pass's GEMMs than with the target's own
+            # layer2 / layer3 in the next forward.  Same stream as the source model's prefetch: one bandwidth-bound chain at a time.
+            with torch.no_grad(), torch.cuda.stream(src):
+                pf = model_target.prefetch_frozen(next_images)
+                if pf is not None:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    _PREFETCHED.update(target_model=model_target, target_prefix=(ev, pf))
     optimizer.zero_grad()                                                                                  # :142
     _arm_overlap(optimizer, [det_pooled, roi_align_features_target if need_source else None], feature_target)
     losses.backward()                                                                                      # :144-145 (amp O0 = identity)

@@ -7,8 +7,11 @@ from . import resnet
 
 
 class _Body(nn.Sequential):
-    def forward(self, x):
-        return self.body(x)
+    def forward(self, x, prefix=None):
+        return self.body(x, prefix)
+
+    def frozen_prefix(self, x):
+        return self.body.frozen_prefix(x)
 
 
 def build_backbone(cfg):

@@ -329,11 +329,33 @@ class ResNet(nn.Module):
             for p in m.parameters():
                 p.requires_grad = False
 
-    def forward(self, x):
+    def frozen_prefix(self, x):
+        """The stem and the leading stages whose parameters are all frozen (FREEZE_CONV_BODY_AT = 2: stem + layer1), run without autograd:
+        their outputs do not depend on the optimiser, so the trainer may compute them for the NEXT batch while the current backward pass
+        runs.  Returns (x, stage outputs so far) or None when the stem itself trains."""
+        if any(p.requires_grad for p in self.stem.parameters()):
+            return None
+        with torch.no_grad():
+            x = self.stem(x)
+            done = []
+            for name in self.stages:
+                if any(p.requires_grad for p in getattr(self, name).parameters()):
+                    break
+                x = run_stage(x, list(getattr(self, name)))
+                done.append(x)
+        return x, done
+
+    def forward(self, x, prefix=None):
+        """`prefix`: the result of frozen_prefix() on the same input (the same values the inline path computes)"""
         outputs, backbone_features = [], []
-        x = self.stem(x)
-        for name in self.stages:
-            x = run_stage(x, list(getattr(self, name)))
+        if prefix is None:
+            prefix = self.frozen_prefix(x)
+        if prefix is None:
+            x, done = self.stem(x), []
+        else:
+            x, done = prefix
+        for i, name in enumerate(self.stages):
+            x = done[i] if i < len(done) else run_stage(x, list(getattr(self, name)))
             if self.return_features[name]:
                 outputs.append(x)
             backbone_features.append(x)

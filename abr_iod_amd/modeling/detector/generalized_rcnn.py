@@ -100,12 +100,18 @@ class GeneralizedRCNN(nn.Module):
         x, result, results_background, _ = self.roi_heads(features, proposals, targets)
         return result, features, results_background
 
-    def forward_begin(self, images, targets, rpn_output_source=None):
+    def prefetch_frozen(self, images):
+        """The frozen stem + leading frozen stages on `images`, on the current stream (see ResNet.frozen_prefix); hand the result to
+        forward_begin(..., prefix=) for the same batch."""
+        images = to_image_list(images)
+        return self.backbone.frozen_prefix(images.tensors)
+
+    def forward_begin(self, images, targets, rpn_output_source=None, prefix=None):
         """Training forward up to the point where the host needs the proposal counts: backbone, RPN head, RPN loss, and the
         proposal selection in flight on its side stream.  The trainer slots the source model's head pass between `forward_begin`
         and `forward_finish`, so the selection (and the host's read-back of its counts) hides behind real work."""
         images = to_image_list(images)
-        features, backbone_features = self.backbone(images.tensors)
+        features, backbone_features = self.backbone(images.tensors, prefix)
         return dict(features=features, backbone_features=backbone_features, targets=targets,
                     rpn=self.rpn.forward_begin(images, features, targets, rpn_output_source))
 

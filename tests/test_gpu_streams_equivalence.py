@@ -1,5 +1,6 @@
 """GPU: every stream-level overlap of the training step -- weight gradients on a side stream, proposal selections on side streams, the
-source model's forward and head pass on a stream of their own (for the NEXT batch pipelined into the current backward pass), weight preparation (dgrad copies, Winograd-domain weights) on its own
+source model's forward and head pass on a stream of their own (for the NEXT batch pipelined into the current backward pass, together with
+the target's frozen stem + layer1), the target's distillation-RoI pass issued ahead of its detection pass, two weight-gradient streams, weight preparation (dgrad copies, Winograd-domain weights) on its own
 stream after the SGD kernel -- changes WHEN kernels run, never what they compute: four training steps with all of them on must
 leave the same parameters as four steps with all of them off (same seeds, so the same sampler draws and soften picks; fp32 atomic
 accumulation order is the only difference).  A missing stream dependency (a kernel reading a buffer another stream has not finished
