@@ -93,6 +93,19 @@ __device__ __forceinline__ void x6_report(unsigned bmin, float nonfin, unsigned*
 bool prof_enabled();
 int prof_start(hipStream_t st, int id, double work);  // returns record index (or -1)
 void prof_stop(hipStream_t st, int rec);
+// Per-launch timing WITHOUT events for kernels that stamp themselves: returns a device {first start, last end} slot (wall_clock64 ticks)
+// for this launch, or nullptr when the launch is not sampled.  The kernel calls prof_stamp_begin / prof_stamp_end with it.  No event pair,
+// so no dispatch bubble in front of the kernel, and the duration is the one a kernel trace reports (first wave in to last wave out).
+unsigned long long* prof_stamp_slot(int id, double work);
+__device__ __forceinline__ void prof_stamp_begin(unsigned long long* ts) {
+    if (ts && threadIdx.x == 0) atomicMin(ts, (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void prof_stamp_end(unsigned long long* ts) {
+    if (ts) {
+        __builtin_amdgcn_s_waitcnt(0);   // this wave's stores have landed: a kernel trace's duration includes them
+        if (threadIdx.x == 0) atomicMax(ts + 1, (unsigned long long)wall_clock64());
+    }
+}
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }

@@ -16,7 +16,10 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-struct ProfRec { hipEvent_t a, b; double work; int id; bool overlapped; };
+struct ProfRec { hipEvent_t a, b; double work; int id; bool overlapped; int slot; };   // slot >= 0: self-stamped launch (no events)
+constexpr int kMaxStampSlots = 1 << 16;
+static unsigned long long* g_ts = nullptr;   // device [kMaxStampSlots][2] = {first start, last end} in wall_clock64 ticks
+static int g_ts_used = 0;
 static bool g_prof = false;
 static bool g_overlap = false;
 static unsigned g_mask = 0xFFFFFFFFu;
@@ -43,10 +46,20 @@ int prof_start(hipStream_t st, int id, double work) {
         // population averages when the number of steps is a multiple of n
         if ((g_seen[id & 31]++ + g_step) % g_every != 0) return -1;
     }
-    ProfRec r{get_event(), get_event(), work, id, g_overlap};
+    ProfRec r{get_event(), get_event(), work, id, g_overlap, -1};
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
     return (int)g_recs.size() - 1;
+}
+unsigned long long* prof_stamp_slot(int id, double work) {
+    if (!g_prof) return nullptr;
+    if (id >= 0 && id < 32) { g_all_launches[id] += 1.0; g_all_work[id] += work; }
+    if (!((g_mask >> id) & 1u) || !g_ts) return nullptr;
+    if (g_every > 1 && (g_seen[id & 31]++ + g_step) % g_every != 0) return nullptr;   // the same systematic sample as prof_start
+    if (g_ts_used >= kMaxStampSlots) return nullptr;
+    ProfRec r{nullptr, nullptr, work, id, g_overlap, g_ts_used++};
+    g_recs.push_back(r);
+    return g_ts + 2 * (size_t)r.slot;
 }
 void prof_stop(hipStream_t st, int rec) {
     if (rec >= 0) (void)hipEventRecord(g_recs[rec].b, st);
@@ -59,6 +72,14 @@ extern "C" int abr_prof_step_begin(void) {
     return ABR_OK;
 }
 extern "C" int abr_prof_begin(void) {
+    if (!abr::g_ts && hipMalloc(&abr::g_ts, sizeof(unsigned long long) * 2 * abr::kMaxStampSlots) != hipSuccess) abr::g_ts = nullptr;
+    if (abr::g_ts) {   // start = all ones (atomicMin), end = 0 (atomicMax)
+        (void)hipDeviceSynchronize();
+        (void)hipMemset2D(abr::g_ts, 16, 0xFF, 8, abr::kMaxStampSlots);
+        (void)hipMemset2D(abr::g_ts + 1, 16, 0x00, 8, abr::kMaxStampSlots);
+        (void)hipDeviceSynchronize();
+    }
+    abr::g_ts_used = 0;
     abr::g_prof = true;
     abr::g_step = 0;
     for (int i = 0; i < 32; i++) abr::g_all_launches[i] = abr::g_all_work[i] = 0.0;
@@ -83,7 +104,29 @@ extern "C" int abr_prof_mark_overlap(int on) {
 extern "C" int abr_prof_end(double* out, int n_ids) {
     abr::g_prof = false;
     for (int i = 0; i < n_ids * 6; i++) out[i] = 0.0;
+    std::vector<unsigned long long> ts;
+    double ticks_per_ms = 1e5;   // wall_clock64: 100 MHz unless the device says otherwise
+    if (abr::g_ts_used > 0) {
+        (void)hipDeviceSynchronize();
+        ts.resize(2 * (size_t)abr::g_ts_used);
+        if (hipMemcpy(ts.data(), abr::g_ts, ts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) ts.clear();
+        int dev = 0, khz = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0)
+            ticks_per_ms = (double)khz;
+    }
     for (auto& r : abr::g_recs) {
+        if (r.slot >= 0) {   // self-stamped launch
+            if ((size_t)(2 * r.slot + 1) < ts.size() && r.id < n_ids) {
+                const unsigned long long t0 = ts[2 * r.slot], t1 = ts[2 * r.slot + 1];
+                if (t1 > t0 && t0 != ~0ull) {
+                    double* o = out + r.id * 6 + (r.overlapped ? 3 : 0);
+                    o[0] += 1.0;
+                    o[1] += (double)(t1 - t0) / ticks_per_ms;
+                    o[2] += r.work;
+                }
+            }
+            continue;
+        }
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.id < n_ids) {
             double* o = out + r.id * 6 + (r.overlapped ? 3 : 0);

@@ -56,6 +56,7 @@ struct FastDiv {
 };
 
 struct ConvP {
+    unsigned long long* prof_ts;   // bench profiling: {first start, last end} stamp slot of this launch (abr::prof_stamp_slot) or nullptr
     int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
     int M, K;  // GEMM sizes
     int out_H, out_W, out_sh, out_sw;
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int NA = BM / 32, NB = BN / 32;  // float4 staging loads per thread for A and B
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    abr::prof_stamp_begin(p.prof_ts);
     constexpr int NBUF = SB ? 1 : 2;
     float* As = smem;                        // [NBUF][BM][LDP]
     float* Bs = smem + NBUF * BM * LDP;      // [NBUF][BN][LDP]
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
         const int st = unit / p.split;  // index of this split tile
         if (tid == 0) s_last = atomicAdd(p.cnt + st, 1) == p.split - 1;
         __syncthreads();
-        if (!s_last) return;
+        if (!s_last) { abr::prof_stamp_end(p.prof_ts); return; }
         if (tid == 0) p.cnt[st] = 0;
         const unsigned base = (unsigned)st * (unsigned)p.split * kPart + (unsigned)tid * 16u;
 #pragma unroll
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     // own slice of the (now idle) operand LDS and streams whole rows: 16 B per lane, 128-256 B contiguous per row, with the
     // residual / mask read the same way.  Waves only touch their own slice, so no workgroup barrier is needed here.
     epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    abr::prof_stamp_end(p.prof_ts);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -426,6 +429,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvP p, con
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int NA = BM / 16, NB = BN / 16;  // float4 staging loads per thread (16 rows x 16 float4 per pass)
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    abr::prof_stamp_begin(p.prof_ts);
     constexpr int NBUF = DB ? 2 : 1;
     __bf16* As = reinterpret_cast<__bf16*>(smem);  // [NBUF][BM][LDH]
     __bf16* Bs = As + NBUF * BM * LDH;             // [NBUF][BN][LDH]
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvP p, con
     }
     __syncthreads();  // the epilogue reuses the operand LDS
     epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    abr::prof_stamp_end(p.prof_ts);
 }
 
 template <int BM, int BN, int WM, int WN, bool DB>
@@ -572,9 +577,8 @@ int launch_bf16(const ConvP& p, const float* x, const float* w, float* out, hipS
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int rec = abr::prof_start(st, abr::PROF_IGEMM_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
+    q.prof_ts = abr::prof_stamp_slot(abr::PROF_IGEMM_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
     kern<<<(unsigned)q.tiles_pb, 256, lds, st>>>(q, x, w, out);
-    abr::prof_stop(st, rec);
     return 0;
 }
 
@@ -605,6 +609,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int NA = BM / 32, NB = PB ? 3 * BN / 64 : BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    abr::prof_stamp_begin(p.prof_ts);
     __bf16* As = reinterpret_cast<__bf16*>(smem);  // [3][BM][LDX]
     __bf16* Bs = As + 3 * BM * LDX;                // [3][BN][LDX]
 
@@ -796,6 +801,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
     if (chk_a | chk_b) abr::x6_report(bmin, nonfin, p.x6_flags);
     __syncthreads();  // the epilogue reuses the operand LDS
     epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    abr::prof_stamp_end(p.prof_ts);
 }
 
 template <int BM, int BN, int WM, int WN, bool PB>
@@ -816,9 +822,8 @@ int launch_x6(const ConvP& p, const float* x, const float* w, float* out, hipStr
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int rec = abr::prof_start(st, abr::PROF_IGEMM_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
+    q.prof_ts = abr::prof_stamp_slot(abr::PROF_IGEMM_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
     kern<<<(unsigned)(q.tiles_pb * q.nbatch), 256, lds, st>>>(q, x, w, out);
-    abr::prof_stop(st, rec);
     return 0;
 }
 
@@ -861,9 +866,8 @@ int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int rec = abr::prof_start(st, prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
+    q.prof_ts = abr::prof_stamp_slot(prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
     kern<<<(unsigned)(q.n_full + (tiles - q.n_full) * q.split), 256, lds, st>>>(q, x, w, out);
-    abr::prof_stop(st, rec);
     return 0;
 }
 
