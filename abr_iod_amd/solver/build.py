@@ -63,10 +63,13 @@ class FusedSGD(object):
     def _grad_writer_streams(self):
         if not self.flat.grads.is_cuda:
             return []
-        # every side stream of this device may hold kernels that write the gradient buffer (weight gradients, a head pass that ran on
-        # its own stream: engine/trainer.py), and so may the stream the step was started on
+        # the streams that hold kernels writing the gradient buffer: the weight-gradient streams (ops._wgrad_stream: key = device index, or
+        # (device, "wgradN")) and the stream the step was started on.  NOT the frozen source model's stream, the proposal-selection streams
+        # or the weight-preparation stream: they never touch gradients, and the source stream carries the next batch's whole prefetch --
+        # a bucket's all-reduce waiting for that would start milliseconds late.
         dev = self.flat.grads.device.index
-        out = [s for k, s in ops._side_streams.items() if (k[0] if isinstance(k, tuple) else k) == dev]
+        out = [s for k, s in ops._side_streams.items()
+               if (k == dev) or (isinstance(k, tuple) and k[0] == dev and str(k[1]).startswith("wgrad"))]
         if getattr(self, "_main_stream", None) is not None:
             out.append(self._main_stream)
         return out
