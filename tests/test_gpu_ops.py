@@ -157,6 +157,53 @@ def test_nms_large_vs_oracle(O):
             assert np.array_equal(keep[i, :nk[i]], want)
 
 
+@pytest.mark.parametrize("case", ["chunk_edges", "all_duplicates", "no_overlap", "limit_inside_block", "ragged_counts"])
+def test_nms_chunked_sweep_edge_cases(O, case):
+    """The NMS runs in chunks of 2048 boxes (lazy mask, csrc/nms.hip) and sweeps 256-box blocks: box counts on / around the chunk and
+    block boundaries, keep limits that fall inside a block, lists where every box or no box is suppressed -- keep lists equal the oracle's."""
+    from abr_iod_amd import ops
+    rng = np.random.default_rng(11)
+
+    def boxes_for(n, spread=1000.0, size=(16, 300)):
+        cx = rng.uniform(0, spread, n); cy = rng.uniform(0, spread * 0.6, n)
+        w = np.exp(rng.uniform(np.log(size[0]), np.log(size[1]), n)); h = np.exp(rng.uniform(np.log(size[0]), np.log(size[1]), n))
+        return np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], -1).astype(np.float32)
+
+    if case == "chunk_edges":
+        sets = [(boxes_for(n), mk) for n, mk in ((1, 5), (63, 100), (64, 100), (255, 300), (256, 300), (257, 300), (2047, 3000), (2048, 3000),
+                                                  (2049, 3000), (4096 + 17, 5000), (6143, 700))]
+    elif case == "all_duplicates":
+        b = np.tile(np.array([[10, 10, 200, 150]], np.float32), (3000, 1))
+        sets = [(b, 100)]
+    elif case == "no_overlap":     # a grid of disjoint boxes: everything is kept until the limit
+        g = np.arange(2500)
+        b = np.stack([(g % 50) * 20, (g // 50) * 20, (g % 50) * 20 + 10, (g // 50) * 20 + 10], -1).astype(np.float32)
+        sets = [(b, 2500), (b, 2048), (b, 300), (b, 257)]
+    elif case == "limit_inside_block":
+        b = boxes_for(5000, spread=4000.0, size=(8, 60))
+        sets = [(b, mk) for mk in (1, 2, 63, 64, 65, 255, 256, 257, 1000, 2049)]
+    else:
+        sets = None
+    if sets is not None:
+        for b, mk in sets:
+            n = len(b)
+            scores = -np.arange(n, dtype=np.float32)
+            keep, nk = ops.nms_sorted_batched(T(b[None]), T(np.array([n], np.int32)), 0.7, mk)
+            want = O.nms(b, scores, 0.7)[:mk]
+            got = keep.cpu().numpy()[0, :int(nk.cpu()[0])]
+            assert np.array_equal(got, want), (case, n, mk, len(got), len(want))
+        return
+    # ragged: four images with different counts in one batched call (one of them empty)
+    n = 5000
+    b = np.stack([boxes_for(n) for _ in range(4)])
+    counts = np.array([5000, 2048, 0, 333], np.int32)
+    keep, nk = ops.nms_sorted_batched(T(b), T(counts), 0.7, 600)
+    keep, nk = keep.cpu().numpy(), nk.cpu().numpy()
+    for i in range(4):
+        want = O.nms(b[i, :counts[i]], -np.arange(counts[i], dtype=np.float32), 0.7)[:600] if counts[i] else np.zeros((0,), np.int64)
+        assert nk[i] == len(want) and np.array_equal(keep[i, :nk[i]], want), i
+
+
 # ------------------------------------------------------------------------------------------ focal / smooth-L1
 def test_sigmoid_focal(gold, O):
     from abr_iod_amd import _C
@@ -712,3 +759,38 @@ def test_winograd_weight_cache_follows_w_version():
         assert close(y_c, ref(w1))
         y_d = ops.conv_forward(x, w1, 1, 1, math=math, w_version=0)          # and never cached with version 0
         assert torch.equal(y_c, y_d)
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x6"])
+def test_wgrad_split_reduction_is_deterministic_and_accumulates(math):
+    """Split-M weight gradients park their partial tiles and a second launch adds them in split order (conv_wgrad.hip::wgrad_reduce_kernel):
+    the same call gives bit-identical results every time (the round-1 fp32 atomics did not), `dw +=` still accumulates over calls
+    (a weight used twice per step), and the values agree with float64.  Shapes: few output tiles x many rows (the split path),
+    direct and Winograd-domain, plus one with a single split (plain stores)."""
+    from abr_iod_amd import ops
+    m = ops.MATH_BF16X6 if math == "bf16x6" else ops.MATH_F32
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for (B, H, W, Cin, Cout, k, pad) in [(2, 38, 63, 256, 1024, 1, 0), (1, 75, 125, 512, 128, 1, 0), (2, 38, 63, 256, 256, 3, 1), (8, 4, 4, 2048, 512, 1, 0)]:
+        x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+        gy = torch.randn(B, H, W, Cout, device="cuda", generator=g)
+        sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
+        runs = []
+        for _ in range(3):
+            dw = torch.zeros(Cout, k, k, Cin, device="cuda")
+            ops.conv_wgrad(x, gy, dw, 1, pad, scale=sc, math=m)
+            runs.append(dw)
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), "split-M reduction must not depend on arrival order"
+        twice = runs[0].clone()
+        ops.conv_wgrad(x, gy, twice, 1, pad, scale=sc, math=m)        # dw += : a second contribution lands on top of the first
+        assert (twice - 2 * runs[0]).abs().max().item() <= 1e-6 * runs[0].abs().max().item()
+        if k == 1:
+            ref = torch.einsum("bhwo,bhwi->oi", gy.double(), x.double()) * sc.double()[:, None]
+            got = runs[0].view(Cout, Cin).double()
+        else:
+            xp = torch.nn.functional.pad(x.double(), (0, 0, 1, 1, 1, 1))
+            ref = torch.stack([torch.stack([torch.einsum("bhwo,bhwi->oi", gy.double(), xp[:, r:r + H, s:s + W]) for s in range(3)], 1) for r in range(3)], 1)
+            ref = ref * sc.double()[:, None, None, None]
+            got = runs[0].double()
+            ref = ref.view_as(got)
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= (5e-5 if k == 3 else 1e-5) * scale
