@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """every GPU test gets a 15-minute ceiling (pytest-timeout) unless it sets its own: a wedged worker process or collective must
+    """every GPU test gets a 10-minute ceiling (pytest-timeout) unless it sets its own: a wedged worker process or collective must
     fail the test, not hang the run"""
     try:
         import pytest_timeout  # noqa: F401
@@ -24,7 +24,7 @@ def pytest_collection_modifyitems(config, items):
         return
     for item in items:
         if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(900))
+            item.add_marker(pytest.mark.timeout(600))
 
 
 def golden(name):

@@ -120,7 +120,7 @@ def _two_rank_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(300)
 def test_two_ranks_exchange_gradients_through_the_hooks():
     """Two processes, one image each, a real exchange (gloo over CUDA tensors, both ranks on this GPU): the hook-issued bucket
     all-reduces plus the one in step() must leave both ranks with the SAME gradient, that gradient must be g_rank0 + g_rank1 (each
@@ -132,7 +132,7 @@ def test_two_ranks_exchange_gradients_through_the_hooks():
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from e2e_common import run_ranks
-    got = sorted(run_ranks(ctx, _two_rank_worker, [(r, world, port) for r in range(world)], timeout=500), key=lambda t: t[0])
+    got = sorted(run_ranks(ctx, _two_rank_worker, [(r, world, port) for r in range(world)], timeout=200), key=lambda t: t[0])
     (_, p0, g0, s0, l0, u0), (_, p1, g1, s1, l1, u1) = got
     # the hooks fired during backward on both ranks: pooled-input hook -> roi_heads; feature-map hook -> roi_heads (already sent), rpn
     assert s0[:3] == ["roi_heads", "roi_heads", "rpn"] and s1 == s0
@@ -200,7 +200,7 @@ def _eq_rank_worker(rank, world, port, draws, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(360)
 def test_two_ranks_one_image_each_equal_one_rank_two_images():
     import numpy as np
     import torch.multiprocessing as mp
@@ -230,7 +230,7 @@ def test_two_ranks_one_image_each_equal_one_rank_two_images():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     from e2e_common import run_ranks
-    got = sorted(run_ranks(ctx, _eq_rank_worker, [(r, world, port, draws) for r in range(world)], timeout=700), key=lambda t: t[0])
+    got = sorted(run_ranks(ctx, _eq_rank_worker, [(r, world, port, draws) for r in range(world)], timeout=260), key=lambda t: t[0])
     (_, g0, p0, ld0, props0), (_, g1, p1, ld1, props1) = got
     # the per-image proposal lists the injected indices refer to are the same lists
     for w, sgl in ((props0, single_props[0]), (props1, single_props[1])):
