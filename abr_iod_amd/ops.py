@@ -624,13 +624,22 @@ _ptr_tables = {}
 _small_tables = {}
 
 
+def _evict_oldest(cache, limit):
+    """Drop the oldest half of a table cache that has reached `limit` entries.  NOT `cache.clear()`: a caller builds several tables for ONE
+    launch, and clearing while it builds the second would free the first -- whose memory the second upload then reuses before the kernel
+    has read it (seen once as a training step with garbage ground-truth boxes).  Callers also keep every table in a local until the
+    launch is enqueued: after that a free is ordered behind the kernel on the same stream."""
+    if len(cache) >= limit:
+        for k in list(cache.keys())[:limit // 2]:
+            del cache[k]
+
+
 def _small_table(values, dtype, dev):
     """device copy of a short list of host integers, cached while the same list repeats (per-image GT counts, ...)"""
     key = (tuple(values), dtype, torch.device(dev))
     t = _small_tables.get(key)
     if t is None:
-        if len(_small_tables) > 256:
-            _small_tables.clear()
+        _evict_oldest(_small_tables, 256)
         t = _small_tables[key] = h2d(list(values), dtype, dev)
     return t
 
@@ -640,8 +649,7 @@ def _pointer_table(tensors, dev):
     key = (tuple(t.data_ptr() for t in tensors), torch.device(dev))
     tab = _ptr_tables.get(key)
     if tab is None:
-        if len(_ptr_tables) > 64:
-            _ptr_tables.clear()
+        _evict_oldest(_ptr_tables, 64)
         tab = _ptr_tables[key] = h2d(list(key[0]), torch.int64, dev)
     return tab
 
@@ -677,8 +685,9 @@ def roi_head_targets(props, scores, keep, n_keep, gt_boxes, gt_labels, hi, lo, w
         _sample_calls[0] += 1
         seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
     ngt_dev = _small_table(n_gt, i32, dev)
+    gtb_tab, gtl_tab = _pointer_table(gtb, dev), _pointer_table(gtl, dev)   # (held in locals until the launch is enqueued: _evict_oldest)
     L.check(L.lib().abr_roi_head_targets(
-        L.ptr(props), L.ptr(keep), L.ptr(n_keep), N, k_pre, post, L.ptr(_pointer_table(gtb, dev)), L.ptr(_pointer_table(gtl, dev)), L.ptr(ngt_dev),
+        L.ptr(props), L.ptr(keep), L.ptr(n_keep), N, k_pre, post, L.ptr(gtb_tab), L.ptr(gtl_tab), L.ptr(ngt_dev),
         g_max, float(hi), float(lo), *[float(v) for v in weights], R, max_pos, seed, L.ptr(out["cand"]), L.ptr(out["labels_all"]),
         L.ptr(out["regt_all"]), L.ptr(out["n_cand"]), L.ptr(out["pos_idx"]), L.ptr(out["neg_idx"]), L.ptr(out["counts"]), L.ptr(out["rois"]),
         L.ptr(out["labels"]), L.ptr(out["reg_targets"]), L.ptr(out["sampled_idx"]), L.ptr(out["n_valid"]), L.ptr(scores), L.ptr(out["obj_all"]),
@@ -698,8 +707,9 @@ def rpn_targets_batched(anchors, vis_list, gt_boxes, hi, lo, weights):
     labels = torch.empty((N, n), dtype=_f32, device=dev)
     tgt = torch.empty((N, n, 4), dtype=_f32, device=dev)
     ws = torch.empty((N * g_max,), dtype=torch.int32, device=dev)
-    L.check(L.lib().abr_rpn_targets_batched(L.ptr(anchors), n, N, L.ptr(_pointer_table(gtb, dev)), L.ptr(_small_table(n_gt, torch.int32, dev)), g_max,
-                                            L.ptr(_pointer_table(vis_list, dev)), float(hi), float(lo), *[float(v) for v in weights], L.ptr(labels),
+    gtb_tab, ngt_tab, vis_tab = _pointer_table(gtb, dev), _small_table(n_gt, torch.int32, dev), _pointer_table(vis_list, dev)
+    L.check(L.lib().abr_rpn_targets_batched(L.ptr(anchors), n, N, L.ptr(gtb_tab), L.ptr(ngt_tab), g_max,
+                                            L.ptr(vis_tab), float(hi), float(lo), *[float(v) for v in weights], L.ptr(labels),
                                             L.ptr(tgt), L.ptr(ws), ws.numel() * 4, L.stream()), "rpn_targets_batched")
     return labels, tgt, (gtb,)
 

@@ -122,3 +122,30 @@ def test_fused_soften_gather_equals_boxlist_path():
     from abr_iod_amd.modeling.roi_heads.box_head.box_head import convert_to_roi_format
     tab = convert_to_roi_format(sel)
     assert tab.data_ptr() == sel[0]._roi_table[0].data_ptr() and torch.equal(tab, convert_to_roi_format(sel2))
+
+
+def test_table_caches_survive_eviction_inside_one_launch():
+    """ops._pointer_table / ops._small_table cache the small device tables a launch needs (GT pointers, GT counts, visibility pointers).
+    A launch builds several of them; when the cache was full, building the second used to CLEAR the cache, which freed the first --
+    and the second upload reused its memory before the kernel had read it (one training step with garbage ground truth, seen once in a
+    long test session).  Fill the caches to the brim and check that the targets still equal the ones computed with empty caches."""
+    from abr_iod_amd import ops
+    rng = np.random.default_rng(0)
+    N, n = 2, 4000
+    anchors = torch.tensor(np.stack([rng.uniform(0, 200, n), rng.uniform(0, 150, n), rng.uniform(210, 400, n), rng.uniform(160, 300, n)], -1), dtype=torch.float32, device="cuda")
+    vis = [torch.ones(n, dtype=torch.uint8, device="cuda") for _ in range(N)]
+    gts = [torch.tensor([[20, 30, 300, 250], [100, 80, 390, 280]], dtype=torch.float32, device="cuda"),
+           torch.tensor([[5, 5, 220, 170]], dtype=torch.float32, device="cuda")]
+    ops._ptr_tables.clear(); ops._small_tables.clear()
+    want = ops.rpn_targets_batched(anchors, vis, gts, 0.7, 0.3, (1.0, 1.0, 1.0, 1.0))[:2]
+    want = [t.clone() for t in want]
+    for fill in (62, 63, 64, 65):                        # the eviction lands on the first / second / third table of the launch
+        ops._ptr_tables.clear(); ops._small_tables.clear()
+        for i in range(fill):
+            ops._ptr_tables[((i,), torch.device("cuda", 0))] = torch.zeros(1, dtype=torch.int64, device="cuda")
+        for i in range(255):
+            ops._small_tables[((i, -1), torch.int32, torch.device("cuda", 0))] = torch.zeros(1, dtype=torch.int32, device="cuda")
+        labels, tgt = ops.rpn_targets_batched(anchors, vis, gts, 0.7, 0.3, (1.0, 1.0, 1.0, 1.0))[:2]
+        torch.cuda.synchronize()
+        assert torch.equal(labels, want[0]) and torch.equal(tgt, want[1]), fill
+    ops._ptr_tables.clear(); ops._small_tables.clear()
