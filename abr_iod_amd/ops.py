@@ -544,7 +544,8 @@ class _LossSum(torch.autograd.Function):
         n = ctx.n
         grads = torch.empty((n,), dtype=_f32, device=g_total.device)
         w = (C.c_float * n)(*ctx.weights)
-        L.check(L.lib().abr_loss_sum_backward(C.cast(w, C.c_void_p), n, L.ptr(g_total.contiguous()), L.ptr(grads), L.stream()), "loss_sum_backward")
+        g_c = g_total.contiguous()   # (a local: a temporary inside the argument list would be released before the launch)
+        L.check(L.lib().abr_loss_sum_backward(C.cast(w, C.c_void_p), n, L.ptr(g_c), L.ptr(grads), L.stream()), "loss_sum_backward")
         return (None, None) + tuple(grads[i] for i in range(n))
 
 
