@@ -67,7 +67,18 @@ def run_ranks(ctx, target, argsets, timeout):
     for p in procs:
         p.start()
     try:
-        got = [q.get(timeout=timeout) for _ in procs]
+        import queue
+        import time
+        got, deadline = [], time.time() + timeout
+        while len(got) < len(procs):
+            try:
+                got.append(q.get(timeout=2.0))
+            except queue.Empty:
+                # a rank that DIED (exception, abort) never reports: fail now with its exit code instead of waiting out the other rank's collective
+                dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+                assert not dead, "rank(s) exited without a result: {}".format(dead)
+                assert time.time() < deadline, "no result from {} of {} ranks after {} s (alive: {})".format(
+                    len(procs) - len(got), len(procs), timeout, [p.is_alive() for p in procs])
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0, p.exitcode
