@@ -1021,6 +1021,14 @@ static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, fl
         else launch_x6<64, 64, 2, 2, false>(p, x, w, out, st);
         return;
     }
+    // Short-K convs (K <= 256: the 1x1 convs of layer1-3 and their dgrads) take 64x64 tiles whatever the grid size: alone they are
+    // as fast as with 128x128 tiles (+-8 % per shape), but in the training step, where two or three other streams' kernels share the CUs,
+    // the small workgroups (four per CU, 31 KB of LDS) interleave better -- step -0.3 ms in a same-session A/B.  ABR_X6_SHORTK_MAXK=0: off.
+    static const int shortk = getenv("ABR_X6_SHORTK_MAXK") ? atoi(getenv("ABR_X6_SHORTK_MAXK")) : 256;
+    if (shortk > 0 && p.K <= shortk && nb == 1 && !pb) {
+        launch_x6<64, 64, 2, 2, false>(p, x, w, out, st);
+        return;
+    }
     if (p.Cout > 64 && t128 >= 2 * cus) {
         if (pb) launch_x6<128, 128, 2, 2, true>(p, x, w, out, st);
         else launch_x6<128, 128, 2, 2, false>(p, x, w, out, st);
