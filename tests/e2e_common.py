@@ -90,3 +90,61 @@ def run_ranks(ctx, target, argsets, timeout):
                 p.join(5)
                 if p.is_alive():
                     p.kill()
+
+
+def oracle_full_size_step(g, name, sd_s, sd_t, images, with_grad=True, H=600, W=1000):
+    """The torch-CPU oracle's full-size step on the REFERENCE's draws stored in fixture `g` (tests/golden/e2e_full_<name>.npz:
+    RPN sampler lists, proposal lists, box-head sampler lists, the 64 soften picks): the six losses of
+    train_incremental.py:82-116 and -- with_grad -- autograd's gradient of their weighted sum w.r.t. the 52 trainable tensors
+    (ROIAlign backward from oracle.c).  Returns (losses dict, total, RefModel of the target)."""
+    import numpy as np
+    from oracle import ops as O
+    from oracle import torch_ref as R
+    from oracle.model_ref import RefModel
+    _, dist_type, _, alpha, beta, gamma, _, n_old = CONFIGS[name]
+    mt = RefModel(sd_t) if with_grad else RefModel(sd_t, trainable_prefixes=())
+    ms = RefModel(sd_s, trainable_prefixes=()) if sd_s is not None else None
+    ctx = torch.enable_grad() if with_grad else torch.no_grad()
+    with ctx:
+        ft = mt.backbone(images)
+        obj, reg = mt.rpn_head(ft)
+        fh, fw = ft.shape[-2:]
+        anchors, vis = O.grid_anchors(O.cell_anchors(), fh, fw, 16, (H, W))
+        n = anchors.shape[0]
+        gts = [g["gt0"], g["gt1"]]
+        labs, tgts, posm, negm = [], [], torch.zeros(2, n, dtype=torch.bool), torch.zeros(2, n, dtype=torch.bool)
+        for i in range(2):
+            lab, tgt, _ = R.rpn_prepare_targets(anchors, vis, gts[i])
+            labs.append(torch.from_numpy(lab)); tgts.append(torch.from_numpy(tgt))
+            posm[i, torch.from_numpy(g[f"rpn_pos{i}"]).long()] = True
+            negm[i, torch.from_numpy(g[f"rpn_neg{i}"]).long()] = True
+        lo, lb = R.rpn_loss(obj, reg, torch.stack(labs), torch.stack(tgts), posm, negm)
+        rois, labels, rts = [], [], []
+        for i in range(2):
+            boxes = g[f"tgt_props{i}"]
+            m = O.matcher(O.box_iou(gts[i], boxes), 0.5, 0.5, False)
+            lab = g[f"gt_labels{i}"][np.clip(m, 0, None)].astype(np.int64)
+            lab[m == -1] = 0; lab[m == -2] = -1
+            tgt = O.box_encode(gts[i][np.clip(m, 0, None)], boxes, (10.0, 10.0, 5.0, 5.0))
+            sel = g[f"head_sel{i}"].astype(np.int64)
+            rois.append(np.concatenate([np.full((len(sel), 1), i, np.float32), boxes[sel]], 1))
+            labels.append(lab[sel]); rts.append(tgt[sel])
+        _, logits, boxreg = mt.box_head(ft, torch.from_numpy(np.concatenate(rois)))
+        lc, lbox = R.box_head_loss(logits, boxreg, torch.from_numpy(np.concatenate(labels)), torch.from_numpy(np.concatenate(rts)), dist_type, n_old)
+        losses = dict(loss_classifier=lc, loss_box_reg=lbox, loss_objectness=lo, loss_rpn_box_reg=lb)
+        total = lc + lbox + lo + lb
+        if ms is not None:
+            with torch.no_grad():
+                fs = ms.backbone(images)
+                rois64 = torch.from_numpy(np.concatenate([np.concatenate([np.full((64, 1), i, np.float32), g[f"src_top128_{i}"][g[f"soften_sel{i}"]]], 1)
+                                                          for i in range(2)]))
+                ps, zs, bs = ms.box_head(fs, rois64)
+            pt, zt, bt = mt.box_head(ft, rois64)
+            k_all = zt.shape[1]
+            l_id = R.roi_distillation_loss(zs, bs.view(-1, n_old + 1, 4), zt, bt.view(-1, k_all, 4), dist_type)
+            l_ard = R.ard_loss(ps, pt, gamma)
+            losses["loss_id"], losses["loss_ard"] = l_id, l_ard
+            total = total + alpha * l_id + beta * l_ard
+        if with_grad:
+            total.backward()
+    return {k: float(v.detach()) for k, v in losses.items()}, float(total.detach()), mt

@@ -10,6 +10,8 @@ initialisation; everything random the reference drew (sampler index lists, the 6
 Proposal lists are compared as sets (tests/e2e_common.py::match_fraction: a 1-ulp score tie re-orders a 2000-box list); the six
 losses are then computed on the REFERENCE's lists, so that they are comparable at the north-star tolerance 1e-4.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -17,6 +19,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 H, W = 600, 1000
+# configurations whose full-size BACKWARD is compared with the oracle's autograd (a CPU forward + backward of the full-width model on two
+# images: 12 s on 8 cores)
+GRAD_CONFIGS = ("15-5", "10-10", "10-5", "finetune")
 
 
 def _close(a, b, tol=1e-4):
@@ -120,8 +125,43 @@ def test_full_size_step_matches_reference(gold, name):
     print(f"[{name}] reference", want)
     for k in got:
         assert _close(got[k], want[k]), (k, got[k], want[k])
-    # and the full-size step is differentiable end to end on these weights
     mt.flat.zero_grad()
     total.backward()
     torch.cuda.synchronize()
     assert torch.isfinite(mt.flat.grads).all() and float(mt.flat.grads.abs().sum()) > 0
+    if name not in GRAD_CONFIGS:
+        return
+    # ---- BACKWARD at the benchmark geometry, in the benchmarked arithmetic (bf16x6 is the default): the gradient of the step's total
+    # w.r.t. all 52 trainable tensors against autograd on the torch-CPU oracle (oracle/model_ref.py; ROIAlign backward from oracle.c) run on
+    # the SAME reference draws.  The reference itself has no CPU backward (csrc/ROIAlign.h:44).  Bounds as in tests/test_gpu_e2e.py.
+    from abr_iod_amd import ops
+    from abr_iod_amd.modeling.backbone.resnet import Conv2d
+    from e2e_common import oracle_full_size_step
+    from abr_iod_amd.modeling.detector.generalized_rcnn import DEFAULT_CONV_MATH
+    assert DEFAULT_CONV_MATH == "bf16x6"
+    if os.environ.get("ABR_CONV_MATH", DEFAULT_CONV_MATH) == "bf16x6":   # the arithmetic bench.py reports
+        assert all(m.math == ops.MATH_BF16X6 for m in mt.modules() if hasattr(m, "math"))
+    sd_s = {k: v.cpu() for k, v in reference_state_dict(ms).items()} if ms is not None else None
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8))))
+    ref_losses, ref_total, ref_t = oracle_full_size_step(g, name, sd_s, sd_t, images.cpu(), with_grad=True)
+    for k in got:
+        assert _close(got[k], ref_losses[k]), (k, got[k], ref_losses[k])
+    assert _close(float(total), ref_total), (float(total), ref_total)
+    convs = {id(m.weight): m for m in mt.modules() if isinstance(m, Conv2d)}
+    rgrads = ref_t.grads()
+    report = []
+    for pname, p in mt.named_parameters():
+        if not p.requires_grad:
+            continue
+        gg = p.grad
+        if id(p) in convs:
+            gg = gg[..., : convs[id(p)].in_channels].permute(0, 3, 1, 2)
+        gg = gg.detach().cpu()
+        r = rgrads[pname]
+        rel = float((gg - r).abs().max()) / max(float(r.abs().max()), 1e-12)
+        rel_l2 = float((gg - r).norm() / max(float(r.norm()), 1e-12))
+        report.append((pname, rel, rel_l2))
+    assert len(report) == 52, len(report)
+    print(f"[{name}] full-size gradients vs oracle: worst max-rel {max(r[1] for r in report):.2e}, worst l2-rel {max(r[2] for r in report):.2e}")
+    for pname, rel, rel_l2 in report:
+        assert rel <= 2e-2 and rel_l2 <= 5e-3, f"grad {pname}: max-rel {rel}, l2-rel {rel_l2}"

@@ -34,34 +34,126 @@ FULL_CONVS = [
     (4, 1024, 38, 63, 1024, 3, 1, 1),    # RPN 3x3
     (4, 1024, 38, 63, 75, 1, 1, 0),      # fused RPN heads (15 objectness + 60 deltas)
     (256, 512, 7, 7, 512, 3, 1, 1),      # layer4 3x3 on the 64-RoI distillation pass
+    # layer4 on the step's 4 x 512 detection RoIs (M = 32768 rows: the 128x128 instance, split-M weight gradients with parked partials)
+    (2048, 1024, 7, 7, 512, 1, 2, 0),    # conv1 (stride in the 1x1, resnet.py:278)
+    (2048, 512, 4, 4, 512, 3, 1, 1),     # conv2: one F(4x4,3x3) tile per RoI
+    (2048, 512, 4, 4, 2048, 1, 1, 0),    # conv3
+    (2048, 1024, 7, 7, 2048, 1, 2, 0),   # stride-2 projection
 ]
+MATHS = ["bf16x6", "f32"]   # bf16x6 = the default arithmetic, the one bench.py reports; f32 = the fp32 MFMA kernels
 
 
-@pytest.mark.parametrize("case", FULL_CONVS)
-def test_full_size_conv_linearity_and_sampled_dot_products(case):
+def _math(name):
     from abr_iod_amd import ops
+    return ops.MATH_BF16X6 if name == "bf16x6" else ops.MATH_F32
+
+
+def _case_tensors(case):
     Bc, Cin, Hc, Wc, Cout, k, s, p = case
     g = torch.Generator(device="cuda").manual_seed(Cin * 7 + Cout)
     x = torch.randn(Bc, Hc, Wc, Cin, device="cuda", generator=g)
     w = torch.randn(Cout, k, k, Cin, device="cuda", generator=g) / (Cin * k * k) ** 0.5
-    y = ops.conv_forward(x, w, s, p)
+    return x, w, g
+
+
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("case", FULL_CONVS)
+def test_full_size_conv_linearity_and_sampled_dot_products(case, math):
+    from abr_iod_amd import ops
+    Bc, Cin, Hc, Wc, Cout, k, s, p = case
+    m = _math(math)
+    x, w, _ = _case_tensors(case)
+    y = ops.conv_forward(x, w, s, p, math=m)
     Ho, Wo = (Hc + 2 * p - k) // s + 1, (Wc + 2 * p - k) // s + 1
     assert tuple(y.shape) == (Bc, Ho, Wo, Cout) and bool(torch.isfinite(y).all())
-    # scaling by a power of two commutes with every fp32 rounding step, whatever the kernel's summation order
-    assert torch.equal(ops.conv_forward(x * 4.0, w, s, p), y * 4.0)
-    assert torch.equal(ops.conv_forward(x, w * 0.5, s, p), y * 0.5)
-    assert torch.equal(ops.conv_forward(x, w, s, p), y)   # and the kernel (split-K included) is run-to-run deterministic
+    # scaling by a power of two commutes with every fp32 rounding step, whatever the kernel's summation order (and with the exact
+    # three-way bf16 split of the bf16x6 kernels)
+    assert torch.equal(ops.conv_forward(x * 4.0, w, s, p, math=m), y * 4.0)
+    assert torch.equal(ops.conv_forward(x, w * 0.5, s, p, math=m), y * 0.5)
+    assert torch.equal(ops.conv_forward(x, w, s, p, math=m), y)   # and the kernel (split-K included) is run-to-run deterministic
     # float64 dot products at 256 sampled output positions, corners and edges included
     rng = np.random.default_rng(Cin + Cout)
     pos = [(0, 0, 0), (Bc - 1, Ho - 1, Wo - 1), (0, Ho - 1, 0), (Bc - 1, 0, Wo - 1)]
     pos += [(int(rng.integers(Bc)), int(rng.integers(Ho)), int(rng.integers(Wo))) for _ in range(252)]
-    xp = torch.nn.functional.pad(x, (0, 0, p, p, p, p)).double()
+    xp = torch.nn.functional.pad(x, (0, 0, p, p, p, p))
     w64 = w.double().reshape(Cout, -1)
-    patches = torch.stack([xp[b, i * s:i * s + k, j * s:j * s + k, :].reshape(-1) for b, i, j in pos])
+    patches = torch.stack([xp[b, i * s:i * s + k, j * s:j * s + k, :].reshape(-1) for b, i, j in pos]).double()
     want = patches @ w64.t()
     got = torch.stack([y[b, i, j] for b, i, j in pos]).double()
     # 1e-4 of the output scale (north_star tolerance); the Winograd path itself stays below 5e-5
     assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    assert ops.x6_range_flags() == 0
+
+
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("case", FULL_CONVS[1:])   # the stem is frozen (FREEZE_CONV_BODY_AT = 2) and has no backward
+def test_full_size_conv_backward_sampled_vs_float64(case, math):
+    """dgrad and wgrad of the BASELINE layer shapes, as Bottleneck.bwd issues them (resnet.py here; the reference: cuDNN dgrad / wgrad
+    behind resnet.py:261-323): the input gradient = the forward kernel on the flipped, FrozenBN-scaled weight copy (a scatter to the
+    even pixels for the stride-2 1x1 convs), the weight gradient = the split-M kernel (parked partials + reduce) or, for the wide 3x3
+    convs, the Winograd-domain gradient, also with the forward's kept V.  Checked against float64 sums at sampled positions."""
+    from abr_iod_amd import ops
+    if case[4] == 75:   # the model's fused RPN head weight is 76 rows (15 + 60 + 1 pad): its dgrad reduces over 76 channels
+        case = case[:4] + (76,) + case[5:]
+    Bc, Cin, Hc, Wc, Cout, k, s, p = case
+    m = _math(math)
+    x, w, g = _case_tensors(case)
+    Ho, Wo = (Hc + 2 * p - k) // s + 1, (Wc + 2 * p - k) // s + 1
+    gy = torch.randn(Bc, Ho, Wo, Cout, device="cuda", generator=g)
+    scale = torch.rand(Cout, device="cuda", generator=g) + 0.5          # FrozenBN scale folded into both gradients
+    rng = np.random.default_rng(Cin * 3 + Cout)
+    # ---- dgrad: dx[b,h,w,:] = sum_{r,t,co} scale[co] gy[b,(h+p-r)/s,(w+p-t)/s,co] w[co,r,t,:]
+    wt = ops.conv_dgrad_weights(w, scale)
+    if s == 1:
+        dx = ops.conv_forward(gy, wt, 1, k - 1 - p, math=m)
+    else:
+        assert k == 1 and p == 0
+        dx = ops.conv_forward(gy, wt, 1, 0, out_hw=(Hc, Wc), out_stride=(s, s), math=m)
+    assert tuple(dx.shape) == (Bc, Hc, Wc, Cin)
+    assert torch.equal(dx, ops.conv_forward(gy, wt, 1, k - 1 - p, math=m) if s == 1 else
+                       ops.conv_forward(gy, wt, 1, 0, out_hw=(Hc, Wc), out_stride=(s, s), math=m))
+    pos = [(0, 0, 0), (Bc - 1, Hc - 1, Wc - 1), (0, Hc - 1, 0), (Bc - 1, 0, Wc - 1)]
+    pos += [(int(rng.integers(Bc)), int(rng.integers(Hc)), int(rng.integers(Wc))) for _ in range(124)]
+    ws64 = (w * scale.view(-1, 1, 1, 1)).double()
+    want = torch.zeros(len(pos), Cin, dtype=torch.float64, device="cuda")
+    for i, (b, h, ww) in enumerate(pos):
+        for r in range(k):
+            for t in range(k):
+                hn, wn = h + p - r, ww + p - t
+                if hn % s or wn % s or not (0 <= hn // s < Ho and 0 <= wn // s < Wo):
+                    continue
+                want[i] += gy[b, hn // s, wn // s].double() @ ws64[:, r, t, :]
+    got = torch.stack([dx[b, h, ww] for b, h, ww in pos]).double()
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), "dgrad"
+    # ---- wgrad: dw[co,r,t,:] += scale[co] sum_{b,ho,wo} gy[b,ho,wo,co] x[b,ho*s+r-p,wo*s+t-p,:]
+    dw = torch.zeros_like(w)
+    ops.conv_wgrad(x, gy, dw, s, p, scale=scale, math=m)
+    dw2 = torch.zeros_like(w)
+    ops.conv_wgrad(x, gy, dw2, s, p, scale=scale, math=m)
+    assert torch.equal(dw, dw2)   # parked partials are added in a fixed order: deterministic
+    v = ops.wino_v_alloc(x, w, s, p, m)
+    if v is not None:             # the step's form: the forward keeps its Winograd-domain input for the weight gradient
+        ops.conv_forward(x, w, s, p, math=m, wino_v=v)
+        dw3 = torch.zeros_like(w)
+        ops.conv_wgrad(x, gy, dw3, s, p, scale=scale, math=m, wino_v=v)
+        assert torch.equal(dw3, dw)
+    ops.conv_wgrad(x, gy, dw2, s, p, scale=scale, math=m)   # accumulates: a weight used twice per step (layer4) receives two launches
+    xp = torch.nn.functional.pad(x, (0, 0, p, p, p, p))
+    taps = [(0, 0, 0), (Cout - 1, k - 1, k - 1)] + [(int(rng.integers(Cout)), int(rng.integers(k)), int(rng.integers(k))) for _ in range(10)]
+    worst = 0.0
+    for co, r, t in taps:
+        xs = xp[:, r:r + (Ho - 1) * s + 1:s, t:t + (Wo - 1) * s + 1:s, :].reshape(-1, Cin)
+        gcol = gy[..., co].reshape(-1)
+        want_v = torch.zeros(Cin, dtype=torch.float64, device="cuda")
+        for lo in range(0, xs.shape[0], 1 << 16):   # float64 in slices (keeps the temporaries small)
+            want_v += gcol[lo:lo + (1 << 16)].double() @ xs[lo:lo + (1 << 16)].double()
+        want_v *= float(scale[co])
+        got_v = dw[co, r, t].double()
+        tol = 1e-4 * max(1.0, want_v.abs().max().item())
+        worst = max(worst, (got_v - want_v).abs().max().item() / tol)
+        assert (got_v - want_v).abs().max().item() < tol, ("wgrad", co, r, t)
+        assert (dw2[co, r, t].double() - 2 * want_v).abs().max().item() < 2 * tol, ("wgrad accumulate", co, r, t)
+    assert ops.x6_range_flags() == 0
 
 
 def _iou(a, b):
