@@ -47,6 +47,8 @@ _SIGS = {
     "abr_prof_event_overhead_ms": (_i, [_vp, _vp]),
     "abr_prof_step_begin": (_i, []),
     "abr_conv_prepare_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp]),
+    "abr_conv_cache_clear": (_i, []),
+    "abr_conv_cache_bytes": (_i64, []),
     "abr_roi_head_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _i, _i, C.c_uint64,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "abr_rpn_targets_batched": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i64, _vp]),
@@ -56,6 +58,7 @@ _SIGS = {
     "abr_gather_proposals": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "abr_x6_range_flags": (_i, [_vp, _i, _vp]),
     "abr_x6_range_flags_async": (_i, [_vp, _vp]),
+    "abr_x6_range_flags_to_device": (_i, [_vp, _vp]),
     "abr_roi_align_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp]),
     "abr_roi_align_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "abr_roi_align_backward_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),

@@ -66,7 +66,8 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
 
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Off by default.
 enum ProfId { PROF_IGEMM_128x128 = 0, PROF_IGEMM_128x64, PROF_IGEMM_64x64, PROF_IGEMM_SMALLC, PROF_WGRAD, PROF_ROIALIGN_FWD,
-              PROF_ROIALIGN_BWD, PROF_IGEMM_BF16, PROF_WGRAD_BF16, PROF_COUNT };
+              PROF_ROIALIGN_BWD, PROF_IGEMM_BF16, PROF_WGRAD_BF16,
+              PROF_X6_128x128, PROF_X6_128x64, PROF_X6_64x64, PROF_COUNT };   // (ids are positions in bench.py's PROF_NAMES)
 // Winograd F(4x4,3x3) transform kernels (conv_winograd.hip); the batched GEMM between them is launched by conv_igemm.hip
 int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, hipStream_t st);
 int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st);
@@ -78,6 +79,8 @@ float* wino_ws(hipStream_t st, size_t floats);
 // cached Winograd-domain weights U [36][N][C] of the tensor at `w` (abr_conv_desc::w_version != 0), transformed on `st` when (w, version)
 // has not been seen; nullptr = no memory (transform into scratch instead)
 float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t st);
+void wino_u_cache_clear();
+size_t wino_u_cache_bytes();
 
 // bf16x6 range guard (see abr_x6_range_flags in include/abr_iod_hip.h).  The flag word lives in device memory owned by common.hip.
 unsigned* x6_flags_ptr();

@@ -206,6 +206,17 @@ extern "C" int abr_x6_range_flags_async(uint32_t* out_pinned_host, void* stream)
     return ABR_OK;
 }
 
+extern "C" int abr_x6_range_flags_to_device(uint32_t* out_device, void* stream) {
+    ABR_REQUIRE(out_device, "x6_range_flags_to_device: null pointer");
+    unsigned* p = abr::x6_flags_ptr();
+    ABR_REQUIRE(p, "x6_range_flags_to_device: no device memory");
+    if (hipMemcpyAsync(out_device, p, sizeof(unsigned), hipMemcpyDeviceToDevice, abr::as_stream(stream)) != hipSuccess) {
+        abr::set_error("x6_range_flags_to_device: copy failed");
+        return ABR_E_LAUNCH;
+    }
+    return ABR_OK;
+}
+
 extern "C" const char* abr_last_error(void) { return abr::g_err; }
 extern "C" int abr_version(void) { return 100; }
 extern "C" int abr_device_info(int32_t* out) {

@@ -24,7 +24,8 @@
 // Grid shaping: XCD-aware tile order; split-K of the LAST round's tiles for long-K GEMMs whose grid does not fill
 // it (partials through system-coherent buffer accesses, deterministic last-arrival reduce); batched mode for the
 // 36 GEMMs of a Winograd F(4x4,3x3) convolution (conv_winograd.hip), which every wide stride-1 3x3 conv takes.
-// fp32 MFMA is bit-for-bit an fmaf chain, so results are exact-fp32 (no TF32/bf16 anywhere).
+// fp32 MFMA is bit-for-bit an fmaf chain, so this kernel's results are exact-fp32.  The DEFAULT arithmetic of the library is the bf16x6
+// kernel further down (conv_igemm_x6_kernel: fp32-accurate contractions on the bf16 matrix cores); this one runs with ABR_MATH_F32.
 // Bound: MFMA (157.3 TFLOP/s fp32 matrix peak); DESIGN.md has the per-layer flop counts and measured rates.
 #include <algorithm>
 #include <map>
@@ -583,7 +584,7 @@ int launch_bf16(const ConvP& p, const float* x, const float* w, float* out, hipS
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// fp32-accurate math on the bf16 matrix cores (abr_conv_desc::math == ABR_MATH_BF16X6; opt-in, not the default).
+// fp32-accurate math on the bf16 matrix cores (abr_conv_desc::math == ABR_MATH_BF16X6; the host's DEFAULT since round 2).
 // Every fp32 operand is split EXACTLY into three bf16 terms, x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0
 // - x1): 3 x (8 bits + sign) cover the 24-bit significand; both subtractions are exact in fp32), and the product is formed from
 // the six cross terms with i + j <= 2 -- x0w0, x0w1, x1w0, x0w2, x1w1, x2w0 -- each an exact bf16 x bf16 product accumulated in
@@ -822,7 +823,8 @@ int launch_x6(const ConvP& p, const float* x, const float* w, float* out, hipStr
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    q.prof_ts = abr::prof_stamp_slot(abr::PROF_IGEMM_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
+    constexpr int prof_id = BM == 128 ? (BN == 128 ? abr::PROF_X6_128x128 : abr::PROF_X6_128x64) : abr::PROF_X6_64x64;   // one row per template instance
+    q.prof_ts = abr::prof_stamp_slot(prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
     kern<<<(unsigned)(q.tiles_pb * q.nbatch), 256, lds, st>>>(q, x, w, out);
     return 0;
 }
@@ -1156,6 +1158,12 @@ extern "C" int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, 
     }
     return ABR_OK;
 }
+
+extern "C" int abr_conv_cache_clear(void) {
+    abr::wino_u_cache_clear();
+    return ABR_OK;
+}
+extern "C" int64_t abr_conv_cache_bytes(void) { return (int64_t)abr::wino_u_cache_bytes(); }
 
 extern "C" int abr_conv_dgrad_weights(const float* w, const float* scale, int Cout, int R, int S, int Cin, float* wt,
                                       void* stream) {

@@ -15,6 +15,11 @@
 // (+ ReLU mask in backward) as conv_igemm.hip.
 #include <map>
 
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -369,33 +374,92 @@ float* wino_ws(hipStream_t st, size_t floats) {
 }
 
 // Winograd-domain weights U kept per weight tensor (abr_conv_desc::w_version).  One entry per weight address; a new version refills the
-// same buffer.  The users of one entry are expected on one stream (forward / dgrad convs run on the caller's main stream); a hit
-// from another stream is ordered behind the fill through an event.  Returns nullptr when there is no memory (caller uses scratch).
+// same buffer.  Ordering: a hit from a stream other than the filling one waits for the fill's event; every stream that has read an entry is
+// remembered, and a REFILL (new version) first makes its stream wait for an event recorded on each of those streams at refill time --
+// everything they had queued, the readers of the old U included, precedes it -- so no reader of version v can see version v+1's bytes
+// whatever stream refills.  Bounded: least-recently-used entries are dropped when the cache exceeds ABR_WINO_CACHE_MB (default 8192), and
+// abr_conv_cache_clear() drops everything (the host calls it when a model's parameter storage is rebuilt or released).  One mutex guards
+// the map.  Returns nullptr when there is no memory (caller uses scratch).
+namespace {
+struct UEntry {
+    float* buf = nullptr; size_t floats = 0; int64_t version = 0; hipStream_t stream = nullptr; hipEvent_t filled = nullptr;
+    std::vector<hipStream_t> readers;   // streams other than `stream` that have been handed this buffer since the last fill
+    uint64_t last_use = 0;
+};
+std::map<const float*, UEntry> g_ucache;
+std::mutex g_ucache_mu;
+uint64_t g_ucache_clock = 0;
+size_t g_ucache_bytes = 0;
+
+void ucache_drop(UEntry& e) {   // (mutex held) wait for every stream that may still read or write the buffer, then free it
+    if (e.stream) (void)hipStreamSynchronize(e.stream);
+    for (hipStream_t r : e.readers) (void)hipStreamSynchronize(r);
+    if (e.buf) { (void)hipFree(e.buf); g_ucache_bytes -= e.floats * sizeof(float); }
+    if (e.filled) (void)hipEventDestroy(e.filled);
+    e = UEntry();
+}
+size_t ucache_limit() {
+    static const size_t mb = getenv("ABR_WINO_CACHE_MB") ? (size_t)atoll(getenv("ABR_WINO_CACHE_MB")) : 8192;
+    return mb << 20;
+}
+}  // namespace
+
 float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t st) {
-    struct Entry { float* buf = nullptr; size_t floats = 0; int64_t version = 0; hipStream_t stream = nullptr; hipEvent_t filled = nullptr; };
-    static std::map<const float*, Entry> cache;
+    std::lock_guard<std::mutex> lock(g_ucache_mu);
     const size_t floats = (size_t)36 * N * C;
-    Entry& e = cache[w];
-    if (e.buf && e.floats != floats) {   // the address now holds a different weight tensor
-        (void)hipStreamSynchronize(e.stream);
-        (void)hipFree(e.buf);
-        e.buf = nullptr; e.version = 0;
-    }
+    UEntry& e = g_ucache[w];
+    e.last_use = ++g_ucache_clock;
+    if (e.buf && e.floats != floats) ucache_drop(e);   // the address now holds a different weight tensor
     if (!e.buf) {
+        while (g_ucache_bytes + floats * sizeof(float) > ucache_limit()) {   // evict least-recently-used entries (never this one)
+            auto victim = g_ucache.end();
+            for (auto it = g_ucache.begin(); it != g_ucache.end(); ++it)
+                if (it->second.buf && &it->second != &e && (victim == g_ucache.end() || it->second.last_use < victim->second.last_use)) victim = it;
+            if (victim == g_ucache.end()) break;
+            ucache_drop(victim->second);
+            g_ucache.erase(victim);
+        }
         if (hipMalloc(&e.buf, floats * sizeof(float)) != hipSuccess) { e.buf = nullptr; return nullptr; }
         e.floats = floats;
+        g_ucache_bytes += floats * sizeof(float);
+        e.last_use = g_ucache_clock;
         if (!e.filled) (void)hipEventCreateWithFlags(&e.filled, hipEventDisableTiming);
     }
     if (e.version == version) {
-        if (st != e.stream) (void)hipStreamWaitEvent(st, e.filled, 0);
+        if (st != e.stream) {
+            (void)hipStreamWaitEvent(st, e.filled, 0);
+            if (std::find(e.readers.begin(), e.readers.end(), st) == e.readers.end()) e.readers.push_back(st);
+        }
         return e.buf;
     }
-    if (e.stream && st != e.stream) (void)hipStreamSynchronize(e.stream);   // readers of the previous version on another stream
+    // refill in place: order it behind everything the other streams that used this buffer (its previous filler included) have queued
+    std::vector<hipStream_t> users = e.readers;
+    if (e.stream && e.stream != st) users.push_back(e.stream);
+    for (hipStream_t r : users) {
+        if (r == st) continue;
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamSynchronize(r); continue; }
+        (void)hipEventRecord(ev, r);
+        (void)hipStreamWaitEvent(st, ev, 0);
+        (void)hipEventDestroy(ev);   // (released by the runtime once it has completed)
+    }
+    e.readers.clear();
     if (wino_weight_transform(w, N, C, e.buf, st)) return nullptr;
     (void)hipEventRecord(e.filled, st);
     e.version = version;
     e.stream = st;
     return e.buf;
+}
+
+void wino_u_cache_clear() {
+    std::lock_guard<std::mutex> lock(g_ucache_mu);
+    for (auto& kv : g_ucache) ucache_drop(kv.second);
+    g_ucache.clear();
+    g_ucache_bytes = 0;
+}
+size_t wino_u_cache_bytes() {
+    std::lock_guard<std::mutex> lock(g_ucache_mu);
+    return g_ucache_bytes;
 }
 
 }  // namespace abr

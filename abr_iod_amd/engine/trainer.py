@@ -41,31 +41,66 @@ SOURCE_HEAD_STREAM = os.environ.get("ABR_SOURCE_HEAD_STREAM", "1") != "0"
 EARLY_SECOND_PASS = os.environ.get("ABR_EARLY_SECOND_PASS", "1") != "0"
 PIPELINE_TARGET_FROZEN = os.environ.get("ABR_PIPELINE_TARGET_FROZEN", "1") != "0"
 PIPELINE_SOURCE = os.environ.get("ABR_PIPELINE_SOURCE", "1") != "0"
-_PREFETCHED = {}
 JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "0") != "0"
 
 
-_x6_watch = [None]
+class TrainerState(object):
+    """What one (source, target) training pair carries from step to step: the work prefetched for the next batch and the bf16x6 range
+    watch.  It lives on the TARGET model object (`trainer_state(model_target)`), not at module level: two trainers in one process do not
+    see each other's prefetch, and a model that is dropped takes its state with it."""
+
+    def __init__(self):
+        self.prefetched = {}     # {"key": ..., "state": soften_begin(next batch), "target_prefix": (event, frozen_prefix(next batch))}
+        self.x6_watch = None
+
+    def drop_prefetch(self):
+        self.prefetched = {}
+
+
+def trainer_state(model_target):
+    st = model_target.__dict__.get("_abr_trainer_state")
+    if st is None:
+        st = TrainerState()
+        model_target.__dict__["_abr_trainer_state"] = st
+    return st
+
+
+def _prefetch_key(images, model_source, model_target):
+    """A prefetch is only valid for the batch it was computed from AND the weights / arithmetic it was computed with: the batch object
+    (identity) plus its storage address and in-place version counter (a buffer refilled in place is a different batch), the weight
+    versions (a checkpoint load or in-place surgery between two steps moves _STATIC_VERSION; optimiser steps only move the trained
+    tensors, which no prefetched quantity reads) and both models' contraction arithmetic."""
+    from ..modeling.backbone import resnet
+    t = images.tensors if hasattr(images, "tensors") else images
+    return (id(images), t.data_ptr(), t._version, tuple(t.shape), id(model_source), id(model_target), resnet._STATIC_VERSION[0],
+            getattr(model_source, "conv_math", None), getattr(model_target, "conv_math", None))
 
 
 def _x6_guard(model_source, model_target, log=None):
-    """bf16x6 arithmetic only: poll the kernels' range guard (ops.X6RangeWatch -- asynchronous, one step behind, no host stall).  When
-    an operand has left the domain in which the three-way bf16 split is exact (a non-zero magnitude below 2^-110, inf or nan) both
-    models switch to the fp32 MFMA kernels for the rest of the run."""
+    """bf16x6 arithmetic only: poll the kernels' range guard (ops.X6RangeWatch -- asynchronous, no host stall).  When an operand has left
+    the domain in which the three-way bf16 split is exact (a non-zero magnitude below 2^-110, inf or nan) both models switch to the fp32
+    MFMA kernels for the rest of the run.  EXPOSURE: the flag word is read one step behind and after optimizer.step(), so the update of
+    the step that tripped the guard -- and of the one after it -- was computed with out-of-domain operands and is NOT redone (a
+    non-finite operand makes the losses non-finite in either arithmetic; a tiny one loses its low-order bits); the warning says so.
+    Under data parallelism the flag is MAX-reduced over the ranks first, so that every rank switches at the same step."""
     if getattr(model_target, "conv_math", "f32") != "bf16x6":
         return
     from .. import ops
-    if _x6_watch[0] is None:
-        _x6_watch[0] = ops.X6RangeWatch()
-    flags = _x6_watch[0].poll()
+    st = trainer_state(model_target)
+    if st.x6_watch is None:
+        st.x6_watch = ops.X6RangeWatch()
+    # every rank polls at the same point of every step, so the reduced word is read at the same step everywhere
+    flags = st.x6_watch.poll(reduce_over_ranks=get_world_size() > 1 and dist.is_available() and dist.is_initialized())
     if flags:
         what = " + ".join(n for b, n in ((ops.X6_FLAG_TINY, "non-zero operand below 2^-110"), (ops.X6_FLAG_NONFINITE, "inf/nan operand")) if flags & b)
         (log or logging.getLogger("abr_iod_amd.trainer")).warning(
-            "bf16x6 range guard tripped ({}): switching both models to the fp32 MFMA kernels".format(what))
+            "bf16x6 range guard tripped ({}): switching both models to the fp32 MFMA kernels from the next step on; the last two "
+            "updates were computed with operands outside the exact-split domain and are not redone".format(what))
         for m in (model_source, model_target):
             if m is not None and hasattr(m, "set_conv_math"):
                 m.set_conv_math("f32")
-        ops.x6_range_flags(reset=True)
+        st.x6_watch.reset()
+        st.drop_prefetch()     # computed in the old arithmetic
 
 
 def reduce_loss_dict(loss_dict):
@@ -137,11 +172,12 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
             if SOURCE_OVERLAP and not faithful_rng and on_gpu and hasattr(model_source, "soften_begin") and not model_source.training:
                 # source backbone + RPN head now, its proposal selection on a side stream; finished after the target's forward
                 pre = None
-                if _PREFETCHED.get("images") is images and _PREFETCHED.get("model") is model_source:
-                    pre = _PREFETCHED["state"]        # enqueued during the previous step's backward pass
-                    if _PREFETCHED.get("target_model") is model_target:
-                        target_prefix = _PREFETCHED.get("target_prefix")
-                _PREFETCHED.clear()
+                tstate = trainer_state(model_target)
+                pf = tstate.prefetched
+                if pf and pf.get("images") is images and pf.get("key") == _prefetch_key(images, model_source, model_target):
+                    pre = pf["state"]                 # enqueued during the previous step's backward pass
+                    target_prefix = pf.get("target_prefix")
+                tstate.drop_prefetch()
                 if pre is not None:
                     deferred = pre
                 elif SOURCE_STREAM:
@@ -262,11 +298,13 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         from .. import ops
         cur = torch.cuda.current_stream()
         src = ops.side_stream((cur.device.index, "source-model"))
+        src.wait_stream(cur)   # next_images may have been produced on the current stream (async upload, device-side padding / augmentation)
         with torch.no_grad(), torch.cuda.stream(src):
             nxt = model_source.soften_begin(next_images)
         nxt["_stream"] = src
-        _PREFETCHED.clear()
-        _PREFETCHED.update(images=next_images, model=model_source, state=nxt)   # (holds the batch object: identity, not id(), is the key)
+        tstate = trainer_state(model_target)
+        # (holds the batch object, so its id() cannot be recycled while the entry lives)
+        tstate.prefetched = dict(images=next_images, key=_prefetch_key(next_images, model_source, model_target), state=nxt)
         if PIPELINE_TARGET_FROZEN and hasattr(model_target, "prefetch_frozen"):
             # the TARGET's frozen stem + layer1 (FREEZE_CONV_BODY_AT = 2) for the next batch too: their output does not depend on this step's
             # update either, and these bandwidth-bound convolutions overlap better with the backward pass's GEMMs than with the target's own
@@ -276,7 +314,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
                 if pf is not None:
                     ev = torch.cuda.Event()
                     ev.record()
-                    _PREFETCHED.update(target_model=model_target, target_prefix=(ev, pf))
+                    tstate.prefetched["target_prefix"] = (ev, pf)
     optimizer.zero_grad()                                                                                  # :142
     _arm_overlap(optimizer, [det_pooled, roi_align_features_target if need_source else None], feature_target)
     losses.backward()                                                                                      # :144-145 (amp O0 = identity)

@@ -70,7 +70,11 @@ class GeneralizedRCNN(nn.Module):
 
     # --- storage: one flat fp32 buffer for parameters, one for gradients (RCCL all-reduce + fused SGD work on them)
     def flatten_parameters(self):
+        rebuilt = getattr(self, "flat", None) is not None
         self.flat = flatten_parameters(self)
+        if rebuilt and self.flat.params.is_cuda:
+            from ... import ops
+            ops.conv_cache_clear()   # the old storage is gone: entries keyed by its addresses would outlive it (and may alias new tensors)
         from ..backbone.resnet import Conv2d, bump_param_version
         bump_param_version()   # new weight storage: nothing derived from an earlier tensor at the same address may be reused
         for m in self.modules():

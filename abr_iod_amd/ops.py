@@ -218,18 +218,39 @@ class X6RangeWatch(object):
 
     def __init__(self):
         self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._dev = None
         self._event = None
 
-    def poll(self):
+    def poll(self, reduce_over_ranks=False):
+        """reduce_over_ranks (data-parallel training): the flag word is MAX-reduced over the process group ON THE DEVICE before it is
+        copied out (4 bytes per step on the collective's stream, still no host stall), so every rank sees a trip at the same poll."""
         seen = 0
+        if self._event is not None and reduce_over_ranks:
+            # ranks must issue the SAME collective sequence and read the SAME poll: wait for the previous copy instead of skipping a round
+            # (free in the training step: its one read-back during the forward pass already passed the previous step's end)
+            self._event.synchronize()
         if self._event is not None and self._event.query():
             seen = int(self._host[0].item()) & 0xFFFFFFFF
             self._event = None
         if self._event is None:
-            L.check(L.lib().abr_x6_range_flags_async(self._host.data_ptr(), L.stream()), "x6_range_flags_async")
+            if reduce_over_ranks:
+                import torch.distributed as dist
+                if self._dev is None:
+                    self._dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+                L.check(L.lib().abr_x6_range_flags_to_device(self._dev.data_ptr(), L.stream()), "x6_range_flags_to_device")
+                dist.all_reduce(self._dev, op=dist.ReduceOp.MAX)   # TINY = 1, NONFINITE = 2, both = 3: MAX keeps "tripped" alive
+                self._host.copy_(self._dev, non_blocking=True)
+            else:
+                L.check(L.lib().abr_x6_range_flags_async(self._host.data_ptr(), L.stream()), "x6_range_flags_async")
             self._event = torch.cuda.Event()
             self._event.record()
         return seen
+
+    def reset(self):
+        """clear the device word AND the copy in flight (its value predates the reset and would re-trip the next poll)"""
+        x6_range_flags(reset=True)    # synchronises the stream: the pending copy has landed
+        self._event = None
+        self._host.zero_()
 
 
 def conv_desc(x_shape, w_shape, stride, pad, scale=None, bias=None, residual=None, mask=None, relu=False,
@@ -292,6 +313,15 @@ def conv_prepare_weights(w, stride, pad, math, w_version):
     weights of a wide 3x3 conv) so that the call itself finds it cached; consumers on other streams are ordered behind it."""
     Cout, R, S, Cin = w.shape
     L.check(L.lib().abr_conv_prepare_weights(L.ptr(w), Cout, R, S, Cin, stride, pad, int(math), int(w_version), L.stream()), "conv_prepare_weights")
+
+
+def conv_cache_clear():
+    """Drop the library's per-weight derived data (Winograd-domain weights); call when parameter storage is released or rebuilt."""
+    L.check(L.lib().abr_conv_cache_clear(), "conv_cache_clear")
+
+
+def conv_cache_bytes():
+    return int(L.lib().abr_conv_cache_bytes())
 
 
 def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino_v=None):

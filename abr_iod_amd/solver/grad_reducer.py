@@ -53,6 +53,8 @@ class GradReducer(object):
         self._works, self._done = [], set()
         self._comm = None
         self._warm = False
+        self.last_issue = []        # [(bucket, bytes, "backward-hook" | "optimizer.step")] of the most recent step, in issue order
+        self._issue_log = []
 
     @property
     def active(self):
@@ -62,13 +64,14 @@ class GradReducer(object):
         """new backward pass: nothing reduced yet"""
         assert not self._works, "finish() was not called for the previous step"
         self._done.clear()
+        self._issue_log = []
         if not self._warm and self.active:
             # the first collective creates the RCCL communicator; do that HERE, on the caller's thread, not inside a gradient hook
             # running on the autograd engine's thread in the middle of backward
             dist.all_reduce(torch.zeros(1, dtype=self.grads.dtype, device=self.grads.device))
             self._warm = True
 
-    def _issue(self, name):
+    def _issue(self, name, where="optimizer.step"):
         """all-reduce bucket `name` and, before it, every earlier bucket of BUCKET_ORDER that has not gone out yet"""
         for b_name in BUCKET_ORDER[: BUCKET_ORDER.index(name) + 1]:
             if b_name in self._done:
@@ -77,6 +80,12 @@ class GradReducer(object):
             for a, b in self.buckets[b_name]:
                 if b > a:
                     self._works.append(dist.all_reduce(self.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
+            self._issue_log.append((b_name, sum(b - a for a, b in self.buckets[b_name]) * self.grads.element_size(), where))
+
+    def describe(self):
+        """the exchange as the last step issued it: one entry per bucket with its bytes, collective count and issue point"""
+        return [{"bucket": n, "bytes": by, "all_reduces": sum(1 for a, b in self.buckets[n] if b > a), "issued_from": w}
+                for n, by, w in self.last_issue]
 
     def reduce_bucket_async(self, name):
         """Called when every kernel that writes bucket `name` has been ENQUEUED (on the current stream or a side stream)."""
@@ -90,9 +99,9 @@ class GradReducer(object):
             for s in self.side_streams():
                 self._comm.wait_stream(s)
             with torch.cuda.stream(self._comm):   # ProcessGroupNCCL orders its own stream after the CURRENT one
-                self._issue(name)
+                self._issue(name, "backward-hook")
         else:
-            self._issue(name)
+            self._issue(name, "backward-hook")
 
     def finish(self):
         """Issue the buckets still outstanding (the caller has joined its side streams) and wait for all of them."""
@@ -102,3 +111,4 @@ class GradReducer(object):
             w.wait()                                  # GPU: the current stream waits on RCCL's; CPU (gloo): blocks
         self._works = []
         self._done.clear()
+        self.last_issue = self._issue_log

@@ -27,9 +27,11 @@ GFLOP_PER_IMG_ARD = 1304.0   # algorithmic conv/linear FLOPs of one ARD training
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense
 PROF_NAMES = ["conv_igemm_kernel<128,128>", "conv_igemm_kernel<128,64>", "conv_igemm_kernel<64,64>", "conv_igemm_kernel<128,64,small_c>",
-              "conv_wgrad_kernel", "roi_align_fwd", "roi_align_bwd", "conv_igemm_bf16_kernel", "conv_wgrad_bf16_kernel"]
-# (ids 7 / 8 are the bf16-MFMA kernels of the chosen arithmetic: conv_igemm_x6_kernel / conv_wgrad_x6_kernel -- all tile instances
-#  together -- under --math bf16x6, conv_igemm_bf16_kernel / conv_wgrad_bf16_kernel under --math bf16)
+              "conv_wgrad_kernel", "roi_align_fwd", "roi_align_bwd", "conv_igemm_bf16_kernel", "conv_wgrad_bf16_kernel",
+              "conv_igemm_x6_kernel<128,128>", "conv_igemm_x6_kernel<128,64>", "conv_igemm_x6_kernel<64,64>"]
+# (positions = abr::ProfId in csrc/common.h.  One row per TEMPLATE INSTANCE of the bf16x6 implicit GEMM, named as rocprofv3 names them
+#  (`conv_igemm_x6_kernel<128, 128, 2, 2, false>` ...), so every row's fraction can be recomputed from profiles/ alone.  id 8 is the
+#  weight-gradient kernel of the chosen arithmetic: conv_wgrad_x6_kernel under --math bf16x6, conv_wgrad_bf16_kernel under --math bf16.)
 
 
 def cpu_baseline(model_target, images, targets, n_old):
@@ -65,7 +67,8 @@ def _pmc_traffic(kernel):
     instances.  None when no summary names the kernel."""
     import glob
     prefix = {"conv_igemm_kernel<128,128>": "conv_igemm_kernel<128, 128,", "conv_wgrad_kernel": "conv_wgrad_kernel<",
-              "conv_igemm_x6_kernel": "conv_igemm_x6_kernel<", "conv_wgrad_x6_kernel": "conv_wgrad_x6_kernel",
+              "conv_igemm_x6_kernel<128,128>": "conv_igemm_x6_kernel<128, 128,", "conv_igemm_x6_kernel<128,64>": "conv_igemm_x6_kernel<128, 64,",
+              "conv_igemm_x6_kernel<64,64>": "conv_igemm_x6_kernel<64, 64,", "conv_wgrad_x6_kernel": "conv_wgrad_x6_kernel",
               "conv_igemm_kernel<64,64>": "conv_igemm_kernel<64, 64,", "conv_igemm_kernel<128,64>": "conv_igemm_kernel<128, 64, 4, 1, false"}.get(kernel)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         hits = [v for k, v in json.load(open(f))["kernels"].items() if prefix and k.startswith(prefix)]
@@ -75,21 +78,21 @@ def _pmc_traffic(kernel):
     return None, None
 
 
-def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0):
-    """The `roofline` object.  Per kernel: achieved = executed flops of the sampled launches / their summed HIP-event durations, over
-    ALL sampled launches (exclusive or overlapped with the other stream: what rocprofv3 --kernel-trace --stats averages too); the
-    two kernels with the most time per step are listed, the top one fills the contract's fields.  `whole_step` relates the step's
-    executed and algorithmic conv flops to the wall-clock step."""
-    def peak_of(name):
-        if "_x6_" in name:
-            return round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)   # six bf16 MFMA products per fp32 multiply-add
-        return PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
+def _peak_of(name):
+    if "_x6_" in name:
+        return round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)   # six bf16 MFMA products per fp32 multiply-add
+    return PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
 
-    def tf(fl, ms):
-        return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0
 
+def _tf(fl, ms):
+    return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0
+
+
+def prof_rows(prof, totals, steps, math, event_overhead_ms=0.0):
+    """One row per conv kernel (per TEMPLATE INSTANCE for the bf16x6 implicit GEMM): achieved = executed flops of the sampled launches /
+    their summed durations, over ALL sampled launches (what rocprofv3 --kernel-trace --stats averages too)."""
     rows = []
-    if a.math == "bf16x6":
+    if math == "bf16x6":
         prof = [(nm.replace("_bf16_kernel", "_x6_kernel"),) + tuple(rest) for nm, *rest in prof]
         totals = {k.replace("_bf16_kernel", "_x6_kernel"): v for k, v in totals.items()}
     for name, n, ms, fl, n_o, ms_o, fl_o in prof:
@@ -102,14 +105,25 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0):
         if "wgrad" in name:   # event-bracketed: the dispatch gap an event pair exposes (measured on an empty kernel) comes off every launch
             ms, ms_o = max(ms - n * event_overhead_ms, 0.5 * ms), max(ms_o - n_o * event_overhead_ms, 0.5 * ms_o)
         avg_ms = (ms + ms_o) / (n + n_o)
-        rows.append({"kernel": name, "launches_per_step": round(launches_all / a.steps, 1), "sampled_launches": int(n + n_o),
-                     "avg_launch_ms": round(avg_ms, 4), "ms_per_step": round(avg_ms * launches_all / a.steps, 3),
+        rows.append({"kernel": name, "launches_per_step": round(launches_all / steps, 1), "sampled_launches": int(n + n_o),
+                     "avg_launch_ms": round(avg_ms, 4), "ms_per_step": round(avg_ms * launches_all / steps, 3),
                      "gflop_per_launch": round(flops_all / max(launches_all, 1) / 1e9, 3),
                      "gflop_per_launch_sampled": round((fl + fl_o) / (n + n_o) / 1e9, 3),
-                     "achieved": tf(fl + fl_o, ms + ms_o), "peak": peak_of(name), "frac": round(tf(fl + fl_o, ms + ms_o) / peak_of(name), 4),
-                     "exclusive": {"launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4), "tflops": tf(fl, ms)},
-                     "overlapped": {"launches": int(n_o), "avg_launch_ms": round(ms_o / max(n_o, 1), 4), "tflops": tf(fl_o, ms_o)}})
+                     "achieved": _tf(fl + fl_o, ms + ms_o), "peak": _peak_of(name), "frac": round(_tf(fl + fl_o, ms + ms_o) / _peak_of(name), 4),
+                     "exclusive": {"launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4), "tflops": _tf(fl, ms)},
+                     "overlapped": {"launches": int(n_o), "avg_launch_ms": round(ms_o / max(n_o, 1), 4), "tflops": _tf(fl_o, ms_o)}})
     rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows, totals
+
+
+def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0, serialised=None):
+    """The `roofline` object.  `kernels_by_time` / `all_conv_kernels`: one row per conv kernel and template instance, timed INSIDE the
+    step (other streams' kernels share the CUs: durations are stretched); `serialised`: the same rows from a short re-run of the step with
+    every stream folded into one (kernel quality without time sharing); `whole_step` relates the step's executed and algorithmic conv
+    flops to the wall clock.  The top row by time fills the contract's fields."""
+    if not prof or not any(r[1] + r[4] > 0 for r in prof if "roi_align" not in r[0]):
+        return {"bound": "mfma", "note": "no conv launch was sampled"}
+    rows, totals = prof_rows(prof, totals, a.steps, a.math, event_overhead_ms)
     top = rows[0]
     traffic, traffic_src = _pmc_traffic(top["kernel"])
     step_s = elapsed / a.steps
@@ -127,7 +141,8 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0):
                    "weight-gradient kernels, whose traced duration includes the end-of-kernel write-back of their parked partial "
                    "tiles (that gap subtracted per launch)".format(round(event_overhead_ms * 1e3, 1)),
          "kernels_by_time": rows[:2],
-         "all_conv_kernels": {x["kernel"]: {k: x[k] for k in ("launches_per_step", "avg_launch_ms", "ms_per_step", "achieved", "frac")} for x in rows},
+         "all_conv_kernels": {x["kernel"]: {k: x[k] for k in ("launches_per_step", "avg_launch_ms", "ms_per_step", "gflop_per_launch", "achieved", "frac")}
+                              for x in rows},
          "whole_step": {"executed_gflop": round(exec_flops_step / 1e9, 1), "executed_tflops": round(exec_flops_step / step_s / 1e12, 2),
                         "algorithmic_gflop": round(alg_flops_step / 1e9, 1), "algorithmic_tflops": round(alg_flops_step / step_s / 1e12, 2),
                         "note": "conv/linear flops of one rank's step / wall-clock step time (everything else in the step included)"}}
@@ -139,7 +154,10 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0):
         r["whole_step"]["vs_fp32_mfma_peak"] = {"peak": PEAK_FP32_MFMA_TFLOPS, "executed_frac": round(exec_flops_step / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                                 "algorithmic_frac": round(alg_flops_step / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
     r["note"] = ("per-launch durations inside the step are stretched by the kernels of the other HIP streams sharing the CUs (3 streams in the "
-                 "forward pass, 2 in the backward pass); they shrink when the streams are serialised or when a profiler slows the host")
+                 "forward pass, 2-3 in the backward pass): a row's ms_per_step can exceed the step, and `frac` of the overlapped step is a "
+                 "time-sharing figure; `serialised` holds the same rows with every stream folded into one = the kernels' own rate")
+    if serialised is not None:
+        r["serialised"] = serialised
     return r
 
 
@@ -188,6 +206,42 @@ def launch_ranks(n):
     return rc or max((abs(p.returncode or 0) for p in procs), default=0)
 
 
+def fold_streams(on, optimizer):
+    """Fold every HIP stream of the step into the current one (or restore the defaults): weight gradients, the source model, proposal
+    selection, the cross-step prefetches and the weight preparation all run in issue order -- the step `roofline.serialised` times.
+    Same work, same results (tests/test_gpu_streams_equivalence.py runs both forms)."""
+    from abr_iod_amd import ops
+    from abr_iod_amd.engine import trainer
+    from abr_iod_amd.modeling.rpn import rpn
+    if on:
+        saved = (trainer.SOURCE_STREAM, trainer.SOURCE_HEAD_STREAM, trainer.PIPELINE_SOURCE, trainer.PIPELINE_TARGET_FROZEN, trainer.EARLY_SECOND_PASS,
+                 ops.WGRAD_SIDE_STREAM, rpn.PROPOSALS_SIDE_STREAM, getattr(optimizer, "_prep_stream", None))
+        trainer.SOURCE_STREAM = trainer.SOURCE_HEAD_STREAM = trainer.PIPELINE_SOURCE = trainer.PIPELINE_TARGET_FROZEN = trainer.EARLY_SECOND_PASS = False
+        ops.WGRAD_SIDE_STREAM = False
+        rpn.PROPOSALS_SIDE_STREAM = False
+        if hasattr(optimizer, "_prep_stream"):
+            optimizer._prep_stream = False
+        return saved
+    (trainer.SOURCE_STREAM, trainer.SOURCE_HEAD_STREAM, trainer.PIPELINE_SOURCE, trainer.PIPELINE_TARGET_FROZEN, trainer.EARLY_SECOND_PASS,
+     ops.WGRAD_SIDE_STREAM, rpn.PROPOSALS_SIDE_STREAM, prep) = optimizer._folded_saved
+    if prep is not None:
+        optimizer._prep_stream = prep
+
+
+def read_prof(_lib):
+    """(rows of abr_prof_end, totals of abr_prof_totals, event-pair overhead in ms) after a profiled region"""
+    buf = (ctypes.c_double * (6 * len(PROF_NAMES)))()
+    _lib.check(_lib.lib().abr_prof_end(ctypes.cast(buf, ctypes.c_void_p), len(PROF_NAMES)), "prof_end")
+    # (name, exclusive launches / ms / flops, overlapped launches / ms / flops)  -- include/abr_iod_hip.h abr_prof_end
+    prof = [(PROF_NAMES[i],) + tuple(buf[6 * i + j] for j in range(6)) for i in range(len(PROF_NAMES))]
+    tot = (ctypes.c_double * (2 * len(PROF_NAMES)))()
+    _lib.check(_lib.lib().abr_prof_totals(ctypes.cast(tot, ctypes.c_void_p), len(PROF_NAMES)), "prof_totals")
+    totals = {PROF_NAMES[i]: (tot[2 * i], tot[2 * i + 1]) for i in range(len(PROF_NAMES))}   # (launches, flops) of ALL launches
+    ov = ctypes.c_double(0.0)
+    _lib.check(_lib.lib().abr_prof_event_overhead_ms(ctypes.cast(ctypes.byref(ov), ctypes.c_void_p), _lib.stream()), "prof_event_overhead_ms")
+    return prof, totals, float(ov.value)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,6 +260,9 @@ def main():
                          "configs[4]'s bf16 MFMA backbone (cfg.DTYPE bfloat16: operands ROUNDED to bf16 in-kernel -- reduced precision, never "
                          "the headline); bf16-all = RPN head and layer4 as well.")
     ap.add_argument("--time-all-kernels", action="store_true", help="event-bracket every conv / ROIAlign launch, not only the dominant kernel")
+    ap.add_argument("--fold-streams", action="store_true",
+                    help="run the whole benchmark with every HIP stream of the step folded into one (for a serialised-stream rocprofv3 profile)")
+    ap.add_argument("--no-serialised-leg", action="store_true", help="skip the short serialised-stream re-run behind the timed region (roofline.serialised)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher self-test: start the ranks, form the process group (gloo when there is no GPU), all-reduce a 1 per rank, print the count")
     a = ap.parse_args()
@@ -266,6 +323,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.fold_streams:
+        optimizer._folded_saved = fold_streams(True, optimizer)
     for _ in range(a.warmup):
         train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t, next_images=images)
 
@@ -287,18 +346,36 @@ def main():
         last = train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t, next_images=images)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = None
+    prof = serialised = None
     if time_kernels:
-        buf = (ctypes.c_double * (6 * len(PROF_NAMES)))()
-        _lib.check(_lib.lib().abr_prof_end(ctypes.cast(buf, ctypes.c_void_p), len(PROF_NAMES)), "prof_end")
-        # (name, exclusive launches / ms / flops, overlapped launches / ms / flops)  -- include/abr_iod_hip.h abr_prof_end
-        prof = [(PROF_NAMES[i],) + tuple(buf[6 * i + j] for j in range(6)) for i in range(len(PROF_NAMES))]
-        tot = (ctypes.c_double * (2 * len(PROF_NAMES)))()
-        _lib.check(_lib.lib().abr_prof_totals(ctypes.cast(tot, ctypes.c_void_p), len(PROF_NAMES)), "prof_totals")
-        prof_totals = {PROF_NAMES[i]: (tot[2 * i], tot[2 * i + 1]) for i in range(len(PROF_NAMES))}   # (launches, flops) of ALL launches
-        ov = ctypes.c_double(0.0)
-        _lib.check(_lib.lib().abr_prof_event_overhead_ms(ctypes.cast(ctypes.byref(ov), ctypes.c_void_p), _lib.stream()), "prof_event_overhead_ms")
-        event_overhead_ms = float(ov.value)
+        prof, prof_totals, event_overhead_ms = read_prof(_lib)
+        if world == 1 and not a.no_serialised_leg and not a.fold_streams:
+            # AFTER the timed region, never part of `value`: the same step with every stream folded into one, every conv launch timed.
+            # Inside the real step up to three streams' kernels share the CUs, so a kernel's in-step duration says how the step's time is
+            # SHARED, not how good the kernel is; these rows are the kernels' own rates (what a stand-alone microbenchmark measures).
+            SER_STEPS = 5
+            optimizer._folded_saved = fold_streams(True, optimizer)
+            try:
+                for _ in range(2):
+                    train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t)
+                torch.cuda.synchronize()
+                _lib.check(_lib.lib().abr_prof_set_mask(0xFFFFFFFF, 1), "prof_set_mask")
+                _lib.check(_lib.lib().abr_prof_begin(), "prof_begin")
+                ts = time.perf_counter()
+                for _ in range(SER_STEPS):
+                    _lib.lib().abr_prof_step_begin()
+                    train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t)
+                torch.cuda.synchronize()
+                es = time.perf_counter() - ts
+                sprof, stot, sov = read_prof(_lib)
+            finally:
+                fold_streams(False, optimizer)
+            srows, _ = prof_rows(sprof, stot, SER_STEPS, a.math, sov)
+            serialised = {"steps": SER_STEPS, "ms_per_step": round(1e3 * es / SER_STEPS, 3),
+                          "conv_kernel_ms_per_step": round(sum(x["ms_per_step"] for x in srows), 3),
+                          "kernels": {x["kernel"]: {k: x[k] for k in ("launches_per_step", "avg_launch_ms", "ms_per_step", "gflop_per_launch", "achieved", "peak", "frac")}
+                                      for x in srows},
+                          "note": "every stream of the step folded into one, every conv launch timed (informational re-run behind the timed region)"}
     rccl_ranks = 1
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -327,18 +404,23 @@ def main():
                                        dist_type, alpha, beta, gamma),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "math": a.math,
                        "rccl_ranks": rccl_ranks, "collective": "RCCL all-reduce of the flat gradient, 3 buckets, 2 under backward" if world > 1 else None,
+                       "gradient_exchange": optimizer.reducer.describe() if world > 1 else None,
                        "gflop_per_img_algorithmic": GFLOP_PER_IMG_ARD},
-            "final_losses": {k: round(float(v), 5) for k, v in loss_dict.items()},
+            "final_losses": {k: round(float(v.detach()), 5) for k, v in loss_dict.items()},
+            "math": a.math,
         }
         if prof:
-            out["roofline"] = roofline(prof, prof_totals, a, elapsed, event_overhead_ms)
+            out["roofline"] = roofline(prof, prof_totals, a, elapsed, event_overhead_ms, serialised)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_target, images, targets, len(cfg_t.MODEL.ROI_BOX_HEAD.NAME_OLD_CLASSES))
         if world == 1 and a.math == "bf16x6" and not a.no_alt_math:
             # Informational only, AFTER the timed region above and never part of `value`: the same workload on the fp32 MFMA kernels
             # (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) -- the arithmetic of round 1's headline, for comparison.
             os.environ["ABR_CONV_MATH"] = "f32"
-            ms6, mt6 = build_models(cfg_s, cfg_t, seed=0)
+            try:
+                ms6, mt6 = build_models(cfg_s, cfg_t, seed=0)
+            finally:
+                os.environ["ABR_CONV_MATH"] = "bf16x6"
             opt6 = make_optimizer(cfg_t, mt6)
             sch6 = make_lr_scheduler(cfg_t, opt6)
             for _ in range(3):
@@ -352,6 +434,9 @@ def main():
             out["alt_math_f32_mfma"] = {"value": round(B * 10 / e6, 3), "unit": "img/s", "ms_per_step": round(1e3 * e6 / 10, 3), "steps": 10,
                                         "note": "informational: the same step on the fp32 MFMA kernels (ABR_CONV_MATH=f32); not the reported value",
                                         "final_total_loss": round(float(l6[1].detach()), 5)}
+            del ms6, mt6, opt6, sch6, l6
+            from abr_iod_amd import ops as _ops
+            _ops.conv_cache_clear()   # the library's per-weight Winograd-domain copies of the models just dropped
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -46,7 +46,7 @@ int abr_device_info(int32_t* out_host);
  * out[id*6+{3,4,5}] = the same for launches made while abr_prof_mark_overlap(1) was in force (the host runs weight-gradient
  * kernels on a second stream next to the dgrad chain: those launches share CUs and their event-bracketed duration is not a
  * property of the kernel).  id = 0 igemm 128x128, 1 igemm 128x64, 2 igemm 64x64, 3 igemm small-C (stem), 4 wgrad, 5/6 ROIAlign
- * fwd/bwd, 7 igemm bf16, 8 wgrad bf16.  Synchronises on the recorded events and stops profiling. */
+ * fwd/bwd, 7 igemm bf16, 8 wgrad bf16 / bf16x6, 9 / 10 / 11 the bf16x6 implicit GEMM's 128x128 / 128x64 / 64x64 tile instances.  Synchronises on the recorded events and stops profiling. */
 int abr_prof_begin(void);
 int abr_prof_mark_overlap(int on);
 /* bit id set = time that kernel (default all); every_nth = n > 1: bracket launch i of a kernel in step s iff (i + s) % n == 0 (an
@@ -74,6 +74,9 @@ int abr_prof_event_overhead_ms(double* out_host, void* stream);
 int abr_x6_range_flags(uint32_t* out_host, int reset, void* stream);
 /* the same word copied to PINNED host memory on `stream` without synchronising (the trainer polls it one step later) */
 int abr_x6_range_flags_async(uint32_t* out_pinned_host, void* stream);
+/* the same word copied to DEVICE memory on `stream` (data-parallel training MAX-reduces it over the ranks with RCCL before reading it,
+ * so that every rank leaves the bf16x6 arithmetic at the same step: engine/trainer.py::_x6_guard) */
+int abr_x6_range_flags_to_device(uint32_t* out_device, void* stream);
 
 /* =====================================================================================================
  * 1. maskrcnn_benchmark._C  (csrc/vision.cpp:10-16)
@@ -249,6 +252,11 @@ int abr_conv_forward(const abr_conv_desc* d_host, const float* x, const float* w
  * (w, w_version) finds it ready (a consumer on another stream is ordered behind it by the library).  A no-op for other convs.  Lets a
  * caller move the per-step weight preparation of its trainable convs off the critical stream (solver/build.py). */
 int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, int Cin, int stride, int pad, int math, int64_t w_version, void* stream);
+/* The library keeps Winograd-domain weights per (weight address, w_version) -- about 36/9 of each wide 3x3 weight.  The cache is bounded
+ * (least-recently-used entries go when it exceeds ABR_WINO_CACHE_MB, default 8192); abr_conv_cache_clear drops every entry after waiting
+ * for the streams that use them (call it when a model's parameter storage is released or rebuilt), abr_conv_cache_bytes reports its size. */
+int abr_conv_cache_clear(void);
+int64_t abr_conv_cache_bytes(void);
 /* floats of the Winograd-domain input V = 36 * B*ceil(H/4)*ceil(W/4) * Cin if BOTH abr_conv_forward and abr_conv_wgrad take the
  * Winograd F(4x4,3x3) path for this descriptor (wide stride-1 pad-1 3x3, no residual / scatter, fp32 or bf16x6 math), else 0 */
 int64_t abr_conv_wino_v_floats(const abr_conv_desc* d_host);

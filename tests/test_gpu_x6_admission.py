@@ -186,7 +186,7 @@ def test_trainer_falls_back_to_fp32_when_the_guard_trips():
     assert mt.conv_math == ms.conv_math == "bf16x6"
     assert all(m.math == ops.MATH_BF16X6 for m in mt.modules() if hasattr(m, "math"))
     ops.x6_range_flags(reset=True)
-    trainer._x6_watch[0] = None
+    trainer.trainer_state(mt).x6_watch = None
     for _ in range(3):                       # clean steps: nothing happens
         trainer._x6_guard(ms, mt)
         torch.cuda.synchronize()
