@@ -31,7 +31,6 @@ class ConvDesc(C.Structure):
         ("math", _i),
         ("wino_v", _vp),
         ("w_planes", _vp),
-        ("w_plane_stride", _i64),
         ("w_version", _i64),
     ]
 
@@ -85,8 +84,8 @@ _SIGS = {
     "abr_conv_forward": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "abr_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "abr_conv_wino_v_floats": (_i64, [C.POINTER(ConvDesc)]),
-    "abr_split_bf16x3": (_i, [_vp, _i64, _vp, _vp]),
-    "abr_conv_dgrad_weights_planes": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "abr_conv_packed_bytes": (_i64, [_i64, _i64]),
+    "abr_conv_pack_weights": (_i, [_vp, _i64, _i, _vp, _vp]),
     "abr_conv_dgrad_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "abr_bias_grad": (_i, [_vp, _i64, _i, _vp, _vp]),
     "abr_nchw_to_nhwc_pad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

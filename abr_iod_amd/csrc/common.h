@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <functional>
+
 #include "abr_iod_hip.h"
 
 namespace abr {
@@ -67,7 +69,7 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Off by default.
 enum ProfId { PROF_IGEMM_128x128 = 0, PROF_IGEMM_128x64, PROF_IGEMM_64x64, PROF_IGEMM_SMALLC, PROF_WGRAD, PROF_ROIALIGN_FWD,
               PROF_ROIALIGN_BWD, PROF_IGEMM_BF16, PROF_WGRAD_BF16,
-              PROF_X6_128x128, PROF_X6_128x64, PROF_X6_64x64, PROF_COUNT };   // (ids are positions in bench.py's PROF_NAMES)
+              PROF_X6_128x128, PROF_X6_128x64, PROF_X6_64x64, PROF_X6W_128x128, PROF_X6W_128x64, PROF_X6W_64x64, PROF_COUNT };   // (ids are positions in bench.py's PROF_NAMES)
 // Winograd F(4x4,3x3) transform kernels (conv_winograd.hip); the batched GEMM between them is launched by conv_igemm.hip
 int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, hipStream_t st);
 int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st);
@@ -79,8 +81,11 @@ float* wino_ws(hipStream_t st, size_t floats);
 // cached Winograd-domain weights U [36][N][C] of the tensor at `w` (abr_conv_desc::w_version != 0), transformed on `st` when (w, version)
 // has not been seen; nullptr = no memory (transform into scratch instead)
 float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t st);
-void wino_u_cache_clear();
-size_t wino_u_cache_bytes();
+// the cache behind it, for every kind of data derived from a weight tensor (conv_winograd.hip): `fill(buf)` writes `bytes` on `st` (0 = ok)
+enum DerivedKind { DERIVED_WINO_U = 0, DERIVED_X6_PLANES = 1, DERIVED_WINO_U_X6_PLANES = 2 };
+void* derived_cached(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, const std::function<int(void*)>& fill);
+void derived_cache_clear();
+size_t derived_cache_bytes();
 
 // bf16x6 range guard (see abr_x6_range_flags in include/abr_iod_hip.h).  The flag word lives in device memory owned by common.hip.
 unsigned* x6_flags_ptr();

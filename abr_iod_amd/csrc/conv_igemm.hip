@@ -80,8 +80,10 @@ struct ConvP {
     long a_bs, w_bs, o_bs;
     int math;  // ABR_MATH_*
     float* v_out;  // Winograd path: keep the transformed input here (abr_conv_desc::wino_v)
-    const void* w_planes;  // bf16x6: pre-split weight planes (abr_conv_desc::w_planes), or NULL
-    unsigned w_plane_bytes;  // distance between two planes
+    const void* w_planes;  // bf16x6: the weights as fragment-packed bf16x3 planes (x6_pack_kernel), or NULL = split w in-kernel
+    unsigned wp_bytes;     // bytes of one packed matrix (ceil(Cout/32)*32 * K * 6)
+    long wp_bs;            // batched mode: bytes between two packed matrices
+    int wp_nblocks;        // 32-row blocks in one packed matrix
     unsigned* x6_flags;      // bf16x6: device word of the range guard (abr::x6_flags_ptr)
     int64_t w_version;       // abr_conv_desc::w_version (0 = nothing derived from w may be cached)
 };
@@ -599,16 +601,14 @@ int launch_bf16(const ConvP& p, const float* x, const float* w, float* out, hipS
 constexpr int BKX = 32;
 constexpr int LDX = BKX + 8;   // LDS row pitch in bf16 elements (80 B)
 
-// PB: the weight operand arrives ALREADY split (three bf16 planes [3][Cout][K] from abr_split_bf16x3, made once per optimiser step):
-// its tiles go global -> registers -> LDS as 16 B chunks with no arithmetic, instead of every workgroup re-splitting them.
-template <int BM, int BN, int WM, int WN, bool PB>
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const float* __restrict__ x_, const float* __restrict__ w_,
                                                              float* __restrict__ out_) {
     const float* x = x_;
     const float* w = w_;
     float* out = out_;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int NA = BM / 32, NB = PB ? 3 * BN / 64 : BN / 32;
+    constexpr int NA = BM / 32, NB = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     abr::prof_stamp_begin(p.prof_ts);
     __bf16* As = reinterpret_cast<__bf16*>(smem);  // [3][BM][LDX]
@@ -643,21 +643,13 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
         a_wi0[i] = (int)wo * p.stride - p.pad;
         a_off0[i] = (((int)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + kq * 4;
     }
-    // fp32 weights: slot i = row srow + 32 i, 16 B = 4 k.  Planes: slot i = plane i / (BN/64), row (i % (BN/64)) * 64 + tid/4, 16 B = 8 k
-    unsigned b_off0[NB];
-    const int prow = tid >> 2, pkc = tid & 3;
+    unsigned b_off0[NB];   // weights: slot i = row srow + 32 i, 16 B = 4 k
 #pragma unroll
     for (int i = 0; i < NB; i++) {
-        if (PB) {
-            const int n = n0 + (i % (BN / 64)) * 64 + prow;
-            b_off0[i] = n < p.Cout ? (unsigned)(i / (BN / 64)) * p.w_plane_bytes + (unsigned)(n * p.K + pkc * 8) * 2u : kOOB;
-        } else {
-            const int n = n0 + srow + 32 * i;
-            b_off0[i] = n < p.Cout ? (unsigned)(n * p.K + kq * 4) * 4u : kOOB;
-        }
+        const int n = n0 + srow + 32 * i;
+        b_off0[i] = n < p.Cout ? (unsigned)(n * p.K + kq * 4) * 4u : kOOB;
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_planes), 0, PB ? 2u * p.w_plane_bytes + p.w_bytes / 2 : 0u, 0x00020000);
     // TWO tiles in flight: a k-tile is only 48 MFMAs (~1500 cycles) per wave, well under the latency of the loads, so tile kt+2 is
     // requested before tile kt is multiplied and is split / parked in LDS one iteration later (register sets alternate by parity)
     u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
@@ -674,15 +666,13 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
             ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB), 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NB; i++)
-            rb[i] = PB ? __builtin_amdgcn_raw_buffer_load_b128(rwp, (int)(valid ? b_off0[i] : kOOB), k0 * 2, 0)
-                       : __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(valid ? b_off0[i] : kOOB), k0 * 4, 0);
+        for (int i = 0; i < NB; i++) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(valid ? b_off0[i] : kOOB), k0 * 4, 0);
     };
     // Range guard of the exact split (abr_x6_range_flags, include/abr_iod_hip.h): every operand element is inspected ONCE per GEMM --
     // the A rows by the workgroups of the first n-tile column, the weights by those of the first m-tile row (a workgroup-uniform
     // branch; the other workgroups pay nothing).  bmin: smallest (bits << 1) - 1 seen (zero wraps to 0xFFFFFFFF and never wins);
     // nonfin: x * 0 summed (NaN as soon as any element is inf or NaN).
-    const bool chk_a = p.x6_flags && tile_n == 0, chk_b = p.x6_flags && tile_m == 0 && !PB;
+    const bool chk_a = p.x6_flags && tile_n == 0, chk_b = p.x6_flags && tile_m == 0;
     unsigned bmin = 0xFFFFFFFFu;
     float nonfin = 0.f;
     auto inspect = [&](const u32x4 v) {
@@ -715,10 +705,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
 #pragma unroll
         for (int i = 0; i < NA; i++) split_store(ra[i], As + (srow + 32 * i) * LDX + kq * 4, BM * LDX);
 #pragma unroll
-        for (int i = 0; i < NB; i++) {
-            if (PB) *reinterpret_cast<u32x4*>(Bs + (i / (BN / 64)) * BN * LDX + ((i % (BN / 64)) * 64 + prow) * LDX + pkc * 8) = rb[i];
-            else split_store(rb[i], Bs + (srow + 32 * i) * LDX + kq * 4, BN * LDX);
-        }
+        for (int i = 0; i < NB; i++) split_store(rb[i], Bs + (srow + 32 * i) * LDX + kq * 4, BN * LDX);
     };
 
     f32x16 acc[TM][TN];
@@ -759,19 +746,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
     };
 
     const int nk = p.K / BKX;
-    if (PB) {   // one tile in flight: the plane loads need six registers more per set, and two sets would halve the occupancy
-        load_tile(0, ra0, rb0, true);
-        store_tile(ra0, rb0);
-        __syncthreads();
-        for (int kt = 0; kt + 1 < nk; kt++) {
-            load_tile(kt + 1, ra0, rb0, true);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_tile();
-            __syncthreads();
-            store_tile(ra0, rb0);
-            __syncthreads();
-        }
-    } else {
+    {
         load_tile(0, ra0, rb0, true);
         load_tile(1, ra1, rb1, nk > 1);
         store_tile(ra0, rb0);
@@ -805,7 +780,247 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
     abr::prof_stamp_end(p.prof_ts);
 }
 
-template <int BM, int BN, int WM, int WN, bool PB>
+// ------------------------------------------------------------------------------------------------------------------------
+// bf16x6 with the WEIGHT operand fed straight from global memory into the MFMA registers (conv_igemm_x6w_kernel).
+// The weights of a conv change once per optimiser step (never, for the frozen source model), so their exact bf16x3 split is
+// made once per version by x6_pack_kernel and stored in MFMA-FRAGMENT order:
+//     chunk(nb, ks, pl) = 64 lanes x 16 B; lane l holds row nb*32 + (l & 31), k = ks*16 + (l >> 5)*8 .. +8 of plane pl
+//     byte address     = (((nb * K/16 + ks) * 3 + pl) * 64 + l) * 16
+// A wave's B fragment is then ONE coalesced 1 KB buffer load into the registers the MFMA reads: no LDS store, no fragment read and
+// no split arithmetic for the weights; LDS carries only the three A planes (30.7 KB per 128-row tile instead of 61.4), which lets
+// three workgroups (or more) share a CU.  Per 16-k step a wave issues TM*3 ds_read_b128 + TN*3 global loads for TM*TN*6 MFMAs.
+// The B fragments of step u of k-tile kt+1 are requested right behind the last MFMA that reads step u of tile kt, so every load has
+// half a k-tile to a whole one (768 - 1536 MFMA cycles per wave) to land.  The six products of a step are interleaved over the
+// wave's accumulators (each accumulator still receives them smallest-first), not issued as six dependent MFMAs back to back.
+// Measured (tools/x6lab/lab7.hip, random operands): 32768x2048x1024 0.70 -> 0.63 ms, 32768x512x2048 0.38 -> 0.32, 9600x1024x256 +22 %.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_x6w_kernel(const ConvP p, const float* __restrict__ x_,
+                                                                                                        float* __restrict__ out_) {
+    const float* x = x_;
+    float* out = out_;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int NA = BM / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    abr::prof_stamp_begin(p.prof_ts);
+    __bf16* As = reinterpret_cast<__bf16*>(smem);  // [3][BM][LDX]
+
+    int tile = (int)abr::xcd_remap(blockIdx.x, gridDim.x);
+    const char* wp = reinterpret_cast<const char*>(p.w_planes);
+    if (p.nbatch > 1) {
+        const int bt = tile / p.tiles_pb;
+        tile -= bt * p.tiles_pb;
+        x += bt * p.a_bs; out += bt * p.o_bs; wp += bt * p.wp_bs;
+    }
+    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kq = tid & 7, srow = tid >> 3;
+
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wp), 0, p.wp_bytes, 0x00020000);
+    int a_hi0[NA], a_wi0[NA], a_off0[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int m = m0 + srow + 32 * i;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        unsigned b, rem, ho, wo;
+        p.d_howo.divmod((unsigned)mm, b, rem);
+        p.d_wo.divmod(rem, ho, wo);
+        a_hi0[i] = (int)ho * p.stride - p.pad;
+        a_wi0[i] = (int)wo * p.stride - p.pad;
+        a_off0[i] = (((int)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + kq * 4;
+    }
+    const int KS = p.K / 16;
+    unsigned bo[TN];   // byte offset of chunk (nb, 0, 0) for this lane; 32-row blocks past the packed matrix read as zeros
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int nb = (n0 + wn * (TN * 32)) / 32 + j;
+        bo[j] = nb < p.wp_nblocks ? (unsigned)(((size_t)nb * KS * 3 * 64 + lane) * 16) : kOOB;
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[NA];
+    u32x4 fbr[2][TN][3];   // [step of the k-tile][n-block][plane]
+    auto load_a = [&](int kt) {
+        const int k0 = kt * BKX;
+        unsigned rs, c0, r, s;
+        p.d_cin.divmod((unsigned)k0, rs, c0);
+        p.d_s.divmod(rs, r, s);
+        const int delta = ((int)r * p.W + (int)s) * p.Cin + (int)c0;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
+            const bool ok = a_ok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB), 0, 0);
+        }
+    };
+    auto load_b = [&](int kt, int u) {
+        const int ks = kt * 2 + u;
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) fbr[u][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rwp, (int)bo[j], (ks * 3 + pl) * 1024, 0);
+    };
+    // range guard: the A rows are inspected by the workgroups of the first n-tile column; the weights were inspected when they were packed
+    const bool chk_a = p.x6_flags && tile_n == 0;
+    unsigned bmin = 0xFFFFFFFFu;
+    float nonfin = 0.f;
+    auto store_a = [&]() {
+        if (chk_a) {
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+                const u32x4 v = ra[i];
+                const unsigned b0 = (v.x << 1) - 1u, b1 = (v.y << 1) - 1u, b2 = (v.z << 1) - 1u, b3 = (v.w << 1) - 1u;
+                bmin = min(min(bmin, min(b0, b1)), min(b2, b3));
+                nonfin = fmaf(__uint_as_float(v.x), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.y), 0.f, nonfin);
+                nonfin = fmaf(__uint_as_float(v.z), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.w), 0.f, nonfin);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const u32x4 v = ra[i];
+            __bf16* dst = As + (srow + 32 * i) * LDX + kq * 4;
+            const f32x4v f = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+            const bf16x4 h0 = __builtin_convertvector(f, bf16x4);
+            const f32x4v r1 = f - __builtin_convertvector(h0, f32x4v);
+            const bf16x4 h1 = __builtin_convertvector(r1, bf16x4);
+            const f32x4v r2 = r1 - __builtin_convertvector(h1, f32x4v);
+            const bf16x4 h2 = __builtin_convertvector(r2, bf16x4);
+            *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(&h0);
+            *reinterpret_cast<uint2*>(dst + BM * LDX) = *reinterpret_cast<const uint2*>(&h1);
+            *reinterpret_cast<uint2*>(dst + 2 * BM * LDX) = *reinterpret_cast<const uint2*>(&h2);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const __bf16* a_frag = As + (wm * (TM * 32) + l31) * LDX + lh * 8;
+    const int nk = p.K / BKX;
+    auto compute_tile = [&](int kt_next) {   // kt_next < nk: the B fragments of that tile are requested as this tile's are consumed
+#pragma unroll
+        for (int u = 0; u < BKX / 16; u++) {
+            bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * BM * LDX + i * 32 * LDX + u * 16);
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) fb[j][pl] = *reinterpret_cast<const bf16x8*>(&fbr[u][j][pl]);
+            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};   // (A plane, B plane) of the six products, smallest first
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa[t]], fb[j][pb[t]], acc[i][j], 0, 0, 0);
+            if (kt_next < nk) load_b(kt_next, u);
+            if (u == 0) __builtin_amdgcn_sched_barrier(0);   // keeps step 0's refill ahead of step 1's MFMAs (lab7: +3 %)
+        }
+    };
+    load_b(0, 0);
+    load_b(0, 1);
+    load_a(0);
+    store_a();
+    __syncthreads();
+    for (int kt = 0; kt + 1 < nk; kt++) {
+        load_a(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tile(kt + 1);
+        __syncthreads();
+        store_a();
+        __syncthreads();
+    }
+    compute_tile(nk);
+    if (chk_a) abr::x6_report(bmin, nonfin, p.x6_flags);
+    __syncthreads();  // the epilogue reuses the operand LDS
+    epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    abr::prof_stamp_end(p.prof_ts);
+}
+
+// fp32 matrix [rows][K] (K % 16 == 0) -> fragment-packed bf16x3 planes (layout above), rows padded with zeros to a multiple of 32.
+// One workgroup = one 32-row block x 64 k: the fp32 block comes in as whole 256 B row segments (coalesced), goes through LDS, and
+// leaves as 4 k-steps x 3 planes x 1 KB chunks.  Every weight element is range-checked here (abr_x6_range_flags), once per version.
+__global__ __launch_bounds__(256) void x6_pack_kernel(const float* __restrict__ w, int rows, int K, uint4* __restrict__ planes, unsigned* flags) {
+    __shared__ float t[32][68];
+    const int nb = blockIdx.y, k0 = blockIdx.x * 64, tid = threadIdx.x;
+    unsigned bmin = 0xFFFFFFFFu;
+    float nonfin = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int r = (tid >> 4) + 16 * h, c = (tid & 15) * 4, row = nb * 32 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows && k0 + c < K) v = *reinterpret_cast<const float4*>(w + (size_t)row * K + k0 + c);
+        *reinterpret_cast<float4*>(&t[r][c]) = v;
+        const unsigned b0 = (__float_as_uint(v.x) << 1) - 1u, b1 = (__float_as_uint(v.y) << 1) - 1u, b2 = (__float_as_uint(v.z) << 1) - 1u,
+                       b3 = (__float_as_uint(v.w) << 1) - 1u;
+        bmin = min(min(bmin, min(b0, b1)), min(b2, b3));
+        nonfin = fmaf(v.x, 0.f, nonfin); nonfin = fmaf(v.y, 0.f, nonfin); nonfin = fmaf(v.z, 0.f, nonfin); nonfin = fmaf(v.w, 0.f, nonfin);
+    }
+    if (flags) abr::x6_report(bmin, nonfin, flags);
+    __syncthreads();
+    const int ksl = tid >> 6, lane = tid & 63, ks = k0 / 16 + ksl;
+    if (ks * 16 >= K) return;
+    const float* src = &t[lane & 31][ksl * 16 + (lane >> 5) * 8];
+    __bf16 h[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float v = src[e];
+        const __bf16 h0 = (__bf16)v;
+        const float r1 = v - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        h[0][e] = h0; h[1][e] = h1; h[2][e] = (__bf16)(r1 - (float)h1);
+    }
+    const size_t c = ((size_t)nb * (K / 16) + ks) * 3;
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) planes[(c + pl) * 64 + lane] = *reinterpret_cast<const uint4*>(h[pl]);
+}
+
+static int64_t x6_packed_bytes(int64_t rows, int64_t K) { return (rows + 31) / 32 * 32 * K * 6; }
+
+static int x6_pack(const float* w, int64_t rows, int K, void* planes, hipStream_t st) {
+    dim3 grid((unsigned)((K + 63) / 64), (unsigned)((rows + 31) / 32));
+    x6_pack_kernel<<<grid, 256, 0, st>>>(w, (int)rows, K, reinterpret_cast<uint4*>(planes), abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_x6w(const ConvP& p, const float* x, float* out, hipStream_t st) {
+    ConvP q = p;
+    q.tiles_m = (p.M + BM - 1) / BM;
+    q.tiles_n = (p.Cout + BN - 1) / BN;
+    q.tiles_pb = q.tiles_m * q.tiles_n;
+    if (q.nbatch < 1) q.nbatch = 1;
+    q.n_full = q.tiles_pb * q.nbatch; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
+    q.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
+    constexpr size_t lds_op = sizeof(__bf16) * 3 * BM * LDX;
+    constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
+    const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
+    auto kern = conv_igemm_x6w_kernel<BM, BN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    constexpr int prof_id = BM == 128 ? (BN == 128 ? abr::PROF_X6W_128x128 : abr::PROF_X6W_128x64) : abr::PROF_X6W_64x64;
+    q.prof_ts = abr::prof_stamp_slot(prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
+    kern<<<(unsigned)(q.tiles_pb * q.nbatch), 256, lds, st>>>(q, x, out);
+    return 0;
+}
+
+template <int BM, int BN, int WM, int WN>
 int launch_x6(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
     ConvP q = p;
     q.tiles_m = (p.M + BM - 1) / BM;
@@ -817,7 +1032,7 @@ int launch_x6(const ConvP& p, const float* x, const float* w, float* out, hipStr
     constexpr size_t lds_op = sizeof(__bf16) * 3 * (BM + BN) * LDX;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
     const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
-    auto kern = conv_igemm_x6_kernel<BM, BN, WM, WN, PB>;
+    auto kern = conv_igemm_x6_kernel<BM, BN, WM, WN>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -875,7 +1090,7 @@ int launch(const ConvP& p, const float* x, const float* w, float* out, hipStream
 
 // (Cout, R*S, Cin) -> (Cin, R*S flipped, Cout), scaled by scale[cout]; 32x32 LDS transpose per (rs) plane.
 __global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                                             int Cout, int RS, int Cin, float* __restrict__ wt, __bf16* __restrict__ planes) {
+                                                             int Cout, int RS, int Cin, float* __restrict__ wt) {
     __shared__ float t[32][33];
     const int rs = blockIdx.z;
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
@@ -891,16 +1106,7 @@ __global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restr
         const int ci = ci0 + i, co = co0 + tx;
         if (ci < Cin && co < Cout) {
             const size_t o = ((size_t)ci * RS + (RS - 1 - rs)) * Cout + co;
-            const float v = t[tx][i];
-            wt[o] = v;
-            if (planes) {   // the bf16x6 planes of the same copy (exact three-way split, see conv_igemm_x6_kernel)
-                const size_t n = (size_t)Cin * RS * Cout;
-                const __bf16 h0 = (__bf16)v;
-                const float r1 = v - (float)h0;
-                const __bf16 h1 = (__bf16)r1;
-                const __bf16 h2 = (__bf16)(r1 - (float)h1);
-                planes[o] = h0; planes[n + o] = h1; planes[2 * n + o] = h2;
-            }
+            wt[o] = t[tx][i];
         }
     }
 }
@@ -1008,38 +1214,35 @@ static void dispatch_igemm_bf16(const ConvP& p, const float* x, const float* w, 
     }
 }
 
-// bf16x6 math mode (fp32-accurate): same tile rules as the bf16 mode
+// bf16x6 math mode (fp32-accurate): same tile rules as the bf16 mode.  With packed weight planes (p.w_planes: the caller's, or the
+// library's per-version cache) the weights-direct kernel runs, else the kernel that splits the weight tile in every workgroup.
 static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
     const int cus = num_cus();
     const int64_t nb = p.nbatch > 1 ? p.nbatch : 1;
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * nb;
     const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64) * nb;
-    const bool pb = p.w_planes != nullptr && nb == 1;
+    static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
+    const bool wd = p.w_planes != nullptr && direct_on;
     static const int force = getenv("ABR_X6_TILE") ? atoi(getenv("ABR_X6_TILE")) : 0;   // experiments: 1 = 128x128, 2 = 128x64, 3 = 64x64
     static const int force_maxk = getenv("ABR_X6_TILE_MAXK") ? atoi(getenv("ABR_X6_TILE_MAXK")) : 1 << 30;
-    if (force && p.K <= force_maxk && nb == 1 && !pb) {
-        if (force == 1) launch_x6<128, 128, 2, 2, false>(p, x, w, out, st);
-        else if (force == 2) launch_x6<128, 64, 4, 1, false>(p, x, w, out, st);
-        else launch_x6<64, 64, 2, 2, false>(p, x, w, out, st);
-        return;
-    }
     // Short-K convs (K <= 256: the 1x1 convs of layer1-3 and their dgrads) take 64x64 tiles whatever the grid size: alone they are
     // as fast as with 128x128 tiles (+-8 % per shape), but in the training step, where two or three other streams' kernels share the CUs,
     // the small workgroups (four per CU, 31 KB of LDS) interleave better -- step -0.3 ms in a same-session A/B.  ABR_X6_SHORTK_MAXK=0: off.
     static const int shortk = getenv("ABR_X6_SHORTK_MAXK") ? atoi(getenv("ABR_X6_SHORTK_MAXK")) : 256;
-    if (shortk > 0 && p.K <= shortk && nb == 1 && !pb) {
-        launch_x6<64, 64, 2, 2, false>(p, x, w, out, st);
-        return;
-    }
-    if (p.Cout > 64 && t128 >= 2 * cus) {
-        if (pb) launch_x6<128, 128, 2, 2, true>(p, x, w, out, st);
-        else launch_x6<128, 128, 2, 2, false>(p, x, w, out, st);
-    } else if (t12864 >= 2 * cus || p.Cout <= 64) {
-        if (pb) launch_x6<128, 64, 4, 1, true>(p, x, w, out, st);
-        else launch_x6<128, 64, 4, 1, false>(p, x, w, out, st);
+    int tile;   // 1 = 128x128, 2 = 128x64, 3 = 64x64
+    if (force && p.K <= force_maxk && nb == 1) tile = force;
+    else if (shortk > 0 && p.K <= shortk && nb == 1) tile = 3;
+    else if (p.Cout > 64 && t128 >= 2 * cus) tile = 1;
+    else if (t12864 >= 2 * cus || p.Cout <= 64) tile = 2;
+    else tile = 3;
+    if (wd) {
+        if (tile == 1) launch_x6w<128, 128, 2, 2>(p, x, out, st);
+        else if (tile == 2) launch_x6w<128, 64, 4, 1>(p, x, out, st);
+        else launch_x6w<64, 64, 2, 2>(p, x, out, st);
     } else {
-        if (pb) launch_x6<64, 64, 2, 2, true>(p, x, w, out, st);
-        else launch_x6<64, 64, 2, 2, false>(p, x, w, out, st);
+        if (tile == 1) launch_x6<128, 128, 2, 2>(p, x, w, out, st);
+        else if (tile == 2) launch_x6<128, 64, 4, 1>(p, x, w, out, st);
+        else launch_x6<64, 64, 2, 2>(p, x, w, out, st);
     }
 }
 
@@ -1049,14 +1252,26 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
     const int64_t T = (int64_t)p.B * th_n * tw_n;
     const size_t nV = (size_t)36 * T * p.Cin, nU = (size_t)36 * p.Cout * p.Cin, nM = (size_t)36 * T * p.Cout;
     if (T * (int64_t)std::max(p.Cin, p.Cout) * 4 >= (int64_t)0x7FFFFFF0) return false;
-    // Winograd-domain weights: from the per-weight cache when the caller vouches for (w, w_version), else transformed into scratch
-    float* Uc = p.w_version ? abr::wino_u_cached(w, p.Cout, p.Cin, p.w_version, st) : nullptr;
-    float* ws = abr::wino_ws(st, (p.v_out ? 0 : nV) + (Uc ? 0 : nU) + nM);
+    // Winograd-domain weights: from the per-weight cache when the caller vouches for (w, w_version), else transformed into scratch.
+    // bf16x6: the cached form is U's fragment-packed bf16x3 planes (36 matrices of Cout x Cin back to back: Cout % 32 == 0 makes the
+    // 36 * Cout rows pack as ONE matrix whose 32-row blocks never straddle two batches), fed to the weights-direct kernel.
+    static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
+    const void* Up = nullptr;
+    if (p.math == ABR_MATH_BF16X6 && p.w_version && direct_on && p.Cout % 32 == 0) {
+        Up = abr::derived_cached(w, abr::DERIVED_WINO_U_X6_PLANES, (size_t)x6_packed_bytes((int64_t)36 * p.Cout, p.Cin), p.w_version, st, [&](void* buf) {
+            float* Uf = abr::wino_ws(st, nU);   // fp32 U in this stream's scratch, consumed by the pack launch right behind it
+            if (!Uf || abr::wino_weight_transform(w, p.Cout, p.Cin, Uf, st)) return 1;
+            return x6_pack(Uf, (int64_t)36 * p.Cout, p.Cin, buf, st);
+        });
+    }
+    float* Uc = (!Up && p.w_version) ? abr::wino_u_cached(w, p.Cout, p.Cin, p.w_version, st) : nullptr;
+    const bool have_u = Uc || Up;
+    float* ws = abr::wino_ws(st, (p.v_out ? 0 : nV) + (have_u ? 0 : nU) + nM);
     if (!ws) return false;
     float* V = p.v_out ? p.v_out : ws;
     float* U = Uc ? Uc : ws + (p.v_out ? 0 : nV);
-    float* Mm = ws + (p.v_out ? 0 : nV) + (Uc ? 0 : nU);
-    if (!Uc && abr::wino_weight_transform(w, p.Cout, p.Cin, U, st)) return false;
+    float* Mm = ws + (p.v_out ? 0 : nV) + (have_u ? 0 : nU);
+    if (!have_u && abr::wino_weight_transform(w, p.Cout, p.Cin, U, st)) return false;
     if (abr::wino_input_transform(x, p.B, p.H, p.W, p.Cin, V, st)) return false;
     ConvP g = p;
     g.B = (int)T; g.H = g.W = 1; g.R = g.S = 1; g.stride = 1; g.pad = 0; g.Ho = g.Wo = 1;
@@ -1066,7 +1281,8 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
     g.d_howo.init(1u); g.d_wo.init(1u); g.d_cin.init((unsigned)p.Cin); g.d_s.init(1u);
     g.x_bytes = (unsigned)(T * p.Cin * 4); g.w_bytes = (unsigned)((int64_t)p.Cout * p.Cin * 4);
     g.nbatch = 36; g.a_bs = (long)T * p.Cin; g.w_bs = (long)p.Cout * p.Cin; g.o_bs = (long)T * p.Cout;
-    g.v_out = nullptr; g.w_planes = nullptr; g.w_plane_bytes = 0;
+    g.v_out = nullptr;
+    g.w_planes = Up; g.wp_bytes = (unsigned)x6_packed_bytes(p.Cout, p.Cin); g.wp_bs = (long)x6_packed_bytes(p.Cout, p.Cin); g.wp_nblocks = p.Cout / 32;
     if (p.math == ABR_MATH_BF16X6) dispatch_igemm_x6(g, V, U, Mm, st);
     else dispatch_igemm(g, V, U, Mm, st);
     return abr::wino_output_transform(Mm, p.B, p.H, p.W, p.Cout, p.scale, p.bias, p.relu, p.mask, out, st) == 0;
@@ -1113,11 +1329,9 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     p.nbatch = 1; p.tiles_pb = 0; p.a_bs = p.w_bs = p.o_bs = 0;
     p.v_out = d->wino_v;
     p.w_version = d->w_version;
-    p.w_planes = d->math == ABR_MATH_BF16X6 ? d->w_planes : nullptr;
-    const int64_t wps = d->w_plane_stride > 0 ? d->w_plane_stride : (int64_t)d->Cout * d->R * d->S * d->Cin;
-    ABR_REQUIRE(!p.w_planes || (wps >= (int64_t)d->Cout * d->R * d->S * d->Cin && wps * 4 + (int64_t)d->Cout * d->R * d->S * d->Cin * 2 < (int64_t)0xFFFFFFF0),
-                "conv_forward: bad w_plane_stride");
-    p.w_plane_bytes = (unsigned)(wps * 2);
+    p.w_planes = d->math == ABR_MATH_BF16X6 ? d->w_planes : nullptr;   // the caller's own abr_conv_pack_weights(w, Cout, R*S*Cin) planes, if any
+    ABR_REQUIRE(x6_packed_bytes(d->Cout, p.K) < (int64_t)0xFFFFFFF0, "conv_forward: weight tensor too large for 32-bit buffer offsets");
+    p.wp_bytes = (unsigned)x6_packed_bytes(d->Cout, p.K); p.wp_bs = 0; p.wp_nblocks = (d->Cout + 31) / 32;
     const int64_t xb = (int64_t)d->B * d->H * d->W * d->Cin * 4, wb = (int64_t)d->Cout * p.K * 4;
     ABR_REQUIRE(xb < (int64_t)0x7FFFFFF0 && wb < (int64_t)0x7FFFFFF0, "conv_forward: input / weight tensors must be < 2 GB (32-bit buffer offsets)");
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
@@ -1141,8 +1355,14 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
             return ABR_OK;
         }
     }
-    if (p.math == ABR_MATH_BF16X6) dispatch_igemm_x6(p, x, w, out, st);
-    else dispatch_igemm(p, x, w, out, st);
+    if (p.math == ABR_MATH_BF16X6) {
+        // weights-direct kernel: the packed planes of (w, w_version) come from the library's cache (filled here on a miss: one small launch)
+        if (!p.w_planes && p.w_version)
+            p.w_planes = abr::derived_cached(w, abr::DERIVED_X6_PLANES, p.wp_bytes, p.w_version, st, [&](void* buf) { return x6_pack(w, d->Cout, p.K, buf, st); });
+        dispatch_igemm_x6(p, x, w, out, st);
+    } else {
+        dispatch_igemm(p, x, w, out, st);
+    }
     ABR_CHECK_LAUNCH("conv_forward");
     return ABR_OK;
 }
@@ -1150,36 +1370,54 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
 extern "C" int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, int Cin, int stride, int pad, int math, int64_t w_version,
                                         void* stream) {
     ABR_REQUIRE(w && w_version != 0, "conv_prepare_weights: needs a weight pointer and a non-zero w_version");
+    ABR_REQUIRE(Cout > 0 && R > 0 && S > 0 && Cin > 0, "conv_prepare_weights: bad shape");
+    hipStream_t st = abr::as_stream(stream);
+    static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
+    const int K = R * S * Cin;
     // the same predicate as abr_conv_forward's Winograd branch (residual / scatter never occur on the convs that prepare)
     if (wino_min_c() > 0 && math != ABR_MATH_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && Cin % BK == 0 && Cout % 4 == 0 &&
         Cin >= wino_min_c() && Cout >= 128) {
-        ABR_REQUIRE(abr::wino_u_cached(w, Cout, Cin, w_version, abr::as_stream(stream)) != nullptr, "conv_prepare_weights: no memory for the Winograd-domain weights");
+        if (math == ABR_MATH_BF16X6 && direct_on && Cout % 32 == 0) {
+            const size_t nU = (size_t)36 * Cout * Cin;
+            void* up = abr::derived_cached(w, abr::DERIVED_WINO_U_X6_PLANES, (size_t)x6_packed_bytes((int64_t)36 * Cout, Cin), w_version, st, [&](void* buf) {
+                float* Uf = abr::wino_ws(st, nU);
+                if (!Uf || abr::wino_weight_transform(w, Cout, Cin, Uf, st)) return 1;
+                return x6_pack(Uf, (int64_t)36 * Cout, Cin, buf, st);
+            });
+            ABR_REQUIRE(up != nullptr, "conv_prepare_weights: no memory for the packed Winograd-domain weights");
+        } else {
+            ABR_REQUIRE(abr::wino_u_cached(w, Cout, Cin, w_version, st) != nullptr, "conv_prepare_weights: no memory for the Winograd-domain weights");
+        }
+        ABR_CHECK_LAUNCH("conv_prepare_weights");
+    } else if (math == ABR_MATH_BF16X6 && direct_on && Cin % BKX == 0 && x6_packed_bytes(Cout, K) < (int64_t)0xFFFFFFF0) {
+        void* pl = abr::derived_cached(w, abr::DERIVED_X6_PLANES, (size_t)x6_packed_bytes(Cout, K), w_version, st, [&](void* buf) { return x6_pack(w, Cout, K, buf, st); });
+        ABR_REQUIRE(pl != nullptr, "conv_prepare_weights: no memory for the packed weight planes");
         ABR_CHECK_LAUNCH("conv_prepare_weights");
     }
     return ABR_OK;
 }
 
 extern "C" int abr_conv_cache_clear(void) {
-    abr::wino_u_cache_clear();
+    abr::derived_cache_clear();
     return ABR_OK;
 }
-extern "C" int64_t abr_conv_cache_bytes(void) { return (int64_t)abr::wino_u_cache_bytes(); }
+extern "C" int64_t abr_conv_cache_bytes(void) { return (int64_t)abr::derived_cache_bytes(); }
+
+extern "C" int64_t abr_conv_packed_bytes(int64_t rows, int64_t K) { return rows > 0 && K > 0 && K % 16 == 0 ? x6_packed_bytes(rows, K) : 0; }
+
+extern "C" int abr_conv_pack_weights(const float* w, int64_t rows, int K, void* planes, void* stream) {
+    ABR_REQUIRE(w && planes && rows > 0 && K > 0 && K % 16 == 0, "conv_pack_weights: needs pointers, rows > 0 and K a positive multiple of 16");
+    ABR_REQUIRE(x6_packed_bytes(rows, K) < (int64_t)0xFFFFFFF0, "conv_pack_weights: packed matrix must stay below 4 GB (32-bit buffer offsets)");
+    ABR_REQUIRE(x6_pack(w, rows, K, planes, abr::as_stream(stream)) == 0, "conv_pack_weights: launch failed");
+    return ABR_OK;
+}
 
 extern "C" int abr_conv_dgrad_weights(const float* w, const float* scale, int Cout, int R, int S, int Cin, float* wt,
                                       void* stream) {
     ABR_REQUIRE(w && wt && Cout > 0 && R > 0 && S > 0 && Cin > 0, "conv_dgrad_weights: bad args");
     dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, R * S);
-    dgrad_weights_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(w, scale, Cout, R * S, Cin, wt, nullptr);
+    dgrad_weights_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(w, scale, Cout, R * S, Cin, wt);
     ABR_CHECK_LAUNCH("conv_dgrad_weights");
-    return ABR_OK;
-}
-
-extern "C" int abr_conv_dgrad_weights_planes(const float* w, const float* scale, int Cout, int R, int S, int Cin, float* wt, void* planes,
-                                             void* stream) {
-    ABR_REQUIRE(w && wt && planes && Cout > 0 && R > 0 && S > 0 && Cin > 0, "conv_dgrad_weights_planes: bad args");
-    dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, R * S);
-    dgrad_weights_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(w, scale, Cout, R * S, Cin, wt, reinterpret_cast<__bf16*>(planes));
-    ABR_CHECK_LAUNCH("conv_dgrad_weights_planes");
     return ABR_OK;
 }
 

@@ -17,7 +17,9 @@
 
 #include <algorithm>
 #include <map>
+#include <functional>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -373,56 +375,57 @@ float* wino_ws(hipStream_t st, size_t floats) {
     return w.buf;
 }
 
-// Winograd-domain weights U kept per weight tensor (abr_conv_desc::w_version).  One entry per weight address; a new version refills the
-// same buffer.  Ordering: a hit from a stream other than the filling one waits for the fill's event; every stream that has read an entry is
-// remembered, and a REFILL (new version) first makes its stream wait for an event recorded on each of those streams at refill time --
-// everything they had queued, the readers of the old U included, precedes it -- so no reader of version v can see version v+1's bytes
-// whatever stream refills.  Bounded: least-recently-used entries are dropped when the cache exceeds ABR_WINO_CACHE_MB (default 8192), and
-// abr_conv_cache_clear() drops everything (the host calls it when a model's parameter storage is rebuilt or released).  One mutex guards
-// the map.  Returns nullptr when there is no memory (caller uses scratch).
+// Data DERIVED from a weight tensor, kept per (weight address, kind) under abr_conv_desc::w_version: the Winograd-domain weights U (fp32,
+// for the fp32 MFMA kernels), the fragment-packed bf16x3 planes of a weight matrix, and the packed planes of U (both for the bf16x6
+// weights-direct kernel).  One entry per (address, kind); a new version refills the same buffer.  Ordering: a hit from a stream other than
+// the filling one waits for the fill's event; every stream that has read an entry is remembered, and a REFILL (new version) first makes
+// its stream wait for an event recorded on each of those streams at refill time -- everything they had queued, the readers of the old
+// bytes included, precedes it -- so no reader of version v can see version v+1's bytes whatever stream refills.  Bounded: least-recently-
+// used entries are dropped when the cache exceeds ABR_WINO_CACHE_MB (default 8192), and abr_conv_cache_clear() drops everything (the host
+// calls it when a model's parameter storage is rebuilt or released).  One mutex guards the map.  Returns nullptr when there is no memory
+// or the fill failed (callers then derive into scratch / split in-kernel).
 namespace {
-struct UEntry {
-    float* buf = nullptr; size_t floats = 0; int64_t version = 0; hipStream_t stream = nullptr; hipEvent_t filled = nullptr;
+struct DEntry {
+    void* buf = nullptr; size_t bytes = 0; int64_t version = 0; hipStream_t stream = nullptr; hipEvent_t filled = nullptr;
     std::vector<hipStream_t> readers;   // streams other than `stream` that have been handed this buffer since the last fill
     uint64_t last_use = 0;
 };
-std::map<const float*, UEntry> g_ucache;
-std::mutex g_ucache_mu;
-uint64_t g_ucache_clock = 0;
-size_t g_ucache_bytes = 0;
+std::map<std::pair<const void*, int>, DEntry> g_dcache;
+std::mutex g_dcache_mu;
+uint64_t g_dcache_clock = 0;
+size_t g_dcache_bytes = 0;
 
-void ucache_drop(UEntry& e) {   // (mutex held) wait for every stream that may still read or write the buffer, then free it
+void dcache_drop(DEntry& e) {   // (mutex held) wait for every stream that may still read or write the buffer, then free it
     if (e.stream) (void)hipStreamSynchronize(e.stream);
     for (hipStream_t r : e.readers) (void)hipStreamSynchronize(r);
-    if (e.buf) { (void)hipFree(e.buf); g_ucache_bytes -= e.floats * sizeof(float); }
+    if (e.buf) { (void)hipFree(e.buf); g_dcache_bytes -= e.bytes; }
     if (e.filled) (void)hipEventDestroy(e.filled);
-    e = UEntry();
+    e = DEntry();
 }
-size_t ucache_limit() {
+size_t dcache_limit() {
     static const size_t mb = getenv("ABR_WINO_CACHE_MB") ? (size_t)atoll(getenv("ABR_WINO_CACHE_MB")) : 8192;
     return mb << 20;
 }
 }  // namespace
 
-float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t st) {
-    std::lock_guard<std::mutex> lock(g_ucache_mu);
-    const size_t floats = (size_t)36 * N * C;
-    UEntry& e = g_ucache[w];
-    e.last_use = ++g_ucache_clock;
-    if (e.buf && e.floats != floats) ucache_drop(e);   // the address now holds a different weight tensor
+void* derived_cached(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, const std::function<int(void*)>& fill) {
+    std::lock_guard<std::mutex> lock(g_dcache_mu);
+    DEntry& e = g_dcache[std::make_pair(w, kind)];
+    e.last_use = ++g_dcache_clock;
+    if (e.buf && e.bytes != bytes) dcache_drop(e);   // the address now holds a different weight tensor
     if (!e.buf) {
-        while (g_ucache_bytes + floats * sizeof(float) > ucache_limit()) {   // evict least-recently-used entries (never this one)
-            auto victim = g_ucache.end();
-            for (auto it = g_ucache.begin(); it != g_ucache.end(); ++it)
-                if (it->second.buf && &it->second != &e && (victim == g_ucache.end() || it->second.last_use < victim->second.last_use)) victim = it;
-            if (victim == g_ucache.end()) break;
-            ucache_drop(victim->second);
-            g_ucache.erase(victim);
+        while (g_dcache_bytes + bytes > dcache_limit()) {   // evict least-recently-used entries (never this one)
+            auto victim = g_dcache.end();
+            for (auto it = g_dcache.begin(); it != g_dcache.end(); ++it)
+                if (it->second.buf && &it->second != &e && (victim == g_dcache.end() || it->second.last_use < victim->second.last_use)) victim = it;
+            if (victim == g_dcache.end()) break;
+            dcache_drop(victim->second);
+            g_dcache.erase(victim);
         }
-        if (hipMalloc(&e.buf, floats * sizeof(float)) != hipSuccess) { e.buf = nullptr; return nullptr; }
-        e.floats = floats;
-        g_ucache_bytes += floats * sizeof(float);
-        e.last_use = g_ucache_clock;
+        if (hipMalloc(&e.buf, bytes) != hipSuccess) { e.buf = nullptr; return nullptr; }
+        e.bytes = bytes;
+        g_dcache_bytes += bytes;
+        e.last_use = g_dcache_clock;
         if (!e.filled) (void)hipEventCreateWithFlags(&e.filled, hipEventDisableTiming);
     }
     if (e.version == version) {
@@ -444,22 +447,28 @@ float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t 
         (void)hipEventDestroy(ev);   // (released by the runtime once it has completed)
     }
     e.readers.clear();
-    if (wino_weight_transform(w, N, C, e.buf, st)) return nullptr;
+    e.version = 0;
+    if (fill(e.buf)) return nullptr;
     (void)hipEventRecord(e.filled, st);
     e.version = version;
     e.stream = st;
     return e.buf;
 }
 
-void wino_u_cache_clear() {
-    std::lock_guard<std::mutex> lock(g_ucache_mu);
-    for (auto& kv : g_ucache) ucache_drop(kv.second);
-    g_ucache.clear();
-    g_ucache_bytes = 0;
+float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t st) {
+    return reinterpret_cast<float*>(derived_cached(w, DERIVED_WINO_U, (size_t)36 * N * C * sizeof(float), version, st,
+                                                   [&](void* buf) { return wino_weight_transform(w, N, C, reinterpret_cast<float*>(buf), st); }));
 }
-size_t wino_u_cache_bytes() {
-    std::lock_guard<std::mutex> lock(g_ucache_mu);
-    return g_ucache_bytes;
+
+void derived_cache_clear() {
+    std::lock_guard<std::mutex> lock(g_dcache_mu);
+    for (auto& kv : g_dcache) dcache_drop(kv.second);
+    g_dcache.clear();
+    g_dcache_bytes = 0;
+}
+size_t derived_cache_bytes() {
+    std::lock_guard<std::mutex> lock(g_dcache_mu);
+    return g_dcache_bytes;
 }
 
 }  // namespace abr

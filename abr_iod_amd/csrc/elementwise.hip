@@ -211,32 +211,6 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
         }
 }
 
-
-// exact 3-way bf16 split (see conv_igemm.hip, bf16x6): 4 values per thread, three 8 B stores
-typedef __bf16 sp_bf16x4 __attribute__((ext_vector_type(4)));
-typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float4* __restrict__ x, int64_t n4, uint2* __restrict__ planes,
-                                                           unsigned* __restrict__ flags) {
-    unsigned bmin = 0xFFFFFFFFu;   // range guard of the exact split, as in conv_igemm_x6_kernel (the consumer does not look at planes again)
-    float nonfin = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 v = x[i];
-        bmin = min(min(bmin, min((__float_as_uint(v.x) << 1) - 1u, (__float_as_uint(v.y) << 1) - 1u)),
-                   min((__float_as_uint(v.z) << 1) - 1u, (__float_as_uint(v.w) << 1) - 1u));
-        nonfin = fmaf(v.x, 0.f, nonfin); nonfin = fmaf(v.y, 0.f, nonfin); nonfin = fmaf(v.z, 0.f, nonfin); nonfin = fmaf(v.w, 0.f, nonfin);
-        const sp_f32x4 f = {v.x, v.y, v.z, v.w};
-        const sp_bf16x4 h0 = __builtin_convertvector(f, sp_bf16x4);
-        const sp_f32x4 r1 = f - __builtin_convertvector(h0, sp_f32x4);
-        const sp_bf16x4 h1 = __builtin_convertvector(r1, sp_bf16x4);
-        const sp_f32x4 r2 = r1 - __builtin_convertvector(h1, sp_f32x4);
-        const sp_bf16x4 h2 = __builtin_convertvector(r2, sp_bf16x4);
-        planes[i] = *reinterpret_cast<const uint2*>(&h0);
-        planes[n4 + i] = *reinterpret_cast<const uint2*>(&h1);
-        planes[2 * n4 + i] = *reinterpret_cast<const uint2*>(&h2);
-    }
-    abr::x6_report(bmin, nonfin, flags);
-}
-
 }  // namespace
 
 extern "C" int abr_nchw_to_nhwc_pad(const float* x, int B, int C, int H, int W, int Cpad, float* out, void* stream) {
@@ -363,18 +337,5 @@ extern "C" int abr_sgd_momentum(float* p, const float* g, float* m, int64_t tota
     sgd_kernel<<<(unsigned)std::min<int64_t>((total / 4 + 255) / 256 + 1, 8192), 256, 0, abr::as_stream(stream)>>>(
         p, g, m, total, seg_end_dev, lr_dev, wd_dev, n_seg, momentum, gscale, first_step);
     ABR_CHECK_LAUNCH("sgd_momentum");
-    return ABR_OK;
-}
-
-extern "C" int abr_split_bf16x3(const float* x, int64_t n, void* planes, void* stream) {
-    ABR_REQUIRE(n >= 0 && n % 4 == 0, "split_bf16x3: n must be a non-negative multiple of 4");
-    if (n == 0) return ABR_OK;
-    ABR_REQUIRE(x && planes, "split_bf16x3: null pointer");
-    const int64_t n4 = n / 4;
-    const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 8192);
-    unsigned* flags = abr::x6_flags_ptr();
-    ABR_REQUIRE(flags, "split_bf16x3: no device memory for the range flags");
-    split_bf16x3_kernel<<<blocks, 256, 0, abr::as_stream(stream)>>>(reinterpret_cast<const float4*>(x), n4, reinterpret_cast<uint2*>(planes), flags);
-    ABR_CHECK_LAUNCH("split_bf16x3");
     return ABR_OK;
 }

@@ -20,16 +20,6 @@ class FlatParams(object):
         self.grads = None       # trainable region only
         self.n_trainable = 0    # elements in the trainable region (incl. alignment padding)
         self.segments = []      # (name, start, end, is_bias) per optimiser tensor, ascending, trainable region
-        self._planes = None     # bf16x3 split of `params` (int16 [3, numel]) for the bf16x6 arithmetic, one launch per parameter version
-        self._planes_version = None
-
-    def planes(self, version):
-        if self._planes is None or self._planes_version != version or self._planes.device != self.params.device:
-            from .. import ops
-            keep = self._planes if (self._planes is not None and self._planes.device == self.params.device) else None
-            self._planes = ops.split_bf16x3(self.params, out=keep)
-            self._planes_version = version
-        return self._planes
 
     def zero_grad(self):
         self.grads.zero_()

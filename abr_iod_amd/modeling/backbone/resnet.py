@@ -28,13 +28,8 @@ StageSpec = namedtuple("StageSpec", ["index", "block_count", "return_features"])
 ResNet50StagesTo4 = tuple(StageSpec(index=i, block_count=c, return_features=r) for (i, c, r) in ((1, 3, False), (2, 4, False), (3, 6, True)))
 ResNet50StagesTo5 = tuple(StageSpec(index=i, block_count=c, return_features=r) for (i, c, r) in ((1, 3, False), (2, 4, False), (3, 6, False), (4, 3, True)))
 
-# bf16x6 arithmetic: hand the kernels weights that were split into bf16 planes once per step (abr_conv_desc::w_planes) instead of letting every
-# workgroup split its weight tile.  Measured NEUTRAL (layer4 GEMMs 0.39-0.95 ms either way, step 32.1 vs 31.8 ms with the extra split
-# launches): under real data the x6 loop is bound by the matrix pipe's sustained clock, not by the split's VALU work -- off by default.
-X6_WEIGHT_PLANES = os.environ.get("ABR_X6_WEIGHT_PLANES", "0") != "0"
-
-# Weight versions: data derived from a weight tensor (the flipped dgrad copies, the library's Winograd-domain weights: abr_conv_desc::
-# w_version) is rebuilt lazily when its version is stale.  _PARAM_VERSION moves with EVERY change (optimiser steps, loads, in-place
+# Weight versions: data derived from a weight tensor (the flipped dgrad copies; inside the library, under abr_conv_desc::w_version, the
+# Winograd-domain weights and the fragment-packed bf16x3 planes the bf16x6 weights-direct kernel reads) is rebuilt lazily when its version is stale.  _PARAM_VERSION moves with EVERY change (optimiser steps, loads, in-place
 # surgery), _STATIC_VERSION only with changes that can touch weights no optimiser owns (loads, surgery, model construction): the
 # frozen source model's derived data therefore survives the target's optimiser steps.  Code that writes weights in place must call
 # bump_param_version().
@@ -65,7 +60,6 @@ class Conv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         self._wt = None
         self._wt_version = -1
-        self._wtp = None          # bf16x3 planes of the dgrad copy (bf16x6 arithmetic)
         self._optimised = False   # set by FusedSGD for the convs it updates: their version moves with every optimiser step
         self._flat = None         # the model's FlatParams (set by GeneralizedRCNN.flatten_parameters): source of weight planes
 
@@ -87,31 +81,18 @@ class Conv2d(nn.Module):
     def oihw(self):
         return self.weight.detach()[..., : self.in_channels].permute(0, 3, 1, 2).contiguous()
 
-    def dgrad_weight(self, scale=None, planes=False):
-        """[Cin,R,S,Cout] flipped copy with the FrozenBN scale folded in; rebuilt only after an optimiser step.
-        planes=True (bf16x6 arithmetic) also keeps its exact bf16x3 split in self._wtp, made by the same launch."""
+    def dgrad_weight(self, scale=None):
+        """[Cin,R,S,Cout] flipped copy with the FrozenBN scale folded in; rebuilt only after an optimiser step."""
         ops.prep_wait()
-        if (self._wt is None or self._wt_version != _PARAM_VERSION[0] or self._wt.device != self.weight.device
-                or (planes and self._wtp is None)):
+        if self._wt is None or self._wt_version != _PARAM_VERSION[0] or self._wt.device != self.weight.device:
             same = self._wt is not None and self._wt.device == self.weight.device
-            if planes and (self._wtp is None or self._wtp.device != self.weight.device):
-                self._wtp = torch.empty((3, self.weight.numel()), dtype=torch.int16, device=self.weight.device)
-            self._wt = ops.conv_dgrad_weights(self.weight.detach(), scale, out=self._wt if same else None, planes=self._wtp if planes else None)
+            self._wt = ops.conv_dgrad_weights(self.weight.detach(), scale, out=self._wt if same else None)
             self._wt_version = _PARAM_VERSION[0]
         return self._wt
 
     def version(self):
         """abr_conv_desc::w_version for this conv's weight and for its dgrad copy: non-zero, changes whenever the values may have"""
         return 2 * _PARAM_VERSION[0] + 1 if self._optimised else 2 * _STATIC_VERSION[0] + 2
-
-    def weight_planes(self):
-        """(plane-0 view of this weight inside the model's split parameter buffer, elements between planes) or (None, 0)"""
-        flat = self._flat
-        if flat is None or flat.params is None or not self.weight.is_cuda:
-            return None, 0
-        pl = flat.planes(_PARAM_VERSION[0])
-        off = (self.weight.data_ptr() - flat.params.data_ptr()) // 4
-        return pl[0, off:off + self.weight.numel()], pl.shape[1]
 
 
 def _grad_buf(p):
@@ -141,35 +122,27 @@ class Bottleneck(nn.Module):
         self.math = ops.MATH_F32   # ops.MATH_BF16: bf16 MFMA contractions (cfg.DTYPE == "bfloat16", see set_conv_math)
 
     def _conv(self, x, conv, stride, pad, **kw):
-        """conv_forward in this block's arithmetic; bf16x6 also hands over the weight's pre-split planes"""
-        if X6_WEIGHT_PLANES and self.math == ops.MATH_BF16X6:
-            pl, st = conv.weight_planes()
-            if pl is not None:
-                kw.update(w_planes=pl, w_plane_stride=st)
+        """conv_forward in this block's arithmetic.  w_version lets the library keep what it derives from the weights (Winograd-domain
+        weights; under bf16x6 the fragment-packed planes its weights-direct kernel reads)."""
         return ops.conv_forward(x, conv.weight, stride, pad, math=self.math, w_version=conv.version(), **kw)
 
     def _dgrad(self, g, conv, scale, pad, **kw):
-        x6 = X6_WEIGHT_PLANES and self.math == ops.MATH_BF16X6
-        wt = conv.dgrad_weight(scale, planes=x6)
-        if x6:
-            kw.update(w_planes=conv._wtp)
-        return ops.conv_forward(g, wt, 1, pad, math=self.math, w_version=conv.version(), **kw)
+        return ops.conv_forward(g, conv.dgrad_weight(scale), 1, pad, math=self.math, w_version=conv.version(), **kw)
 
     def prepare_derived(self):
         """Rebuild, on the current stream, everything this block derives from its trainable weights: the flipped / BN-scaled dgrad
-        copies and, for the 3x3 conv, the Winograd-domain weights of the weight and of its dgrad copy (FusedSGD.step runs this on the
-        weight-preparation stream right after the update)."""
-        x6 = X6_WEIGHT_PLANES and self.math == ops.MATH_BF16X6
+        copies and, inside the library, what abr_conv_forward derives from the weight and from its dgrad copy (Winograd-domain weights of
+        the 3x3 conv, packed bf16x3 planes under bf16x6).  FusedSGD.step runs this on the weight-preparation stream right after the update."""
         pairs = [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
         if self.downsample is not None:
             pairs.append((self.downsample[0], self.downsample[1]))
         for conv, bn in pairs:
             if not (conv.weight.requires_grad and conv.weight.is_cuda):
                 continue
-            wt = conv.dgrad_weight(bn.scale_bias()[0], planes=x6)
-            if conv.kernel_size == 3 and conv.stride == 1 and conv.padding == 1:
-                ops.conv_prepare_weights(conv.weight, 1, 1, self.math, conv.version())
-                ops.conv_prepare_weights(wt, 1, 1, self.math, conv.version())
+            wt = conv.dgrad_weight(bn.scale_bias()[0])
+            ops.conv_prepare_weights(conv.weight, conv.stride, conv.padding, self.math, conv.version())
+            # the dgrad conv is stride 1 with pad k-1-p (a scatter for the stride-2 1x1 convs): same derived data either way
+            ops.conv_prepare_weights(wt, 1, conv.kernel_size - 1 - conv.padding, self.math, conv.version())
 
     # x, returns NHWC tensors.  `stride` may be overridden to 1 when the caller already sub-sampled (bin_step=2 ROIAlign)
     def fwd(self, x, save, stride=None):

@@ -138,7 +138,7 @@ class _RPNHeadFn(Function):
         xh = as_nhwc(x)
         v = ops.wino_v_alloc(xh, head.conv.weight, 1, 1, head.math) if head.conv.weight.requires_grad else None
         t = ops.conv_forward(xh, head.conv.weight, 1, 1, bias=head.conv.bias, relu=True, math=head.math, wino_v=v, w_version=head.conv.version())
-        y = ops.conv_forward(t, head.fused_weight, 1, 0, bias=head.fused_bias, math=head.math)
+        y = ops.conv_forward(t, head.fused_weight, 1, 0, bias=head.fused_bias, math=head.math, w_version=head.fused_version())
         ctx.head, ctx.saved = head, (xh, t, v)
         ctx.need_dx = x.requires_grad
         return from_nhwc(y)
@@ -232,10 +232,18 @@ class RPNHead(nn.Module):
             return
         if self.fused_weight_grad is not None and (self.cls_logits.weight.requires_grad or self.bbox_pred.weight.requires_grad):
             self.fused_dgrad_weight()
+            ops.conv_prepare_weights(self.fused_weight, 1, 0, self.math, self.fused_version())
         if self.conv.weight.requires_grad:
             wt = self.conv.dgrad_weight()
             ops.conv_prepare_weights(self.conv.weight, 1, 1, self.math, self.conv.version())
             ops.conv_prepare_weights(wt, 1, 1, self.math, self.conv.version())
+
+    def fused_version(self):
+        """abr_conv_desc::w_version of the fused cls | bbox weight (Conv2d.version's rule: it moves with optimiser steps iff an optimiser
+        owns one of its two halves)"""
+        from ..backbone.resnet import _PARAM_VERSION, _STATIC_VERSION
+        opt = self.cls_logits._optimised or self.bbox_pred._optimised
+        return 2 * _PARAM_VERSION[0] + 1 if opt else 2 * _STATIC_VERSION[0] + 2
 
     def fused_dgrad_weight(self):
         from ..backbone.resnet import _PARAM_VERSION
@@ -252,7 +260,7 @@ class RPNHead(nn.Module):
             return _RPNHeadFn.apply(x, self, *params)
         xh = as_nhwc(x)
         t = ops.conv_forward(xh, self.conv.weight, 1, 1, bias=self.conv.bias, relu=True, math=self.math, w_version=self.conv.version())
-        return from_nhwc(ops.conv_forward(t, self.fused_weight, 1, 0, bias=self.fused_bias, math=self.math))
+        return from_nhwc(ops.conv_forward(t, self.fused_weight, 1, 0, bias=self.fused_bias, math=self.math, w_version=self.fused_version()))
 
     def forward(self, x):
         logits, bbox_reg = [], []

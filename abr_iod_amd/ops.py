@@ -290,15 +290,15 @@ def wino_v_alloc(x, w, stride, pad, math=MATH_F32):
 
 
 def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, mask=None, relu=False,
-                 out=None, out_hw=None, out_stride=(1, 1), math=MATH_F32, wino_v=None, w_planes=None, w_plane_stride=0, w_version=0):
+                 out=None, out_hw=None, out_stride=(1, 1), math=MATH_F32, wino_v=None, w_planes=None, w_version=0):
     """x [B,H,W,Cin] NHWC, w [Cout,R,S,Cin] OHWI -> [B,Ho,Wo,Cout] (or scattered into `out` [B,out_H,out_W,Cout]).
     math=MATH_BF16: operands rounded to bf16 inside the kernel, bf16 MFMA, fp32 accumulate (fp32 tensors in and out)."""
     L.require_cuda(x, w)
     x, w = L.f32c(x), L.f32c(w)
     d = conv_desc(x.shape, w.shape, stride, pad, scale, bias, residual, mask, relu, out_hw, out_stride, math)
     d.wino_v = L.ptr(wino_v)
-    d.w_planes, d.w_plane_stride = L.ptr(w_planes), int(w_plane_stride)
-    d.w_version = int(w_version)   # non-zero: the library may keep data derived from (w, w_version) -- the Winograd-domain weights
+    d.w_planes = L.ptr(w_planes)   # MATH_BF16X6: the caller's own pack_weights(w) planes (else the library packs (w, w_version) itself)
+    d.w_version = int(w_version)   # non-zero: the library may keep data derived from (w, w_version): Winograd-domain weights, packed bf16x3 planes
     if out is None:
         if out_hw is not None:
             out = torch.zeros((d.B, d.out_H, d.out_W, d.Cout), dtype=_f32, device=x.device)
@@ -447,27 +447,28 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino
     return dw
 
 
-def split_bf16x3(x, out=None):
-    """exact three-way bf16 split of an fp32 tensor -> int16 [3, numel] (planes p0, p1, p2 with x == p0 + p1 + p2)"""
-    L.require_cuda(x)
-    x = L.f32c(x)
-    n = x.numel()
+def pack_weights(w, out=None):
+    """w [Cout,R,S,Cin] (or any [rows, K] fp32 matrix, K % 16 == 0) -> its fragment-packed exact bf16x3 planes (uint8 buffer of
+    abr_conv_packed_bytes bytes) for conv_forward(..., math=MATH_BF16X6, w_planes=): the weights-direct bf16x6 kernel loads weight
+    fragments straight from them (include/abr_iod_hip.h, abr_conv_pack_weights)."""
+    L.require_cuda(w)
+    w = L.f32c(w)
+    rows, K = w.shape[0], w.numel() // w.shape[0]
+    n = int(L.lib().abr_conv_packed_bytes(rows, K))
+    if n <= 0:
+        raise RuntimeError("pack_weights: K = {} is not a positive multiple of 16".format(K))
     if out is None:
-        out = torch.empty((3, n), dtype=torch.int16, device=x.device)
-    L.check(L.lib().abr_split_bf16x3(L.ptr(x), n, L.ptr(out), L.stream()), "split_bf16x3")
+        out = torch.empty(n, dtype=torch.uint8, device=w.device)
+    L.check(L.lib().abr_conv_pack_weights(L.ptr(w), rows, K, L.ptr(out), L.stream()), "conv_pack_weights")
     return out
 
 
-def conv_dgrad_weights(w, scale=None, out=None, planes=None):
-    """w [Cout,R,S,Cin] -> [Cin,R,S,Cout] flipped, scaled by scale[Cout]; `planes` (int16 [3, numel]) also receives its bf16x3 split"""
+def conv_dgrad_weights(w, scale=None, out=None):
+    """w [Cout,R,S,Cin] -> [Cin,R,S,Cout] flipped, scaled by scale[Cout]"""
     w = L.f32c(w)
     Cout, R, S, Cin = w.shape
     if out is None:
         out = _empty((Cin, R, S, Cout), w)
-    if planes is not None:
-        L.check(L.lib().abr_conv_dgrad_weights_planes(L.ptr(w), L.ptr(scale), Cout, R, S, Cin, L.ptr(out), L.ptr(planes), L.stream()),
-                "dgrad_weights_planes")
-        return out
     L.check(L.lib().abr_conv_dgrad_weights(L.ptr(w), L.ptr(scale), Cout, R, S, Cin, L.ptr(out), L.stream()), "dgrad_weights")
     return out
 

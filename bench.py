@@ -28,9 +28,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense
 PROF_NAMES = ["conv_igemm_kernel<128,128>", "conv_igemm_kernel<128,64>", "conv_igemm_kernel<64,64>", "conv_igemm_kernel<128,64,small_c>",
               "conv_wgrad_kernel", "roi_align_fwd", "roi_align_bwd", "conv_igemm_bf16_kernel", "conv_wgrad_bf16_kernel",
-              "conv_igemm_x6_kernel<128,128>", "conv_igemm_x6_kernel<128,64>", "conv_igemm_x6_kernel<64,64>"]
+              "conv_igemm_x6_kernel<128,128>", "conv_igemm_x6_kernel<128,64>", "conv_igemm_x6_kernel<64,64>",
+              "conv_igemm_x6w_kernel<128,128>", "conv_igemm_x6w_kernel<128,64>", "conv_igemm_x6w_kernel<64,64>"]
 # (positions = abr::ProfId in csrc/common.h.  One row per TEMPLATE INSTANCE of the bf16x6 implicit GEMM, named as rocprofv3 names them
-#  (`conv_igemm_x6_kernel<128, 128, 2, 2, false>` ...), so every row's fraction can be recomputed from profiles/ alone.  id 8 is the
+#  (`conv_igemm_x6w_kernel<128, 128, 2, 2>` ...: x6w = the weights-direct form, x6 = the form that splits the weight tile per workgroup),
+#  so every row's fraction can be recomputed from profiles/ alone.  id 8 is the
 #  weight-gradient kernel of the chosen arithmetic: conv_wgrad_x6_kernel under --math bf16x6, conv_wgrad_bf16_kernel under --math bf16.)
 
 
@@ -69,6 +71,8 @@ def _pmc_traffic(kernel):
     prefix = {"conv_igemm_kernel<128,128>": "conv_igemm_kernel<128, 128,", "conv_wgrad_kernel": "conv_wgrad_kernel<",
               "conv_igemm_x6_kernel<128,128>": "conv_igemm_x6_kernel<128, 128,", "conv_igemm_x6_kernel<128,64>": "conv_igemm_x6_kernel<128, 64,",
               "conv_igemm_x6_kernel<64,64>": "conv_igemm_x6_kernel<64, 64,", "conv_wgrad_x6_kernel": "conv_wgrad_x6_kernel",
+              "conv_igemm_x6w_kernel<128,128>": "conv_igemm_x6w_kernel<128, 128,", "conv_igemm_x6w_kernel<128,64>": "conv_igemm_x6w_kernel<128, 64,",
+              "conv_igemm_x6w_kernel<64,64>": "conv_igemm_x6w_kernel<64, 64,",
               "conv_igemm_kernel<64,64>": "conv_igemm_kernel<64, 64,", "conv_igemm_kernel<128,64>": "conv_igemm_kernel<128, 64, 4, 1, false"}.get(kernel)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         hits = [v for k, v in json.load(open(f))["kernels"].items() if prefix and k.startswith(prefix)]
@@ -79,7 +83,7 @@ def _pmc_traffic(kernel):
 
 
 def _peak_of(name):
-    if "_x6_" in name:
+    if "_x6_" in name or "_x6w_" in name:
         return round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)   # six bf16 MFMA products per fp32 multiply-add
     return PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
 

@@ -46,7 +46,7 @@ int abr_device_info(int32_t* out_host);
  * out[id*6+{3,4,5}] = the same for launches made while abr_prof_mark_overlap(1) was in force (the host runs weight-gradient
  * kernels on a second stream next to the dgrad chain: those launches share CUs and their event-bracketed duration is not a
  * property of the kernel).  id = 0 igemm 128x128, 1 igemm 128x64, 2 igemm 64x64, 3 igemm small-C (stem), 4 wgrad, 5/6 ROIAlign
- * fwd/bwd, 7 igemm bf16, 8 wgrad bf16 / bf16x6, 9 / 10 / 11 the bf16x6 implicit GEMM's 128x128 / 128x64 / 64x64 tile instances.  Synchronises on the recorded events and stops profiling. */
+ * fwd/bwd, 7 igemm bf16, 8 wgrad bf16 / bf16x6, 9 / 10 / 11 the bf16x6 implicit GEMM's 128x128 / 128x64 / 64x64 tile instances, 12 / 13 / 14 the same tiles of its weights-direct form.  Synchronises on the recorded events and stops profiling. */
 int abr_prof_begin(void);
 int abr_prof_mark_overlap(int on);
 /* bit id set = time that kernel (default all); every_nth = n > 1: bracket launch i of a kernel in step s iff (i + s) % n == 0 (an
@@ -234,25 +234,25 @@ typedef struct {
        gradient takes the Winograd path, V is read from there and the input transform is skipped (x is not touched).  NULL =
        self-contained calls. */
     float* wino_v;
-    /* ABR_MATH_BF16X6, abr_conv_forward only: the weight tensor already split into three bf16 planes by abr_split_bf16x3
-       ([3][Cout*R*S*Cin]); the kernel then loads the planes instead of splitting w in every workgroup.  NULL = split in-kernel. */
+    /* ABR_MATH_BF16X6, abr_conv_forward only: the weights as FRAGMENT-PACKED bf16x3 planes made by abr_conv_pack_weights(w, Cout,
+       R*S*Cin) (abr_conv_packed_bytes bytes): the weights-direct kernel then loads every weight fragment straight from these planes
+       into the matrix-core registers -- no per-workgroup split, no LDS traffic for the weights.  NULL with w_version != 0: the library
+       packs (w, w_version) itself on first use and keeps the planes; NULL with w_version == 0: the weight tile is split in every workgroup. */
     const void* w_planes;
-    int64_t w_plane_stride;  /* elements between two planes (0 = Cout*R*S*Cin: a stand-alone abr_split_bf16x3 of w); larger when
-                                the planes are a slice of a bigger split buffer, e.g. the whole flat parameter buffer split at once */
     /* abr_conv_forward: non-zero = "the weight tensor at address w has not changed since the last call that passed this same
-       (w, w_version) pair": the library then keeps data derived from it -- the Winograd-domain weights U = G g G^T, 36*Cout*Cin
-       floats -- and skips the weight transform on later calls (the frozen source model: once; a trainable conv: once per optimiser
+       (w, w_version) pair": the library then keeps data derived from it -- the Winograd-domain weights U = G g G^T (36*Cout*Cin
+       floats, or their packed bf16x3 planes under ABR_MATH_BF16X6) and the packed bf16x3 planes of w -- and skips the derivation on later calls (the frozen source model: once; a trainable conv: once per optimiser
        step, shared by its forward passes).  0 = derive it again on every call. */
     int64_t w_version;
 } abr_conv_desc;
 
 int abr_conv_forward(const abr_conv_desc* d_host, const float* x, const float* w, float* out, void* stream);
 /* Derive, on `stream`, whatever abr_conv_forward would derive from the weight tensor (w, w_version != 0) of a conv with this geometry and
- * arithmetic -- today: the Winograd-domain weights of a wide stride-1 3x3 conv -- so that the next abr_conv_forward with the same
- * (w, w_version) finds it ready (a consumer on another stream is ordered behind it by the library).  A no-op for other convs.  Lets a
+ * arithmetic -- the Winograd-domain weights of a wide stride-1 3x3 conv, the packed bf16x3 planes of any bf16x6 conv -- so that the next abr_conv_forward with the same
+ * (w, w_version) finds it ready (a consumer on another stream is ordered behind it by the library).  Lets a
  * caller move the per-step weight preparation of its trainable convs off the critical stream (solver/build.py). */
 int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, int Cin, int stride, int pad, int math, int64_t w_version, void* stream);
-/* The library keeps Winograd-domain weights per (weight address, w_version) -- about 36/9 of each wide 3x3 weight.  The cache is bounded
+/* The library keeps this derived data per (weight address, kind, w_version) -- 36/9 of each wide 3x3 weight, 1.5x of every other bf16x6 weight.  The cache is bounded
  * (least-recently-used entries go when it exceeds ABR_WINO_CACHE_MB, default 8192); abr_conv_cache_clear drops every entry after waiting
  * for the streams that use them (call it when a model's parameter storage is released or rebuilt), abr_conv_cache_bytes reports its size. */
 int abr_conv_cache_clear(void);
@@ -260,9 +260,13 @@ int64_t abr_conv_cache_bytes(void);
 /* floats of the Winograd-domain input V = 36 * B*ceil(H/4)*ceil(W/4) * Cin if BOTH abr_conv_forward and abr_conv_wgrad take the
  * Winograd F(4x4,3x3) path for this descriptor (wide stride-1 pad-1 3x3, no residual / scatter, fp32 or bf16x6 math), else 0 */
 int64_t abr_conv_wino_v_floats(const abr_conv_desc* d_host);
-/* exact three-way split x = p0 + p1 + p2 with p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (round to nearest even):
- * planes [3][n] bf16 (6 n bytes).  n % 4 == 0. */
-int abr_split_bf16x3(const float* x, int64_t n, void* planes, void* stream);
+/* Fragment-packed bf16x3 planes of an fp32 matrix w [rows][K] (K % 16 == 0; a conv weight: rows = Cout, K = R*S*Cin) for
+ * abr_conv_desc::w_planes.  Exact three-way split x = p0 + p1 + p2 (p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1), RNE), stored in
+ * the order the bf16 MFMA consumes it: chunk (nb, ks, pl) = 64 lanes x 16 B at byte (((nb * K/16 + ks) * 3 + pl) * 64 + lane) * 16, lane l
+ * holding row nb*32 + (l & 31), k = ks*16 + (l >> 5)*8 .. +8 of plane pl; rows are zero-padded to a multiple of 32.  The elements are
+ * range-checked for the bf16x6 arithmetic as they are packed (abr_x6_range_flags). */
+int64_t abr_conv_packed_bytes(int64_t rows, int64_t K);
+int abr_conv_pack_weights(const float* w, int64_t rows, int K, void* planes, void* stream);
 
 /* dW[Cout,R,S,Cin] (+)= sum_m gy[m,Cout]^T * im2col(x)[m,RSCin], columns scaled by d->scale (FrozenBN).
  * Accumulates with fp32 atomics into dw (caller zeroes it once per step). */
@@ -272,9 +276,6 @@ int abr_conv_wgrad(const abr_conv_desc* d_host, const float* x, const float* gy,
  * that turns dgrad into abr_conv_forward(gy, wt). */
 int abr_conv_dgrad_weights(const float* w, const float* scale, int Cout, int R, int S, int Cin, float* wt,
                            void* stream);
-/* the same, also emitting the three bf16 planes of wt ([3][Cin*R*S*Cout]) for abr_conv_desc::w_planes */
-int abr_conv_dgrad_weights_planes(const float* w, const float* scale, int Cout, int R, int S, int Cin, float* wt, void* planes,
-                                  void* stream);
 /* db[c] += sum_m gy[m,c] (bias gradient of nn.Conv2d / nn.Linear) */
 int abr_bias_grad(const float* gy, int64_t M, int C, float* db, void* stream);
 

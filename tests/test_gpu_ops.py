@@ -689,52 +689,70 @@ def test_winograd_input_transform_is_shared_between_forward_and_wgrad(math):
     assert ops.wino_v_alloc(torch.randn(1, 16, 16, 256, device="cuda"), torch.zeros(256, 3, 3, 256, device="cuda"), 1, 1, ops.MATH_BF16) is None
 
 
-def test_bf16x6_presplit_weight_planes_give_identical_results():
-    """abr_split_bf16x3 + abr_conv_desc::w_planes: splitting the weights once (whole buffers, strided planes) must give bit-identical
-    outputs to splitting them inside every workgroup; the planes themselves add back to the fp32 value exactly."""
+def _unpack_planes(planes, rows, K):
+    """inverse of abr_conv_pack_weights (include/abr_iod_hip.h): uint8 buffer -> float64 [3, rows_padded, K] of the three bf16 planes"""
+    nb, ks = (rows + 31) // 32, K // 16
+    t = planes.view(torch.bfloat16).view(nb, ks, 3, 64, 8).double()      # chunk (nb, ks, plane): 64 lanes x 8 bf16
+    lane = torch.arange(64, device=planes.device)
+    out = torch.zeros(3, nb * 32, K, dtype=torch.float64, device=planes.device)
+    for half in range(2):   # lane l: row nb*32 + (l & 31), k = ks*16 + (l >> 5)*8 ..
+        sel = t[:, :, :, lane[half * 32:(half + 1) * 32], :]               # [nb, ks, 3, 32 rows, 8]
+        out.view(3, nb, 32, ks, 16)[:, :, :, :, half * 8:half * 8 + 8] = sel.permute(2, 0, 3, 1, 4)
+    return out
+
+
+def test_bf16x6_packed_weight_planes_are_exact_and_give_identical_results():
+    """abr_conv_pack_weights + the weights-direct bf16x6 kernel (conv_igemm_x6w_kernel): the fragment-packed planes add back to the fp32
+    weights EXACTLY (rows zero-padded to 32), and feeding them straight into the matrix cores -- the caller's planes or the library's
+    per-(w, w_version) cache -- gives results bit-identical to splitting the weight tile inside every workgroup, on all three tile
+    instances, for ragged Cout, a narrow direct 3x3, a stride-2 1x1 and the dgrad form."""
     from abr_iod_amd import ops
     g = torch.Generator(device="cuda").manual_seed(11)
-    buf = torch.randn(3 * 64 * 1024, device="cuda", generator=g) * torch.logspace(-6, 3, 3 * 64 * 1024, device="cuda")
-    pl = ops.split_bf16x3(buf)
-    back = sum(pl[i].view(torch.bfloat16).double() for i in range(3))
-    assert torch.equal(back.float(), buf) and torch.equal(back, buf.double())          # exact, not merely close
-    for (B, H, W, Cin, Cout, k, s, p, off) in [(8, 16, 16, 256, 512, 1, 1, 0, 0), (2, 38, 63, 256, 76, 1, 1, 0, 64),
-                                               (2, 19, 23, 64, 64, 3, 1, 1, 128), (1, 38, 63, 128, 256, 1, 2, 0, 4096)]:
-        n = Cout * k * k * Cin
-        w = buf[off:off + n].view(Cout, k, k, Cin) * 0.05
-        flat = buf.clone(); flat[off:off + n] = w.reshape(-1)
-        planes = ops.split_bf16x3(flat)                                                # planes of a bigger buffer: stride = its numel
+    for rows, K in [(76, 1024), (512, 256), (64, 576), (33, 48)]:
+        w = torch.randn(rows, K, device="cuda", generator=g) * torch.logspace(-6, 3, K, device="cuda")
+        pl = _unpack_planes(ops.pack_weights(w), rows, K)
+        back = pl.sum(0)
+        assert torch.equal(back[:rows], w.double()) and not bool(back[rows:].any())     # exact, not merely close; pad rows are zero
+        assert torch.equal(pl[0][:rows].float(), w.bfloat16().float())                  # plane 0 = bf16(w), round to nearest even
+    cases = [(64, 32, 32, 512, 256, 1, 1, 0),    # 128x128 tiles
+             (2, 19, 23, 64, 64, 3, 1, 1),       # 128x64 tiles, narrow direct 3x3
+             (2, 38, 63, 256, 76, 1, 1, 0),      # 64x64 tiles (K <= 256), Cout = 76: the last 32-row block is zero-padded
+             (1, 38, 63, 128, 256, 1, 2, 0),     # stride-2 1x1
+             (2, 38, 63, 1024, 76, 1, 1, 0)]     # the fused RPN heads
+    for ver, (B, H, W, Cin, Cout, k, s, p) in enumerate(cases):
+        w = torch.randn(Cout, k, k, Cin, device="cuda", generator=g) / (Cin * k * k) ** 0.5
         x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
         sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
-        want = ops.conv_forward(x, flat[off:off + n].view(Cout, k, k, Cin), s, p, scale=sc, relu=True, math=ops.MATH_BF16X6)
-        got = ops.conv_forward(x, flat[off:off + n].view(Cout, k, k, Cin), s, p, scale=sc, relu=True, math=ops.MATH_BF16X6,
-                               w_planes=planes[0, off:off + n], w_plane_stride=planes.shape[1])
+        want = ops.conv_forward(x, w, s, p, scale=sc, relu=True, math=ops.MATH_BF16X6)                       # weight tile split per workgroup
+        got = ops.conv_forward(x, w, s, p, scale=sc, relu=True, math=ops.MATH_BF16X6, w_planes=ops.pack_weights(w))
         assert torch.equal(got, want)
-        # dgrad copy + its planes from one launch
-        wt_planes = torch.empty((3, n), dtype=torch.int16, device="cuda")
-        wsrc = flat[off:off + n].view(Cout, k, k, Cin).contiguous()
-        wt = ops.conv_dgrad_weights(wsrc, sc, planes=wt_planes)
-        assert torch.equal(wt, ops.conv_dgrad_weights(wsrc, sc))
-        assert torch.equal(sum(wt_planes[i].view(torch.bfloat16).double() for i in range(3)).float().view_as(wt), wt)
-        if s == 1:
+        assert torch.equal(ops.conv_forward(x, w, s, p, scale=sc, relu=True, math=ops.MATH_BF16X6, w_version=100 + ver), want)   # library cache
+        assert torch.equal(ops.conv_forward(x, w, s, p, scale=sc, relu=True, math=ops.MATH_BF16X6, w_version=100 + ver), want)   # ... hit
+        if s == 1 and Cout % 32 == 0:
+            wt = ops.conv_dgrad_weights(w, sc)
             gy = torch.randn(B, H, W, Cout, device="cuda", generator=g)
             a = ops.conv_forward(gy, wt, 1, k - 1 - p, math=ops.MATH_BF16X6)
-            b = ops.conv_forward(gy, wt, 1, k - 1 - p, math=ops.MATH_BF16X6, w_planes=wt_planes)
-            assert torch.equal(a, b)
+            assert torch.equal(a, ops.conv_forward(gy, wt, 1, k - 1 - p, math=ops.MATH_BF16X6, w_planes=ops.pack_weights(wt)))
+            assert torch.equal(a, ops.conv_forward(gy, wt, 1, k - 1 - p, math=ops.MATH_BF16X6, w_version=200 + ver))
+    # an out-of-domain weight is caught when it is packed (the weights-direct kernel does not inspect weights again)
+    assert ops.x6_range_flags() == 0
+    w = torch.randn(64, 1, 1, 64, device="cuda", generator=g)
+    w[3, 0, 0, 5] = 2.0 ** -120
+    ops.pack_weights(w)
+    assert ops.x6_range_flags() & ops.X6_FLAG_TINY
 
 
-def test_bf16x6_optional_loops_pass_the_same_parity_tests():
-    """The opt-in variants of the bf16x6 arithmetic (ABR_X6_V2=1: double-buffered k-16 loop; ABR_X6_WEIGHT_PLANES=1: weights split
-    once per step in the model) are selected by process-wide environment switches: run their parity tests in child processes."""
+def test_bf16x6_in_kernel_split_fallback_passes_the_same_parity_tests():
+    """ABR_X6_WEIGHTS_DIRECT=0 keeps every bf16x6 conv on the kernel that splits the weight tile in each workgroup (what runs whenever a
+    caller passes neither planes nor a w_version).  It is a process-wide switch: run the step-level parity test in a child process."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env_extra, target in (({"ABR_X6_V2": "1"}, "tests/test_gpu_ops.py::test_conv_bf16x6_mode_is_fp32_accurate"),
-                              ({"ABR_X6_WEIGHT_PLANES": "1"}, "tests/test_gpu_e2e.py::test_train_step_losses_and_grads_vs_oracle")):
-        r = subprocess.run([sys.executable, "-m", "pytest", target, "-x", "-q", "-p", "no:cacheprovider"], cwd=root,
-                           env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_e2e.py::test_train_step_losses_and_grads_vs_oracle", "-x", "-q", "-p",
+                        "no:cacheprovider", "-k", "15-5-bf16x6"], cwd=root, env=dict(os.environ, ABR_X6_WEIGHTS_DIRECT="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_winograd_weight_cache_follows_w_version():
