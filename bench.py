@@ -154,7 +154,10 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0, serialised=None):
         r["whole_step"]["peak"] = peak_step
         r["whole_step"]["executed_frac"] = round(exec_flops_step / step_s / 1e12 / peak_step, 4)
         r["whole_step"]["algorithmic_frac"] = round(alg_flops_step / step_s / 1e12 / peak_step, 4)
-    if a.math == "bf16x6":   # for orientation: the same flops against what the fp32 matrix pipe (round 1's arithmetic) could ever deliver
+    if not getattr(a, "standard_geometry", True):   # the 1304 GFLOP / image count is the 600x1000 step's
+        for k in ("algorithmic_gflop", "algorithmic_tflops", "algorithmic_frac"):
+            r["whole_step"].pop(k, None)
+    elif a.math == "bf16x6":   # for orientation: the same flops against what the fp32 matrix pipe (round 1's arithmetic) could ever deliver
         r["whole_step"]["vs_fp32_mfma_peak"] = {"peak": PEAK_FP32_MFMA_TFLOPS, "executed_frac": round(exec_flops_step / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                                 "algorithmic_frac": round(alg_flops_step / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
     r["note"] = ("per-launch durations inside the step are stretched by the kernels of the other HIP streams sharing the CUs (3 streams in the "
@@ -254,6 +257,14 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=4)
     ap.add_argument("--task", choices=sorted(TASKS), default="15-5",
                     help="15-5 = BASELINE configs[2] (the metric's configuration); 10-10 with --batch-per-gpu 2 = configs[3]; 10-5 = configs[4]")
+    ap.add_argument("--image-size", default="600x1000",
+                    help="HxW of the synthetic images.  600x1000 = the VOC-shaped geometry BASELINE.json's metric is quoted on (the default and the only "
+                         "reported value); 800x1333 = the reference's own INPUT defaults (config/defaults.py:44-46: no voc YAML overrides them), an "
+                         "informational line that shows the kernels are not tuned to one geometry (C4 50x84, 63 000 anchors)")
+    ap.add_argument("--mosaic-squares", action="store_true",
+                    help="BASELINE.json configs[4]'s shape variety: every second step runs a batch of SQUARE images (min(H,W) on a side), as the "
+                         "mosaic canvases of the box-rehearsal data path are (voc_abr.py:712-714: mean(w,h)^2 -> ~600x600 after the resize); aspect "
+                         "grouping keeps each batch homogeneous (data/build.py:93-100).  Informational (the metric's batches are all 600x1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the short informational re-run on the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -269,6 +280,9 @@ def main():
     ap.add_argument("--no-serialised-leg", action="store_true", help="skip the short serialised-stream re-run behind the timed region (roofline.serialised)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher self-test: start the ranks, form the process group (gloo when there is no GPU), all-reduce a 1 per rank, print the count")
+    ap.add_argument("--inject-failure", type=int, default=-1,
+                    help="(tests of the launcher only) with --rendezvous-only: this rank raises right after the rendezvous while the others enter a "
+                         "second collective -- launch_ranks must end them and return non-zero")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus))
@@ -289,6 +303,10 @@ def main():
             dist.all_reduce(one)
         if int(os.environ.get("RANK", "0")) == 0:
             print(json.dumps({"rendezvous_only": True, "ranks": int(one.item()), "backend": ("rccl" if gpu else "gloo") if world > 1 else None}), flush=True)
+        if a.inject_failure >= 0 and world > 1:
+            if int(os.environ.get("RANK", "0")) == a.inject_failure:
+                raise RuntimeError("injected failure on rank {} after the rendezvous".format(a.inject_failure))
+            dist.all_reduce(one)   # the survivors wait here for a rank that is gone: only the launcher can end them
         if world > 1:
             dist.destroy_process_group()
         return
@@ -319,8 +337,17 @@ def main():
     model_source, model_target = build_models(cfg_s, cfg_t, seed=0)       # same seed on every rank = broadcast weights
     optimizer = make_optimizer(cfg_t, model_target)
     scheduler = make_lr_scheduler(cfg_t, optimizer)
-    images, targets = synthetic_batch(B, 600, 1000, seed=42 + rank,        # each rank its own shard of the global batch
+    IH, IW = (int(v) for v in a.image_size.lower().split("x"))
+    images, targets = synthetic_batch(B, IH, IW, seed=42 + rank,           # each rank its own shard of the global batch
                                       label_range=(n_old_cls + 1, n_old_cls + n_new_cls + 1))
+    batches = [(images, targets)]
+    if a.mosaic_squares:
+        side = min(IH, IW)
+        batches.append(synthetic_batch(B, side, side, seed=1042 + rank, label_range=(n_old_cls + 1, n_old_cls + n_new_cls + 1)))
+    standard = (IH, IW) == (600, 1000) and not a.mosaic_squares
+    a.standard_geometry = standard
+    if not standard:
+        a.no_cpu_baseline = a.no_alt_math = True   # those legs describe the metric's own geometry
 
     def barrier():
         if world > 1:
@@ -329,8 +356,12 @@ def main():
 
     if a.fold_streams:
         optimizer._folded_saved = fold_streams(True, optimizer)
-    for _ in range(a.warmup):
-        train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t, next_images=images)
+    def batch_of(i):
+        return batches[i % len(batches)]
+
+    for i in range(a.warmup):
+        im, tg = batch_of(i)
+        train_step(model_source, model_target, im, tg, optimizer, scheduler, cfg_t, next_images=batch_of(i + 1)[0])
 
     time_kernels = (rank == 0) and not a.no_kernel_timing
     barrier()
@@ -344,10 +375,11 @@ def main():
         _lib.check(_lib.lib().abr_prof_begin(), "prof_begin")
     t0 = time.perf_counter()
     last = None
-    for _ in range(a.steps):
+    for i in range(a.steps):
         if time_kernels:
             _lib.lib().abr_prof_step_begin()
-        last = train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t, next_images=images)
+        im, tg = batch_of(a.warmup + i)
+        last = train_step(model_source, model_target, im, tg, optimizer, scheduler, cfg_t, next_images=batch_of(a.warmup + i + 1)[0])
     barrier()
     elapsed = time.perf_counter() - t0
     prof = serialised = None
@@ -403,13 +435,15 @@ def main():
             if a.math == "bf16x6" else "bf16 MFMA operands / f32 accumulate / f32 tensors ({}); f32 elsewhere".format(
                 "backbone layer1-3" if a.math == "bf16" else "backbone, RPN head, layer4"),
             "config": {"workload": "BASELINE.json {}: task {} ABR step, --feat {} --dist_type {} (alpha {}, beta {}, gamma {}), "
-                                   "R50-C4, 600x1000, 512 RoIs/img + 64 distillation RoIs/img, source+target models, gradient all-reduce + SGD step".format(
+                                   "R50-C4, {}, 512 RoIs/img + 64 distillation RoIs/img, source+target models, gradient all-reduce + SGD step".format(
                                        {"15-5": "configs[2]", "10-10": "configs[3]", "10-5": "configs[4]"}.get(a.task, "(extra task)"), a.task, feat,
-                                       dist_type, alpha, beta, gamma),
+                                       dist_type, alpha, beta, gamma, "{}x{}".format(IH, IW) + (" alternating with {0}x{0} (mosaic-shaped) batches".format(min(IH, IW))
+                                                                                                 if a.mosaic_squares else "")),
+                       "informational": None if standard else "not the metric's geometry (BASELINE.json: 600x1000 batches): GFLOP / roofline figures per image do not apply",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "math": a.math,
                        "rccl_ranks": rccl_ranks, "collective": "RCCL all-reduce of the flat gradient, 3 buckets, 2 under backward" if world > 1 else None,
                        "gradient_exchange": optimizer.reducer.describe() if world > 1 else None,
-                       "gflop_per_img_algorithmic": GFLOP_PER_IMG_ARD},
+                       "gflop_per_img_algorithmic": GFLOP_PER_IMG_ARD if standard else None},
             "final_losses": {k: round(float(v.detach()), 5) for k, v in loss_dict.items()},
             "math": a.math,
         }

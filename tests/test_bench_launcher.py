@@ -35,3 +35,35 @@ def test_bench_under_an_outer_launcher_does_not_spawn():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["ranks"] == 1 and d["backend"] is None
+
+
+def _run_bench(args, timeout):
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    return r, time.time() - t0
+
+
+def test_bench_launcher_forms_an_8_rank_group():
+    """`python bench.py --gpus 8` without an outer launcher (what the driver's 8-GPU run may do): eight fresh rank processes, one
+    rendezvous on 127.0.0.1, every rank counted (gloo here; RCCL when eight GPUs are visible)."""
+    import json
+    r, _ = _run_bench(["--gpus", "8", "--rendezvous-only"], 600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"rendezvous_only": True, "ranks": 8, "backend": "gloo"}
+
+
+def test_bench_launcher_reaps_siblings_when_a_rank_dies_after_rendezvous():
+    """A rank that raises after the process group exists leaves the others inside a collective: launch_ranks must notice the dead child,
+    end the survivors and return non-zero, instead of waiting with them (tools/train_incremental.py:406-411 relies on the launcher too)."""
+    r, took = _run_bench(["--gpus", "3", "--rendezvous-only", "--inject-failure", "1"], 300)
+    assert r.returncode != 0
+    assert "injected failure on rank 1" in r.stderr
+    assert took < 120, took   # ended by the launcher, not by a collective timeout (gloo's default is 30 minutes)
+    import subprocess
+    left = subprocess.run(["pgrep", "-f", "bench.py --gpus 3 --rendezvous-only --inject-failure"], capture_output=True, text=True).stdout.split()
+    assert not left, left   # no orphaned rank processes

@@ -175,3 +175,4 @@ def test_bucketed_overlapped_allreduce_equals_one_allreduce():
     for rank, results in got:
         for r in results:
             assert torch.equal(r, want)
+

@@ -40,6 +40,17 @@ FULL_CONVS = [
     (2048, 512, 4, 4, 2048, 1, 1, 0),    # conv3
     (2048, 1024, 7, 7, 2048, 1, 2, 0),   # stride-2 projection
 ]
+# the reference's own INPUT defaults are 800 x 1333 (config/defaults.py:44-46; no configs/voc YAML overrides them): stem 400x667 -> layer1
+# 200x334 -> layer2 100x167 -> layer3 / C4 50x84 (63 000 anchors).  None of these extents is a multiple of the 128-row GEMM tile or of the
+# 4x4 Winograd tile in both directions: the same kernels, other tail cases.
+SCALE_CONVS = [
+    (2, 4, 800, 1333, 64, 7, 2, 3),      # stem
+    (2, 64, 200, 334, 256, 1, 1, 0),     # layer1 expand (M = 133 600)
+    (2, 128, 100, 167, 128, 3, 1, 1),    # layer2 3x3: Winograd, 167 = 41 tiles + 3 columns
+    (2, 256, 200, 334, 512, 1, 2, 0),    # layer2 stride-2 projection
+    (2, 256, 50, 84, 256, 3, 1, 1),      # layer3 3x3: Winograd, 50 = 12 tiles + 2 rows
+    (2, 1024, 50, 84, 1024, 3, 1, 1),    # RPN 3x3
+]
 MATHS = ["bf16x6", "f32"]   # bf16x6 = the default arithmetic, the one bench.py reports; f32 = the fp32 MFMA kernels
 
 
@@ -57,7 +68,7 @@ def _case_tensors(case):
 
 
 @pytest.mark.parametrize("math", MATHS)
-@pytest.mark.parametrize("case", FULL_CONVS)
+@pytest.mark.parametrize("case", FULL_CONVS + SCALE_CONVS)
 def test_full_size_conv_linearity_and_sampled_dot_products(case, math):
     from abr_iod_amd import ops
     Bc, Cin, Hc, Wc, Cout, k, s, p = case
@@ -86,7 +97,7 @@ def test_full_size_conv_linearity_and_sampled_dot_products(case, math):
 
 
 @pytest.mark.parametrize("math", MATHS)
-@pytest.mark.parametrize("case", FULL_CONVS[1:])   # the stem is frozen (FREEZE_CONV_BODY_AT = 2) and has no backward
+@pytest.mark.parametrize("case", FULL_CONVS[1:] + SCALE_CONVS[2:])   # the stem is frozen (FREEZE_CONV_BODY_AT = 2) and has no backward
 def test_full_size_conv_backward_sampled_vs_float64(case, math):
     """dgrad and wgrad of the BASELINE layer shapes, as Bottleneck.bwd issues them (resnet.py here; the reference: cuDNN dgrad / wgrad
     behind resnet.py:261-323): the input gradient = the forward kernel on the flipped, FrozenBN-scaled weight copy (a scatter to the
@@ -269,3 +280,54 @@ def test_full_size_ard_term_vanishes_at_step0(full):
     assert 0.0 < d < 1.0 and np.isfinite(float(total.detach()))
     for p in ms.parameters():   # the source model is frozen and runs under no_grad (train_incremental.py:80-86)
         assert p.grad is None or not bool(p.grad.any())
+
+
+def test_reference_scale_800x1333_step():
+    """The reference trains at INPUT.MIN_SIZE_TRAIN 800 / MAX_SIZE_TRAIN 1333 unless a YAML says otherwise, and no configs/voc YAML does
+    (config/defaults.py:44-46): one ARD + ID step of the full-width model at that geometry -- C4 map 50x84, 63 000 anchors per image,
+    12000 -> 2000 proposals, 512 + 64 RoIs per image.  Checks the geometry, the selection invariants, finite losses that equal a second
+    run bit for bit in their index work, and that the update moves what it should."""
+    import random
+    from abr_iod_amd import ops
+    from abr_iod_amd.engine import train_step
+    from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
+    from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer
+    from abr_iod_amd.structures.image_list import to_image_list
+    Hs, Ws, Bs = 800, 1333, 2
+    cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0)
+    images, targets = synthetic_batch(Bs, Hs, Ws, seed=11)
+    ms, mt = build_models(cfg_s, cfg_t, seed=0)
+    il = to_image_list(images)
+    with torch.no_grad():
+        feats, _ = mt.backbone(il.tensors)
+        assert tuple(feats[0].shape) == (Bs, 1024, 50, 84)
+        (props, _), anchors, (obj, reg) = mt.rpn(il, feats, targets)
+    assert anchors[0][0].bbox.shape[0] == 50 * 84 * 15 == 63000
+    assert tuple(obj[0].shape) == (Bs, 15, 50, 84) and tuple(reg[0].shape) == (Bs, 60, 50, 84)
+    for bl, tg in zip(props, targets):
+        n_gt = len(tg)
+        assert n_gt < len(bl) <= cfg_t.MODEL.RPN.POST_NMS_TOP_N_TRAIN + n_gt
+        bb = bl.bbox[:-n_gt].double()
+        assert bool((bb[:, 0] >= 0).all()) and bool((bb[:, 1] >= 0).all()) and bool((bb[:, 2] <= Ws - 1).all()) and bool((bb[:, 3] <= Hs - 1).all())
+        iou = _iou(bb, bb); iou.fill_diagonal_(0)
+        assert iou.max().item() <= cfg_t.MODEL.RPN.NMS_THRESH + 1e-9
+    runs = []
+    for _ in range(2):
+        ms, mt = build_models(cfg_s, cfg_t, seed=0)
+        ops._sample_calls[0] = 0
+        random.seed(0)
+        opt = make_optimizer(cfg_t, mt); sch = make_lr_scheduler(cfg_t, opt)
+        before = mt.flat.params.clone()
+        ld, total = train_step(ms, mt, images, targets, opt, sch, cfg_t)
+        torch.cuda.synchronize()
+        runs.append(({k: float(v.detach()) for k, v in ld.items()}, float(total.detach()), before, mt))
+    ld, total, before, mt = runs[0]
+    assert set(ld) == {"loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg", "distillation_loss"}
+    assert all(np.isfinite(v) for v in ld.values()) and np.isfinite(total)
+    for k, v in ld.items():
+        assert abs(runs[1][0][k] - v) <= 1e-6 * max(abs(v), 1e-3), k
+    ev = mt.roi_heads.box.loss_evaluator
+    for inds, pr in zip(ev.last_sampled_inds, ev._proposals):
+        assert inds.numel() == cfg_t.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE == len(pr)
+    assert torch.isfinite(mt.flat.params).all() and not torch.equal(mt.flat.params, before)
+    assert ops.x6_range_flags() == 0
