@@ -603,17 +603,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const f
                 G[0][pl] = *reinterpret_cast<const bf16x8*>(&g0); G[1][pl] = *reinterpret_cast<const bf16x8*>(&g1);
                 A[0][pl] = *reinterpret_cast<const bf16x8*>(&a0); A[1][pl] = *reinterpret_cast<const bf16x8*>(&a1);
             }
+            // the six products of a step (smallest terms first for every accumulator) interleaved over the four accumulators: no MFMA
+            // waits on the result of the one issued just before it (as in conv_igemm_x6w_kernel)
+            constexpr int pg[6] = {2, 0, 1, 1, 0, 0}, pa[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int t = 0; t < 6; t++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) {   // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][2], A[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][0], A[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][1], A[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][1], A[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][0], A[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][0], A[j][0], acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][pg[t]], A[j][pa[t]], acc[i][j], 0, 0, 0);
         }
     };
     if (mt0 < mt1) {

@@ -445,8 +445,13 @@ def main():
                        "gradient_exchange": optimizer.reducer.describe() if world > 1 else None,
                        "gflop_per_img_algorithmic": GFLOP_PER_IMG_ARD if standard else None},
             "final_losses": {k: round(float(v.detach()), 5) for k, v in loss_dict.items()},
+            "conv_math_at_end": getattr(model_target, "conv_math", None),   # "f32" here = the range guard took the run off the bf16x6 kernels
             "math": a.math,
         }
+        if a.math == "bf16x6":
+            from abr_iod_amd import ops as _o
+            fl = _o.x6_range_flags(reset=False)
+            out["x6_range_guard"] = {"flags": fl, "tiny_operands_seen": bool(fl & _o.X6_FLAG_TINY), "non_finite_operands_seen": bool(fl & _o.X6_FLAG_NONFINITE)}
         if prof:
             out["roofline"] = roofline(prof, prof_totals, a, elapsed, event_overhead_ms, serialised)
         if world == 1 and not a.no_cpu_baseline:

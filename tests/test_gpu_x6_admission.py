@@ -8,8 +8,11 @@ Domain.  The split x = x0 + x1 + x2 is exact for x = 0 and for finite 2^-110 <= 
     must stay within 2x the fp32 MFMA kernel's on the same data (the two are statistically the same size: x6 is the smaller one on
     most cases, the larger by up to 1.7x under extreme exponent spread) and below 32 ulp, and the range guard must stay silent;
   * OUTSIDE it -- non-zero magnitudes below 2^-110 (incl. fp32 subnormals), inf, nan -- the hardware range guard must raise its
-    flag (every operand element is inspected once per GEMM), non-finite operands must make exactly the outputs non-finite that the
-    fp32 kernel makes non-finite, and the trainer must switch the models to the fp32 MFMA kernels.
+    flag (every operand element is inspected once per GEMM); non-finite operands must make exactly the outputs non-finite that the
+    fp32 kernel makes non-finite, and the trainer must switch the models to the fp32 MFMA kernels; tiny operands sprinkled among
+    ordinary ones (what real training produces: the input gradients of padded image regions) must leave the result within the SAME
+    bound as inside the domain -- each costs an absolute error below 2^-119 of the other operand -- which is why the trainer only logs
+    them unless ABR_X6_STRICT=1.
 Covered contractions: 1x1 conv forward (= plain GEMM), 3x3 through the Winograd domain, the input gradient, the weight gradient."""
 import pytest
 import torch
@@ -150,6 +153,43 @@ def test_out_of_domain_magnitudes_raise_the_flag(which):
         assert ops.x6_range_flags(reset=True) == ops.X6_FLAG_TINY
 
 
+@pytest.mark.parametrize("frac", [0.01, 0.5])
+def test_tiny_operands_among_ordinary_ones_cost_nothing_measurable(frac):
+    """Out-of-domain magnitudes (2^-112 ... fp32 subnormals) mixed into ordinary operands, in both operands and in every role: the guard
+    reports them, and the error against float64 -- relative to the reduction's natural scale sum|x||w| -- stays within the in-domain
+    bound (2 x the fp32 kernel's, 8 ulp).  The all-tiny reduction (the only case with bf16-like RELATIVE accuracy) is bounded absolutely."""
+    from abr_iod_amd import ops
+    rn, ru = _gen(7)
+    x, w = rn(M, K), rn(N, K)
+    tiny_x = ru(M, K) < frac
+    x[tiny_x] = (torch.sign(rn(M, K)) * (0.5 + ru(M, K)) * torch.exp2(-112 - 30 * ru(M, K)))[tiny_x]      # 2^-112 ... 2^-142 (subnormal)
+    tiny_w = ru(N, K) < frac / 4
+    w[tiny_w] = (torch.sign(rn(N, K)) * (0.5 + ru(N, K)) * 2.0 ** -115)[tiny_w]
+    ops.x6_range_flags(reset=True)
+    y64 = x.double() @ w.double().t()
+    scale = x.double().abs() @ w.double().abs().t()
+    e32 = _rel_err(_gemm(x, w, ops.MATH_F32), y64, scale)
+    e6 = _rel_err(_gemm(x, w, ops.MATH_BF16X6), y64, scale)
+    assert ops.x6_range_flags(reset=True) == ops.X6_FLAG_TINY
+    print(f"{frac:.0%} tiny elements: forward f32 {e32 / EPS:.1f} ulp, x6 {e6 / EPS:.1f} ulp")
+    assert e6 <= max(2.0 * e32, 8 * EPS), (e6, e32)
+    G, X = w.t()[:M].contiguous(), x[:, :N].contiguous()
+    d64 = G.double().t() @ X.double()
+    dscale = G.double().abs().t() @ X.double().abs()
+    w32 = _rel_err(_wgrad(X, G, ops.MATH_F32), d64, dscale)
+    w6 = _rel_err(_wgrad(X, G, ops.MATH_BF16X6), d64, dscale)
+    assert ops.x6_range_flags(reset=True) == ops.X6_FLAG_TINY
+    assert w6 <= max(2.0 * w32, 8 * EPS), (w6, w32)
+    # a reduction made of tiny operands ONLY: bf16-like relative accuracy on a result that is itself ~2^-115 of the operand scale --
+    # bounded absolutely by 2^-9 |x| |w| per product
+    xt = torch.sign(rn(M, K)) * (0.5 + ru(M, K)) * 2.0 ** -115
+    wn = rn(N, K)
+    yt = _gemm(xt, wn, ops.MATH_BF16X6).double()
+    bound = (2.0 ** -9) * (xt.double().abs() @ wn.double().abs().t())
+    assert bool(((yt - xt.double() @ wn.double().t()).abs() <= bound).all())
+    ops.x6_range_flags(reset=True)
+
+
 def test_non_finite_operands_propagate_and_raise_the_flag():
     from abr_iod_amd import ops
     rn, _ = _gen(3)
@@ -169,11 +209,15 @@ def test_non_finite_operands_propagate_and_raise_the_flag():
     assert (~torch.isfinite(y6)).any(dim=0).nonzero().flatten().tolist() == [5]
 
 
-def test_trainer_falls_back_to_fp32_when_the_guard_trips():
+@pytest.mark.parametrize("trip", ["nonfinite", "tiny-strict", "tiny"])
+def test_trainer_falls_back_to_fp32_when_the_guard_trips(trip, monkeypatch):
+    """inf / nan operands: both models leave the bf16x6 arithmetic.  Tiny operands: logged once, no switch (see _x6_guard for why) --
+    unless ABR_X6_STRICT=1."""
     import logging
     import os
     from abr_iod_amd import ops
     from abr_iod_amd.engine import trainer
+    monkeypatch.setattr(trainer, "X6_STRICT", trip == "tiny-strict")
     from abr_iod_amd.engine.synthetic import build_models, make_cfgs
     tiny = ["MODEL.RESNETS.STEM_OUT_CHANNELS", 16, "MODEL.RESNETS.RES2_OUT_CHANNELS", 32, "MODEL.RESNETS.WIDTH_PER_GROUP", 8,
             "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 128]
@@ -192,13 +236,24 @@ def test_trainer_falls_back_to_fp32_when_the_guard_trips():
         torch.cuda.synchronize()
     assert mt.conv_math == "bf16x6"
     rn, _ = _gen(4)
-    _gemm(rn(M, K) * 2.0 ** -125, rn(N, K), ops.MATH_BF16X6)          # some bf16x6 kernel of the step sees an out-of-domain operand
+    bad = rn(M, K)
+    if trip == "nonfinite":
+        bad[5, 7] = float("inf")
+    else:
+        bad = bad * 2.0 ** -125
+    _gemm(bad, rn(N, K), ops.MATH_BF16X6)          # some bf16x6 kernel of the step sees an out-of-domain operand
     records = []
     h = logging.Handler(); h.emit = records.append
-    log = logging.getLogger("x6test"); log.addHandler(h)
-    for _ in range(3):                       # the poll is asynchronous: the flag is seen one or two steps later
+    log = logging.getLogger("x6test." + trip); log.addHandler(h); log.setLevel(logging.INFO)
+    for _ in range(4):                       # the poll is asynchronous: the flag is seen one or two steps later
         trainer._x6_guard(ms, mt, log)
         torch.cuda.synchronize()
+    if trip == "tiny":
+        assert mt.conv_math == ms.conv_math == "bf16x6"
+        assert all(m.math == ops.MATH_BF16X6 for m in mt.modules() if hasattr(m, "math"))
+        assert len(records) == 1 and "below 2^-110" in records[0].getMessage() and records[0].levelno == logging.INFO   # once, not per step
+        ops.x6_range_flags(reset=True)
+        return
     assert mt.conv_math == ms.conv_math == "f32"
     assert all(m.math == ops.MATH_F32 for m in mt.modules() if hasattr(m, "math"))
     assert len(records) == 1 and "range guard tripped" in records[0].getMessage()
