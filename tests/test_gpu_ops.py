@@ -718,16 +718,19 @@ def test_bf16x6_packed_weight_planes_are_exact_and_give_identical_results():
              (2, 19, 23, 64, 64, 3, 1, 1),       # 128x64 tiles, narrow direct 3x3
              (2, 38, 63, 256, 76, 1, 1, 0),      # 64x64 tiles (K <= 256), Cout = 76: the last 32-row block is zero-padded
              (1, 38, 63, 128, 256, 1, 2, 0),     # stride-2 1x1
-             (2, 38, 63, 1024, 76, 1, 1, 0)]     # the fused RPN heads
+             (2, 38, 63, 1024, 76, 1, 1, 0),     # the fused RPN heads
+             (4, 150, 250, 64, 256, 1, 1, 0)]    # layer1 expand at the benchmark's size (residual + ReLU epilogue)
     for ver, (B, H, W, Cin, Cout, k, s, p) in enumerate(cases):
         w = torch.randn(Cout, k, k, Cin, device="cuda", generator=g) / (Cin * k * k) ** 0.5
         x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
         sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
-        want = ops.conv_forward(x, w, s, p, scale=sc, relu=True, math=ops.MATH_BF16X6)                       # weight tile split per workgroup
-        got = ops.conv_forward(x, w, s, p, scale=sc, relu=True, math=ops.MATH_BF16X6, w_planes=ops.pack_weights(w))
+        res = torch.randn(B, (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1, Cout, device="cuda", generator=g) if k == 1 and s == 1 else None
+        kw = dict(scale=sc, relu=True, residual=res, math=ops.MATH_BF16X6)
+        want = ops.conv_forward(x, w, s, p, **kw)                                                  # weight tile split per workgroup
+        got = ops.conv_forward(x, w, s, p, w_planes=ops.pack_weights(w), **kw)
         assert torch.equal(got, want)
-        assert torch.equal(ops.conv_forward(x, w, s, p, scale=sc, relu=True, math=ops.MATH_BF16X6, w_version=100 + ver), want)   # library cache
-        assert torch.equal(ops.conv_forward(x, w, s, p, scale=sc, relu=True, math=ops.MATH_BF16X6, w_version=100 + ver), want)   # ... hit
+        assert torch.equal(ops.conv_forward(x, w, s, p, w_version=100 + ver, **kw), want)         # library cache
+        assert torch.equal(ops.conv_forward(x, w, s, p, w_version=100 + ver, **kw), want)         # ... hit
         if s == 1 and Cout % 32 == 0:
             wt = ops.conv_dgrad_weights(w, sc)
             gy = torch.randn(B, H, W, Cout, device="cuda", generator=g)

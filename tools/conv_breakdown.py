@@ -16,6 +16,7 @@ from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batc
 from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer  # noqa: E402
 
 REC = collections.OrderedDict()
+BYTES = {}
 ON = [False]
 
 
@@ -51,12 +52,17 @@ def _fwd_key(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, mask=N
     Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
     M = B * Ho * Wo
     tag = "dgrad" if mask is not None or out is not None or out_hw is not None else "fwd"
+    # algorithmic HBM bytes of the call: the input pixels the conv reads (a stride-2 1x1 reads a quarter), weights, output, + the residual / mask tensors
+    n_out = M * Cout * (out_stride[0] * out_stride[1] if out_hw is not None else 1)
+    nbytes = 4.0 * (x.numel() / (stride * stride if R == 1 else 1) + w.numel() + n_out + (M * Cout if residual is not None else 0) + (M * Cout if mask is not None else 0))
+    BYTES[(tag, M, Cout, R * S * Cin, f"{R}x{S}s{stride} {H}x{W}")] = nbytes
     return (tag, M, Cout, R * S * Cin, f"{R}x{S}s{stride} {H}x{W}"), 2.0 * M * Cout * R * S * Cin
 
 
 def _wg_key(x, gy, dw, stride=1, pad=0, scale=None, *_a, **_):
     Cout, R, S, Cin = dw.shape
     M = gy.numel() // Cout
+    BYTES[("wgrad", M, Cout, R * S * Cin, f"{R}x{S}s{stride} {x.shape[1]}x{x.shape[2]}")] = 4.0 * (x.numel() / (stride * stride if R == 1 else 1) + gy.numel() + dw.numel())
     return ("wgrad", M, Cout, R * S * Cin, f"{R}x{S}s{stride} {x.shape[1]}x{x.shape[2]}"), 2.0 * M * Cout * R * S * Cin
 
 
@@ -98,9 +104,11 @@ def main():
     rows.sort(reverse=True)
     tot = sum(r[3] for r in rows)
     print(f"total conv ms/step {tot:.2f}; lost vs {a.target_tf:.0f} TF: {sum(r[0] for r in rows):.2f} ms")
-    print(f"{'lost ms':>8s} {'ms':>7s} {'calls':>5s} {'TF/s':>6s}  kind   M       N     K     geometry")
+    print("(TF/s on ALGORITHMIC flops: a Winograd 3x3 executes 1/4 of them; TB/s = algorithmic HBM bytes of the call -- input, weights, output, residual / mask -- / its time)")
+    print(f"{'lost ms':>8s} {'ms':>7s} {'calls':>5s} {'TF/s':>6s} {'TB/s':>5s}  kind   M       N     K     geometry")
     for lost, key, cnt, t, tf in rows:
-        print(f"{lost:8.3f} {t:7.3f} {cnt:5.0f} {tf:6.1f}  {key[1]:6s} {key[2]:7d} {key[3]:5d} {key[4]:5d} {key[5]}")
+        tbs = BYTES.get(key[1:], 0.0) * cnt / (t * 1e-3) / 1e12 if t > 0 else 0.0
+        print(f"{lost:8.3f} {t:7.3f} {cnt:5.0f} {tf:6.1f} {tbs:5.2f}  {key[1]:6s} {key[2]:7d} {key[3]:5d} {key[4]:5d} {key[5]}")
 
 
 if __name__ == "__main__":
