@@ -60,7 +60,7 @@ _SIGS = {
     "abr_x6_range_flags_to_device": (_i, [_vp, _vp]),
     "abr_roi_align_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp]),
     "abr_roi_align_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "abr_roi_align_backward_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "abr_roi_align_backward_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _i]),
     "abr_roi_align_backward_gather": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "abr_roi_align_taps": (_i, [_vp, _i, _i, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     "abr_nms_workspace_bytes": (_i64, [_i, _i]),

@@ -434,13 +434,18 @@ __global__ __launch_bounds__(64) void roi_bwd_tables_kernel(const float* __restr
 
 constexpr int kXT = 8;  // pixels per workgroup along x
 
-// Pass 1b: for every feature row y, the ORDERED list of RoIs (of any image, ascending index) whose footprint covers that row.  The
-// gather workgroups of row y then walk ~K*h/H entries instead of all K rectangles (2048 scalar tests each at B = 4, most of them
-// misses).  Ordered block compaction (ballot + prefix), so the summation order of the gather stays the fixed ascending-RoI order.
-__global__ __launch_bounds__(256) void roi_row_lists_kernel(const RoiRect* __restrict__ rect, int K, int32_t* __restrict__ lists,
-                                                            int32_t* __restrict__ counts) {
+// Pass 1b: for every gather workgroup -- (image b, feature row y, x-tile of kXT pixels) -- the ORDERED list (ascending RoI index) of the RoIs
+// of image b whose footprint touches that row and that x-tile.  The gather then walks only RoIs it has work for: with one list per ROW
+// (round 2) a workgroup skipped ~12 of every 13 entries -- other images' RoIs, RoIs left or right of its 8 pixels -- at the price of two
+// dependent scalar loads each, and that walk, not the gradient traffic, was most of the kernel (2048 RoIs: 273 -> see DESIGN.md).
+// Ordered block compaction (ballot + prefix), so the summation order of the gather stays the fixed ascending-RoI order.
+__global__ __launch_bounds__(256) void roi_tile_lists_kernel(const RoiRect* __restrict__ rect, int K, int H, int n_xt, int32_t* __restrict__ lists,
+                                                             int32_t* __restrict__ counts) {
     __shared__ int wave_cnt[4];
-    const int y = blockIdx.x;
+    const int xt = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int x0 = xt * kXT;
+    const int lid = (b * H + y) * n_xt + xt;
+    int32_t* out = lists + (size_t)lid * K;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int base = 0;
     for (int r0 = 0; r0 < K; r0 += 256) {
@@ -448,18 +453,18 @@ __global__ __launch_bounds__(256) void roi_row_lists_kernel(const RoiRect* __res
         bool hit = false;
         if (r < K) {
             const RoiRect rc = rect[r];
-            hit = y >= rc.ymin && y <= rc.ymax && rc.xmax >= rc.xmin;
+            hit = rc.b == b && y >= rc.ymin && y <= rc.ymax && rc.xmax >= rc.xmin && rc.xmax >= x0 && rc.xmin < x0 + kXT;
         }
         const unsigned long long m = __ballot(hit);
         if (lane == 0) wave_cnt[wave] = __popcll(m);
         __syncthreads();
         int off = base;
         for (int w = 0; w < wave; w++) off += wave_cnt[w];
-        if (hit) lists[(size_t)y * K + off + __popcll(m & ((1ull << lane) - 1ull))] = r;
+        if (hit) out[off + __popcll(m & ((1ull << lane) - 1ull))] = r;
         base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
     }
-    if (threadIdx.x == 0) counts[y] = base;
+    if (threadIdx.x == 0) counts[lid] = base;
 }
 
 template <int PO>  // PO = compile-time bound on PHo and PWo (4 for bin_step=2 on 7x7, 8 otherwise)
@@ -478,12 +483,11 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
     float4 acc[kXT];
 #pragma unroll
     for (int i = 0; i < kXT; i++) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int32_t* row_list = lists + (size_t)y * K;
-    const int n_row = counts[y];
+    const int lid = (b * H + y) * (int)(gridDim.x / cchunks) + xt;
+    const int32_t* row_list = lists + (size_t)lid * K;
+    const int n_row = counts[lid];
     for (int e = 0; e < n_row; e++) {
-        const int r = row_list[e];   // wave-uniform: scalar loads
-        const RoiRect rc = rect[r];
-        if (rc.b != b || rc.xmax < x0 || rc.xmin >= x0 + kXT) continue;
+        const int r = row_list[e];   // wave-uniform: scalar load; every entry is a RoI of this image that touches this row and these pixels
         const float* wyr = Wy + (size_t)r * PHo * H + y;
         const float* g = grad + (size_t)r * PHo * PWo * C + cv * 4;
         float4 T[PO];
@@ -704,10 +708,11 @@ extern "C" int abr_roi_align_backward(const float* grad, const float* rois, int 
 
 static inline int round8(int w) { return (w + 7) / 8 * 8; }
 
-extern "C" int64_t abr_roi_align_backward_ws_bytes(int K, int H, int W, int PH, int PW, int bin_step) {
+extern "C" int64_t abr_roi_align_backward_ws_bytes(int K, int B, int H, int W, int PH, int PW, int bin_step) {
     const int PHo = (PH + bin_step - 1) / bin_step, PWo = (PW + bin_step - 1) / bin_step;
+    const int64_t n_lists = (int64_t)B * H * ((W + kXT - 1) / kXT);
     return (int64_t)K * ((int64_t)PHo * H + (int64_t)PWo * round8(W)) * 4 + (int64_t)K * sizeof(RoiRect) + 256 +
-           ((int64_t)H * K + H) * 4 + 64;   // + per-row RoI lists and their lengths
+           (n_lists * K + n_lists) * 4 + 64;   // + one RoI list (worst case K entries) and its length per gather workgroup
 }
 
 extern "C" int abr_roi_align_backward_gather(const float* grad, const float* rois, int K, int B, int C, int H, int W, float scale,
@@ -724,7 +729,7 @@ extern "C" int abr_roi_align_backward_gather(const float* grad, const float* roi
         return ABR_OK;
     }
     ABR_REQUIRE(grad && rois && workspace, "roi_align_backward_gather: null pointer");
-    ABR_REQUIRE(ws_bytes >= abr_roi_align_backward_ws_bytes(K, H, W, PH, PW, bin_step), "roi_align_backward_gather: workspace too small");
+    ABR_REQUIRE(ws_bytes >= abr_roi_align_backward_ws_bytes(K, B, H, W, PH, PW, bin_step), "roi_align_backward_gather: workspace too small");
     const int Wp = round8(W);
     float* Wy = (float*)workspace;
     float* Wx = Wy + (size_t)K * PHo * H;
@@ -733,10 +738,11 @@ extern "C" int abr_roi_align_backward_gather(const float* grad, const float* roi
     ABR_REQUIRE(lds <= 60 * 1024, "roi_align_backward_gather: feature map too large for the table builder");
     roi_bwd_tables_kernel<<<K, 64, lds, st>>>(rois, K, H, W, Wp, scale, PH, PW, sr, bin_step, PHo, PWo, Wy, Wx, rect);
     int32_t* lists = (int32_t*)(((uintptr_t)(rect + K) + 63) & ~(uintptr_t)63);
-    int32_t* counts = lists + (size_t)H * K;
-    roi_row_lists_kernel<<<H, 256, 0, st>>>(rect, K, lists, counts);
+    const int n_xt = (W + kXT - 1) / kXT;
+    int32_t* counts = lists + (size_t)B * H * n_xt * K;
+    roi_tile_lists_kernel<<<dim3((unsigned)n_xt, (unsigned)H, (unsigned)B), 256, 0, st>>>(rect, K, H, n_xt, lists, counts);
     const int cchunks = (C / 4 + 255) / 256;
-    dim3 grid((unsigned)(((W + kXT - 1) / kXT) * cchunks), (unsigned)H, (unsigned)B);
+    dim3 grid((unsigned)(n_xt * cchunks), (unsigned)H, (unsigned)B);
     const int rec = abr::prof_start(st, abr::PROF_ROIALIGN_BWD, 0.0);
     if (PHo <= 4 && PWo <= 4)
         roi_align_bwd_gather_kernel<4><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);

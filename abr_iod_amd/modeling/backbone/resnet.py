@@ -320,6 +320,11 @@ class ResNet(nn.Module):
 
     def forward(self, x, prefix=None):
         """`prefix`: the result of frozen_prefix() on the same input (the same values the inline path computes)"""
+        if torch.is_grad_enabled() and x.requires_grad and self.frozen_prefix is not None and not any(p.requires_grad for p in self.stem.parameters()):
+            # the frozen stem / stages run without autograd (their kernels have no backward): a gradient w.r.t. the IMAGE would silently be
+            # dropped.  The reference's training loop never asks for one (images come from the data loader); fail loudly instead.
+            raise NotImplementedError("gradients with respect to the input image are not implemented: the frozen stem (FREEZE_CONV_BODY_AT >= 1) "
+                                      "has no backward pass")
         outputs, backbone_features = [], []
         if prefix is None:
             prefix = self.frozen_prefix(x)

@@ -45,7 +45,7 @@ def roi_align_backward(grad, rois, spatial_scale, ph, pw, sampling_ratio, B, H, 
     if out is None:
         out = _empty((B, H, W, Ch), grad)
     if method == "gather" and Ch % 4 == 0 and -(-ph // bin_step) <= 8 and -(-pw // bin_step) <= 8:
-        nbytes = L.lib().abr_roi_align_backward_ws_bytes(K, H, W, ph, pw, bin_step)
+        nbytes = L.lib().abr_roi_align_backward_ws_bytes(K, B, H, W, ph, pw, bin_step)
         key = (grad.device,)
         ws = _roi_bwd_ws.get(key)
         if ws is None or ws.numel() < nbytes:

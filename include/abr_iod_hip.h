@@ -102,7 +102,7 @@ int abr_roi_align_backward(const float* grad, const float* rois, int K, int B, i
 /* Same result as abr_roi_align_backward(layout=ABR_NHWC) without atomics: every feature pixel gathers from the RoIs that
  * cover it (two kernels: per-RoI separable weight tables, then one coalesced write per dFeat element, deterministic order).
  * workspace: abr_roi_align_backward_ws_bytes(...) bytes.  This is the form the training step uses. */
-int64_t abr_roi_align_backward_ws_bytes(int K, int H, int W, int PH, int PW, int bin_step);
+int64_t abr_roi_align_backward_ws_bytes(int K, int B, int H, int W, int PH, int PW, int bin_step);
 int abr_roi_align_backward_gather(const float* grad, const float* rois, int K, int B, int C, int H, int W,
                                   float spatial_scale, int PH, int PW, int sampling_ratio, int bin_step, int accumulate,
                                   float* grad_feat, void* workspace, int64_t workspace_bytes, void* stream);
