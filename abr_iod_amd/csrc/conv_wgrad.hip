@@ -680,9 +680,11 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
     // workgroup keeps at least 8 stages (256 rows) of work.
     // Prefer two workgroups per CU when each still gets >= 64 stages: a lone workgroup cannot hide its own prologue / atomics
     // epilogue (head 1x1 gradients: 113 -> 126..134 TF alone; -1.0 ms per training step).  ABR_WGRAD_OCC2=0 turns it off.
-    // Since the step runs TWO weight-gradient streams next to the dgrad chain, the preference is off by default: alone the layer4 gradients are
-    // 20 % faster with it (0.43 vs 0.53 ms), in the step two concurrent 512-workgroup grids oversubscribe the CUs (step +0.13 ms).
-    static const bool occ2 = getenv("ABR_WGRAD_OCC2") && atoi(getenv("ABR_WGRAD_OCC2")) != 0;
+    // Round 2 had this off (next to the heavier dgrad kernels of that round two concurrent 512-workgroup grids oversubscribed the CUs: +0.13 ms);
+    // with the weights-direct dgrad kernels (35 KB of LDS, 3 waves / SIMD) it is worth -0.25 ms per step in four same-session A/B rounds and
+    // lifts the kernel's own rate 132 -> 148 TF-eq, so it is ON by default since round 3.
+    static const bool occ2 = !(getenv("ABR_WGRAD_OCC2") && atoi(getenv("ABR_WGRAD_OCC2")) == 0);
+    static const int occ2_min_stages = getenv("ABR_WGRAD_OCC2_MINSTAGES") ? atoi(getenv("ABR_WGRAD_OCC2_MINSTAGES")) : 64;
     // ABR_WGRAD_WGS_PER_CU = k > 1: small-output gradients (few tiles, long M) are split until k workgroups per CU are resident
     // (never below 6 stages = 192 rows per workgroup): a lone 256-thread workgroup per CU leaves three quarters of the wave slots
     // empty and cannot overlap its own fetch / split / MFMA / atomic phases
@@ -696,7 +698,7 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
         const long rounds = (wgs + cus - 1) / cus;
         double eff = (double)wgs / (double)(rounds * cus);
         if (wgs < cus) eff *= 0.5;                 // not even one workgroup per CU
-        else if (occ2 && wgs < 2L * cus && m_tiles / (2 * sp) >= 64) eff *= 0.85;  // a lone workgroup per CU cannot hide its own prologue /
+        else if (occ2 && wgs < 2L * cus && m_tiles / (2 * sp) >= occ2_min_stages) eff *= 0.85;  // a lone workgroup per CU cannot hide its own prologue /
                                                    // atomics epilogue: take two when each still gets >= 64 stages (head 1x1s: +11..15 %)
         eff -= 0.0002 * sp;                        // tie-break: fewer partial sums
         if (eff > best) { best = eff; splits = sp; }
