@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgP p, const
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int MRX = 32;
 
-__global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgP p, const float* __restrict__ x_, const float* __restrict__ gy_,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_wgrad_x6_kernel(const WgP p, const float* __restrict__ x_, const float* __restrict__ gy_,
                                                              float* __restrict__ dw_) {
     const float* x = x_;
     const float* gy = gy_;
