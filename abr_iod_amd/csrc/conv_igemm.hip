@@ -1229,11 +1229,14 @@ static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, fl
     // as fast as with 128x128 tiles (+-8 % per shape), but in the training step, where two or three other streams' kernels share the CUs,
     // the small workgroups (four per CU, 31 KB of LDS) interleave better -- step -0.3 ms in a same-session A/B.  ABR_X6_SHORTK_MAXK=0: off.
     static const int shortk = getenv("ABR_X6_SHORTK_MAXK") ? atoi(getenv("ABR_X6_SHORTK_MAXK")) : 256;
+    // grid-size rules: the biggest tile whose grid still gives every CU t*_min10 / 10 workgroups (experiments: ABR_X6_T128_MIN10, ABR_X6_T12864_MIN10)
+    static const int t128_min10 = getenv("ABR_X6_T128_MIN10") ? atoi(getenv("ABR_X6_T128_MIN10")) : 20;
+    static const int t12864_min10 = getenv("ABR_X6_T12864_MIN10") ? atoi(getenv("ABR_X6_T12864_MIN10")) : 20;
     int tile;   // 1 = 128x128, 2 = 128x64, 3 = 64x64
     if (force && p.K <= force_maxk && nb == 1) tile = force;
     else if (shortk > 0 && p.K <= shortk && nb == 1) tile = 3;
-    else if (p.Cout > 64 && t128 >= 2 * cus) tile = 1;
-    else if (t12864 >= 2 * cus || p.Cout <= 64) tile = 2;
+    else if (p.Cout > 64 && t128 * 10 >= (int64_t)t128_min10 * cus) tile = 1;
+    else if (t12864 * 10 >= (int64_t)t12864_min10 * cus || p.Cout <= 64) tile = 2;
     else tile = 3;
     if (wd) {
         if (tile == 1) launch_x6w<128, 128, 2, 2>(p, x, out, st);
