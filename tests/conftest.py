@@ -34,3 +34,18 @@ def golden(name):
 @pytest.fixture(scope="session")
 def gold():
     return golden
+
+
+@pytest.fixture(autouse=True)
+def _fresh_x6_range_flags(request):
+    """GPU tests: clear the bf16x6 range-guard word before every test -- it is process-wide device state (abr_x6_range_flags), and a test that
+    legitimately raises it (tiny operands of a padded batch, injected inf / nan) must not leak into the next test's `== 0` assertion."""
+    if request.node.get_closest_marker("gpu") is not None:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                from abr_iod_amd import ops
+                ops.x6_range_flags(reset=True)
+        except Exception:
+            pass
+    yield
