@@ -74,6 +74,20 @@ template <>
 __device__ __forceinline__ vf<2> vld<2>(const float* p) { const float2 t = *reinterpret_cast<const float2*>(p); return {{t.x, t.y}}; }
 template <>
 __device__ __forceinline__ vf<4> vld<4>(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); return {{t.x, t.y, t.z, t.w}}; }
+template <int V>
+__device__ __forceinline__ vf<V> vld_buf(__amdgpu_buffer_rsrc_t r, unsigned byte_off);
+template <>
+__device__ __forceinline__ vf<2> vld_buf<2>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+    return {{__uint_as_float(t.x), __uint_as_float(t.y)}};
+}
+template <>
+__device__ __forceinline__ vf<4> vld_buf<4>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return {{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)}};
+}
 __device__ __forceinline__ void vst(float* p, vf<2> a) { *reinterpret_cast<float2*>(p) = make_float2(a.v[0], a.v[1]); }
 __device__ __forceinline__ void vst(float* p, vf<4> a) { *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]); }
 
@@ -98,12 +112,16 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const int C2 = C / V;
     const int64_t total = T * C2;
     const int64_t ps = T * C;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (unsigned)((int64_t)B * H * W * C * 4), 0x00020000);   // (< 2 GB: checked by the caller)
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int c = V * (int)(idx % C2);
         const int64_t t = idx / C2;
         const int tw = (int)(t % tw_n), th = (int)((t / tw_n) % th_n), b = (int)(t / ((int64_t)tw_n * th_n));
         const int y0 = 4 * th - 1, x0 = 4 * tw - 1;
         f2 tcol[6][6];  // B^T d, built column by column so that only one input column is live at a time
+        // the 36 taps come through BUFFER loads: a 32-bit offset against a range-checked descriptor, halo taps get an out-of-range offset
+        // and read as zeros in hardware -- no exec-masked block and no 64-bit address chain per tap (as in the conv kernels' gathers)
+        const int base = (b * H * W) * C + c;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             const int xx = x0 + j;
@@ -112,7 +130,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 const int y = y0 + i;
-                d[i] = (xin && (unsigned)y < (unsigned)H) ? vld<V>(x + (((int64_t)b * H + y) * W + xx) * C + c) : vzero<V>();
+                const bool in = xin & ((unsigned)y < (unsigned)H);
+                d[i] = vld_buf<V>(rx, in ? (unsigned)(base + (y * W + xx) * C) * 4u : 0x80000000u);
             }
             bt6(d[0], d[1], d[2], d[3], d[4], d[5], tcol[0][j], tcol[1][j], tcol[2][j], tcol[3][j], tcol[4][j], tcol[5][j]);
         }
@@ -198,6 +217,20 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         f2 sc, bi;
 #pragma unroll
         for (int e = 0; e < V; e++) { sc.v[e] = scale ? scale[n + e] : 1.f; bi.v[e] = bias ? bias[n + e] : 0.f; }
+        // the ReLU mask of the producer (dgrad): all 16 mask vectors of the tile are requested BEFORE the first is used (pixels past the
+        // image read the tile's first pixel, which always exists, and are not stored) -- inside the store loop each mask load was followed
+        // by its own wait, 16 dependent round trips per tile
+        f2 mk[4][4];
+        if (mask) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int oy = 4 * th + i, ox = 4 * tw + j;
+                    const bool in = oy < H && ox < W;
+                    mk[i][j] = vld<V>(mask + (((int64_t)b * H + (in ? oy : 4 * th)) * W + (in ? ox : 4 * tw)) * N + n);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             f2 y[4];
@@ -216,9 +249,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                     if (relu) v.v[e] = fmaxf(v.v[e], 0.f);
                 }
                 if (mask) {
-                    const f2 mk = vld<V>(mask + o);
 #pragma unroll
-                    for (int e = 0; e < V; e++) v.v[e] = mk.v[e] > 0.f ? v.v[e] : 0.f;
+                    for (int e = 0; e < V; e++) v.v[e] = mk[i][j].v[e] > 0.f ? v.v[e] : 0.f;
                 }
                 vst(out + o, v);
             }
@@ -298,12 +330,17 @@ __global__ __launch_bounds__(256) void wino_wgrad_inverse_kernel(const float* __
             gt3(vld<V>(u + (0 + j) * ps), vld<V>(u + (6 + j) * ps), vld<V>(u + (12 + j) * ps), vld<V>(u + (18 + j) * ps), vld<V>(u + (24 + j) * ps),
                 vld<V>(u + (30 + j) * ps), tcol[0][j], tcol[1][j], tcol[2][j]);
         const float sc = scale ? scale[n] : 1.f;
+        fv old[3][3];   // dw += : the nine current values are requested together, ahead of the arithmetic (not one read-modify-write at a time)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) old[r][q] = vld<V>(dw + ((n * 3 + r) * 3 + q) * C + c);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             fv g0, g1, g2;
             gt3(tcol[r][0], tcol[r][1], tcol[r][2], tcol[r][3], tcol[r][4], tcol[r][5], g0, g1, g2);
             float* o = dw + ((n * 3 + r) * 3) * C + c;
-            vst(o, vld<V>(o) + sc * g0); vst(o + C, vld<V>(o + C) + sc * g1); vst(o + 2 * C, vld<V>(o + 2 * C) + sc * g2);
+            vst(o, old[r][0] + sc * g0); vst(o + C, old[r][1] + sc * g1); vst(o + 2 * C, old[r][2] + sc * g2);
         }
     }
 }
