@@ -63,6 +63,8 @@ def test_reference_error_behaviour():
     images, targets = synthetic_batch(1, 160, 224, max_boxes=1)
     with pytest.raises(ValueError):  # generalized_rcnn.py:63-64
         mt(images, None)
+    with pytest.raises(NotImplementedError):  # a gradient w.r.t. the image would be dropped silently by the frozen stem: refused instead
+        mt.backbone(images.clone().requires_grad_(True))
     empty = BoxList(torch.zeros((0, 4), device="cuda"), (224, 160)); empty.add_field("labels", torch.zeros((0,), dtype=torch.int64, device="cuda"))
     with pytest.raises((ValueError, RuntimeError)):  # matcher.py:53-57: no ground-truth boxes
         mt(images, [empty])

@@ -24,3 +24,34 @@ def test_grad_writer_stream_filter():
     dev = 0
     picked = [k for k in keys if (k == dev) or (isinstance(k, tuple) and k[0] == dev and str(k[1]).startswith("wgrad"))]
     assert picked == [0, (0, "wgrad1")]
+
+
+def test_prefetch_key_follows_the_batch_the_weights_and_the_arithmetic():
+    """engine/trainer.py::_prefetch_key: work prefetched for the next batch (the frozen source model's forward, the target's frozen prefix) is
+    only reused for THE batch it was computed from, with the weights and the arithmetic it was computed with (object identity
+    alone reused stale features after an in-place refill of the batch buffer, a checkpoint load or a change of the contraction arithmetic)."""
+    import types
+    import torch
+    from abr_iod_amd.engine import trainer
+    from abr_iod_amd.modeling.backbone import resnet
+    ms, mt = types.SimpleNamespace(conv_math="bf16x6"), types.SimpleNamespace(conv_math="bf16x6")
+    x = torch.zeros(2, 3, 8, 8)
+    k0 = trainer._prefetch_key(x, ms, mt)
+    assert trainer._prefetch_key(x, ms, mt) == k0
+    x.add_(1.0)                                   # the same buffer refilled in place: a different batch
+    k1 = trainer._prefetch_key(x, ms, mt)
+    assert k1 != k0
+    assert trainer._prefetch_key(x.clone(), ms, mt) != k1     # another object / storage
+    resnet.bump_param_version()                   # checkpoint load / in-place weight surgery
+    k2 = trainer._prefetch_key(x, ms, mt)
+    assert k2 != k1
+    resnet.bump_trained_version()                 # an optimiser step moves only trained tensors: frozen-model prefetches stay valid
+    assert trainer._prefetch_key(x, ms, mt) == k2
+    mt.conv_math = "f32"                          # the range guard switched the arithmetic
+    assert trainer._prefetch_key(x, ms, mt) != k2
+    # the state lives on the target model object, not in the module
+    a, b = types.SimpleNamespace(), types.SimpleNamespace()
+    sa, sb = trainer.trainer_state(a), trainer.trainer_state(b)
+    assert sa is trainer.trainer_state(a) and sa is not sb
+    sa.prefetched = {"images": x}
+    assert sb.prefetched == {}
