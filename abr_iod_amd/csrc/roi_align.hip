@@ -553,46 +553,56 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
         }
     }
     } else {
-    // 8 bins per axis (all-bin pooling of the 64-RoI distillation passes): the batched form above needs 8 x 8 gradient vectors and 64 uniform
-    // weights live at once and spills (1.08 vs 0.80 ms on 2048 RoIs); this form keeps one bin row in flight at a time
+    // 8 bins per axis (all-bin pooling of the 64-RoI distillation passes): the batched form above would need 8 x 8 gradient vectors and 64
+    // uniform weights live at once and spills (1.08 vs 0.80 ms on 2048 RoIs); here ONE bin row's vectors are requested together (column
+    // indices past PWo clamped: their weight is zero), then the next row's, and the column weights come two bin columns at a time
+    int r_next = n_row > 0 ? row_list[0] : 0;
     for (int e = 0; e < n_row; e++) {
-        const int r = row_list[e];   // wave-uniform: scalar load; every entry is a RoI of this image that touches this row and these pixels
+        const int r = __builtin_amdgcn_readfirstlane(r_next);
+        if (e + 1 < n_row) r_next = row_list[e + 1];
         const float* wyr = Wy + (size_t)r * PHo * H + y;
         const float* g = grad + (size_t)r * PHo * PWo * C + cv * 4;
+        const float* wxr = Wx + (size_t)r * PWo * Wp + x0;
+        float wy[PO];
+#pragma unroll
+        for (int pi = 0; pi < PO; pi++) wy[pi] = pi < PHo ? wyr[(pi < PHo ? pi : 0) * H] : 0.f;
         float4 T[PO];
 #pragma unroll
         for (int j = 0; j < PO; j++) T[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         bool any = false;
 #pragma unroll
         for (int pi = 0; pi < PO; pi++) {
-            if (pi < PHo) {
-                const float wy = wyr[pi * H];
-                if (wy != 0.f) {
-                    any = true;
-                    if (c_ok) {
+            const float w = wy[pi];
+            if (w != 0.f) {   // wave-uniform
+                any = true;
+                if (c_ok) {
+                    float4 gv[PO];
 #pragma unroll
-                        for (int j = 0; j < PO; j++)
-                            if (j < PWo) {
-                                const float4 v = *reinterpret_cast<const float4*>(g + ((size_t)pi * PWo + j) * C);
-                                T[j].x += wy * v.x; T[j].y += wy * v.y; T[j].z += wy * v.z; T[j].w += wy * v.w;
-                            }
-                    }
+                    for (int j = 0; j < PO; j++) gv[j] = *reinterpret_cast<const float4*>(g + ((size_t)pi * PWo + (j < PWo ? j : PWo - 1)) * C);
+#pragma unroll
+                    for (int j = 0; j < PO; j++) { T[j].x += w * gv[j].x; T[j].y += w * gv[j].y; T[j].z += w * gv[j].z; T[j].w += w * gv[j].w; }
                 }
             }
         }
         if (!any) continue;
-        const float* wxr = Wx + (size_t)r * PWo * Wp + x0;
 #pragma unroll
-        for (int j = 0; j < PO; j++) {
-            if (j < PWo) {
-                const float4 w0 = *reinterpret_cast<const float4*>(wxr + j * Wp);       // 8 consecutive pixels, 32 B aligned
-                const float4 w1 = *reinterpret_cast<const float4*>(wxr + j * Wp + 4);
-                const float wv[kXT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        for (int j0 = 0; j0 < PO; j0 += 2) {
+            float wv[2][kXT];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int j = j0 + q;
+                const float* src = wxr + (j < PWo ? j : PWo - 1) * Wp;
+                const float4 w0 = *reinterpret_cast<const float4*>(src), w1 = *reinterpret_cast<const float4*>(src + 4);
+                const float keep = j < PWo ? 1.f : 0.f;
+                wv[q][0] = keep * w0.x; wv[q][1] = keep * w0.y; wv[q][2] = keep * w0.z; wv[q][3] = keep * w0.w;
+                wv[q][4] = keep * w1.x; wv[q][5] = keep * w1.y; wv[q][6] = keep * w1.z; wv[q][7] = keep * w1.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++)
 #pragma unroll
                 for (int i = 0; i < kXT; i++) {
-                    acc[i].x += wv[i] * T[j].x; acc[i].y += wv[i] * T[j].y; acc[i].z += wv[i] * T[j].z; acc[i].w += wv[i] * T[j].w;
+                    acc[i].x += wv[q][i] * T[j0 + q].x; acc[i].y += wv[q][i] * T[j0 + q].y; acc[i].z += wv[q][i] * T[j0 + q].z; acc[i].w += wv[q][i] * T[j0 + q].w;
                 }
-            }
         }
     }
     }
