@@ -165,6 +165,10 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0, serialised=None):
                  "time-sharing figure; `serialised` holds the same rows with every stream folded into one = the kernels' own rate")
     if serialised is not None:
         r["serialised"] = serialised
+        own = serialised["kernels"].get(top["kernel"])
+        if own:   # the same kernel's OWN rate (streams folded): the kernel-quality figure next to the in-step, time-shared one above
+            r["own_rate"] = {"kernel": top["kernel"], "achieved": own["achieved"], "peak": own["peak"], "frac": own["frac"], "avg_launch_ms": own["avg_launch_ms"],
+                             "source": "roofline.serialised (informational re-run behind the timed region)"}
     return r
 
 
