@@ -138,12 +138,16 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][
             float* o = out + row_off + ncol;
             if (vec_ok) {
                 if (p.residual) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.residual + row_off + ncol);
+                    typedef float nt4 __attribute__((ext_vector_type(4)));
+                    const nt4 rr_ = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(p.residual + row_off + ncol));
+                    const float4 rr = make_float4(rr_.x, rr_.y, rr_.z, rr_.w);
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (p.mask) {
-                    const float4 mm = *reinterpret_cast<const float4*>(p.mask + row_off + ncol);
+                    typedef float nt4m __attribute__((ext_vector_type(4)));
+                    const nt4m mm_ = __builtin_nontemporal_load(reinterpret_cast<const nt4m*>(p.mask + row_off + ncol));
+                    const float4 mm = make_float4(mm_.x, mm_.y, mm_.z, mm_.w);
                     v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f; v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
                 }
                 *reinterpret_cast<float4*>(o) = v;
