@@ -68,6 +68,7 @@ struct WgP {
     // (256 workgroups x 16 K atomics = 4 M per launch cost ~30 us whatever the shape).  nullptr: atomics into dw
     float* ws;
     int final_store;             // the reduction stores (dw = sum: the Winograd-domain dU, never zero-filled) instead of dw += sum
+    int map4;                    // accumulator interleave of conv_wgrad_x6_kernel (n = n0 + 4 i + 2 wm + tm) instead of n0 + wm*64 + 2 i + tm
 };
 
 typedef f32x16 wg_f32x16;
@@ -78,13 +79,13 @@ constexpr unsigned kPartBytes = 16u * 256u * 16u;   // one partial tile (128 x 1
 
 __device__ __forceinline__ void wgrad_store_tile(const WgP& p, const float (&v)[4], int tm, int tn, int c, int n0, int k0, int wm, int wn, int l31, int lh,
                                                  bool store, float* __restrict__ dw) {
-    const int k = k0 + wn * 64 + 2 * l31 + tn;
+    const int k = p.map4 ? k0 + 4 * l31 + 2 * wn + tn : k0 + wn * 64 + 2 * l31 + tn;
     if (k >= p.K) return;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int r = 4 * c + e;
         const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int n = n0 + wm * 64 + 2 * i + tm;
+        const int n = p.map4 ? n0 + 4 * i + 2 * wm + tm : n0 + wm * 64 + 2 * i + tm;
         if (n >= p.Cout) continue;
         const float sc = p.scale ? p.scale[n] : 1.f;
         if (store) dw[(size_t)n * p.K + k] = v[e] * sc;
@@ -450,8 +451,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgP p, const
 
 // ------------------------------------------------------------------------------------------------------------------------
 // fp32-accurate weight gradient on the bf16 matrix cores (ABR_MATH_BF16X6, see conv_igemm.hip): each operand value is split
-// exactly into three bf16 terms, the six cross products with i + j <= 2 are accumulated in fp32.  Same [m-pair][column] LDS
-// tiles as the bf16 kernel, three planes per operand; stage = 32 rows (48 KB of operand LDS, 48 MFMAs per wave and stage).
+// exactly into three bf16 terms, the six cross products with i + j <= 2 are accumulated in fp32.  Stage = 32 rows of m.
+//
+// LDS image (48 KB: 2 operands x 3 planes x 8 KB): the MFMA wants, per lane, eight bf16 that are CONSECUTIVE IN m for one column, while both
+// operands arrive m-major.  The transpose is done by the loader, in registers, for free: a thread fetches the SAME four columns of eight
+// consecutive rows (eight 16 B loads; a half-wave still covers a full 512 B row segment per load), so after the split it owns, per plane and
+// column, the eight m-values of one fragment half = one 16 B chunk = one ds_write_b128.  Chunks are laid out [octet of m][j][q] with column
+// c = 4 q + j (q = the thread's column group): a store instruction's lanes write consecutive chunks, and a wave's fragment read (lanes =
+// q 0..31 of ONE j) is a conflict-free ds_read_b128 whose four dwords ARE the MFMA operand -- the former [m-pair][column] image needed four
+// ds_read_b64 and eight v_mov per fragment (96 v_mov per 48 MFMAs; the compiler fused the reads into half-rate ds_read2st64_b64).
+// The price is the accumulator interleave: sub-tile (tm, tn) of wave (wm, wn), element (i, l) is dW[n0 + 4 i + 2 wm + tm][k0 + 4 l + 2 wn + tn]
+// (WgP::map4; undone by the epilogue / reduction addressing like the 2 i + tm interleave of the other two kernels).
+// Waves 0-1 stage gy, waves 2-3 stage x (wave-uniform branch): 8 loads, 32 values to split, 12 ds_write_b128 per thread and stage.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int MRX = 32;
 
@@ -462,9 +473,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     float* dw = dw_;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     abr::prof_stamp_begin(p.prof_ts);
-    constexpr int PL = (MRX / 2) * TN_;                  // dwords per plane (TN_ == TK_)
-    unsigned* Gs = reinterpret_cast<unsigned*>(smem);    // [3][MRX/2][TN_]
-    unsigned* As = Gs + 3 * PL;                          // [3][MRX/2][TK_]
+    constexpr int PL = (MRX / 8) * 128 * 4;              // dwords per plane: [4 octets][4 j][32 q] chunks of 4 dwords
+    unsigned* Gs = reinterpret_cast<unsigned*>(smem);    // [3][PL]
+    unsigned* As = Gs + 3 * PL;                          // [3][PL]
 
     const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
     // workgroup -> (row slice, output tile): the output tile is the FAST index, so the workgroups one XCD runs side by side (a
@@ -486,52 +497,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int q = tid & 31, rp = tid >> 5;   // 16 B column group; row pairs rp + 8*i (i < 2)
-    const int gn = n0 + q * 4;
-    const bool g_ok = gn < p.Cout;
-    const int ak = k0 + q * 4;
-    const bool k_ok = ak < p.K;
-    int fr = 0, fs = 0, fc = 0;
-    if (k_ok) {
-        const int rs = ak / p.Cin;
-        fc = ak % p.Cin;
-        fr = rs / p.S;
-        fs = rs % p.S;
-    }
+    const bool is_x = __builtin_amdgcn_readfirstlane(wave) >= 2;   // which operand this wave stages (in an SGPR: the resource descriptor and the branches on it stay scalar)
+    const int q = tid & 31, oct = (tid >> 5) & 3; // 16 B column group; rows oct*8 .. +8 of the stage
     const int mt0 = split * p.mt_per_split;
     const int mt1 = min(mt0 + p.mt_per_split, (p.M + MRX - 1) / MRX);
 
     constexpr unsigned kOOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rgy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, p.gy_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
-    const unsigned g_voff = g_ok ? (unsigned)(2 * rp * p.Cout + gn) * 4u : kOOB;
-    const unsigned a_voff_plain = k_ok ? (unsigned)(2 * rp * p.Cin + fc) * 4u : kOOB;
+    const __amdgpu_buffer_rsrc_t rsrc = is_x ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, p.gy_bytes, 0x00020000);
+    // gy / plain x: row m of the operand starts at m * ld floats; column group at col
+    const int col = (is_x ? k0 : n0) + q * 4;
+    const int ld = is_x ? p.Cin : p.Cout;
+    const bool col_ok = col < (is_x ? p.K : p.Cout);
+    int fr = 0, fs = 0, fc = col;
+    if (is_x && col_ok && !p.plain) {
+        const int rs = col / p.Cin;
+        fc = col % p.Cin;
+        fr = rs / p.S;
+        fs = rs % p.S;
+    }
+    const bool gather = is_x && !p.plain;         // wave-uniform
+    const unsigned voff_plain = col_ok ? (unsigned)(oct * 8 * ld + fc) * 4u : kOOB;
     const int a_const = ((fr - p.pad) * p.W + (fs - p.pad)) * p.Cin + fc;
-    u32x4 rg[2][2], ra[2][2];
+    u32x4 rr[8];
     auto load_tile = [&](int mt) {
+        if (!gather) {
+            const unsigned base = voff_plain + (unsigned)(mt * MRX * ld) * 4u;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 8; i++) rr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + (unsigned)(i * ld) * 4u), 0, 0);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const int mrow = mt * MRX + 16 * i + e;
-                rg[i][e] = __builtin_amdgcn_raw_buffer_load_b128(rgy, (int)(g_voff + (unsigned)(mrow * p.Cout) * 4u), 0, 0);
-                if (p.plain) {
-                    ra[i][e] = __builtin_amdgcn_raw_buffer_load_b128(rxx, (int)(a_voff_plain + (unsigned)(mrow * p.Cin) * 4u), 0, 0);
-                } else {
-                    const int m = mrow + 2 * rp;
-                    unsigned b, rem, ho, wo;
-                    p.d_howo.divmod((unsigned)m, b, rem);
-                    p.d_wo.divmod(rem, ho, wo);
-                    const int hi = (int)ho * p.stride - p.pad + fr, wi = (int)wo * p.stride - p.pad + fs;
-                    const bool ok = k_ok & (m < p.M) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-                    const int off = (((int)b * p.H + (int)ho * p.stride) * p.W + (int)wo * p.stride) * p.Cin + a_const;
-                    ra[i][e] = __builtin_amdgcn_raw_buffer_load_b128(rxx, (int)(ok ? (unsigned)off * 4u : kOOB), 0, 0);
-                }
+            for (int i = 0; i < 8; i++) {
+                const int m = mt * MRX + oct * 8 + i;
+                unsigned b, rem, ho, wo;
+                p.d_howo.divmod((unsigned)m, b, rem);
+                p.d_wo.divmod(rem, ho, wo);
+                const int hi = (int)ho * p.stride - p.pad + fr, wi = (int)wo * p.stride - p.pad + fs;
+                const bool ok = col_ok & (m < p.M) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+                const int off = (((int)b * p.H + (int)ho * p.stride) * p.W + (int)wo * p.stride) * p.Cin + a_const;
+                rr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? (unsigned)off * 4u : kOOB), 0, 0);
             }
+        }
     };
     // range guard of the exact split (abr_x6_range_flags): gy is inspected by the workgroups of the first k-tile column, x by those of
-    // the first n-tile row -- every operand element once per GEMM, workgroup-uniform branches (see conv_igemm_x6_kernel)
-    const bool chk_g = p.x6_flags && tile_k == 0, chk_x = p.x6_flags && tile_n == 0;
+    // the first n-tile row -- every operand element once per GEMM, wave-uniform branch (see conv_igemm_x6_kernel)
+    const bool chk = p.x6_flags && (is_x ? tile_n == 0 : tile_k == 0);
     unsigned bmin = 0xFFFFFFFFu;
     float nonfin = 0.f;
     auto inspect = [&](const u32x4 v) {
@@ -540,38 +550,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         nonfin = fmaf(__uint_as_float(v.x), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.y), 0.f, nonfin);
         nonfin = fmaf(__uint_as_float(v.z), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.w), 0.f, nonfin);
     };
-    // rows (m, m+1) of one 16 B column group -> three planes of four bf16x2 dwords
-    auto split_store = [](const u32x4 lo, const u32x4 hi, unsigned* dst, int plane) {
-        u32x4 o0, o1, o2;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const f32x2v f = {__uint_as_float(lo[c]), __uint_as_float(hi[c])};
-            const bf16x2 h0 = __builtin_convertvector(f, bf16x2);
-            const f32x2v r1 = f - __builtin_convertvector(h0, f32x2v);
-            const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
-            const f32x2v r2 = r1 - __builtin_convertvector(h1, f32x2v);
-            const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
-            o0[c] = *reinterpret_cast<const unsigned*>(&h0);
-            o1[c] = *reinterpret_cast<const unsigned*>(&h1);
-            o2[c] = *reinterpret_cast<const unsigned*>(&h2);
-        }
-        *reinterpret_cast<u32x4*>(dst) = o0;
-        *reinterpret_cast<u32x4*>(dst + plane) = o1;
-        *reinterpret_cast<u32x4*>(dst + 2 * plane) = o2;
-    };
+    unsigned* const st_base = (is_x ? As : Gs) + (oct * 4 * 32 + q) * 4;   // chunk (oct, j, q) at + j * 128 dwords
     auto store_tile = [&]() {
-        if (chk_g) {
+        if (chk) {
 #pragma unroll
-            for (int i = 0; i < 2; i++) { inspect(rg[i][0]); inspect(rg[i][1]); }
-        }
-        if (chk_x) {
-#pragma unroll
-            for (int i = 0; i < 2; i++) { inspect(ra[i][0]); inspect(ra[i][1]); }
+            for (int i = 0; i < 8; i++) inspect(rr[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            split_store(rg[i][0], rg[i][1], Gs + (rp + 8 * i) * TN_ + q * 4, PL);
-            split_store(ra[i][0], ra[i][1], As + (rp + 8 * i) * TK_ + q * 4, PL);
+        for (int j = 0; j < 4; j++) {         // column 4 q + j: eight m-values -> one 16 B chunk per plane
+            u32x4 o0, o1, o2;
+#pragma unroll
+            for (int pp = 0; pp < 4; pp++) {  // rows (2 pp, 2 pp + 1) -> one bf16x2 dword per plane
+                const f32x2v f = {__uint_as_float(rr[2 * pp][j]), __uint_as_float(rr[2 * pp + 1][j])};
+                const bf16x2 h0 = __builtin_convertvector(f, bf16x2);
+                const f32x2v r1 = f - __builtin_convertvector(h0, f32x2v);
+                const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
+                const f32x2v r2 = r1 - __builtin_convertvector(h1, f32x2v);
+                const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
+                o0[pp] = *reinterpret_cast<const unsigned*>(&h0);
+                o1[pp] = *reinterpret_cast<const unsigned*>(&h1);
+                o2[pp] = *reinterpret_cast<const unsigned*>(&h2);
+            }
+            *reinterpret_cast<u32x4*>(st_base + j * 128) = o0;
+            *reinterpret_cast<u32x4*>(st_base + j * 128 + PL) = o1;
+            *reinterpret_cast<u32x4*>(st_base + j * 128 + 2 * PL) = o2;
         }
     };
 
@@ -584,25 +586,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
+    // fragment (s, t) of an operand: chunk (octet 2 s + lh, j = 2 w + t, q = l31)
+    const unsigned* const g_rd = Gs + ((lh * 4 + 2 * wm) * 32 + l31) * 4;
+    const unsigned* const a_rd = As + ((lh * 4 + 2 * wn) * 32 + l31) * 4;
     auto compute_tile = [&]() {
-        const unsigned* g = Gs + wm * 64 + 2 * l31 + 4 * lh * TN_;
-        const unsigned* a = As + wn * 64 + 2 * l31 + 4 * lh * TK_;
 #pragma unroll
         for (int s = 0; s < MRX / 16; s++) {
             bf16x8 G[2][3], A[2][3];   // [column sub-tile][plane]
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
-                uint2 fg[4], fa[4];
+            for (int pl = 0; pl < 3; pl++)
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    fg[t] = *reinterpret_cast<const uint2*>(g + pl * PL + (8 * s + t) * TN_);
-                    fa[t] = *reinterpret_cast<const uint2*>(a + pl * PL + (8 * s + t) * TK_);
+                for (int t = 0; t < 2; t++) {
+                    G[t][pl] = *reinterpret_cast<const bf16x8*>(g_rd + pl * PL + (s * 8 + t) * 128);
+                    A[t][pl] = *reinterpret_cast<const bf16x8*>(a_rd + pl * PL + (s * 8 + t) * 128);
                 }
-                const u32x4 g0 = {fg[0].x, fg[1].x, fg[2].x, fg[3].x}, g1 = {fg[0].y, fg[1].y, fg[2].y, fg[3].y};
-                const u32x4 a0 = {fa[0].x, fa[1].x, fa[2].x, fa[3].x}, a1 = {fa[0].y, fa[1].y, fa[2].y, fa[3].y};
-                G[0][pl] = *reinterpret_cast<const bf16x8*>(&g0); G[1][pl] = *reinterpret_cast<const bf16x8*>(&g1);
-                A[0][pl] = *reinterpret_cast<const bf16x8*>(&a0); A[1][pl] = *reinterpret_cast<const bf16x8*>(&a1);
-            }
             // the six products of a step (smallest terms first for every accumulator) interleaved over the four accumulators: no MFMA
             // waits on the result of the one issued just before it (as in conv_igemm_x6w_kernel)
             constexpr int pg[6] = {2, 0, 1, 1, 0, 0}, pa[6] = {0, 2, 1, 0, 1, 0};
@@ -629,7 +626,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         }
         compute_tile();
     }
-    if (chk_g | chk_x) abr::x6_report(bmin, nonfin, p.x6_flags);
+    if (chk) abr::x6_report(bmin, nonfin, p.x6_flags);
 
     wgrad_finish(p, acc, n0, k0, wm, wn, l31, lh, tid, gtile, split, dw);
     abr::prof_stamp_end(p.prof_ts);
@@ -734,6 +731,7 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
             attr6 = true;
         }
+        p.map4 = 1;
         p.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
         // Timed with a HIP-event pair, not with in-kernel stamps: a kernel trace's duration of these kernels includes the write-back of the
         // parked partial tiles at kernel end, which first-workgroup-in / last-workgroup-out stamps miss by ~10 % (the raw event figure is
@@ -803,7 +801,7 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     p.tiles_k = (p.K + TK_ - 1) / TK_;
     if (p.M == 0) return ABR_OK;
     p.nbatch = 1; p.tiles_pb = 0; p.x_bs = p.gy_bs = p.dw_bs = 0; p.overwrite = 0;
-    p.ws = nullptr; p.final_store = 0;
+    p.ws = nullptr; p.final_store = 0; p.map4 = 0;
     p.x6_flags = nullptr;
     static const int tile_fast = !(getenv("ABR_WGRAD_TILE_FAST") && atoi(getenv("ABR_WGRAD_TILE_FAST")) == 0);
     p.tile_fast = tile_fast;
