@@ -1,0 +1,34 @@
+#!/bin/bash
+# Regenerates the round's evidence set in ONE GPU session (run from the repo root on the GPU box: bash tools/refresh_profiles.sh r03); every
+# output lands in gpurun_out/refresh/ under its profiles/ name -- copy what is to be judged into profiles/.  Every step runs under `timeout`.
+R=${1:-rXX}
+O=gpurun_out/refresh
+mkdir -p $O
+export TMPDIR=/tmp
+B="--no-cpu-baseline --no-alt-math"
+timeout 600 python bench.py > $O/${R}_bench_default.jsonl 2> $O/bench_default.err
+timeout 300 python bench.py --image-size 800x1333 --steps 10 > $O/${R}_bench_800x1333.jsonl 2>/dev/null
+timeout 300 python bench.py --task 10-5 --mosaic-squares --steps 20 > $O/${R}_bench_10-5_mosaic_squares.jsonl 2>/dev/null
+timeout 300 python bench.py --task 10-5 --mosaic-squares --math bf16 --steps 20 --no-kernel-timing > $O/${R}_bench_10-5_mosaic_squares_bf16_backbone.jsonl 2>/dev/null
+# rocprofv3 kernel trace of the bench command (+ the PMC HBM-traffic passes), then the matrix-pipe counters
+STEPS=5 WARMUP=2 timeout 900 bash tools/profile_bench.sh > $O/profile_bench.log 2>&1
+cp gpurun_out/prof_kernel_stats.csv $O/${R}_bench_kernel_stats.csv
+cp gpurun_out/prof_kernel_stats.json $O/${R}_bench_kernel_stats.json
+cp gpurun_out/prof_bench.jsonl $O/${R}_bench_under_rocprof.jsonl
+[ -f gpurun_out/pmc_traffic.json ] && cp gpurun_out/pmc_traffic.json $O/${R}_pmc_traffic.json
+timeout 900 bash tools/pmc_mfma.sh > $O/pmc_mfma.log 2>&1
+[ -f gpurun_out/pmc_mfma.json ] && cp gpurun_out/pmc_mfma.json $O/${R}_pmc_mfma.json
+# every stream folded into one: the kernels' own durations as a kernel trace sees them
+rm -rf gpurun_out/prof_ser
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_ser -o s -- python3 $OLDPWD/bench.py --steps 5 --warmup 2 $B --no-serialised-leg --fold-streams > $OLDPWD/$O/${R}_serialised_streams_bench.jsonl 2>/dev/null )
+cp gpurun_out/prof_ser/s_kernel_stats.csv $O/${R}_serialised_streams_kernel_stats.csv 2>/dev/null
+# per-shape table, HBM-bound kernels, epilogue probe, main-loop knock-out labs
+timeout 600 python tools/conv_breakdown.py --target-tf 200 2>&1 | grep -v amdgpu.ids > $O/${R}_conv_shapes_bf16x6.txt
+timeout 600 python tools/microbench.py --only nothing 2>/dev/null > $O/${R}_microbench_hbm_kernels.txt
+timeout 300 python tools/epilogue_probe.py 2>&1 | grep -v amdgpu > $O/${R}_epilogue_probe.txt
+( echo "# tools/x6lab/flab.hip: forward (conv_igemm_x6w_kernel<128,128>) main loop with ONE ingredient removed per row (results wrong, time only)"
+  timeout 250 tools/x6lab/flab
+  echo
+  echo "# tools/x6lab/wlab.hip: weight-gradient (conv_wgrad_x6_kernel) main loop, the same; 'producer / consumer' = 512-thread variant with loader waves"
+  timeout 250 tools/x6lab/wlab ) > $O/${R}_x6lab_knockouts.txt 2>&1
+ls -la $O
