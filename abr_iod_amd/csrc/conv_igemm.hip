@@ -426,6 +426,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// Exact three-way bf16 split of four fp32 values (x = h0 + h1 + h2), one uint2 of four bf16 per plane.  Written on PAIRS: one v_cvt_pk_bf16_f32
+// rounds two values, its two halves come back as fp32 by a shift and a mask -- as a 4-vector the compiler rounds every element a second time
+// for the residual chain (56 instead of 24 v_cvt_pk per 16 values and k-tile in the MFMA loops, where VALU issue slots are what runs out).
+// The residual subtractions are pinned to v_sub_f32 (abr::x6_sub): left alone the compiler packs them into v_pk_add_f32, which costs the step
+// 0.23 ms next to the other streams' MFMAs (five of five same-session A/B rounds; the kernels' own rates are the same).
+__device__ __forceinline__ void x6_split4(const float a, const float b, const float c, const float d, uint2& o0, uint2& o1, uint2& o2) {
+    const f32x2v f0 = {a, b}, f1 = {c, d};
+    const bf16x2 p0 = __builtin_convertvector(f0, bf16x2), q0 = __builtin_convertvector(f1, bf16x2);
+    const f32x2v p0f = __builtin_convertvector(p0, f32x2v), q0f = __builtin_convertvector(q0, f32x2v);
+    const f32x2v r0 = {abr::x6_sub(a, p0f.x), abr::x6_sub(b, p0f.y)}, s0 = {abr::x6_sub(c, q0f.x), abr::x6_sub(d, q0f.y)};
+    const bf16x2 p1 = __builtin_convertvector(r0, bf16x2), q1 = __builtin_convertvector(s0, bf16x2);
+    const f32x2v p1f = __builtin_convertvector(p1, f32x2v), q1f = __builtin_convertvector(q1, f32x2v);
+    const f32x2v r1 = {abr::x6_sub(r0.x, p1f.x), abr::x6_sub(r0.y, p1f.y)}, s1 = {abr::x6_sub(s0.x, q1f.x), abr::x6_sub(s0.y, q1f.y)};
+    const bf16x2 p2 = __builtin_convertvector(r1, bf16x2), q2 = __builtin_convertvector(s1, bf16x2);
+    o0 = make_uint2(*reinterpret_cast<const unsigned*>(&p0), *reinterpret_cast<const unsigned*>(&q0));
+    o1 = make_uint2(*reinterpret_cast<const unsigned*>(&p1), *reinterpret_cast<const unsigned*>(&q1));
+    o2 = make_uint2(*reinterpret_cast<const unsigned*>(&p2), *reinterpret_cast<const unsigned*>(&q2));
+}
 
 constexpr int BKH = 64;        // k per tile
 constexpr int LDH = BKH + 8;   // LDS row pitch in bf16 elements (144 B)
@@ -687,15 +708,11 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
     };
     // exact three-way split of four fp32 values into bf16 planes
     auto split_store = [](const u32x4 v, __bf16* dst, int plane_stride) {
-        const f32x4v f = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-        const bf16x4 h0 = __builtin_convertvector(f, bf16x4);
-        const f32x4v r1 = f - __builtin_convertvector(h0, f32x4v);
-        const bf16x4 h1 = __builtin_convertvector(r1, bf16x4);
-        const f32x4v r2 = r1 - __builtin_convertvector(h1, f32x4v);
-        const bf16x4 h2 = __builtin_convertvector(r2, bf16x4);
-        *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(&h0);
-        *reinterpret_cast<uint2*>(dst + plane_stride) = *reinterpret_cast<const uint2*>(&h1);
-        *reinterpret_cast<uint2*>(dst + 2 * plane_stride) = *reinterpret_cast<const uint2*>(&h2);
+        uint2 o0, o1, o2;
+        x6_split4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), o0, o1, o2);
+        *reinterpret_cast<uint2*>(dst) = o0;
+        *reinterpret_cast<uint2*>(dst + plane_stride) = o1;
+        *reinterpret_cast<uint2*>(dst + 2 * plane_stride) = o2;
     };
     auto store_tile = [&](u32x4 (&ra)[NA], u32x4 (&rb)[NB]) {
         if (chk_a) {
@@ -888,15 +905,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         for (int i = 0; i < NA; i++) {
             const u32x4 v = ra[i];
             __bf16* dst = As + (srow + 32 * i) * LDX + kq * 4;
-            const f32x4v f = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-            const bf16x4 h0 = __builtin_convertvector(f, bf16x4);
-            const f32x4v r1 = f - __builtin_convertvector(h0, f32x4v);
-            const bf16x4 h1 = __builtin_convertvector(r1, bf16x4);
-            const f32x4v r2 = r1 - __builtin_convertvector(h1, f32x4v);
-            const bf16x4 h2 = __builtin_convertvector(r2, bf16x4);
-            *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(&h0);
-            *reinterpret_cast<uint2*>(dst + BM * LDX) = *reinterpret_cast<const uint2*>(&h1);
-            *reinterpret_cast<uint2*>(dst + 2 * BM * LDX) = *reinterpret_cast<const uint2*>(&h2);
+            uint2 o0, o1, o2;
+            x6_split4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), o0, o1, o2);
+            *reinterpret_cast<uint2*>(dst) = o0;
+            *reinterpret_cast<uint2*>(dst + BM * LDX) = o1;
+            *reinterpret_cast<uint2*>(dst + 2 * BM * LDX) = o2;
         }
     };
 

@@ -563,9 +563,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             for (int pp = 0; pp < 4; pp++) {  // rows (2 pp, 2 pp + 1) -> one bf16x2 dword per plane
                 const f32x2v f = {__uint_as_float(rr[2 * pp][j]), __uint_as_float(rr[2 * pp + 1][j])};
                 const bf16x2 h0 = __builtin_convertvector(f, bf16x2);
-                const f32x2v r1 = f - __builtin_convertvector(h0, f32x2v);
+                const f32x2v h0f = __builtin_convertvector(h0, f32x2v);
+                const f32x2v r1 = {abr::x6_sub(f.x, h0f.x), abr::x6_sub(f.y, h0f.y)};   // (not v_pk_add_f32: see conv_igemm.hip::x6_split4)
                 const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
-                const f32x2v r2 = r1 - __builtin_convertvector(h1, f32x2v);
+                const f32x2v h1f = __builtin_convertvector(h1, f32x2v);
+                const f32x2v r2 = {abr::x6_sub(r1.x, h1f.x), abr::x6_sub(r1.y, h1f.y)};
                 const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
                 o0[pp] = *reinterpret_cast<const unsigned*>(&h0);
                 o1[pp] = *reinterpret_cast<const unsigned*>(&h1);
