@@ -815,7 +815,10 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
 // wave's accumulators (each accumulator still receives them smallest-first), not issued as six dependent MFMAs back to back.
 // Measured (tools/x6lab/lab7.hip, random operands): 32768x2048x1024 0.70 -> 0.63 ms, 32768x512x2048 0.38 -> 0.32, 9600x1024x256 +22 %.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+// PLAIN: 1x1, stride 1, no padding (every GEMM but the strided 1x1s and the direct 3x3s; all 36 x n Winograd GEMMs): row m of A is x + m * Cin, the
+// k-tile advances through the load's scalar offset -- no per-row address / halo arithmetic in the MFMA loop (it was 36 VALU instructions per k-tile,
+// four of them quarter-rate 32-bit multiplies the compiler rematerialised the offsets with).
+template <int BM, int BN, int WM, int WN, bool PLAIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_x6w_kernel(const ConvP p, const float* __restrict__ x_,
                                                                                                         float* __restrict__ out_) {
     const float* x = x_;
@@ -844,17 +847,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wp), 0, p.wp_bytes, 0x00020000);
     int a_hi0[NA], a_wi0[NA], a_off0[NA];
     bool a_ok[NA];
+    unsigned a_voff[NA];   // PLAIN: byte offset of (row, kq) or out of range
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int m = m0 + srow + 32 * i;
         a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
-        unsigned b, rem, ho, wo;
-        p.d_howo.divmod((unsigned)mm, b, rem);
-        p.d_wo.divmod(rem, ho, wo);
-        a_hi0[i] = (int)ho * p.stride - p.pad;
-        a_wi0[i] = (int)wo * p.stride - p.pad;
-        a_off0[i] = (((int)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + kq * 4;
+        if constexpr (PLAIN) {
+            a_voff[i] = a_ok[i] ? (unsigned)(m * p.Cin + kq * 4) * 4u : kOOB;
+        } else {
+            const int mm = a_ok[i] ? m : 0;
+            unsigned b, rem, ho, wo;
+            p.d_howo.divmod((unsigned)mm, b, rem);
+            p.d_wo.divmod(rem, ho, wo);
+            a_hi0[i] = (int)ho * p.stride - p.pad;
+            a_wi0[i] = (int)wo * p.stride - p.pad;
+            a_off0[i] = (((int)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + kq * 4;
+        }
     }
     const int KS = p.K / 16;
     unsigned bo[TN];   // byte offset of chunk (nb, 0, 0) for this lane; 32-row blocks past the packed matrix read as zeros
@@ -868,15 +876,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     u32x4 fbr[2][TN][3];   // [step of the k-tile][n-block][plane]
     auto load_a = [&](int kt) {
         const int k0 = kt * BKX;
-        unsigned rs, c0, r, s;
-        p.d_cin.divmod((unsigned)k0, rs, c0);
-        p.d_s.divmod(rs, r, s);
-        const int delta = ((int)r * p.W + (int)s) * p.Cin + (int)c0;
+        if constexpr (PLAIN) {
 #pragma unroll
-        for (int i = 0; i < NA; i++) {
-            const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
-            const bool ok = a_ok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB), 0, 0);
+            for (int i = 0; i < NA; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)a_voff[i], k0 * 4, 0);
+        } else {
+            unsigned rs, c0, r, s;
+            p.d_cin.divmod((unsigned)k0, rs, c0);
+            p.d_s.divmod(rs, r, s);
+            const int delta = ((int)r * p.W + (int)s) * p.Cin + (int)c0;
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+                const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
+                const bool ok = a_ok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB), 0, 0);
+            }
         }
     };
     auto load_b = [&](int kt, int u) {
@@ -1025,10 +1038,12 @@ int launch_x6w(const ConvP& p, const float* x, float* out, hipStream_t st) {
     constexpr size_t lds_op = sizeof(__bf16) * 3 * BM * LDX;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
     const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
-    auto kern = conv_igemm_x6w_kernel<BM, BN, WM, WN>;
+    const bool plain = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
+    auto kern = plain ? conv_igemm_x6w_kernel<BM, BN, WM, WN, true> : conv_igemm_x6w_kernel<BM, BN, WM, WN, false>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x6w_kernel<BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x6w_kernel<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     constexpr int prof_id = BM == 128 ? (BN == 128 ? abr::PROF_X6W_128x128 : abr::PROF_X6W_128x64) : abr::PROF_X6W_64x64;
