@@ -18,6 +18,29 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// x - y as ONE v_sub_f32 (the compiler would pack two of them into a v_pk_add_f32, which is slow beside MFMAs); -DPK_ADD restores the packed form
+__device__ __forceinline__ float sub1(float x, float y) {
+#ifdef PK_ADD
+    return x - y;
+#else
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#endif
+}
+__device__ __forceinline__ void split_pair(const f32x2v f, unsigned& o0, unsigned& o1, unsigned& o2) {
+    const bf16x2 h0 = __builtin_convertvector(f, bf16x2);
+    const f32x2v h0f = __builtin_convertvector(h0, f32x2v);
+    const f32x2v r1 = {sub1(f.x, h0f.x), sub1(f.y, h0f.y)};
+    const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
+    const f32x2v h1f = __builtin_convertvector(h1, f32x2v);
+    const f32x2v r2 = {sub1(r1.x, h1f.x), sub1(r1.y, h1f.y)};
+    const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
+    o0 = *reinterpret_cast<const unsigned*>(&h0);
+    o1 = *reinterpret_cast<const unsigned*>(&h1);
+    o2 = *reinterpret_cast<const unsigned*>(&h2);
+}
+
 enum { KO_LOAD = 1, KO_SPLIT = 2, KO_STORE = 4, KO_BAR = 8, KO_MFMA = 16, KO_EPI = 32, KO_READ = 64, KO_EPIQ = 128, KO_EPINT = 256, OPT_PRIO = 512, OPT_PRIO_M = 1024 };
 constexpr int MRX = 32;
 
@@ -62,14 +85,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
                     o0[pp] = rr[2 * pp][j]; o1[pp] = rr[2 * pp + 1][j]; o2[pp] = rr[2 * pp][j] ^ rr[2 * pp + 1][j];
                 } else {
                     const f32x2v f = {__uint_as_float(rr[2 * pp][j]), __uint_as_float(rr[2 * pp + 1][j])};
-                    const bf16x2 h0 = __builtin_convertvector(f, bf16x2);
-                    const f32x2v r1 = f - __builtin_convertvector(h0, f32x2v);
-                    const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
-                    const f32x2v r2 = r1 - __builtin_convertvector(h1, f32x2v);
-                    const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
-                    o0[pp] = *reinterpret_cast<const unsigned*>(&h0);
-                    o1[pp] = *reinterpret_cast<const unsigned*>(&h1);
-                    o2[pp] = *reinterpret_cast<const unsigned*>(&h2);
+                    unsigned a0, a1, a2;
+                    split_pair(f, a0, a1, a2);
+                    o0[pp] = a0; o1[pp] = a1; o2[pp] = a2;
                 }
             }
             if constexpr (KO & KO_STORE) {
@@ -212,14 +230,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                         o0[pp] = r[2 * pp][e]; o1[pp] = r[2 * pp + 1][e]; o2[pp] = r[2 * pp][e] ^ r[2 * pp + 1][e];
                     } else {
                     const f32x2v f = {__uint_as_float(r[2 * pp][e]), __uint_as_float(r[2 * pp + 1][e])};
-                    const bf16x2 h0 = __builtin_convertvector(f, bf16x2);
-                    const f32x2v r1 = f - __builtin_convertvector(h0, f32x2v);
-                    const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
-                    const f32x2v r2 = r1 - __builtin_convertvector(h1, f32x2v);
-                    const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
-                    o0[pp] = *reinterpret_cast<const unsigned*>(&h0);
-                    o1[pp] = *reinterpret_cast<const unsigned*>(&h1);
-                    o2[pp] = *reinterpret_cast<const unsigned*>(&h2);
+                    unsigned a0, a1, a2;
+                    split_pair(f, a0, a1, a2);
+                    o0[pp] = a0; o1[pp] = a1; o2[pp] = a2;
                     }
                 }
                 unsigned* d = st_base + boff + e * 256;
