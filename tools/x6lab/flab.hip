@@ -69,6 +69,32 @@ __global__ void pack_b(const float* __restrict__ B, u32x4* __restrict__ Bp, int 
 }
 
 
+// the library's split (conv_igemm.hip::x6_split4): on pairs, residual subtractions as single v_sub_f32 (-DPK_ADD: left to the compiler = v_pk_add_f32)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float sub1(float x, float y) {
+#ifdef PK_ADD
+    return x - y;
+#else
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#endif
+}
+__device__ __forceinline__ void split_pair(const float a, const float b, unsigned& o0, unsigned& o1, unsigned& o2) {
+    const f32x2v f = {a, b};
+    const bf16x2 h0 = __builtin_convertvector(f, bf16x2);
+    const f32x2v h0f = __builtin_convertvector(h0, f32x2v);
+    const f32x2v r1 = {sub1(a, h0f.x), sub1(b, h0f.y)};
+    const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
+    const f32x2v h1f = __builtin_convertvector(h1, f32x2v);
+    const f32x2v r2 = {sub1(r1.x, h1f.x), sub1(r1.y, h1f.y)};
+    const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
+    o0 = *reinterpret_cast<const unsigned*>(&h0);
+    o1 = *reinterpret_cast<const unsigned*>(&h1);
+    o2 = *reinterpret_cast<const unsigned*>(&h2);
+}
+
 enum { KO_ALOAD = 1, KO_SPLIT = 2, KO_STORE = 4, KO_BLOAD = 8, KO_BAR = 16, KO_READ = 32, KO_MFMA = 64, KO_EPI = 128 };
 
 template <int KO>
@@ -104,13 +130,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if constexpr (KO & KO_SPLIT) {
                 o0 = make_uint2(ra[i].x, ra[i].y); o1 = make_uint2(ra[i].z, ra[i].w); o2 = make_uint2(ra[i].x ^ ra[i].z, ra[i].y ^ ra[i].w);
             } else {
-                const f32x4v f = {__uint_as_float(ra[i].x), __uint_as_float(ra[i].y), __uint_as_float(ra[i].z), __uint_as_float(ra[i].w)};
-                const bf16x4 h0 = __builtin_convertvector(f, bf16x4);
-                const f32x4v r1 = f - __builtin_convertvector(h0, f32x4v);
-                const bf16x4 h1 = __builtin_convertvector(r1, bf16x4);
-                const f32x4v r2 = r1 - __builtin_convertvector(h1, f32x4v);
-                const bf16x4 h2 = __builtin_convertvector(r2, bf16x4);
-                o0 = *reinterpret_cast<const uint2*>(&h0); o1 = *reinterpret_cast<const uint2*>(&h1); o2 = *reinterpret_cast<const uint2*>(&h2);
+                split_pair(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y), o0.x, o1.x, o2.x);
+                split_pair(__uint_as_float(ra[i].z), __uint_as_float(ra[i].w), o0.y, o1.y, o2.y);
             }
             if constexpr (KO & KO_STORE) {
                 asm volatile("" ::"v"(o0), "v"(o1), "v"(o2));
