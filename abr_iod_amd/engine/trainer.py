@@ -41,6 +41,10 @@ SOURCE_HEAD_STREAM = os.environ.get("ABR_SOURCE_HEAD_STREAM", "1") != "0"
 EARLY_SECOND_PASS = os.environ.get("ABR_EARLY_SECOND_PASS", "1") != "0"
 PIPELINE_TARGET_FROZEN = os.environ.get("ABR_PIPELINE_TARGET_FROZEN", "1") != "0"
 PIPELINE_SOURCE = os.environ.get("ABR_PIPELINE_SOURCE", "1") != "0"
+# Opt-in (off by default, and off in bench.py's headline): when the source and the target model hold IDENTICAL frozen stem / layer1 weights
+# (the reference's setup: both are loaded from the same checkpoint and FREEZE_CONV_BODY_AT = 2 never lets them move), that prefix is the same
+# function of the same batch in both models -- compute it once per batch and feed both.  Verified by comparing the tensors, never assumed.
+SHARE_FROZEN_PREFIX = [os.environ.get("ABR_SHARE_FROZEN_PREFIX", "0") != "0"]
 JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "0") != "0"
 
 
@@ -53,6 +57,8 @@ class TrainerState(object):
         self.prefetched = {}     # {"key": ..., "state": soften_begin(next batch), "target_prefix": (event, frozen_prefix(next batch))}
         self.x6_watch = None
         self.x6_tiny_logged = False
+        self.share_key = None    # (weight versions) the frozen-prefix comparison below was made for
+        self.share_ok = False
 
     def drop_prefetch(self):
         self.prefetched = {}
@@ -64,6 +70,32 @@ def trainer_state(model_target):
         st = TrainerState()
         model_target.__dict__["_abr_trainer_state"] = st
     return st
+
+
+def frozen_prefix_shareable(model_source, model_target):
+    """True iff the two backbones' frozen prefix (stem + leading stages without trainable parameters) is the same function: the same stages are
+    frozen in both, same arithmetic, and every parameter and buffer of them compares equal.  The comparison runs once per weight version
+    (resnet._STATIC_VERSION moves on checkpoint loads / in-place surgery; training never touches frozen tensors)."""
+    from ..modeling.backbone import resnet
+    st = trainer_state(model_target)
+    key = (id(model_source), resnet._STATIC_VERSION[0], getattr(model_source, "conv_math", None), getattr(model_target, "conv_math", None))
+    if st.share_key == key:
+        return st.share_ok
+    ok = False
+    bs, bt = getattr(getattr(model_source, "backbone", None), "body", None), getattr(getattr(model_target, "backbone", None), "body", None)
+    if bs is not None and bt is not None and hasattr(bs, "frozen_stage_names") and getattr(model_source, "conv_math", 0) == getattr(model_target, "conv_math", 1):
+        ns, nt = bs.frozen_stage_names(), bt.frozen_stage_names()
+        if ns is not None and ns == nt:
+            ok = True
+            for name in ["stem"] + list(nt):
+                ms_, mt_ = getattr(bs, name), getattr(bt, name)
+                ts_ = list(ms_.named_parameters()) + list(ms_.named_buffers())
+                tt_ = dict(list(mt_.named_parameters()) + list(mt_.named_buffers()))
+                if len(ts_) != len(tt_) or any(n not in tt_ or v.shape != tt_[n].shape or v.dtype != tt_[n].dtype or not torch.equal(v, tt_[n]) for n, v in ts_):
+                    ok = False
+                    break
+    st.share_key, st.share_ok = key, ok
+    return ok
 
 
 def _prefetch_key(images, model_source, model_target):
@@ -320,13 +352,23 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         cur = torch.cuda.current_stream()
         src = ops.side_stream((cur.device.index, "source-model"))
         src.wait_stream(cur)   # next_images may have been produced on the current stream (async upload, device-side padding / augmentation)
-        with torch.no_grad(), torch.cuda.stream(src):
-            nxt = model_source.soften_begin(next_images)
-        nxt["_stream"] = src
         tstate = trainer_state(model_target)
+        shared = None
+        if (SHARE_FROZEN_PREFIX[0] and PIPELINE_TARGET_FROZEN and hasattr(model_target, "prefetch_frozen")
+                and frozen_prefix_shareable(model_source, model_target)):
+            with torch.no_grad(), torch.cuda.stream(src):
+                shared = model_target.prefetch_frozen(next_images)     # ONE stem + layer1 pass for both models
+                if shared is not None:
+                    ev_shared = torch.cuda.Event()
+                    ev_shared.record()
+        with torch.no_grad(), torch.cuda.stream(src):
+            nxt = model_source.soften_begin(next_images, prefix=shared) if shared is not None else model_source.soften_begin(next_images)
+        nxt["_stream"] = src
         # (holds the batch object, so its id() cannot be recycled while the entry lives)
         tstate.prefetched = dict(images=next_images, key=_prefetch_key(next_images, model_source, model_target), state=nxt)
-        if PIPELINE_TARGET_FROZEN and hasattr(model_target, "prefetch_frozen"):
+        if shared is not None:
+            tstate.prefetched["target_prefix"] = (ev_shared, shared)
+        elif PIPELINE_TARGET_FROZEN and hasattr(model_target, "prefetch_frozen"):
             # the TARGET's frozen stem + layer1 (FREEZE_CONV_BODY_AT = 2) for the next batch too: their output does not depend on this step's
             # update either, and these bandwidth-bound convolutions overlap better with the backward pass's GEMMs than with the target's own
             # layer2 / layer3 in the next forward.  Same stream as the source model's prefetch: one bandwidth-bound chain at a time.

@@ -302,6 +302,17 @@ class ResNet(nn.Module):
             for p in m.parameters():
                 p.requires_grad = False
 
+    def frozen_stage_names(self):
+        """names of the leading stages without trainable parameters (what frozen_prefix computes after the stem), or None when the stem trains"""
+        if any(p.requires_grad for p in self.stem.parameters()):
+            return None
+        names = []
+        for name in self.stages:
+            if any(p.requires_grad for p in getattr(self, name).parameters()):
+                break
+            names.append(name)
+        return names
+
     def frozen_prefix(self, x):
         """The stem and the leading stages whose parameters are all frozen (FREEZE_CONV_BODY_AT = 2: stem + layer1), run without autograd:
         their outputs do not depend on the optimiser, so the trainer may compute them for the NEXT batch while the current backward pass

@@ -155,14 +155,15 @@ class GeneralizedRCNN(nn.Module):
         (all_proposals, _), anchors, rpn_output = self.rpn(images, features, targets)
         return self._soften_from_proposals(all_proposals, features, backbone_features, anchors, rpn_output, selected_indices)
 
-    def soften_begin(self, images, defer=True):
+    def soften_begin(self, images, defer=True, prefix=None):
         """First half of generate_soften_proposal for the frozen source model: backbone + RPN head on the current stream, the
         proposal selection (top-k, decode, NMS) on a side stream with nothing read back.  The trainer enqueues the target model's
         forward between `soften_begin` and `soften_finish`, so the selection's latency-bound kernels hide behind the target's
         backbone convolutions."""
         assert not self.training, "the soften pass runs the source model in eval mode (train_incremental.py:80)"
         images = to_image_list(images)
-        features, backbone_features = self.backbone(images.tensors)
+        # `prefix`: frozen_prefix() of a backbone whose frozen stem / stages were verified identical to this one's (trainer.frozen_prefix_shareable)
+        features, backbone_features = self.backbone(images.tensors, prefix) if prefix is not None else self.backbone(images.tensors)
         (pending, _), anchors, rpn_output = self.rpn(images, features, None, defer_proposals=defer and images.tensors.is_cuda)
         return dict(features=features, backbone_features=backbone_features, pending=pending, anchors=anchors, rpn_output=rpn_output)
 

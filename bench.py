@@ -282,6 +282,9 @@ def main():
     ap.add_argument("--fold-streams", action="store_true",
                     help="run the whole benchmark with every HIP stream of the step folded into one (for a serialised-stream rocprofv3 profile)")
     ap.add_argument("--no-serialised-leg", action="store_true", help="skip the short serialised-stream re-run behind the timed region (roofline.serialised)")
+    ap.add_argument("--share-frozen-prefix", action="store_true",
+                    help="(informational, never the headline) compute the frozen stem + layer1 ONCE per batch for the source and the target model when "
+                         "their frozen weights compare equal (engine/trainer.py::SHARE_FROZEN_PREFIX); the reference computes them in both models")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher self-test: start the ranks, form the process group (gloo when there is no GPU), all-reduce a 1 per rank, print the count")
     ap.add_argument("--inject-failure", type=int, default=-1,
@@ -327,6 +330,8 @@ def main():
 
     from abr_iod_amd import _lib
     from abr_iod_amd.engine import train_step
+    from abr_iod_amd.engine import trainer as _trainer
+    _trainer.SHARE_FROZEN_PREFIX[0] = bool(a.share_frozen_prefix)   # the headline ALWAYS computes both models' frozen prefix, whatever the environment says
     from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
     from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer
 
@@ -443,7 +448,10 @@ def main():
                                        {"15-5": "configs[2]", "10-10": "configs[3]", "10-5": "configs[4]"}.get(a.task, "(extra task)"), a.task, feat,
                                        dist_type, alpha, beta, gamma, "{}x{}".format(IH, IW) + (" alternating with {0}x{0} (mosaic-shaped) batches".format(min(IH, IW))
                                                                                                  if a.mosaic_squares else "")),
-                       "informational": None if standard else "not the metric's geometry (BASELINE.json: 600x1000 batches): GFLOP / roofline figures per image do not apply",
+                       "informational": ("the frozen stem + layer1 computed once for both models (--share-frozen-prefix): NOT the reference's work per step, "
+                                         "not the headline" if a.share_frozen_prefix else None) if standard
+                                        else "not the metric's geometry (BASELINE.json: 600x1000 batches): GFLOP / roofline figures per image do not apply",
+                       "shared_frozen_prefix": bool(a.share_frozen_prefix),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "math": a.math,
                        "rccl_ranks": rccl_ranks, "collective": "RCCL all-reduce of the flat gradient, 3 buckets, 2 under backward" if world > 1 else None,
                        "gradient_exchange": optimizer.reducer.describe() if world > 1 else None,

@@ -55,3 +55,50 @@ def test_prefetch_key_follows_the_batch_the_weights_and_the_arithmetic():
     assert sa is trainer.trainer_state(a) and sa is not sb
     sa.prefetched = {"images": x}
     assert sb.prefetched == {}
+
+
+def test_frozen_prefix_is_shared_only_between_identical_frozen_weights():
+    """engine/trainer.py::frozen_prefix_shareable (the opt-in ABR_SHARE_FROZEN_PREFIX): tensors are compared, never assumed equal; the verdict is
+    cached per weight version and re-made when resnet._STATIC_VERSION moves (checkpoint load / in-place surgery)."""
+    import torch
+    from abr_iod_amd.engine import trainer
+    from abr_iod_amd.modeling.backbone import resnet
+
+    class Body(torch.nn.Module):
+        def __init__(self, frozen=("layer1",)):
+            super().__init__()
+            self.stem = torch.nn.Conv2d(3, 4, 3)
+            self.layer1 = torch.nn.Sequential(torch.nn.Conv2d(4, 4, 1), torch.nn.BatchNorm2d(4))
+            self.layer2 = torch.nn.Conv2d(4, 4, 1)
+            self._frozen = list(frozen)
+            for m in [self.stem] + [getattr(self, n) for n in frozen]:
+                for p in m.parameters():
+                    p.requires_grad = False
+
+        def frozen_stage_names(self):
+            return list(self._frozen)
+
+    class Model(object):
+        def __init__(self, body, math="bf16x6"):
+            self.backbone = type("B", (), {})()
+            self.backbone.body = body
+            self.conv_math = math
+
+    torch.manual_seed(0)
+    bs = Body()
+    bt = Body()
+    bt.load_state_dict(bs.state_dict())
+    with torch.no_grad():
+        bt.layer2.weight.add_(1.0)                       # trainable stages may differ
+    ms, mt = Model(bs), Model(bt)
+    assert trainer.frozen_prefix_shareable(ms, mt)
+    with torch.no_grad():
+        bs.layer1[1].running_mean[2] += 1e-3             # one frozen BUFFER moves ...
+    assert trainer.frozen_prefix_shareable(ms, mt)       # ... the cached verdict stands until the weight version moves
+    resnet._STATIC_VERSION[0] += 1
+    assert not trainer.frozen_prefix_shareable(ms, mt)
+    bt.load_state_dict(bs.state_dict())
+    resnet._STATIC_VERSION[0] += 1
+    assert trainer.frozen_prefix_shareable(ms, mt)
+    assert not trainer.frozen_prefix_shareable(ms, Model(Body(frozen=()), "bf16x6"))       # different frozen sets
+    assert not trainer.frozen_prefix_shareable(ms, Model(bt, "f32"))                        # different arithmetic

@@ -9,6 +9,7 @@ B="--no-cpu-baseline --no-alt-math"
 timeout 600 python bench.py > $O/${R}_bench_default.jsonl 2> $O/bench_default.err
 timeout 300 python bench.py --image-size 800x1333 --steps 10 > $O/${R}_bench_800x1333.jsonl 2>/dev/null
 timeout 300 python bench.py --task 10-5 --mosaic-squares --steps 20 > $O/${R}_bench_10-5_mosaic_squares.jsonl 2>/dev/null
+timeout 300 python bench.py --share-frozen-prefix --no-cpu-baseline --no-alt-math > $O/${R}_bench_shared_frozen_prefix.jsonl 2>/dev/null
 timeout 300 python bench.py --task 10-5 --mosaic-squares --math bf16 --steps 20 --no-kernel-timing > $O/${R}_bench_10-5_mosaic_squares_bf16_backbone.jsonl 2>/dev/null
 # rocprofv3 kernel trace of the bench command (+ the PMC HBM-traffic passes), then the matrix-pipe counters
 STEPS=5 WARMUP=2 timeout 900 bash tools/profile_bench.sh > $O/profile_bench.log 2>&1
