@@ -31,7 +31,7 @@ PROF_NAMES = ["conv_igemm_kernel<128,128>", "conv_igemm_kernel<128,64>", "conv_i
               "conv_igemm_x6_kernel<128,128>", "conv_igemm_x6_kernel<128,64>", "conv_igemm_x6_kernel<64,64>",
               "conv_igemm_x6w_kernel<128,128>", "conv_igemm_x6w_kernel<128,64>", "conv_igemm_x6w_kernel<64,64>"]
 # (positions = abr::ProfId in csrc/common.h.  One row per TEMPLATE INSTANCE of the bf16x6 implicit GEMM, named as rocprofv3 names them
-#  (`conv_igemm_x6w_kernel<128, 128, 2, 2>` ...: x6w = the weights-direct form, x6 = the form that splits the weight tile per workgroup),
+#  (`conv_igemm_x6w_kernel<128, 128, 1, 4, true>` ...: x6w = the weights-direct form, x6 = the form that splits the weight tile per workgroup),
 #  so every row's fraction can be recomputed from profiles/ alone.  id 8 is the
 #  weight-gradient kernel of the chosen arithmetic: conv_wgrad_x6_kernel under --math bf16x6, conv_wgrad_bf16_kernel under --math bf16.)
 
