@@ -35,6 +35,14 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PrepItem(C.Structure):
+    """abr_prep_item (include/abr_iod_hip.h section 3): one tensor of abr_conv_prepare_batch."""
+
+    _fields_ = [("w", _vp), ("scale", _vp), ("wt", _vp),
+                ("Cout", C.c_int32), ("R", C.c_int32), ("S", C.c_int32), ("Cin", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("math", C.c_int32),
+                ("w_version", _i64)]
+
+
 _SIGS = {
     "abr_version": (_i, []),
     "abr_device_info": (_i, [_vp]),
@@ -46,6 +54,7 @@ _SIGS = {
     "abr_prof_event_overhead_ms": (_i, [_vp, _vp]),
     "abr_prof_step_begin": (_i, []),
     "abr_conv_prepare_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp]),
+    "abr_conv_prepare_batch": (_i, [_vp, _i, _vp]),
     "abr_conv_cache_clear": (_i, []),
     "abr_conv_cache_bytes": (_i64, []),
     "abr_roi_head_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _i, _i, C.c_uint64,

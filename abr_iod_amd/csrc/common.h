@@ -84,6 +84,32 @@ float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t 
 // the cache behind it, for every kind of data derived from a weight tensor (conv_winograd.hip): `fill(buf)` writes `bytes` on `st` (0 = ok)
 enum DerivedKind { DERIVED_WINO_U = 0, DERIVED_X6_PLANES = 1, DERIVED_WINO_U_X6_PLANES = 2 };
 void* derived_cached(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, const std::function<int(void*)>& fill);
+// The same in two halves, for fills that are launched together (abr_conv_prepare_batch): derived_acquire returns the entry's buffer and, when the
+// entry does not hold `version` yet, a token (the refill is already ordered behind the entry's readers); the caller fills every such buffer on `st`
+// and then hands the tokens to derived_commit, which records the fill events.  Entries with a pending token are never evicted.
+void* derived_acquire(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, void** token);
+void derived_commit(void* const* tokens, int n, hipStream_t st);
+
+// One job of a batched weight preparation (a table of these lives in device memory; workgroup b belongs to the job with first_block <= b).
+struct PrepJob {
+    const float* src;     // transpose: w [Cout][RS][Cin]; wino: w [N][3][3][C]; pack: matrix [rows][K]
+    const float* scale;   // transpose: FrozenBN scale per Cout, or nullptr
+    void* dst;            // transpose: wt [Cin][RS][Cout]; wino: U [36][N][C]; pack: planes
+    int a, b, c;          // transpose: Cout, RS, Cin; wino: N, C, -; pack: rows, K, -
+    int gx, gy;           // the job's grid (x, y) as the single-job kernel would have it (z = blocks / (gx * gy))
+    int first_block;
+};
+int prep_transpose_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);   // conv_igemm.hip
+int prep_pack_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);        // conv_igemm.hip
+int prep_wino_u_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);      // conv_winograd.hip (C % 4 == 0 jobs only)
+__device__ __forceinline__ int prep_find_job(const PrepJob* jobs, int njobs, int block) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= block) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
 void derived_cache_clear();
 size_t derived_cache_bytes();
 

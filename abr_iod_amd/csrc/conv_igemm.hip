@@ -30,6 +30,10 @@
 #include <algorithm>
 #include <map>
 
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -1143,6 +1147,73 @@ __global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restr
     }
 }
 
+// dgrad_weights_kernel / x6_pack_kernel over a TABLE of tensors (abr_conv_prepare_batch): workgroup -> (job, the job's own block indices)
+__global__ __launch_bounds__(256) void dgrad_weights_multi_kernel(const abr::PrepJob* __restrict__ jobs, int njobs) {
+    __shared__ float t[32][33];
+    const int j = abr::prep_find_job(jobs, njobs, blockIdx.x);
+    const abr::PrepJob jb = jobs[j];
+    const float* __restrict__ w = jb.src;
+    const float* __restrict__ scale = jb.scale;
+    float* __restrict__ wt = reinterpret_cast<float*>(jb.dst);
+    const int Cout = jb.a, RS = jb.b, Cin = jb.c;
+    const int lb = blockIdx.x - jb.first_block;
+    const int bx = lb % jb.gx, by = (lb / jb.gx) % jb.gy, rs = lb / (jb.gx * jb.gy);
+    const int co0 = by * 32, ci0 = bx * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int co = co0 + i, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[((size_t)co * RS + rs) * Cin + ci] * (scale ? scale[co] : 1.f);
+        t[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int ci = ci0 + i, co = co0 + tx;
+        if (ci < Cin && co < Cout) wt[((size_t)ci * RS + (RS - 1 - rs)) * Cout + co] = t[tx][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void x6_pack_multi_kernel(const abr::PrepJob* __restrict__ jobs, int njobs, unsigned* flags) {
+    __shared__ float t[32][68];
+    const int j = abr::prep_find_job(jobs, njobs, blockIdx.x);
+    const abr::PrepJob jb = jobs[j];
+    const float* __restrict__ w = jb.src;
+    uint4* __restrict__ planes = reinterpret_cast<uint4*>(jb.dst);
+    const int rows = jb.a, K = jb.b;
+    const int lb = blockIdx.x - jb.first_block;
+    const int nb = lb / jb.gx, k0 = (lb % jb.gx) * 64, tid = threadIdx.x;
+    unsigned bmin = 0xFFFFFFFFu;
+    float nonfin = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int r = (tid >> 4) + 16 * h, c = (tid & 15) * 4, row = nb * 32 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows && k0 + c < K) v = *reinterpret_cast<const float4*>(w + (size_t)row * K + k0 + c);
+        *reinterpret_cast<float4*>(&t[r][c]) = v;
+        const unsigned b0 = (__float_as_uint(v.x) << 1) - 1u, b1 = (__float_as_uint(v.y) << 1) - 1u, b2 = (__float_as_uint(v.z) << 1) - 1u,
+                       b3 = (__float_as_uint(v.w) << 1) - 1u;
+        bmin = min(min(bmin, min(b0, b1)), min(b2, b3));
+        nonfin = fmaf(v.x, 0.f, nonfin); nonfin = fmaf(v.y, 0.f, nonfin); nonfin = fmaf(v.z, 0.f, nonfin); nonfin = fmaf(v.w, 0.f, nonfin);
+    }
+    if (flags) abr::x6_report(bmin, nonfin, flags);
+    __syncthreads();
+    const int ksl = tid >> 6, lane = tid & 63, ks = k0 / 16 + ksl;
+    if (ks * 16 >= K) return;
+    const float* src = &t[lane & 31][ksl * 16 + (lane >> 5) * 8];
+    __bf16 h[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float v = src[e];
+        const __bf16 h0 = (__bf16)v;
+        const float r1 = v - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        h[0][e] = h0; h[1][e] = h1; h[2][e] = (__bf16)(r1 - (float)h1);
+    }
+    const size_t c = ((size_t)nb * (K / 16) + ks) * 3;
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) planes[(c + pl) * 64 + lane] = *reinterpret_cast<const uint4*>(h[pl]);
+}
+
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ gy, int64_t M, int C, int rows_per_block,
                                                          float* __restrict__ db) {
     // block = 64 columns x 4 row-lanes; grid.x = column chunks, grid.y = row chunks
@@ -1431,6 +1502,161 @@ extern "C" int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, 
         void* pl = abr::derived_cached(w, abr::DERIVED_X6_PLANES, (size_t)x6_packed_bytes(Cout, K), w_version, st, [&](void* buf) { return x6_pack(w, Cout, K, buf, st); });
         ABR_REQUIRE(pl != nullptr, "conv_prepare_weights: no memory for the packed weight planes");
         ABR_CHECK_LAUNCH("conv_prepare_weights");
+    }
+    return ABR_OK;
+}
+
+namespace abr {
+int prep_transpose_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st) {
+    if (njobs <= 0 || blocks <= 0) return 0;
+    dgrad_weights_multi_kernel<<<(unsigned)blocks, 256, 0, st>>>(jobs_dev, njobs);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int prep_pack_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st) {
+    if (njobs <= 0 || blocks <= 0) return 0;
+    x6_pack_multi_kernel<<<(unsigned)blocks, 256, 0, st>>>(jobs_dev, njobs, abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+}  // namespace abr
+
+// Job tables of abr_conv_prepare_batch: a RING of pinned host staging + device slots per stream.  A call takes the next njobs slots; a region is
+// reused only after the upload that last used it has completed -- thousands of jobs (tens of optimiser steps) later, so the host never waits for
+// the stream (a single staging buffer made every call wait for the previous call's upload, which sits behind the whole backward pass).
+namespace {
+constexpr size_t kPrepRing = 8192;
+struct PrepTables {
+    abr::PrepJob* host = nullptr;
+    abr::PrepJob* dev = nullptr;
+    size_t head = 0;                                   // next free slot
+    std::vector<std::pair<size_t, hipEvent_t>> inflight;   // (end slot of a past call's region, its upload event), oldest first
+    size_t inflight_begin = 0;                         // first slot still covered by `inflight`
+    float* u_scratch = nullptr;   // fp32 Winograd-domain weights on their way to being packed
+    size_t u_floats = 0;
+};
+std::map<hipStream_t, PrepTables> g_prep_tables;
+std::mutex g_prep_mu;
+
+// slots [*first, *first + n) of the ring, free of any upload still in flight
+bool prep_ring_take(PrepTables& T, size_t n, size_t* first) {
+    if (n > kPrepRing) return false;
+    if (!T.host) {
+        if (hipHostMalloc(&T.host, kPrepRing * sizeof(abr::PrepJob)) != hipSuccess || hipMalloc(&T.dev, kPrepRing * sizeof(abr::PrepJob)) != hipSuccess) return false;
+    }
+    if (T.head + n > kPrepRing) {   // wrap: everything recorded so far must be done before slot 0 is written again
+        for (auto& pr : T.inflight) { (void)hipEventSynchronize(pr.second); (void)hipEventDestroy(pr.second); }
+        T.inflight.clear();
+        T.head = 0;
+    }
+    *first = T.head;
+    T.head += n;
+    return true;
+}
+}  // namespace
+
+extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* stream) {
+    ABR_REQUIRE(n >= 0 && (n == 0 || items), "conv_prepare_batch: bad args");
+    if (n == 0) return ABR_OK;
+    hipStream_t st = abr::as_stream(stream);
+    static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
+    std::lock_guard<std::mutex> lock(g_prep_mu);
+    PrepTables& T = g_prep_tables[st];
+    std::vector<abr::PrepJob> tj, uj, pj;        // transposes, Winograd weight transforms, packings
+    std::vector<void*> tokens;
+    std::vector<size_t> u_off;                    // per uj entry: offset (floats) of its U inside the scratch
+    size_t u_total = 0;
+    int tb = 0, ub = 0, pb = 0;                   // workgroups of the three launches
+    auto add_pack = [&](const float* src, int64_t rows, int K, void* dst) {
+        abr::PrepJob j{};
+        j.src = src; j.dst = dst; j.a = (int)rows; j.b = K; j.gx = (K + 63) / 64; j.gy = (int)((rows + 31) / 32); j.first_block = pb;
+        pb += j.gx * j.gy;
+        pj.push_back(j);
+    };
+    // what abr_conv_prepare_weights derives from tensor `w` ([Cout][R][S][Cin]) of a conv with this geometry: returns 1 when it had to go the per-tensor way
+    auto derive = [&](const float* w, int Cout, int R, int S, int Cin, int stride, int pad, int math, int64_t ver) -> int {
+        const int K = R * S * Cin;
+        if (wino_min_c() > 0 && math != ABR_MATH_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && Cin % BK == 0 && Cout % 4 == 0 &&
+            Cin >= wino_min_c() && Cout >= 128) {
+            if (!(math == ABR_MATH_BF16X6 && direct_on && Cout % 32 == 0 && Cin % 4 == 0)) return 1;
+            void* tok = nullptr;
+            void* planes = abr::derived_acquire(w, abr::DERIVED_WINO_U_X6_PLANES, (size_t)x6_packed_bytes((int64_t)36 * Cout, Cin), ver, st, &tok);
+            if (!planes) return 1;
+            if (!tok) return 0;   // already there
+            tokens.push_back(tok);
+            abr::PrepJob j{};
+            j.src = w; j.a = Cout; j.b = Cin; j.gx = (int)(((int64_t)Cout * (Cin / 4) + 255) / 256); j.gy = 1; j.first_block = ub;
+            ub += j.gx;
+            uj.push_back(j);
+            u_off.push_back(u_total);
+            // the packing job reads the fp32 U from the scratch: its src is patched in once the scratch address is known
+            add_pack(reinterpret_cast<const float*>(u_total), (int64_t)36 * Cout, Cin, planes);
+            pj.back().c = 1;   // src is a scratch offset
+            u_total += (size_t)36 * Cout * Cin;
+            return 0;
+        }
+        if (math == ABR_MATH_BF16X6 && direct_on && Cin % BKX == 0 && x6_packed_bytes(Cout, K) < (int64_t)0xFFFFFFF0) {
+            void* tok = nullptr;
+            void* planes = abr::derived_acquire(w, abr::DERIVED_X6_PLANES, (size_t)x6_packed_bytes(Cout, K), ver, st, &tok);
+            if (!planes) return 1;
+            if (tok) { tokens.push_back(tok); add_pack(w, Cout, K, planes); }
+            return 0;
+        }
+        return 0;   // nothing to derive
+    };
+    std::vector<int> single_fwd, single_bwd;
+    for (int i = 0; i < n; i++) {
+        const abr_prep_item& it = items[i];
+        ABR_REQUIRE(it.w && it.w_version != 0 && it.Cout > 0 && it.R > 0 && it.S > 0 && it.Cin > 0, "conv_prepare_batch: bad item");
+        if (derive(it.w, it.Cout, it.R, it.S, it.Cin, it.stride, it.pad, it.math, it.w_version)) single_fwd.push_back(i);
+        if (it.wt) {
+            abr::PrepJob j{};
+            j.src = it.w; j.scale = it.scale; j.dst = it.wt; j.a = it.Cout; j.b = it.R * it.S; j.c = it.Cin;
+            j.gx = (it.Cin + 31) / 32; j.gy = (it.Cout + 31) / 32; j.first_block = tb;
+            tb += j.gx * j.gy * it.R * it.S;
+            tj.push_back(j);
+            // the dgrad conv: [Cin][R][S][Cout] weights, stride 1, pad R-1-pad
+            if (derive(it.wt, it.Cin, it.R, it.S, it.Cout, 1, it.R - 1 - it.pad, it.math, it.w_version)) single_bwd.push_back(i);
+        }
+    }
+    const size_t njobs = tj.size() + uj.size() + pj.size();
+    if (njobs) {
+        if (T.u_floats < u_total) {
+            if (T.u_scratch) { (void)hipStreamSynchronize(st); (void)hipFree(T.u_scratch); T.u_scratch = nullptr; T.u_floats = 0; }
+            ABR_REQUIRE(hipMalloc(&T.u_scratch, u_total * sizeof(float)) == hipSuccess, "conv_prepare_batch: no memory for the Winograd-domain scratch");
+            T.u_floats = u_total;
+        }
+        for (size_t k = 0; k < uj.size(); k++) uj[k].dst = T.u_scratch + u_off[k];
+        for (auto& j : pj)
+            if (j.c == 1) { j.src = T.u_scratch + reinterpret_cast<size_t>(j.src); j.c = 0; }
+        size_t first = 0;
+        ABR_REQUIRE(prep_ring_take(T, njobs, &first), "conv_prepare_batch: no memory for the job tables");
+        abr::PrepJob* h = T.host + first;
+        abr::PrepJob* d = T.dev + first;
+        std::copy(tj.begin(), tj.end(), h);
+        std::copy(uj.begin(), uj.end(), h + tj.size());
+        std::copy(pj.begin(), pj.end(), h + tj.size() + uj.size());
+        ABR_REQUIRE(hipMemcpyAsync(d, h, njobs * sizeof(abr::PrepJob), hipMemcpyHostToDevice, st) == hipSuccess, "conv_prepare_batch: table upload failed");
+        hipEvent_t up = nullptr;
+        if (hipEventCreateWithFlags(&up, hipEventDisableTiming) == hipSuccess) {
+            (void)hipEventRecord(up, st);
+            T.inflight.emplace_back(first + njobs, up);
+        }
+        int bad = abr::prep_transpose_multi(d, (int)tj.size(), tb, st);
+        bad |= abr::prep_wino_u_multi(d + tj.size(), (int)uj.size(), ub, st);
+        bad |= abr::prep_pack_multi(d + tj.size() + uj.size(), (int)pj.size(), pb, st);
+        ABR_REQUIRE(!bad, "conv_prepare_batch: launch failed");
+        abr::derived_commit(tokens.data(), (int)tokens.size(), st);
+        ABR_CHECK_LAUNCH("conv_prepare_batch");
+    }
+    // shapes the batched kernels do not take: the per-tensor calls (after the transposes above, which every dgrad copy went through)
+    for (int i : single_fwd) {
+        const abr_prep_item& it = items[i];
+        const int rc = abr_conv_prepare_weights(it.w, it.Cout, it.R, it.S, it.Cin, it.stride, it.pad, it.math, it.w_version, stream);
+        if (rc != ABR_OK) return rc;
+    }
+    for (int i : single_bwd) {
+        const abr_prep_item& it = items[i];
+        const int rc = abr_conv_prepare_weights(it.wt, it.Cin, it.R, it.S, it.Cout, 1, it.R - 1 - it.pad, it.math, it.w_version, stream);
+        if (rc != ABR_OK) return rc;
     }
     return ABR_OK;
 }

@@ -184,6 +184,36 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     }
 }
 
+// the same for a table of weight tensors (abr_conv_prepare_batch): workgroup -> (job, 256 (n, c4) items of it)
+__global__ __launch_bounds__(256) void wino_weight_multi_kernel(const abr::PrepJob* __restrict__ jobs, int njobs) {
+    typedef vf<4> fv;
+    const int j = abr::prep_find_job(jobs, njobs, blockIdx.x);
+    const abr::PrepJob jb = jobs[j];
+    const float* w = jb.src;
+    float* U = reinterpret_cast<float*>(jb.dst);
+    const int N = jb.a, C = jb.b, Cv = C / 4;
+    const int64_t total = (int64_t)N * Cv, ps = (int64_t)N * C;
+    const int64_t idx = (int64_t)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = 4 * (int)(idx % Cv);
+    const int64_t n = idx / Cv;
+    fv g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) g[r][q] = vld<4>(w + ((n * 3 + r) * 3 + q) * C + c);
+    fv t[6][3];  // G g
+#pragma unroll
+    for (int q = 0; q < 3; q++) g6(g[0][q], g[1][q], g[2][q], t[0][q], t[1][q], t[2][q], t[3][q], t[4][q], t[5][q]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        fv u0, u1, u2, u3, u4, u5;
+        g6(t[i][0], t[i][1], t[i][2], u0, u1, u2, u3, u4, u5);
+        float* o = U + ((int64_t)(6 * i) * N + n) * C + c;
+        vst(o, u0); vst(o + ps, u1); vst(o + 2 * ps, u2); vst(o + 3 * ps, u3); vst(o + 4 * ps, u4); vst(o + 5 * ps, u5);
+    }
+}
+
 // A^T (4x6) on a 6-vector
 template <typename T>
 __device__ __forceinline__ void at4(const T m0, const T m1, const T m2, const T m3, const T m4, const T m5, T& o0, T& o1, T& o2, T& o3) {
@@ -376,6 +406,12 @@ int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+int prep_wino_u_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st) {
+    if (njobs <= 0 || blocks <= 0) return 0;
+    wino_weight_multi_kernel<<<(unsigned)blocks, 256, 0, st>>>(jobs_dev, njobs);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 int wino_output_transform(const float* Mm, int B, int H, int W, int N, const float* scale, const float* bias, int relu, const float* mask,
                           float* out, hipStream_t st) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
@@ -426,6 +462,7 @@ struct DEntry {
     void* buf = nullptr; size_t bytes = 0; int64_t version = 0; hipStream_t stream = nullptr; hipEvent_t filled = nullptr;
     std::vector<hipStream_t> readers;   // streams other than `stream` that have been handed this buffer since the last fill
     uint64_t last_use = 0;
+    int64_t pending = 0;                // derived_acquire handed out a token for this version; derived_commit has not run yet
 };
 std::map<std::pair<const void*, int>, DEntry> g_dcache;
 std::mutex g_dcache_mu;
@@ -445,16 +482,16 @@ size_t dcache_limit() {
 }
 }  // namespace
 
-void* derived_cached(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, const std::function<int(void*)>& fill) {
-    std::lock_guard<std::mutex> lock(g_dcache_mu);
+// (mutex held) the entry for (w, kind) with a buffer of `bytes`; *needs_fill = it does not hold `version`; a refill is ordered behind the readers
+static DEntry* dcache_acquire_locked(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, bool* needs_fill) {
     DEntry& e = g_dcache[std::make_pair(w, kind)];
     e.last_use = ++g_dcache_clock;
     if (e.buf && e.bytes != bytes) dcache_drop(e);   // the address now holds a different weight tensor
     if (!e.buf) {
-        while (g_dcache_bytes + bytes > dcache_limit()) {   // evict least-recently-used entries (never this one)
+        while (g_dcache_bytes + bytes > dcache_limit()) {   // evict least-recently-used entries (never this one, never one with a fill pending)
             auto victim = g_dcache.end();
             for (auto it = g_dcache.begin(); it != g_dcache.end(); ++it)
-                if (it->second.buf && &it->second != &e && (victim == g_dcache.end() || it->second.last_use < victim->second.last_use)) victim = it;
+                if (it->second.buf && &it->second != &e && !it->second.pending && (victim == g_dcache.end() || it->second.last_use < victim->second.last_use)) victim = it;
             if (victim == g_dcache.end()) break;
             dcache_drop(victim->second);
             g_dcache.erase(victim);
@@ -465,12 +502,13 @@ void* derived_cached(const void* w, int kind, size_t bytes, int64_t version, hip
         e.last_use = g_dcache_clock;
         if (!e.filled) (void)hipEventCreateWithFlags(&e.filled, hipEventDisableTiming);
     }
-    if (e.version == version) {
+    if (e.version == version && !e.pending) {
         if (st != e.stream) {
             (void)hipStreamWaitEvent(st, e.filled, 0);
             if (std::find(e.readers.begin(), e.readers.end(), st) == e.readers.end()) e.readers.push_back(st);
         }
-        return e.buf;
+        *needs_fill = false;
+        return &e;
     }
     // refill in place: order it behind everything the other streams that used this buffer (its previous filler included) have queued
     std::vector<hipStream_t> users = e.readers;
@@ -485,11 +523,47 @@ void* derived_cached(const void* w, int kind, size_t bytes, int64_t version, hip
     }
     e.readers.clear();
     e.version = 0;
-    if (fill(e.buf)) return nullptr;
-    (void)hipEventRecord(e.filled, st);
-    e.version = version;
-    e.stream = st;
-    return e.buf;
+    *needs_fill = true;
+    return &e;
+}
+
+void* derived_cached(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, const std::function<int(void*)>& fill) {
+    std::lock_guard<std::mutex> lock(g_dcache_mu);
+    bool needs_fill = false;
+    DEntry* e = dcache_acquire_locked(w, kind, bytes, version, st, &needs_fill);
+    if (!e) return nullptr;
+    if (!needs_fill) return e->buf;
+    if (fill(e->buf)) return nullptr;
+    (void)hipEventRecord(e->filled, st);
+    e->version = version;
+    e->stream = st;
+    e->pending = 0;
+    return e->buf;
+}
+
+void* derived_acquire(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, void** token) {
+    std::lock_guard<std::mutex> lock(g_dcache_mu);
+    *token = nullptr;
+    bool needs_fill = false;
+    DEntry* e = dcache_acquire_locked(w, kind, bytes, version, st, &needs_fill);
+    if (!e) return nullptr;
+    if (needs_fill) {
+        e->pending = version;
+        *token = e;
+    }
+    return e->buf;
+}
+
+void derived_commit(void* const* tokens, int n, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_dcache_mu);
+    for (int i = 0; i < n; i++) {
+        DEntry* e = reinterpret_cast<DEntry*>(tokens[i]);
+        if (!e) continue;
+        (void)hipEventRecord(e->filled, st);
+        e->version = e->pending;
+        e->stream = st;
+        e->pending = 0;
+    }
 }
 
 float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t st) {

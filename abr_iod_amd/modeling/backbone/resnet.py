@@ -90,6 +90,14 @@ class Conv2d(nn.Module):
             self._wt_version = _PARAM_VERSION[0]
         return self._wt
 
+    def dgrad_buffer(self):
+        """the (possibly stale) buffer of the dgrad copy, allocated on first use: FusedSGD's batched weight preparation fills it"""
+        if self._wt is None or self._wt.device != self.weight.device:
+            Cout, R, S, Cin = self.weight.shape
+            self._wt = torch.empty((Cin, R, S, Cout), dtype=self.weight.dtype, device=self.weight.device)
+            self._wt_version = -1
+        return self._wt
+
     def version(self):
         """abr_conv_desc::w_version for this conv's weight and for its dgrad copy: non-zero, changes whenever the values may have"""
         return 2 * _PARAM_VERSION[0] + 1 if self._optimised else 2 * _STATIC_VERSION[0] + 2
@@ -143,6 +151,15 @@ class Bottleneck(nn.Module):
             ops.conv_prepare_weights(conv.weight, conv.stride, conv.padding, self.math, conv.version())
             # the dgrad conv is stride 1 with pad k-1-p (a scatter for the stride-2 1x1 convs): same derived data either way
             ops.conv_prepare_weights(wt, 1, conv.kernel_size - 1 - conv.padding, self.math, conv.version())
+
+    def prep_entries(self):
+        """(conv, FrozenBN scale, stride, pad, math) of the trainable convs: FusedSGD prepares them all in one batched call instead of
+        prepare_derived()'s four launches per conv"""
+        pairs = [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+        if self.downsample is not None:
+            pairs.append((self.downsample[0], self.downsample[1]))
+        return [(conv, bn.scale_bias()[0], conv.stride, conv.padding, self.math) for conv, bn in pairs
+                if conv.weight.requires_grad and conv.weight.is_cuda]
 
     # x, returns NHWC tensors.  `stride` may be overridden to 1 when the caller already sub-sampled (bin_step=2 ROIAlign)
     def fwd(self, x, save, stride=None):

@@ -238,6 +238,15 @@ class RPNHead(nn.Module):
             ops.conv_prepare_weights(self.conv.weight, 1, 1, self.math, self.conv.version())
             ops.conv_prepare_weights(wt, 1, 1, self.math, self.conv.version())
 
+    def prep_entries(self):
+        """the 3x3 head conv goes with FusedSGD's batched preparation; prepare_rest() does the fused 1x1 heads"""
+        return [(self.conv, None, 1, 1, self.math)] if (self.conv.weight.requires_grad and self.conv.weight.is_cuda) else []
+
+    def prepare_rest(self):
+        if self.fused_weight.is_cuda and self.fused_weight_grad is not None and (self.cls_logits.weight.requires_grad or self.bbox_pred.weight.requires_grad):
+            self.fused_dgrad_weight()
+            ops.conv_prepare_weights(self.fused_weight, 1, 0, self.math, self.fused_version())
+
     def fused_version(self):
         """abr_conv_desc::w_version of the fused cls | bbox weight (Conv2d.version's rule: it moves with optimiser steps iff an optimiser
         owns one of its two halves)"""

@@ -315,6 +315,24 @@ def conv_prepare_weights(w, stride, pad, math, w_version):
     L.check(L.lib().abr_conv_prepare_weights(L.ptr(w), Cout, R, S, Cin, stride, pad, int(math), int(w_version), L.stream()), "conv_prepare_weights")
 
 
+def conv_prepare_batch(entries):
+    """entries: [(w [Cout,R,S,Cin], scale or None, wt or None, stride, pad, math, w_version)] -- what conv_prepare_weights(w, ...) derives,
+    and for wt != None the dgrad copy wt = conv_dgrad_weights(w, scale) plus what conv_prepare_weights(wt, 1, R-1-pad, ...) derives from
+    it, for ALL entries in three launches on the current stream (abr_conv_prepare_batch)."""
+    if not entries:
+        return
+    arr = (L.PrepItem * len(entries))()
+    keep = []
+    for a, (w, scale, wt, stride, pad, math, ver) in zip(arr, entries):
+        Cout, R, S, Cin = w.shape
+        if scale is not None:
+            scale = L.f32c(scale)
+            keep.append(scale)
+        a.w, a.scale, a.wt = L.ptr(w), L.ptr(scale), L.ptr(wt)
+        a.Cout, a.R, a.S, a.Cin, a.stride, a.pad, a.math, a.w_version = Cout, R, S, Cin, int(stride), int(pad), int(math), int(ver)
+    L.check(L.lib().abr_conv_prepare_batch(C.cast(arr, C.c_void_p), len(entries), L.stream()), "conv_prepare_batch")
+
+
 def conv_cache_clear():
     """Drop the library's per-weight derived data (Winograd-domain weights); call when parameter storage is released or rebuilt."""
     L.check(L.lib().abr_conv_cache_clear(), "conv_cache_clear")

@@ -32,6 +32,12 @@ class FusedSGD(object):
         # the update on a stream of their own, off the next step's critical path (ABR_WEIGHT_PREP_STREAM=0: lazily, at first use)
         self._derived = [m for m in model.modules() if hasattr(m, "prepare_derived") and any(p.requires_grad for p in m.parameters())]
         self._prep_stream = os.environ.get("ABR_WEIGHT_PREP_STREAM", "1") != "0"
+        self._batch_prep = os.environ.get("ABR_BATCH_WEIGHT_PREP", "1") != "0"
+        # stage of every module with derived data (backbone.body.layer2 -> "layer2", rpn.head -> "rpn", ...): one preparation batch per stage
+        self._derived_group = {}
+        for name, m in model.named_modules():
+            parts = name.split(".")
+            self._derived_group[id(m)] = next((p_ for p_ in parts if p_.startswith("layer")), parts[0] if parts else "")
         self.momentum = momentum
         self.param_groups = []
         for name, a, b, is_bias in self.flat.segments:
@@ -105,8 +111,36 @@ class FusedSGD(object):
             prep = ops.side_stream((self.flat.params.device.index, "weight-prep"))
             prep.wait_stream(cur)            # behind the SGD kernel and every reader of the previous copies
             with torch.cuda.stream(prep), torch.no_grad():
-                for m in self._derived:
-                    m.prepare_derived()
+                if self._batch_prep:
+                    # every trainable conv's derived data in a dozen launches (ops.conv_prepare_batch) instead of ~190 (~8 ms of host time, and
+                    # a host-paced train of tiny kernels on a hardware queue the source model's head pass shares).  In the order of first use,
+                    # one batch per stage: the next forward pass waits for a stage's data only (the library orders consumers behind the fill of
+                    # THEIR entry); the dgrad copies and what derives from them, first needed ~10 ms later, come last.
+                    from ..modeling.backbone.resnet import _PARAM_VERSION
+                    groups, convs, rest = [], [], []
+                    for m in self._derived:
+                        if hasattr(m, "prep_entries"):
+                            ent = [(conv, scale, stride, pad, math) for conv, scale, stride, pad, math in m.prep_entries()]
+                            key = self._derived_group.get(id(m), "")
+                            if not groups or groups[-1][0] != key:
+                                groups.append((key, []))
+                            groups[-1][1].extend(ent)
+                            if hasattr(m, "prepare_rest"):
+                                rest.append(m.prepare_rest)
+                        else:
+                            rest.append(m.prepare_derived)
+                    for _, ent in groups:    # forward halves, stage by stage
+                        ops.conv_prepare_batch([(conv.weight.detach(), None, None, stride, pad, math, conv.version()) for conv, _, stride, pad, math in ent])
+                    for fn in rest:
+                        fn()
+                    allent = [e for _, ent in groups for e in ent]
+                    ops.conv_prepare_batch([(conv.weight.detach(), scale, conv.dgrad_buffer(), stride, pad, math, conv.version())
+                                            for conv, scale, stride, pad, math in allent])
+                    for conv, _, _, _, _ in allent:
+                        conv._wt_version = _PARAM_VERSION[0]
+                else:
+                    for m in self._derived:
+                        m.prepare_derived()
             ops.prep_done(prep)
 
     def _reference_params(self):

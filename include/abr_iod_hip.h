@@ -252,6 +252,19 @@ int abr_conv_forward(const abr_conv_desc* d_host, const float* x, const float* w
  * (w, w_version) finds it ready (a consumer on another stream is ordered behind it by the library).  Lets a
  * caller move the per-step weight preparation of its trainable convs off the critical stream (solver/build.py). */
 int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, int Cin, int stride, int pad, int math, int64_t w_version, void* stream);
+/* The same for a whole model in a handful of launches.  Item i: what abr_conv_prepare_weights derives from w; and, when wt != NULL, first the
+ * dgrad copy wt = abr_conv_dgrad_weights(w, scale) and then what abr_conv_prepare_weights(wt, Cin -> Cout swapped, stride 1, pad R-1-pad) derives
+ * from THAT.  All transposes go out as one launch, all Winograd weight transforms as one, all bf16x3 packings as one (a model's ~190 per-tensor
+ * launches after every optimiser step were ~1 ms of device time the next step waited for, and ~8 ms of host time).  Results and cache entries are
+ * the ones the per-tensor calls produce.  Items whose shape the batched kernels do not take (Cin % 4 != 0 Winograd weights) go the per-tensor way. */
+typedef struct abr_prep_item {
+    const float* w;       /* [Cout][R][S][Cin] */
+    const float* scale;   /* FrozenBN scale folded into the dgrad copy, or NULL */
+    float* wt;            /* [Cin][R][S][Cout] dgrad copy (flipped taps), or NULL: forward derivation only */
+    int32_t Cout, R, S, Cin, stride, pad, math;
+    int64_t w_version;
+} abr_prep_item;
+int abr_conv_prepare_batch(const abr_prep_item* items_host, int n, void* stream);
 /* The library keeps this derived data per (weight address, kind, w_version) -- 36/9 of each wide 3x3 weight, 1.5x of every other bf16x6 weight.  The cache is bounded
  * (least-recently-used entries go when it exceeds ABR_WINO_CACHE_MB, default 8192); abr_conv_cache_clear drops every entry after waiting
  * for the streams that use them (call it when a model's parameter storage is released or rebuilt), abr_conv_cache_bytes reports its size. */
