@@ -112,7 +112,7 @@ class FusedSGD(object):
             prep.wait_stream(cur)            # behind the SGD kernel and every reader of the previous copies
             with torch.cuda.stream(prep), torch.no_grad():
                 if self._batch_prep:
-                    # every trainable conv's derived data in a dozen launches (ops.conv_prepare_batch) instead of ~190 (~8 ms of host time, and
+                    # every trainable conv's derived data in a dozen launches (ops.conv_prepare_batch) instead of ~190 (3.2 -> 1.0 ms of host time per step, and
                     # a host-paced train of tiny kernels on a hardware queue the source model's head pass shares).  In the order of first use,
                     # one batch per stage: the next forward pass waits for a stage's data only (the library orders consumers behind the fill of
                     # THEIR entry); the dgrad copies and what derives from them, first needed ~10 ms later, come last.

@@ -255,7 +255,7 @@ int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, int Cin, in
 /* The same for a whole model in a handful of launches.  Item i: what abr_conv_prepare_weights derives from w; and, when wt != NULL, first the
  * dgrad copy wt = abr_conv_dgrad_weights(w, scale) and then what abr_conv_prepare_weights(wt, Cin -> Cout swapped, stride 1, pad R-1-pad) derives
  * from THAT.  All transposes go out as one launch, all Winograd weight transforms as one, all bf16x3 packings as one (a model's ~190 per-tensor
- * launches after every optimiser step were ~1 ms of device time the next step waited for, and ~8 ms of host time).  Results and cache entries are
+ * launches after every optimiser step were a host-paced train of tiny kernels and ~3 ms of host time).  Results and cache entries are
  * the ones the per-tensor calls produce.  Items whose shape the batched kernels do not take (Cin % 4 != 0 Winograd weights) go the per-tensor way. */
 typedef struct abr_prep_item {
     const float* w;       /* [Cout][R][S][Cin] */
