@@ -41,6 +41,9 @@ SOURCE_HEAD_STREAM = os.environ.get("ABR_SOURCE_HEAD_STREAM", "1") != "0"
 EARLY_SECOND_PASS = os.environ.get("ABR_EARLY_SECOND_PASS", "1") != "0"
 PIPELINE_TARGET_FROZEN = os.environ.get("ABR_PIPELINE_TARGET_FROZEN", "1") != "0"
 PIPELINE_SOURCE = os.environ.get("ABR_PIPELINE_SOURCE", "1") != "0"
+# the next batch's source-model prefetch right behind the current batch's head pass on the source stream (-0.39 ms per step against issuing it
+# before the backward pass): see train_step
+EARLY_PREFETCH = os.environ.get("ABR_EARLY_PREFETCH", "1") != "0"
 # Opt-in (off by default, and off in bench.py's headline): when the source and the target model hold IDENTICAL frozen stem / layer1 weights
 # (the reference's setup: both are loaded from the same checkpoint and FREEZE_CONV_BODY_AT = 2 never lets them move), that prefix is the same
 # function of the same batch in both models -- compute it once per batch and feed both.  Verified by comparing the tensors, never assumed.
@@ -250,6 +253,48 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
                 if faithful_rng:
                     model_source.roi_heads.box.loss_evaluator.subsample(soften_proposal, targets)
 
+    prefetched_now = [False]
+
+    def enqueue_prefetch():
+        if prefetched_now[0]:
+            return
+        prefetched_now[0] = True
+        if (PIPELINE_SOURCE and need_source and next_images is not None and SOURCE_STREAM and SOURCE_OVERLAP and not faithful_rng
+                and hasattr(model_source, "soften_begin") and not model_source.training
+                and (next_images.tensors if hasattr(next_images, "tensors") else next_images).is_cuda):
+            # software pipelining: the frozen source model's backbone + RPN head for the NEXT batch go onto the source stream now, where they
+            # run next to this step's backward pass (their result does not depend on this step's update)
+            from .. import ops
+            cur = torch.cuda.current_stream()
+            src = ops.side_stream((cur.device.index, "source-model"))
+            src.wait_stream(cur)   # next_images may have been produced on the current stream (async upload, device-side padding / augmentation)
+            tstate = trainer_state(model_target)
+            shared = None
+            if (SHARE_FROZEN_PREFIX[0] and PIPELINE_TARGET_FROZEN and hasattr(model_target, "prefetch_frozen")
+                    and frozen_prefix_shareable(model_source, model_target)):
+                with torch.no_grad(), torch.cuda.stream(src):
+                    shared = model_target.prefetch_frozen(next_images)     # ONE stem + layer1 pass for both models
+                    if shared is not None:
+                        ev_shared = torch.cuda.Event()
+                        ev_shared.record()
+            with torch.no_grad(), torch.cuda.stream(src):
+                nxt = model_source.soften_begin(next_images, prefix=shared) if shared is not None else model_source.soften_begin(next_images)
+            nxt["_stream"] = src
+            # (holds the batch object, so its id() cannot be recycled while the entry lives)
+            tstate.prefetched = dict(images=next_images, key=_prefetch_key(next_images, model_source, model_target), state=nxt)
+            if shared is not None:
+                tstate.prefetched["target_prefix"] = (ev_shared, shared)
+            elif PIPELINE_TARGET_FROZEN and hasattr(model_target, "prefetch_frozen"):
+                # the TARGET's frozen stem + layer1 (FREEZE_CONV_BODY_AT = 2) for the next batch too: their output does not depend on this step's
+                # update either, and these bandwidth-bound convolutions overlap better with the backward pass's GEMMs than with the target's own
+                # layer2 / layer3 in the next forward.  Same stream as the source model's prefetch: one bandwidth-bound chain at a time.
+                with torch.no_grad(), torch.cuda.stream(src):
+                    pf = model_target.prefetch_frozen(next_images)
+                    if pf is not None:
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        tstate.prefetched["target_prefix"] = (ev, pf)
+
     joint = need_source and JOINT_ROI_PASS and deferred is None and hasattr(model_target, "forward_joint")
     if joint:   # :89-95 as one pass: the distillation RoIs share the detection pass's trip through layer4
         (loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results), \
@@ -279,6 +324,14 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
                 soften_result, _, soften_proposal, feature_source, _, _, rpn_output_source, roi_align_features_source = \
                     model_source.soften_finish(deferred)
         deferred = None
+        src_done = None
+        if src is not None:
+            src_done = torch.cuda.Event()
+            src_done.record(src)      # the source's results for THIS batch are complete here, whatever is queued on its stream afterwards
+        if EARLY_PREFETCH and src is not None:
+            # the next batch's source-model prefetch goes onto the source stream NOW, behind the head pass just queued there: it has nothing to
+            # wait for, the host is idle until the proposal counts come back, and the device has the proposal selection's wait to fill
+            enqueue_prefetch()
         ready = getattr(soften_proposal[0], "_roi_ready", None) if (EARLY_SECOND_PASS and src is not None and soften_proposal) else None
         if ready is not None:
             # :93-95 ahead of the second half of :89-90.  The target's pass over the distillation RoIs needs its backbone features and the
@@ -296,7 +349,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
             model_target.forward_finish(begun)                                                             # :89-90 (second half)
         if src is not None:       # everything the source stream produced becomes visible to the main stream here
             cur = torch.cuda.current_stream()
-            cur.wait_stream(src)
+            cur.wait_event(src_done)
             outs = [soften_result[0], soften_result[1], roi_align_features_source] + list(feature_source) + [p.bbox for p in soften_proposal] + \
                    [x for pair in rpn_output_source for x in pair]
             tab = getattr(soften_proposal[0], "_roi_table", None) if soften_proposal else None
@@ -343,41 +396,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         loss_dict_target["distillation_loss"] = distillation_losses.clone().detach()
         losses = faster_rcnn_losses + distillation_losses                                                  # :128
 
-    if (PIPELINE_SOURCE and need_source and next_images is not None and SOURCE_STREAM and SOURCE_OVERLAP and not faithful_rng
-            and hasattr(model_source, "soften_begin") and not model_source.training
-            and (next_images.tensors if hasattr(next_images, "tensors") else next_images).is_cuda):
-        # software pipelining: the frozen source model's backbone + RPN head for the NEXT batch go onto the source stream now, where they
-        # run next to this step's backward pass (their result does not depend on this step's update)
-        from .. import ops
-        cur = torch.cuda.current_stream()
-        src = ops.side_stream((cur.device.index, "source-model"))
-        src.wait_stream(cur)   # next_images may have been produced on the current stream (async upload, device-side padding / augmentation)
-        tstate = trainer_state(model_target)
-        shared = None
-        if (SHARE_FROZEN_PREFIX[0] and PIPELINE_TARGET_FROZEN and hasattr(model_target, "prefetch_frozen")
-                and frozen_prefix_shareable(model_source, model_target)):
-            with torch.no_grad(), torch.cuda.stream(src):
-                shared = model_target.prefetch_frozen(next_images)     # ONE stem + layer1 pass for both models
-                if shared is not None:
-                    ev_shared = torch.cuda.Event()
-                    ev_shared.record()
-        with torch.no_grad(), torch.cuda.stream(src):
-            nxt = model_source.soften_begin(next_images, prefix=shared) if shared is not None else model_source.soften_begin(next_images)
-        nxt["_stream"] = src
-        # (holds the batch object, so its id() cannot be recycled while the entry lives)
-        tstate.prefetched = dict(images=next_images, key=_prefetch_key(next_images, model_source, model_target), state=nxt)
-        if shared is not None:
-            tstate.prefetched["target_prefix"] = (ev_shared, shared)
-        elif PIPELINE_TARGET_FROZEN and hasattr(model_target, "prefetch_frozen"):
-            # the TARGET's frozen stem + layer1 (FREEZE_CONV_BODY_AT = 2) for the next batch too: their output does not depend on this step's
-            # update either, and these bandwidth-bound convolutions overlap better with the backward pass's GEMMs than with the target's own
-            # layer2 / layer3 in the next forward.  Same stream as the source model's prefetch: one bandwidth-bound chain at a time.
-            with torch.no_grad(), torch.cuda.stream(src):
-                pf = model_target.prefetch_frozen(next_images)
-                if pf is not None:
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    tstate.prefetched["target_prefix"] = (ev, pf)
+    enqueue_prefetch()
     optimizer.zero_grad()                                                                                  # :142
     _arm_overlap(optimizer, [det_pooled, roi_align_features_target if need_source else None], feature_target)
     losses.backward()                                                                                      # :144-145 (amp O0 = identity)
