@@ -118,6 +118,24 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     }
 }
 
+// the same through the ReLU that produced y (the pooled tensor): gx = y > 0 ? g / HW : 0 -- the pooling's and the ReLU's backward in one pass
+// over the [N, HW, C] tensor instead of a write + (two reads + a write)
+__global__ __launch_bounds__(256) void avgpool_bwd_masked_kernel(const float* __restrict__ g, const float* __restrict__ y, int64_t N, int HW, int C,
+                                                                  float* __restrict__ gx) {
+    const int cv = C / 4;
+    const int64_t total = N * HW * cv;
+    const float inv = 1.f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = i % cv;
+        const int64_t n = i / ((int64_t)HW * cv);
+        float4 v = reinterpret_cast<const float4*>(g)[n * cv + c];
+        const float4 yv = reinterpret_cast<const float4*>(y)[i];
+        v.x = yv.x > 0.f ? v.x * inv : 0.f; v.y = yv.y > 0.f ? v.y * inv : 0.f;
+        v.z = yv.z > 0.f ? v.z * inv : 0.f; v.w = yv.w > 0.f ? v.w * inv : 0.f;
+        reinterpret_cast<float4*>(gx)[i] = v;
+    }
+}
+
 // out may alias g (in place): no __restrict__ on those two
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* g, const float* __restrict__ y, int64_t n4, int64_t n, float* out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -263,6 +281,16 @@ extern "C" int abr_avgpool_backward(const float* g, int N, int HW, int C, float*
     const int64_t total = (int64_t)N * HW * (C / 4);
     avgpool_bwd_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 8192), 256, 0, abr::as_stream(stream)>>>(g, N, HW, C, gx);
     ABR_CHECK_LAUNCH("avgpool_backward");
+    return ABR_OK;
+}
+
+extern "C" int abr_avgpool_relu_backward(const float* g, const float* y, int N, int HW, int C, float* gx, void* stream) {
+    ABR_REQUIRE(N >= 0 && HW > 0 && C % 4 == 0, "avgpool_relu_backward: bad args");
+    if (N == 0) return ABR_OK;
+    ABR_REQUIRE(g && y && gx, "avgpool_relu_backward: null pointer");
+    const int64_t total = (int64_t)N * HW * (C / 4);
+    avgpool_bwd_masked_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 8192), 256, 0, abr::as_stream(stream)>>>(g, y, N, HW, C, gx);
+    ABR_CHECK_LAUNCH("avgpool_relu_backward");
     return ABR_OK;
 }
 

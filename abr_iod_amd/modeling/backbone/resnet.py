@@ -230,7 +230,8 @@ class _StageFn(Function):
     @staticmethod
     def backward(ctx, gout):
         g = as_nhwc(gout)
-        owned = masked = False
+        owned = False
+        masked = bool(getattr(gout, "_abr_relu_masked", False))   # the producer of gout already applied this stage's final ReLU mask (box predictor)
         n = len(ctx.blocks)
         for i in range(n - 1, -1, -1):
             need = ctx.need_dx or i > 0
@@ -246,7 +247,9 @@ def run_stage(x, blocks, first_stride=None, need_dx=True):
     """x logical [B,C,H,W] -> logical output; differentiable when any block parameter requires grad."""
     params = [p for b in blocks for p in b.parameters()]
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        return _StageFn.apply(x, blocks, first_stride, need_dx and x.requires_grad, *params)
+        out = _StageFn.apply(x, blocks, first_stride, need_dx and x.requires_grad, *params)
+        out._abr_relu_output = True      # (a bottleneck ends in a ReLU: consumers may fuse its backward into theirs, see _PredictorFn)
+        return out
     h = as_nhwc(x)
     for i, blk in enumerate(blocks):
         h, _ = blk.fwd(h, False, stride=first_stride if i == 0 else None)

@@ -16,6 +16,7 @@ MI355X-first differences (results identical):
   * IoU/Matcher/labels/encode are one kernel per image; both loss terms and their gradients are one kernel each.
 """
 import torch
+import os
 from torch import nn
 from torch.autograd import Function
 
@@ -96,6 +97,9 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ predictor
+FUSE_POOL_RELU_BWD = os.environ.get("ABR_FUSE_POOL_RELU_BWD", "1") != "0"
+
+
 class _PredictorFn(Function):
     @staticmethod
     def forward(ctx, x, pred, *params):
@@ -105,6 +109,9 @@ class _PredictorFn(Function):
         y = ops.conv_forward(pooled.view(K_, 1, 1, -1), pred.fused_weight, 1, 0, bias=pred.fused_bias).view(K_, -1)
         ctx.pred, ctx.saved, ctx.xshape = pred, pooled, tuple(xh.shape)
         ctx.need_dx = x.requires_grad
+        # x is layer4's output, i.e. a ReLU's: its backward is fused into the pooling's (one pass over the [K,4,4,2048] tensor instead of
+        # three), and the gradient handed to layer4 says so (_StageFn.backward skips its own mask; masking twice would be harmless)
+        ctx.relu_of = xh if (FUSE_POOL_RELU_BWD and x.requires_grad and getattr(x, "_abr_relu_output", False) and xh.is_contiguous()) else None
         return y
 
     @staticmethod
@@ -117,8 +124,10 @@ class _PredictorFn(Function):
         gx = None
         if ctx.need_dx:
             gp = ops.conv_forward(g, pred.fused_dgrad_weight(), 1, 0).view(K_, -1)
-            gx = from_nhwc(ops.avgpool_backward(gp, ctx.xshape))
-        ctx.saved = None
+            gx = from_nhwc(ops.avgpool_backward(gp, ctx.xshape, relu_of=ctx.relu_of))
+            if ctx.relu_of is not None:
+                gx._abr_relu_masked = True
+        ctx.saved = ctx.relu_of = None
         return (gx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 

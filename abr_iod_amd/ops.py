@@ -534,12 +534,18 @@ def avgpool_forward(x):
     return out
 
 
-def avgpool_backward(g, shape):
+def avgpool_backward(g, shape, relu_of=None):
+    """g [N, C] -> [N, H, W, C] / (H*W); relu_of = the pooled tensor itself when it is a ReLU's output: that ReLU's backward rides along
+    (gx = relu_of > 0 ? g / HW : 0) and the caller's gradient is already masked"""
     g = L.f32c(g)
     N, Ch = g.shape
     gx = _empty(shape, g)
-    L.check(L.lib().abr_avgpool_backward(L.ptr(g), N, gx.numel() // (N * Ch) if N else 1, Ch, L.ptr(gx), L.stream()),
-            "avgpool_backward")
+    HW = gx.numel() // (N * Ch) if N else 1
+    if relu_of is not None:
+        assert tuple(relu_of.shape) == tuple(shape) and relu_of.is_contiguous()
+        L.check(L.lib().abr_avgpool_relu_backward(L.ptr(g), L.ptr(relu_of), N, HW, Ch, L.ptr(gx), L.stream()), "avgpool_relu_backward")
+    else:
+        L.check(L.lib().abr_avgpool_backward(L.ptr(g), N, HW, Ch, L.ptr(gx), L.stream()), "avgpool_backward")
     return gx
 
 

@@ -302,6 +302,8 @@ int abr_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* out, voi
 /* AdaptiveAvgPool2d(1)  roi_box_predictors.py:28 : x [N,HW,C] -> out [N,C] ; backward spreads g/HW */
 int abr_avgpool_forward(const float* x, int N, int HW, int C, float* out, void* stream);
 int abr_avgpool_backward(const float* g, int N, int HW, int C, float* gx, void* stream);
+/* the same fused with the backward of the ReLU that produced the pooled tensor y [N, HW, C]: gx = y > 0 ? g / HW : 0 */
+int abr_avgpool_relu_backward(const float* g, const float* y, int N, int HW, int C, float* gx, void* stream);
 /* out[row] = mean_c x[row, c] for x [rows, C] -- per-(RoI, bin) channel mean of NHWC pooled features
  * (tools/prototype_box_selection.py:84 `torch.mean(roi_align_features, dim=1)`) */
 int abr_channel_mean(const float* x, int64_t rows, int C, float* out, void* stream);

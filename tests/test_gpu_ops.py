@@ -815,3 +815,16 @@ def test_wgrad_split_reduction_is_deterministic_and_accumulates(math):
             ref = ref.view_as(got)
         scale = float(ref.abs().max())
         assert float((got - ref).abs().max()) <= (5e-5 if k == 3 else 1e-5) * scale
+
+
+def test_avgpool_backward_fused_with_the_relu_of_its_input():
+    """ops.avgpool_backward(g, shape, relu_of=y): the pooling's backward and the backward of the ReLU that produced the pooled tensor in one pass"""
+    from abr_iod_amd import ops
+    torch.manual_seed(0)
+    y = torch.relu(torch.randn(37, 4, 4, 64, device="cuda"))
+    g = torch.randn(37, 64, device="cuda")
+    want = ops.relu_backward(ops.avgpool_backward(g, tuple(y.shape)), y)
+    got = ops.avgpool_backward(g, tuple(y.shape), relu_of=y)
+    assert torch.equal(got, want)
+    ref = (g.view(37, 1, 1, 64) / 16.0).expand(37, 4, 4, 64) * (y > 0)
+    assert torch.equal(got, ref)
