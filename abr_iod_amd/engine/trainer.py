@@ -262,8 +262,9 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         if (PIPELINE_SOURCE and need_source and next_images is not None and SOURCE_STREAM and SOURCE_OVERLAP and not faithful_rng
                 and hasattr(model_source, "soften_begin") and not model_source.training
                 and (next_images.tensors if hasattr(next_images, "tensors") else next_images).is_cuda):
-            # software pipelining: the frozen source model's backbone + RPN head for the NEXT batch go onto the source stream now, where they
-            # run next to this step's backward pass (their result does not depend on this step's update)
+            # software pipelining: the frozen source model's backbone + RPN head for the NEXT batch go onto the source stream now (their result
+            # does not depend on this step's update): with EARLY_PREFETCH right behind the current batch's source head pass, where they fill the
+            # proposal selection's wait and run next to the RoI heads; otherwise just before the backward pass
             from .. import ops
             cur = torch.cuda.current_stream()
             src = ops.side_stream((cur.device.index, "source-model"))
