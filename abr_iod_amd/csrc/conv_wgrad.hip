@@ -9,15 +9,17 @@
 //
 // Shape of the problem on this path: the OUTPUT is small (<= 1024 x 9216) and the REDUCTION axis m is huge
 // (9.5k-37k pixels/RoI-cells), the opposite of forward.  So: a workgroup owns a 128(n) x 128(k) tile of dW
-// and a contiguous slice of m (split-M); partial tiles are combined with hardware fp32 atomics
-// (global_atomic_add_f32) straight into the gradient buffer, which also folds in the accumulation over the
-// two RoI passes of one step (512-RoI detection pass + 64-RoI distillation pass share the head weights).
-// Both operands arrive m-major (gy rows, NHWC pixels), i.e. the MFMA's reduction index is the SLOW axis in
-// memory: rows are staged as-is into LDS ([m][128], 512 B coalesced per row) and a lane picks its operand
-// with one ds_read_b64 = two adjacent n (or k) of row m; accumulator tile t then holds n = base + 2i + t.
-// That interleave is undone in the epilogue addressing, so no transpose is ever materialised.
-// Operand fetch is buffer loads with hardware range checking (no branches), single-buffered LDS (3 workgroups/CU); wide
-// stride-1 3x3 convs go through the Winograd domain instead (36 batched plain GEMMs over the tile axis, conv_winograd.hip).
+// and a contiguous slice of m (split-M); partial tiles are parked in a scratch with plain coalesced stores and summed in
+// split order by wgrad_reduce_kernel (deterministic; ABR_WGRAD_REDUCE=0: fp32 atomics straight into the gradient buffer, the
+// round-1 scheme).  `dw +=` also folds in the accumulation over the two RoI passes of one step (the 512-RoI detection pass and
+// the 64-RoI distillation pass share the head weights).
+// Both operands arrive m-major (gy rows, NHWC pixels), i.e. the MFMA's reduction index is the SLOW axis in memory.
+// fp32 kernel: rows are staged as-is into LDS ([m][128], 512 B coalesced per row) and a lane picks its operand with one
+// ds_read_b64 = two adjacent n (or k) of row m; accumulator tile t then holds n = base + 2i + t -- undone in the epilogue
+// addressing, no transpose is ever materialised.  bf16x6 kernel (the default arithmetic): the loader transposes in registers
+// (conv_wgrad_x6_kernel below).  Operand fetch is buffer loads with hardware range checking (no branches), single-buffered LDS
+// (3 workgroups/CU); wide stride-1 3x3 convs go through the Winograd domain instead (36 batched plain GEMMs over the tile axis,
+// conv_winograd.hip).
 #include <algorithm>
 
 #include <map>
