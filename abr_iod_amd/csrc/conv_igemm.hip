@@ -653,7 +653,11 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int kq = tid & 7, srow = tid >> 3;
+    // A thread stores 8 B per plane at (row * 80 + kq * 8) B.  ds_write_b64 is served in groups of 16 consecutive lanes over 32 banks: with rows
+    // (s, s + 1) in a group the two 64 B runs start 20 dwords apart and share 4 banks (every store took 2 LDS cycles per group: 25 - 33 % of all LDS
+    // cycles, SQ_LDS_BANK_CONFLICT of profiles/r03_pmc_mfma.json).  Rows (s, s + 4) start 80 dwords = 16 banks apart: conflict-free.  Lane bit 3
+    // therefore carries row bit 2 and lane bit 5 row bit 0; each 8-lane set still fetches one 128 B row segment, the fragment reads do not change.
+    const int kq = tid & 7, srow = ((tid >> 3) & ~5) | (((tid >> 3) & 1) << 2) | ((tid >> 5) & 1);
 
     constexpr unsigned kOOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
@@ -844,7 +848,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int kq = tid & 7, srow = tid >> 3;
+    // A thread stores 8 B per plane at (row * 80 + kq * 8) B.  ds_write_b64 is served in groups of 16 consecutive lanes over 32 banks: with rows
+    // (s, s + 1) in a group the two 64 B runs start 20 dwords apart and share 4 banks (every store took 2 LDS cycles per group: 25 - 33 % of all LDS
+    // cycles, SQ_LDS_BANK_CONFLICT of profiles/r03_pmc_mfma.json).  Rows (s, s + 4) start 80 dwords = 16 banks apart: conflict-free.  Lane bit 3
+    // therefore carries row bit 2 and lane bit 5 row bit 0; each 8-lane set still fetches one 128 B row segment, the fragment reads do not change.
+    const int kq = tid & 7, srow = ((tid >> 3) & ~5) | (((tid >> 3) & 1) << 2) | ((tid >> 5) & 1);
 
     constexpr unsigned kOOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
@@ -1083,7 +1091,9 @@ int launch_x6(const ConvP& p, const float* x, const float* w, float* out, hipStr
 // split-K scratch: partial tiles (64 KB each for 128x128) + tickets, one set per stream (streams may run convs concurrently)
 struct SplitWs { float* ws = nullptr; int* cnt = nullptr; };
 static SplitWs* split_ws(hipStream_t st) {
-    static std::map<hipStream_t, SplitWs> pool;
+    static std::map<hipStream_t, SplitWs> pool;   // node-based: the returned pointer stays valid; the mutex covers first-use insertion from
+    static std::mutex mu;                           // concurrent host threads (forward on the Python thread, backward on autograd's; ctypes drops the GIL)
+    std::lock_guard<std::mutex> g(mu);
     SplitWs& w = pool[st];
     if (!w.ws) {
         if (hipMalloc(&w.ws, (size_t)kMaxSplitUnits * 128 * 128 * sizeof(float)) != hipSuccess) return nullptr;

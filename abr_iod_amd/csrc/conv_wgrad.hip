@@ -23,6 +23,7 @@
 #include <algorithm>
 
 #include <map>
+#include <mutex>
 
 #include "common.h"
 
@@ -648,6 +649,8 @@ static bool wgrad_ticket_enabled() {
 static float* wgrad_scratch(hipStream_t st, size_t units) {
     struct Ws { float* ws = nullptr; size_t units = 0; };
     static std::map<hipStream_t, Ws> pool;
+    static std::mutex mu;   // host threads may issue weight gradients for different streams concurrently
+    std::lock_guard<std::mutex> g(mu);
     Ws& w = pool[st];
     if (w.units < units) {
         if (w.ws) { (void)hipStreamSynchronize(st); (void)hipFree(w.ws); w.ws = nullptr; w.units = 0; }

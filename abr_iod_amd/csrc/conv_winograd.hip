@@ -439,6 +439,8 @@ int wino_wgrad_inverse(const float* dU, int N, int C, const float* scale, float*
 float* wino_ws(hipStream_t st, size_t floats) {
     struct Ws { float* buf = nullptr; size_t floats = 0; };
     static std::map<hipStream_t, Ws> pool;
+    static std::mutex mu;   // host threads may run Winograd convs for different streams concurrently
+    std::lock_guard<std::mutex> g(mu);
     Ws& w = pool[st];
     if (w.floats < floats) {
         if (w.buf) { (void)hipStreamSynchronize(st); (void)hipFree(w.buf); w.buf = nullptr; w.floats = 0; }

@@ -12,6 +12,7 @@
 //      equal scores by ascending index;
 //   4. the first k are written out as fp32 scores + int64 indices.
 // Scores are non-negative floats, so their bit patterns order like the values.
+#include <algorithm>
 #include <map>
 #include <mutex>
 
@@ -164,8 +165,10 @@ extern "C" int abr_topk_sigmoid(const float* logits, int64_t img_stride, int N, 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    // scratch per stream (launches on a stream are ordered): keys [N][n] + level-1 histograms [N][4096], the latter zero on entry (phase 2 cleans up)
-    struct Ws { void* p = nullptr; size_t bytes = 0; int hist_imgs = 0; };
+    // scratch per stream (launches on a stream are ordered): level-1 histograms [cap_imgs][4096] at the FRONT, keys [N][n] behind them.  The histogram
+    // region is zero on entry (allocation zero-fills it, phase 2 cleans what it used); its position does not depend on n or N, so a later call with a
+    // smaller feature map / another batch size never finds stale key bits where it expects zeros.  Grow-only: keyed on capacity, not on N ==.
+    struct Ws { void* p = nullptr; int cap_imgs = 0; size_t cap_keys = 0; };
     static std::mutex mu;
     static std::map<hipStream_t, Ws> pool;
     hipStream_t st = abr::as_stream(stream);
@@ -174,16 +177,18 @@ extern "C" int abr_topk_sigmoid(const float* logits, int64_t img_stride, int N, 
     {
         std::lock_guard<std::mutex> g(mu);
         Ws& w = pool[st];
-        const size_t need = (size_t)N * n * 4 + (size_t)N * HB * 4;
-        if (w.bytes < need || w.hist_imgs != N) {
-            if (w.p) { (void)hipStreamSynchronize(st); (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
-            ABR_REQUIRE(hipMalloc(&w.p, need) == hipSuccess, "topk_sigmoid: scratch allocation failed");
-            w.bytes = need;
-            w.hist_imgs = N;
-            (void)hipMemsetAsync(static_cast<char*>(w.p) + (size_t)N * n * 4, 0, (size_t)N * HB * 4, st);
+        const size_t need_keys = (size_t)N * n;
+        if (w.cap_imgs < N || w.cap_keys < need_keys) {
+            const int imgs = std::max(std::max(N, w.cap_imgs), 8);
+            const size_t nkeys = std::max(need_keys, w.cap_keys);
+            if (w.p) { (void)hipStreamSynchronize(st); (void)hipFree(w.p); w.p = nullptr; w.cap_imgs = 0; w.cap_keys = 0; }
+            ABR_REQUIRE(hipMalloc(&w.p, (size_t)imgs * HB * 4 + nkeys * 4) == hipSuccess, "topk_sigmoid: scratch allocation failed");
+            w.cap_imgs = imgs;
+            w.cap_keys = nkeys;
+            (void)hipMemsetAsync(w.p, 0, (size_t)imgs * HB * 4, st);
         }
-        keys = static_cast<unsigned*>(w.p);
-        hist = reinterpret_cast<int*>(static_cast<char*>(w.p) + (size_t)N * n * 4);
+        hist = static_cast<int*>(w.p);
+        keys = reinterpret_cast<unsigned*>(static_cast<char*>(w.p) + (size_t)w.cap_imgs * HB * 4);
     }
     const int G = 64;
     const int per = ((n + G - 1) / G + KT - 1) / KT * KT;

@@ -488,6 +488,52 @@ def test_topk_sigmoid_matches_torch():
     assert idx[0, :50].tolist() == sorted(idx[0, :50].tolist())               # tie group: ascending index
 
 
+def test_topk_sigmoid_scratch_survives_changing_shapes():
+    """The ranking's per-stream scratch (key array + level-1 histogram) is reused across calls: a SMALLER feature map after a larger one, and
+    another batch size, on the same stream must not find stale bytes where the histogram expects zeros (ragged VOC batches, the 600x600 mosaic
+    batches next to 600x1000 ones, variable-size inference).  Every call of the sequence is checked against torch."""
+    from abr_iod_amd import ops
+    torch.manual_seed(1)
+    A, ld = 15, 76
+    seq = [(4, 38 * 63, 12000), (4, 38 * 38, 6000), (2, 25 * 40, 2000), (4, 38 * 63, 12000), (1, 13 * 17, 300), (5, 38 * 38, 12000), (3, 50 * 84, 12000)]
+    for N, hw, k in seq:
+        y = torch.randn(N, hw, ld, device="cuda") * 4
+        k = min(k, hw * A)
+        sc, idx = ops.topk_sigmoid(y, A, k)
+        s_all = torch.sigmoid(y[:, :, :A].reshape(N, -1))
+        ref_s, _ = s_all.topk(k, dim=1, sorted=True)
+        assert torch.allclose(sc, ref_s, rtol=2e-7, atol=0), (N, hw, k)
+        assert int(idx.min()) >= 0 and int(idx.max()) < hw * A, (N, hw, k)
+        assert torch.allclose(s_all.gather(1, idx), sc, rtol=2e-7, atol=0)
+        assert all(len(set(idx[i].tolist())) == k for i in range(N))
+
+
+def test_rpn_postprocessor_matches_reference_order(gold):
+    """RPNPostProcessor (inference.py:76-147) on the fixed logits of tests/golden/rpn.npz, training and test mode: the proposals come out in the
+    reference's ORDER (descending objectness, NMS survivors, first post_nms, GT appended in training) with the reference's boxes and scores."""
+    from abr_iod_amd.modeling.box_coder import BoxCoder
+    from abr_iod_amd.modeling.rpn.rpn import AnchorGenerator, RPNPostProcessor
+    from abr_iod_amd.structures.bounding_box import BoxList
+    from abr_iod_amd.structures.image_list import ImageList
+    g = gold("rpn")
+    obj, reg = T(g["objectness"]), T(g["box_regression"])
+    sizes = [tuple(int(v) for v in s) for s in g["image_sizes"]]
+    ag = AnchorGenerator(sizes=(32, 64, 128, 256, 512), aspect_ratios=(0.5, 1.0, 2.0), anchor_strides=(16,), straddle_thresh=0).cuda()
+    anchors = ag(ImageList(torch.zeros(2, 3, 160, 224, device="cuda"), sizes), [torch.zeros(2, 8, 10, 14, device="cuda")])
+    for i in (0, 1):
+        assert np.array_equal(anchors[i][0].bbox.cpu().numpy(), g[f"anchors{i}"])
+    targets = [BoxList(T(g["gt0"]), (224, 160)), BoxList(T(g["gt1"]), (200, 150))]
+    for tag, (pre, post, train) in {"train": (600, 100, True), "test": (300, 50, False)}.items():
+        pp = RPNPostProcessor(pre_nms_top_n=pre, post_nms_top_n=post, nms_thresh=0.7, min_size=0, box_coder=BoxCoder((1., 1., 1., 1.)))
+        pp.train(train)
+        res = pp(anchors, [obj], [reg], targets if train else None)
+        for i, b in enumerate(res):
+            wb, ws = g[f"{tag}_boxes{i}"], g[f"{tag}_scores{i}"]
+            assert tuple(b.bbox.shape) == wb.shape, (tag, i, b.bbox.shape, wb.shape)
+            np.testing.assert_allclose(b.get_field("objectness").cpu().numpy(), ws, rtol=3e-7, atol=0)    # same order: scores line up one by one
+            np.testing.assert_allclose(b.bbox.cpu().numpy(), wb, rtol=1e-5, atol=2e-4)
+
+
 def test_conv_split_k_equals_unsplit(tmp_path):
     """abr_conv_forward splits the K range of badly quantised tiles over several workgroups (partial sums + last-arrival reduce).
     Same inputs with the plan disabled (ABR_IGEMM_SPLIT=0, read once per process -> two child processes): equal up to fp32
