@@ -43,6 +43,17 @@ def make_buckets(segments):
     return out
 
 
+def modelled_ring_allreduce_ms(nbytes, world, link_gb_s=153.0, links=7, hop_us=8.0):
+    """Ring all-reduce of `nbytes` over point-to-point xGMI (MI355X_MICROARCH / the task's hardware notes: 7 links x ~153 GB/s per GPU, each
+    ring step bound by ONE link): 2 (w - 1) / w of the buffer crosses each link, plus a per-hop latency for the 2 (w - 1) steps.  RCCL spreads
+    a large message over several rings (one per link direction), so the bandwidth term is divided by min(links, w - 1).  A MODEL for planning,
+    printed next to the measured step time -- never a measurement."""
+    if world <= 1:
+        return 0.0
+    rings = max(1, min(links, world - 1))
+    return 2.0 * (world - 1) / world * nbytes / (link_gb_s * 1e9 * rings) * 1e3 + 2 * (world - 1) * hop_us * 1e-3
+
+
 class GradReducer(object):
     def __init__(self, grads, segments, side_streams=()):
         """grads: the flat gradient tensor; side_streams: callable returning the streams (besides the current one) that write it."""
@@ -84,7 +95,10 @@ class GradReducer(object):
 
     def describe(self):
         """the exchange as the last step issued it: one entry per bucket with its bytes, collective count and issue point"""
-        return [{"bucket": n, "bytes": by, "all_reduces": sum(1 for a, b in self.buckets[n] if b > a), "issued_from": w}
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        return [{"bucket": n, "bytes": by, "all_reduces": sum(1 for a, b in self.buckets[n] if b > a), "issued_from": w,
+                 "modelled_ring_ms": round(modelled_ring_allreduce_ms(by, world), 4),
+                 "exposed": w != "backward-hook"}       # a bucket sent from step() has no backward work left to hide under
                 for n, by, w in self.last_issue]
 
     def reduce_bucket_async(self, name):

@@ -372,7 +372,9 @@ def main():
         im, tg = batch_of(i)
         train_step(model_source, model_target, im, tg, optimizer, scheduler, cfg_t, next_images=batch_of(i + 1)[0])
 
-    time_kernels = (rank == 0) and not a.no_kernel_timing
+    # EVERY rank samples kernel timings inside the timed region (or none does): the stamps / event pairs cost a few microseconds per sampled
+    # launch, and the slowest rank sets the step -- rank 0 must not carry work the others do not.  Only rank 0 reports.
+    time_kernels = not a.no_kernel_timing
     barrier()
     if time_kernels:
         # Every conv / ROIAlign launch is COUNTED (flops per launch: abr_prof_totals); launch i of a kernel in step s is bracketed with
@@ -394,6 +396,8 @@ def main():
     prof = serialised = None
     if time_kernels:
         prof, prof_totals, event_overhead_ms = read_prof(_lib)
+        if rank != 0:
+            prof = None
         if world == 1 and not a.no_serialised_leg and not a.fold_streams:
             # AFTER the timed region, never part of `value`: the same step with every stream folded into one, every conv launch timed.
             # Inside the real step up to three streams' kernels share the CUs, so a kernel's in-step duration says how the step's time is

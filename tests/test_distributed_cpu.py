@@ -57,7 +57,7 @@ def _worker(rank, world, port, out):
         losses.append(loss.detach())
     red = reduce_loss_dict({"b": losses[-1].clone(), "a": losses[0].clone()})
     if rank == 0:
-        out.put((flat.params.clone(), {k: float(v) for k, v in red.items()}, [float(l) for l in losses]))
+        out.put((flat.params.detach().numpy().copy(), {k: float(v) for k, v in red.items()}, [float(l) for l in losses]))   # numpy: nothing shared by file descriptor
     else:
         out.put((None, None, [float(l) for l in losses]))
     dist.barrier()
@@ -89,7 +89,7 @@ def test_flat_allreduce_matches_single_process():
     ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     from abr_iod_amd.modeling._flat import flatten_parameters
     flat = flatten_parameters(model)  # same layout as in the workers
-    assert torch.allclose(params0, flat.params, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(torch.from_numpy(params0), flat.params, rtol=1e-5, atol=1e-6)
     # reduce_loss_dict: rank 0 holds the mean over ranks, keys sorted (engine/trainer.py:27-36)
     assert abs(red["a"] - sum(l[0] for l in per_rank_losses) / world) < 1e-6
     assert abs(red["b"] - sum(l[-1] for l in per_rank_losses) / world) < 1e-6
@@ -158,7 +158,7 @@ def _reducer_worker(rank, world, port, out):
             red.reduce_bucket_async(name)
         red.finish()                    # FusedSGD.all_reduce_grads
         red.begin()                     # the next step starts clean
-        results.append(grads.clone())
+        results.append(grads.clone().numpy())   # (numpy: a torch tensor on a queue is shared by file descriptor and the worker may exit first)
     out.put((rank, results))
     dist.barrier()
     dist.destroy_process_group()
@@ -174,5 +174,5 @@ def test_bucketed_overlapped_allreduce_equals_one_allreduce():
     want = torch.arange(2048, dtype=torch.float32) * 3   # rank 0 holds 1x, rank 1 holds 2x: every element summed exactly once
     for rank, results in got:
         for r in results:
-            assert torch.equal(r, want)
+            assert torch.equal(torch.from_numpy(r), want)
 
