@@ -69,7 +69,7 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Off by default.
 enum ProfId { PROF_IGEMM_128x128 = 0, PROF_IGEMM_128x64, PROF_IGEMM_64x64, PROF_IGEMM_SMALLC, PROF_WGRAD, PROF_ROIALIGN_FWD,
               PROF_ROIALIGN_BWD, PROF_IGEMM_BF16, PROF_WGRAD_BF16,
-              PROF_X6_128x128, PROF_X6_128x64, PROF_X6_64x64, PROF_X6W_128x128, PROF_X6W_128x64, PROF_X6W_64x64, PROF_COUNT };   // (ids are positions in bench.py's PROF_NAMES)
+              PROF_X6_128x128, PROF_X6_128x64, PROF_X6_64x64, PROF_X6W_128x128, PROF_X6W_128x64, PROF_X6W_64x64, PROF_X6W_TAIL64, PROF_COUNT };   // (ids are positions in bench.py's PROF_NAMES)
 // Winograd F(4x4,3x3) transform kernels (conv_winograd.hip); the batched GEMM between them is launched by conv_igemm.hip
 int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, hipStream_t st);
 int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st);

@@ -992,6 +992,263 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     abr::prof_stamp_end(p.prof_ts);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Fused TAIL of a 64-wide bottleneck that has no backward pass (the frozen stem's layer1, run by BOTH models every step):
+//     o2  = relu(bn2(conv3x3(o1)))          150000 x 64 x 576   -- conv_igemm_x6w_kernel<128,64,2,2,false>'s main loop, unchanged
+//     out = relu(bn3(conv1x1(o2)) + idt)    150000 x 256 x 64   -- the same products in the same order as the stand-alone launch
+// in ONE launch: a workgroup owns 128 output pixels and all channels; o2 (128 x 64) never leaves the CU -- it goes from the accumulators
+// through the conv epilogue arithmetic (scale, bias, ReLU) and the exact bf16x3 split straight into LDS planes in A-fragment order
+// (pitch 144 B: conflict-free ds_read_b128) and is multiplied by conv3's packed weights (global -> MFMA registers) right there.  Saved per
+// block: o2's write and read (77 MB at B = 4), one launch, and conv3's prologue / short K = 64 main loop -- that launch moved 346 MB to
+// execute 4.9 GF and ran at 59 TF-eq.  Results are bit-identical to the two launches (tests/test_gpu_ops.py::test_bottleneck_tail_fused).
+// Reference: maskrcnn_benchmark/modeling/backbone/resnet.py:327-346 (conv2 -> bn2 -> relu -> conv3 -> bn3 -> += identity -> relu).
+// p = conv2 (R = S = 3, stride 1, pad 1, Cin = Cout = 64), q = conv3 (1x1, Cin = 64, Cout = 256, residual, relu); both with packed planes.
+constexpr int T64_O2P = 72;   // O2 plane pitch in bf16 elements (144 B)
+constexpr size_t kTail64Lds = sizeof(__bf16) * 3 * 128 * T64_O2P + sizeof(float) * 4 * 32 * (32 + EPAD);
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_tail64_x6w_kernel(const ConvP p, const ConvP q, const float* __restrict__ x,
+                                                                                                       float* __restrict__ out) {
+    constexpr int BM = 128, WN = 2, TM = 2, NA = BM / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    abr::prof_stamp_begin(p.prof_ts);
+    __bf16* As = reinterpret_cast<__bf16*>(smem);   // phase A: [3][BM][LDX] operand planes;  phase B: [3][BM][T64_O2P] planes of o2 (aliased)
+    float* ep_all = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + sizeof(__bf16) * 3 * 128 * T64_O2P);
+
+    const int tile_m = (int)abr::xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = tile_m * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kq = tid & 7, srow = ((tid >> 3) & ~5) | (((tid >> 3) & 1) << 2) | ((tid >> 5) & 1);   // (conflict-free store rows, see the x6w kernel)
+
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_planes), 0, p.wp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwq = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.w_planes), 0, q.wp_bytes, 0x00020000);
+    int a_hi0[NA], a_wi0[NA], a_off0[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int m = m0 + srow + 32 * i;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        unsigned b, rem, ho, wo;
+        p.d_howo.divmod((unsigned)mm, b, rem);
+        p.d_wo.divmod(rem, ho, wo);
+        a_hi0[i] = (int)ho - p.pad;
+        a_wi0[i] = (int)wo - p.pad;
+        a_off0[i] = (((int)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + kq * 4;
+    }
+    const int KS = p.K / 16;
+    const unsigned bo = (unsigned)(((size_t)wn * KS * 3 * 64 + lane) * 16);   // conv2's n-block wn
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra0[NA], ra1[NA], ra2[NA];   // THREE k-tiles of A in flight (tile t in set t % 3): see the loop
+    u32x4 fbr[2][3];
+    auto load_a = [&](int kt, u32x4 (&ra)[NA]) {
+        unsigned rs, c0, r, s;
+        p.d_cin.divmod((unsigned)(kt * BKX), rs, c0);
+        p.d_s.divmod(rs, r, s);
+        const int delta = ((int)r * p.W + (int)s) * p.Cin + (int)c0;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
+            const bool ok = a_ok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB), 0, 0);
+        }
+    };
+    auto load_b = [&](int kt, int u) {
+        const int ks = kt * 2 + u;
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) fbr[u][pl] = __builtin_amdgcn_raw_buffer_load_b128(rwp, (int)bo, (ks * 3 + pl) * 1024, 0);
+    };
+    unsigned bmin = 0xFFFFFFFFu;
+    float nonfin = 0.f;
+    auto store_a = [&](u32x4 (&ra)[NA]) {
+        if (p.x6_flags) {
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+                const u32x4 v = ra[i];
+                const unsigned b0 = (v.x << 1) - 1u, b1 = (v.y << 1) - 1u, b2 = (v.z << 1) - 1u, b3 = (v.w << 1) - 1u;
+                bmin = min(min(bmin, min(b0, b1)), min(b2, b3));
+                nonfin = fmaf(__uint_as_float(v.x), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.y), 0.f, nonfin);
+                nonfin = fmaf(__uint_as_float(v.z), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.w), 0.f, nonfin);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const u32x4 v = ra[i];
+            __bf16* dst = As + (srow + 32 * i) * LDX + kq * 4;
+            uint2 o0, o1, o2;
+            x6_split4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), o0, o1, o2);
+            *reinterpret_cast<uint2*>(dst) = o0;
+            *reinterpret_cast<uint2*>(dst + BM * LDX) = o1;
+            *reinterpret_cast<uint2*>(dst + 2 * BM * LDX) = o2;
+        }
+    };
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const __bf16* a_frag = As + (wm * (TM * 32) + l31) * LDX + lh * 8;
+    const int nk = p.K / BKX;
+    constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};   // (A plane, B plane) of the six products, smallest first
+    auto compute_tile = [&](int kt_next) {
+#pragma unroll
+        for (int u = 0; u < BKX / 16; u++) {
+            bf16x8 fa[TM][3], fb[3];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * BM * LDX + i * 32 * LDX + u * 16);
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) fb[pl] = *reinterpret_cast<const bf16x8*>(&fbr[u][pl]);
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+#pragma unroll
+                for (int i = 0; i < TM; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa[t]], fb[pb[t]], acc[i], 0, 0, 0);
+            if (kt_next < nk) load_b(kt_next, u);
+            if (u == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // A 128 x 64 tile gives a wave only 24 MFMAs (~0.4 us) per k-tile: one tile of prefetch, as in the stand-alone kernel, leaves every
+    // store phase waiting for memory (that kernel spends ~3 us per k-tile and workgroup, a quarter of it in MFMAs).  This kernel runs at two
+    // waves per SIMD (LDS-bound occupancy), so the registers for two more tiles in flight are free: tile kt + 3 is requested when tile kt starts.
+    load_b(0, 0);
+    load_b(0, 1);
+    load_a(0, ra0);
+    if (nk > 1) load_a(1, ra1);
+    if (nk > 2) load_a(2, ra2);
+    store_a(ra0);
+    __syncthreads();
+    auto k_iter = [&](int kt, u32x4 (&r_free)[NA], u32x4 (&r_next)[NA]) {   // LDS holds tile kt; r_free held it; r_next holds tile kt + 1
+        if (kt + 3 < nk) load_a(kt + 3, r_free);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tile(kt + 1);
+        __syncthreads();
+        store_a(r_next);
+        __syncthreads();
+    };
+    {
+        int kt = 0;
+        for (; kt + 3 < nk; kt += 3) {
+            k_iter(kt, ra0, ra1);
+            k_iter(kt + 1, ra1, ra2);
+            k_iter(kt + 2, ra2, ra0);
+        }
+        if (kt + 1 < nk) {
+            k_iter(kt, ra0, ra1);
+            if (kt + 2 < nk) k_iter(kt + 1, ra1, ra2);
+        }
+    }
+    compute_tile(nk);
+    if (p.x6_flags) abr::x6_report(bmin, nonfin, p.x6_flags);
+
+    // ---- conv3's weight fragments of this wave's first 32 output channels: on their way while o2 is formed
+    const int KS3 = q.K / 16;   // 4
+    u32x4 fq[4][3];             // [k-step][plane] of the n-block in hand (the second block's are requested behind the first block's MFMAs)
+    auto load_q = [&](int j) {
+        const unsigned bq = (unsigned)(((size_t)(2 * wave + j) * KS3 * 3 * 64 + lane) * 16);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) fq[u][pl] = __builtin_amdgcn_raw_buffer_load_b128(rwq, (int)bq, (u * 3 + pl) * 1024, 0);
+    };
+    load_q(0);
+    __syncthreads();   // every wave is done with conv2's operand planes: the region becomes o2's
+
+    // ---- epilogue of conv2 (the arithmetic of epilogue_rows: v * scale + bias, ReLU), exact split, planes of o2 into LDS
+    {
+        const int n = wn * 32 + l31;
+        const float sc = p.scale ? p.scale[n] : 1.f, bi = p.bias ? p.bias[n] : 0.f;
+        unsigned bmin2 = 0xFFFFFFFFu;
+        float nonfin2 = 0.f;
+        __bf16* o2p = As + n;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float v0 = acc[i][r] * sc + bi, v1 = acc[i][r + 1] * sc + bi;
+                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                if (q.x6_flags) {   // conv3's operand: inspected once, as the stand-alone launch's first n-tile column does
+                    const unsigned b0 = (__float_as_uint(v0) << 1) - 1u, b1 = (__float_as_uint(v1) << 1) - 1u;
+                    bmin2 = min(bmin2, min(b0, b1));
+                    nonfin2 = fmaf(v0, 0.f, nonfin2); nonfin2 = fmaf(v1, 0.f, nonfin2);
+                }
+                uint2 h0, h1, h2;
+                x6_split4(v0, v1, 0.f, 0.f, h0, h1, h2);
+                const int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // rows of accumulator registers r, r + 1
+                unsigned short* d0 = reinterpret_cast<unsigned short*>(o2p + row * T64_O2P);
+                d0[0] = (unsigned short)(h0.x & 0xFFFFu);                 d0[T64_O2P] = (unsigned short)(h0.x >> 16);
+                d0[128 * T64_O2P] = (unsigned short)(h1.x & 0xFFFFu);     d0[128 * T64_O2P + T64_O2P] = (unsigned short)(h1.x >> 16);
+                d0[2 * 128 * T64_O2P] = (unsigned short)(h2.x & 0xFFFFu); d0[2 * 128 * T64_O2P + T64_O2P] = (unsigned short)(h2.x >> 16);
+            }
+        if (q.x6_flags) abr::x6_report(bmin2, nonfin2, q.x6_flags);
+    }
+    __syncthreads();
+
+    // ---- conv3: [128 x 64] (LDS planes) x [64 x 256] (packed planes, global -> registers); wave w owns output channels [64 w, 64 w + 64)
+    // in two passes of 32.  The output phase moves 256 KB per workgroup (residual in, result out) with only eight waves on the CU: every
+    // residual vector of a pass (16 x 16 B per lane) is requested BEFORE the pass's MFMAs -- with epilogue_rows' four loads in flight per
+    // wave this phase alone took 107 of the launch's 214 us.  The arithmetic is epilogue_rows': (v * scale + bias) + residual, ReLU.
+    const __bf16* o_frag = As + l31 * T64_O2P + lh * 8;
+    float* ep = ep_all + wave * (32 * (32 + EPAD));
+    constexpr int EP = 32 + EPAD;
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    const int c4 = (lane & 7) * 4, erow = lane >> 3;   // 8 lanes per 128 B row segment, 8 rows per wave iteration
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int ncol = (2 * wave + j) * 32 + c4;
+        nt4 res[4][4];
+        if (q.residual) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int m = m0 + i * 32 + it * 8 + erow;
+                    res[i][it] = m < q.M ? __builtin_nontemporal_load(reinterpret_cast<const nt4*>(q.residual + (size_t)m * q.Cout + ncol)) : nt4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        const float4 sc4 = q.scale ? *reinterpret_cast<const float4*>(q.scale + ncol) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 bi4 = q.bias ? *reinterpret_cast<const float4*>(q.bias + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x16 acc3[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc3[i][r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            bf16x8 fa[4][3], fb[3];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(o_frag + pl * 128 * T64_O2P + i * 32 * T64_O2P + u * 16);
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) fb[pl] = *reinterpret_cast<const bf16x8*>(&fq[u][pl]);
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc3[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa[t]], fb[pb[t]], acc3[i], 0, 0, 0);
+        }
+        if (j == 0) load_q(1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) ep[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + l31] = acc3[i][r];   // wave-private transpose (as epilogue_rows)
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int row = it * 8 + erow, m = m0 + i * 32 + row;
+                float4 v = *reinterpret_cast<const float4*>(ep + row * EP + c4);
+                v.x = v.x * sc4.x + bi4.x; v.y = v.y * sc4.y + bi4.y; v.z = v.z * sc4.z + bi4.z; v.w = v.w * sc4.w + bi4.w;
+                if (q.residual) { v.x += res[i][it].x; v.y += res[i][it].y; v.z += res[i][it].z; v.w += res[i][it].w; }
+                if (q.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (m < q.M) *reinterpret_cast<float4*>(out + (size_t)m * q.Cout + ncol) = v;
+            }
+        }
+    }
+    abr::prof_stamp_end(p.prof_ts);
+}
+
 // fp32 matrix [rows][K] (K % 16 == 0) -> fragment-packed bf16x3 planes (layout above), rows padded with zeros to a multiple of 32.
 // One workgroup = one 32-row block x 64 k: the fp32 block comes in as whole 256 B row segments (coalesced), goes through LDS, and
 // leaves as 4 k-steps x 3 planes x 1 KB chunks.  Every weight element is range-checked here (abr_x6_range_flags), once per version.
@@ -1483,6 +1740,66 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
         dispatch_igemm(p, x, w, out, st);
     }
     ABR_CHECK_LAUNCH("conv_forward");
+    return ABR_OK;
+}
+
+// ConvP of a plain (unsplit, unbatched) launch from the caller's descriptor: the part of abr_conv_forward's set-up the fused launch shares
+static void convp_from_desc(const abr_conv_desc* d, ConvP& p) {
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.R = d->R; p.S = d->S;
+    p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.M = d->B * d->Ho * d->Wo;
+    p.K = d->R * d->S * d->Cin;
+    p.out_H = d->Ho; p.out_W = d->Wo; p.out_sh = p.out_sw = 1; p.scatter = 0;
+    p.relu = d->relu;
+    p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.mask = d->mask;
+    p.tiles_m = (p.M + 127) / 128; p.tiles_n = 1;
+    p.nbatch = 1; p.tiles_pb = p.tiles_m; p.a_bs = p.w_bs = p.o_bs = 0;
+    p.n_full = p.tiles_m; p.split = 1; p.ws = nullptr; p.cnt = nullptr;
+    p.v_out = nullptr;
+    p.w_version = d->w_version;
+    p.w_planes = d->w_planes;
+    p.wp_bytes = (unsigned)x6_packed_bytes(d->Cout, p.K); p.wp_bs = 0; p.wp_nblocks = (d->Cout + 31) / 32;
+    p.x_bytes = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * 4); p.w_bytes = (unsigned)((int64_t)d->Cout * p.K * 4);
+    p.d_howo.init((unsigned)(p.Ho * p.Wo)); p.d_wo.init((unsigned)p.Wo); p.d_cin.init((unsigned)p.Cin); p.d_s.init((unsigned)p.S);
+    p.math = d->math;
+    p.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
+    p.prof_ts = nullptr;
+}
+
+extern "C" int abr_conv_tail64_forward(const abr_conv_desc* d2, const abr_conv_desc* d3, const float* x, const float* w2, const float* w3, float* out,
+                                       void* stream) {
+    ABR_REQUIRE(d2 && d3 && x && w2 && w3 && out, "conv_tail64_forward: null pointer");
+    ABR_REQUIRE(d2->math == ABR_MATH_BF16X6 && d3->math == ABR_MATH_BF16X6, "conv_tail64_forward: bf16x6 arithmetic only");
+    ABR_REQUIRE(d2->R == 3 && d2->S == 3 && d2->stride == 1 && d2->pad == 1 && d2->Cin == 64 && d2->Cout == 64 && d2->Ho == d2->H && d2->Wo == d2->W &&
+                    !d2->residual && !d2->mask,
+                "conv_tail64_forward: the first conv must be 3x3, stride 1, pad 1, 64 -> 64 channels, without residual / mask");
+    ABR_REQUIRE(d3->R == 1 && d3->S == 1 && d3->stride == 1 && d3->pad == 0 && d3->Cin == 64 && d3->Cout == 256 && d3->B == d2->B && d3->H == d2->H &&
+                    d3->W == d2->W && d3->Ho == d2->H && d3->Wo == d2->W && !d3->mask,
+                "conv_tail64_forward: the second conv must be 1x1, stride 1, 64 -> 256 channels, on the first conv's output");
+    ABR_REQUIRE((d2->out_H <= 0 || d2->out_H == d2->Ho) && (d3->out_H <= 0 || d3->out_H == d3->Ho) && d2->out_sh <= 1 && d3->out_sh <= 1 &&
+                    (d2->out_W <= 0 || d2->out_W == d2->Wo) && (d3->out_W <= 0 || d3->out_W == d3->Wo) && d2->out_sw <= 1 && d3->out_sw <= 1,
+                "conv_tail64_forward: no scattered outputs");
+    ABR_REQUIRE((int64_t)d2->B * d2->H * d2->W * 256 * 4 < (int64_t)0x7FFFFFF0, "conv_tail64_forward: tensors must be < 2 GB (32-bit buffer offsets)");
+    hipStream_t st = abr::as_stream(stream);
+    ConvP p, q;
+    convp_from_desc(d2, p);
+    convp_from_desc(d3, q);
+    // packed planes of both weights: the caller's, or the library's per-version cache (filled here on a miss), or packed into stream scratch
+    auto planes_of = [&](const abr_conv_desc* d, const float* w, ConvP& c) -> bool {
+        if (c.w_planes) return true;
+        if (d->w_version)
+            c.w_planes = abr::derived_cached(w, abr::DERIVED_X6_PLANES, c.wp_bytes, d->w_version, st, [&](void* buf) { return x6_pack(w, d->Cout, c.K, buf, st); });
+        return c.w_planes != nullptr;
+    };
+    ABR_REQUIRE(planes_of(d2, w2, p) && planes_of(d3, w3, q), "conv_tail64_forward: needs w_version != 0 (or caller-packed planes) for both weights");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tail64_x6w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTail64Lds);
+        attr_set = true;
+    }
+    p.prof_ts = abr::prof_stamp_slot(abr::PROF_X6W_TAIL64, 2.0 * (double)p.M * ((double)p.Cout * p.K + (double)q.Cout * q.K));
+    conv_tail64_x6w_kernel<<<(unsigned)p.tiles_m, 256, kTail64Lds, st>>>(p, q, x, out);
+    ABR_CHECK_LAUNCH("conv_tail64_forward");
     return ABR_OK;
 }
 

@@ -170,12 +170,17 @@ class Bottleneck(nn.Module):
         o1 = self._conv(x, self.conv1, s, 0, scale=s1, bias=b1, relu=True)
         # the weight gradient of conv2 transforms the same o1 with the same B^T d B: keep the forward's V for it when training
         v2 = ops.wino_v_alloc(o1, self.conv2.weight, 1, 1, self.math) if (save and self.conv2.weight.requires_grad) else None
-        o2 = self._conv(o1, self.conv2, 1, 1, scale=s2, bias=b2, relu=True, wino_v=v2)
         if self.downsample is not None:
             sd, bd = self.downsample[1].scale_bias()
             idt = self._conv(x, self.downsample[0], s, 0, scale=sd, bias=bd)
         else:
             idt = x
+        if not save and ops.bottleneck_tail64_applies(o1, self.conv2.weight, self.conv3.weight, self.math):
+            # no backward pass (the frozen layer1 of both models): conv2 -> bn2 -> relu -> conv3 -> bn3 -> += identity -> relu in one launch,
+            # o2 stays on the compute unit (same products in the same order: bit-identical to the two launches below)
+            out = ops.bottleneck_tail64(o1, self.conv2.weight, self.conv3.weight, s2, b2, s3, b3, idt, self.conv2.version(), self.conv3.version())
+            return out, None
+        o2 = self._conv(o1, self.conv2, 1, 1, scale=s2, bias=b2, relu=True, wino_v=v2)
         out = self._conv(o2, self.conv3, 1, 0, scale=s3, bias=b3, residual=idt, relu=True)
         return out, ((x, o1, o2, out, s, v2) if save else None)
 

@@ -308,6 +308,30 @@ def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, ma
     return out
 
 
+FUSE_TAIL64 = os.environ.get("ABR_FUSE_TAIL64", "1") != "0"
+
+
+def bottleneck_tail64_applies(o1, w2, w3, math):
+    """the fused tail takes the 64-wide bottleneck of the frozen layer1 in the bf16x6 arithmetic (abr_conv_tail64_forward)"""
+    return (FUSE_TAIL64 and math == MATH_BF16X6 and tuple(w2.shape) == (64, 3, 3, 64) and tuple(w3.shape) == (256, 1, 1, 64)
+            and o1.shape[-1] == 64 and o1.numel() * 4 * 4 < 0x7FFFFFF0)
+
+
+def bottleneck_tail64(o1, w2, w3, scale2, bias2, scale3, bias3, residual, w2_version, w3_version, out=None):
+    """relu(bn3(conv1x1(relu(bn2(conv3x3(o1)))) + residual) in ONE launch (resnet.py:327-346 without a backward pass): o1 [B,H,W,64] NHWC,
+    w2 [64,3,3,64], w3 [256,1,1,64] OHWI -> [B,H,W,256]; bit-identical to the two conv_forward calls it replaces."""
+    L.require_cuda(o1, w2, w3)
+    o1, w2, w3 = L.f32c(o1), L.f32c(w2), L.f32c(w3)
+    d2 = conv_desc(o1.shape, w2.shape, 1, 1, scale2, bias2, None, None, True, math=MATH_BF16X6)
+    B, H, W, _ = o1.shape
+    d3 = conv_desc((B, H, W, 64), w3.shape, 1, 0, scale3, bias3, residual, None, True, math=MATH_BF16X6)
+    d2.w_version, d3.w_version = int(w2_version), int(w3_version)
+    if out is None:
+        out = _empty((B, H, W, 256), o1)
+    L.check(L.lib().abr_conv_tail64_forward(C.byref(d2), C.byref(d3), L.ptr(o1), L.ptr(w2), L.ptr(w3), L.ptr(out), L.stream()), "conv_tail64_forward")
+    return out
+
+
 def conv_prepare_weights(w, stride, pad, math, w_version):
     """Derive on the CURRENT stream what conv_forward(.., w, stride, pad, math=, w_version=) would derive from w (the Winograd-domain
     weights of a wide 3x3 conv) so that the call itself finds it cached; consumers on other streams are ordered behind it."""

@@ -29,7 +29,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense
 PROF_NAMES = ["conv_igemm_kernel<128,128>", "conv_igemm_kernel<128,64>", "conv_igemm_kernel<64,64>", "conv_igemm_kernel<128,64,small_c>",
               "conv_wgrad_kernel", "roi_align_fwd", "roi_align_bwd", "conv_igemm_bf16_kernel", "conv_wgrad_bf16_kernel",
               "conv_igemm_x6_kernel<128,128>", "conv_igemm_x6_kernel<128,64>", "conv_igemm_x6_kernel<64,64>",
-              "conv_igemm_x6w_kernel<128,128>", "conv_igemm_x6w_kernel<128,64>", "conv_igemm_x6w_kernel<64,64>"]
+              "conv_igemm_x6w_kernel<128,128>", "conv_igemm_x6w_kernel<128,64>", "conv_igemm_x6w_kernel<64,64>", "conv_tail64_x6w_kernel"]
 # (positions = abr::ProfId in csrc/common.h.  One row per TEMPLATE INSTANCE of the bf16x6 implicit GEMM, named as rocprofv3 names them
 #  (`conv_igemm_x6w_kernel<128, 128, 1, 4, true>` ...: x6w = the weights-direct form, x6 = the form that splits the weight tile per workgroup),
 #  so every row's fraction can be recomputed from profiles/ alone.  id 8 is the

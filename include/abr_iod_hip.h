@@ -247,6 +247,13 @@ typedef struct {
 } abr_conv_desc;
 
 int abr_conv_forward(const abr_conv_desc* d_host, const float* x, const float* w, float* out, void* stream);
+/* The tail of a 64-wide bottleneck WITHOUT a backward pass (maskrcnn_benchmark/modeling/backbone/resnet.py:327-346 for the frozen layer1:
+ * conv2 3x3 -> bn2 -> relu -> conv3 1x1 -> bn3 -> += identity -> relu) as ONE launch: d2 = the 3x3 conv (64 -> 64, stride 1, pad 1, scale / bias /
+ * relu as in abr_conv_forward), d3 = the 1x1 conv (64 -> 256, scale / bias / residual / relu), both ABR_MATH_BF16X6 with w_version != 0 (or
+ * caller-packed w_planes).  out [B,H,W,256] is bit-identical to abr_conv_forward(d2) followed by abr_conv_forward(d3); the intermediate tensor
+ * never leaves the compute unit. */
+int abr_conv_tail64_forward(const abr_conv_desc* d2_host, const abr_conv_desc* d3_host, const float* x, const float* w2, const float* w3, float* out,
+                            void* stream);
 /* Derive, on `stream`, whatever abr_conv_forward would derive from the weight tensor (w, w_version != 0) of a conv with this geometry and
  * arithmetic -- the Winograd-domain weights of a wide stride-1 3x3 conv, the packed bf16x3 planes of any bf16x6 conv -- so that the next abr_conv_forward with the same
  * (w, w_version) finds it ready (a consumer on another stream is ordered behind it by the library).  Lets a

@@ -488,6 +488,34 @@ def test_topk_sigmoid_matches_torch():
     assert idx[0, :50].tolist() == sorted(idx[0, :50].tolist())               # tie group: ascending index
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 37, 53), (1, 8, 8), (4, 150, 250)])
+def test_bottleneck_tail_fused(B, H, W):
+    """abr_conv_tail64_forward (conv3x3 64->64 + bn + relu + conv1x1 64->256 + bn + residual + relu in one launch, o2 kept on the compute unit)
+    equals the two abr_conv_forward launches it replaces BIT FOR BIT (same products, same order), ragged last tile included; and both agree with
+    float64 (resnet.py:327-346)."""
+    from abr_iod_amd import ops
+    torch.manual_seed(B * 1000 + H)
+    o1 = torch.relu(torch.randn(B, H, W, 64, device="cuda"))
+    w2 = torch.randn(64, 3, 3, 64, device="cuda") * 0.06
+    w3 = torch.randn(256, 1, 1, 64, device="cuda") * 0.15
+    s2, b2 = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.2
+    s3, b3 = torch.rand(256, device="cuda") + 0.5, torch.randn(256, device="cuda") * 0.2
+    idt = torch.randn(B, H, W, 256, device="cuda")
+    o2 = ops.conv_forward(o1, w2, 1, 1, scale=s2, bias=b2, relu=True, math=ops.MATH_BF16X6, w_version=7)
+    want = ops.conv_forward(o2, w3, 1, 0, scale=s3, bias=b3, residual=idt, relu=True, math=ops.MATH_BF16X6, w_version=7)
+    assert ops.bottleneck_tail64_applies(o1, w2, w3, ops.MATH_BF16X6)
+    got = ops.bottleneck_tail64(o1, w2, w3, s2, b2, s3, b3, idt, 7, 7)
+    assert torch.equal(got, want)
+    assert ops.x6_range_flags(reset=False) == 0
+    if H <= 40:
+        x64 = o1.double().permute(0, 3, 1, 2)
+        r2 = torch.relu(torch.nn.functional.conv2d(x64, w2.double().permute(0, 3, 1, 2), padding=1) * s2.double().view(1, -1, 1, 1) + b2.double().view(1, -1, 1, 1))
+        r3 = torch.relu(torch.nn.functional.conv2d(r2, w3.double().permute(0, 3, 1, 2)) * s3.double().view(1, -1, 1, 1) + b3.double().view(1, -1, 1, 1)
+                        + idt.double().permute(0, 3, 1, 2))
+        err = (got.double().permute(0, 3, 1, 2) - r3).abs().max().item()
+        assert err < 2e-5 * r3.abs().max().item(), err
+
+
 def test_topk_sigmoid_scratch_survives_changing_shapes():
     """The ranking's per-stream scratch (key array + level-1 histogram) is reused across calls: a SMALLER feature map after a larger one, and
     another batch size, on the same stream must not find stale bytes where the histogram expects zeros (ragged VOC batches, the 600x600 mosaic
