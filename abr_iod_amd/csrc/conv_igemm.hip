@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     };
     unsigned bmin = 0xFFFFFFFFu;
     float nonfin = 0.f;
-    auto store_a = [&](u32x4 (&ra)[NA]) {
+    auto store_a = [&](u32x4 (&ra)[NA], int buf) {
         if (p.x6_flags) {
 #pragma unroll
             for (int i = 0; i < NA; i++) {
@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const u32x4 v = ra[i];
-            __bf16* dst = As + (srow + 32 * i) * LDX + kq * 4;
+            __bf16* dst = As + buf * (3 * BM * LDX) + (srow + 32 * i) * LDX + kq * 4;
             uint2 o0, o1, o2;
             x6_split4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), o0, o1, o2);
             *reinterpret_cast<uint2*>(dst) = o0;
@@ -1093,14 +1093,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const __bf16* a_frag = As + (wm * (TM * 32) + l31) * LDX + lh * 8;
     const int nk = p.K / BKX;
     constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};   // (A plane, B plane) of the six products, smallest first
-    auto compute_tile = [&](int kt_next) {
+    auto compute_tile = [&](int kt_next, int buf) {
 #pragma unroll
         for (int u = 0; u < BKX / 16; u++) {
             bf16x8 fa[TM][3], fb[3];
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * BM * LDX + i * 32 * LDX + u * 16);
+                for (int pl = 0; pl < 3; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + buf * (3 * BM * LDX) + pl * BM * LDX + i * 32 * LDX + u * 16);
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) fb[pl] = *reinterpret_cast<const bf16x8*>(&fbr[u][pl]);
 #pragma unroll
@@ -1111,22 +1111,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             if (u == 0) __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // A 128 x 64 tile gives a wave only 24 MFMAs (~0.4 us) per k-tile: one tile of prefetch, as in the stand-alone kernel, leaves every
-    // store phase waiting for memory (that kernel spends ~3 us per k-tile and workgroup, a quarter of it in MFMAs).  This kernel runs at two
-    // waves per SIMD (LDS-bound occupancy), so the registers for two more tiles in flight are free: tile kt + 3 is requested when tile kt starts.
+    // A 128 x 64 tile gives a wave only 24 MFMAs (~0.4 us) per k-tile, and this kernel runs at two waves per SIMD (LDS-bound occupancy): the
+    // registers for THREE k-tiles of A in flight are free, and the operand planes are double-buffered in LDS (61 KB of the 74 KB this kernel
+    // owns anyway) so that the split / store of tile kt + 1 shares ONE barrier interval with the MFMAs of tile kt instead of waiting behind them.
     load_b(0, 0);
     load_b(0, 1);
     load_a(0, ra0);
     if (nk > 1) load_a(1, ra1);
     if (nk > 2) load_a(2, ra2);
-    store_a(ra0);
+    store_a(ra0, 0);
     __syncthreads();
-    auto k_iter = [&](int kt, u32x4 (&r_free)[NA], u32x4 (&r_next)[NA]) {   // LDS holds tile kt; r_free held it; r_next holds tile kt + 1
+    auto k_iter = [&](int kt, u32x4 (&r_free)[NA], u32x4 (&r_next)[NA]) {   // LDS buffer kt & 1 holds tile kt; r_free held it; r_next holds tile kt + 1
         if (kt + 3 < nk) load_a(kt + 3, r_free);
         __builtin_amdgcn_sched_barrier(0);
-        compute_tile(kt + 1);
-        __syncthreads();
-        store_a(r_next);
+        compute_tile(kt + 1, kt & 1);
+        store_a(r_next, (kt + 1) & 1);   // the other buffer: last read for tile kt - 1, before the previous barrier
         __syncthreads();
     };
     {
@@ -1141,10 +1140,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             if (kt + 2 < nk) k_iter(kt + 1, ra1, ra2);
         }
     }
-    compute_tile(nk);
+    compute_tile(nk, (nk - 1) & 1);
     if (p.x6_flags) abr::x6_report(bmin, nonfin, p.x6_flags);
 
-    // ---- conv3's weight fragments of this wave's first 32 output channels: on their way while o2 is formed
+// ---- conv3's weight fragments of this wave's first 32 output channels: on their way while o2 is formed
     const int KS3 = q.K / 16;   // 4
     u32x4 fq[4][3];             // [k-step][plane] of the n-block in hand (the second block's are requested behind the first block's MFMAs)
     auto load_q = [&](int j) {

@@ -11,6 +11,10 @@ timeout 300 python bench.py --image-size 800x1333 --steps 10 > $O/${R}_bench_800
 timeout 300 python bench.py --task 10-5 --mosaic-squares --steps 20 > $O/${R}_bench_10-5_mosaic_squares.jsonl 2>/dev/null
 timeout 300 python bench.py --share-frozen-prefix --no-cpu-baseline --no-alt-math > $O/${R}_bench_shared_frozen_prefix.jsonl 2>/dev/null
 timeout 300 python bench.py --task 10-5 --mosaic-squares --math bf16 --steps 20 --no-kernel-timing > $O/${R}_bench_10-5_mosaic_squares_bf16_backbone.jsonl 2>/dev/null
+# parity evidence: the full-size golden / oracle comparisons with their measured numbers (losses, proposal match, worst max-rel / rel-L2 of the 52
+# gradients per configuration and arithmetic) -- with -q alone the printed worst values are lost
+( timeout 1500 python -m pytest tests/test_gpu_e2e_full_golden.py tests/test_gpu_e2e.py tests/test_gpu_e2e_golden.py tests/test_gpu_configs4_whole.py -q -s -p no:cacheprovider 2>&1 \
+    | grep -E "^\[|worst|max-rel|l2-rel|passed|failed|^GPU |^oracle|proposal|present" | grep -v amdgpu.ids ) > $O/${R}_fullsize_parity.log
 # rocprofv3 kernel trace of the bench command (+ the PMC HBM-traffic passes), then the matrix-pipe counters
 STEPS=5 WARMUP=2 timeout 900 bash tools/profile_bench.sh > $O/profile_bench.log 2>&1
 cp gpurun_out/prof_kernel_stats.csv $O/${R}_bench_kernel_stats.csv
