@@ -89,6 +89,8 @@ void* derived_cached(const void* w, int kind, size_t bytes, int64_t version, hip
 // and then hands the tokens to derived_commit, which records the fill events.  Entries with a pending token are never evicted.
 void* derived_acquire(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, void** token);
 void derived_commit(void* const* tokens, int n, hipStream_t st);
+// the fill did NOT happen (an error between acquire and commit): the entries hold no version and are evictable / refillable again
+void derived_abandon(void* const* tokens, int n);
 
 // One job of a batched weight preparation (a table of these lives in device memory; workgroup b belongs to the job with first_block <= b).
 struct PrepJob {

@@ -1888,6 +1888,12 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
     PrepTables& T = g_prep_tables[st];
     std::vector<abr::PrepJob> tj, uj, pj;        // transposes, Winograd weight transforms, packings
     std::vector<void*> tokens;
+    // every early return between the acquires below and derived_commit releases the tokens (entries left pending would never be evictable and
+    // would repack on every later call)
+    struct TokenGuard {
+        std::vector<void*>& t; bool committed = false;
+        ~TokenGuard() { if (!committed && !t.empty()) abr::derived_abandon(t.data(), (int)t.size()); }
+    } token_guard{tokens};
     std::vector<size_t> u_off;                    // per uj entry: offset (floats) of its U inside the scratch
     size_t u_total = 0;
     int tb = 0, ub = 0, pb = 0;                   // workgroups of the three launches
@@ -1971,6 +1977,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
         bad |= abr::prep_pack_multi(d + tj.size() + uj.size(), (int)pj.size(), pb, st);
         ABR_REQUIRE(!bad, "conv_prepare_batch: launch failed");
         abr::derived_commit(tokens.data(), (int)tokens.size(), st);
+        token_guard.committed = true;
         ABR_CHECK_LAUNCH("conv_prepare_batch");
     }
     // shapes the batched kernels do not take: the per-tensor calls (after the transposes above, which every dgrad copy went through)

@@ -456,7 +456,7 @@ float* wino_ws(hipStream_t st, size_t floats) {
 // the filling one waits for the fill's event; every stream that has read an entry is remembered, and a REFILL (new version) first makes
 // its stream wait for an event recorded on each of those streams at refill time -- everything they had queued, the readers of the old
 // bytes included, precedes it -- so no reader of version v can see version v+1's bytes whatever stream refills.  Bounded: least-recently-
-// used entries are dropped when the cache exceeds ABR_WINO_CACHE_MB (default 8192), and abr_conv_cache_clear() drops everything (the host
+// used entries are dropped when the cache exceeds ABR_WINO_CACHE_MB (default 4096: two full models need ~1.2 GB), and abr_conv_cache_clear() drops everything (the host
 // calls it when a model's parameter storage is rebuilt or released).  One mutex guards the map.  Returns nullptr when there is no memory
 // or the fill failed (callers then derive into scratch / split in-kernel).
 namespace {
@@ -479,7 +479,7 @@ void dcache_drop(DEntry& e) {   // (mutex held) wait for every stream that may s
     e = DEntry();
 }
 size_t dcache_limit() {
-    static const size_t mb = getenv("ABR_WINO_CACHE_MB") ? (size_t)atoll(getenv("ABR_WINO_CACHE_MB")) : 8192;
+    static const size_t mb = getenv("ABR_WINO_CACHE_MB") ? (size_t)atoll(getenv("ABR_WINO_CACHE_MB")) : 4096;
     return mb << 20;
 }
 }  // namespace
@@ -565,6 +565,16 @@ void derived_commit(void* const* tokens, int n, hipStream_t st) {
         e->version = e->pending;
         e->stream = st;
         e->pending = 0;
+    }
+}
+
+void derived_abandon(void* const* tokens, int n) {
+    std::lock_guard<std::mutex> lock(g_dcache_mu);
+    for (int i = 0; i < n; i++) {
+        DEntry* e = reinterpret_cast<DEntry*>(tokens[i]);
+        if (!e) continue;
+        e->pending = 0;
+        e->version = 0;   // the buffer holds no complete version: the next lookup refills it
     }
 }
 

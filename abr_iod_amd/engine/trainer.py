@@ -334,6 +334,20 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
             # wait for, the host is idle until the proposal counts come back, and the device has the proposal selection's wait to fill
             enqueue_prefetch()
         ready = getattr(soften_proposal[0], "_roi_ready", None) if (EARLY_SECOND_PASS and src is not None and soften_proposal) else None
+        joint_ov = JOINT_ROI_PASS and need_source and bool(soften_proposal) and hasattr(model_target.roi_heads, "forward_joint")
+        if joint_ov:
+            # ABR_JOINT_ROI in the overlapped step: the 64 distillation RoIs per image ride along with the 512 detection RoIs through ONE
+            # layer4 / predictor pass (rows of the same GEMMs) instead of a second pass of M = 4096-row launches at ~half the big pass's rate
+            cur = torch.cuda.current_stream()
+            if src_done is not None:
+                cur.wait_event(src_done)
+            tab = getattr(soften_proposal[0], "_roi_table", None)
+            if tab is not None:
+                tab[0].record_stream(cur)
+            (loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results), \
+                (target_result, _, roi_align_features_target) = model_target.forward_finish(begun, soften_proposals=soften_proposal)
+            second_done = True
+            ready = None
         if ready is not None:
             # :93-95 ahead of the second half of :89-90.  The target's pass over the distillation RoIs needs its backbone features and the
             # SOURCE's proposals -- not the target's own proposals, whose selection (top-k, NMS) the main stream would otherwise sit and
@@ -346,8 +360,9 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
             target_result, _, roi_align_features_target = model_target.forward(images, targets, features=begun["features"],
                                                                                proposals=soften_proposal)  # :93-95
             second_done = True
-        loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results = \
-            model_target.forward_finish(begun)                                                             # :89-90 (second half)
+        if not joint_ov:
+            loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results = \
+                model_target.forward_finish(begun)                                                         # :89-90 (second half)
         if src is not None:       # everything the source stream produced becomes visible to the main stream here
             cur = torch.cuda.current_stream()
             cur.wait_event(src_done)

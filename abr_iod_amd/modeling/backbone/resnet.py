@@ -236,7 +236,9 @@ class _StageFn(Function):
     def backward(ctx, gout):
         g = as_nhwc(gout)
         owned = False
-        masked = bool(getattr(gout, "_abr_relu_masked", False))   # the producer of gout already applied this stage's final ReLU mask (box predictor)
+        # the producer of gout (the box predictor's fused pooling + ReLU backward) already applied this stage's final ReLU mask -- valid only while
+        # gout is still exactly the tensor that producer wrote (same storage, same version: nothing was accumulated into it since)
+        masked = getattr(gout, "_abr_relu_masked", None) == (gout.data_ptr(), gout._version)
         n = len(ctx.blocks)
         for i in range(n - 1, -1, -1):
             need = ctx.need_dx or i > 0

@@ -35,6 +35,15 @@ DEFAULT_CONV_MATH = "bf16x6"
 FUSED_SOFTEN = os.environ.get("ABR_FUSED_SOFTEN", "1") != "0"
 
 
+def _drop_derived_cache():
+    """weakref finalizer of a model's flat parameter storage (see flatten_parameters)"""
+    try:
+        from ... import ops
+        ops.conv_cache_clear()
+    except Exception:   # never raise from a finalizer
+        pass
+
+
 class GeneralizedRCNN(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -75,6 +84,12 @@ class GeneralizedRCNN(nn.Module):
         if rebuilt and self.flat.params.is_cuda:
             from ... import ops
             ops.conv_cache_clear()   # the old storage is gone: entries keyed by its addresses would outlive it (and may alias new tensors)
+        if self.flat.params.is_cuda:
+            # the library keeps packed planes / Winograd-domain copies per weight ADDRESS (raw hipMalloc, outside torch's caching allocator): drop
+            # them when this storage dies (a model that is deleted, a long pytest session building model after model), not only when it is rebuilt
+            import weakref
+            fin = weakref.finalize(self.flat, _drop_derived_cache)
+            fin.atexit = False   # not during interpreter shutdown (the runtime may already be gone)
         from ..backbone.resnet import Conv2d, bump_param_version
         bump_param_version()   # new weight storage: nothing derived from an earlier tensor at the same address may be reused
         for m in self.modules():
@@ -119,14 +134,23 @@ class GeneralizedRCNN(nn.Module):
         return dict(features=features, backbone_features=backbone_features, targets=targets,
                     rpn=self.rpn.forward_begin(images, features, targets, rpn_output_source))
 
-    def forward_finish(self, state):
+    def forward_finish(self, state, soften_proposals=None):
+        """`soften_proposals` (the source model's distillation RoIs): they ride along with the detection RoIs through ONE layer4 / predictor pass
+        (train_incremental.py:89-95 as forward_joint does it); the result is then (the 8-tuple, the second call's 3-tuple)."""
         features, targets = state["features"], state["targets"]
         (proposals, proposal_losses), anchors, rpn_output = self.rpn.forward_finish(state["rpn"])
-        x, result, soften_results, detector_losses, roi_align_features = self.roi_heads(features, proposals, targets)
+        second = None
+        if soften_proposals is not None:
+            (x, result, soften_results, detector_losses, roi_align_features), (t_scores, t_bboxes, mask_logits, t_raf) = \
+                self.roi_heads.forward_joint(features, proposals, targets, soften_proposals)
+            second = ((t_scores, t_bboxes), mask_logits, t_raf)
+        else:
+            x, result, soften_results, detector_losses, roi_align_features = self.roi_heads(features, proposals, targets)
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)
-        return losses, features, state["backbone_features"], anchors, rpn_output, result, roi_align_features, soften_results
+        first = (losses, features, state["backbone_features"], anchors, rpn_output, result, roi_align_features, soften_results)
+        return first if second is None else (first, second)
 
     def forward_joint(self, images, targets, soften_proposals, rpn_output_source=None):
         """`forward(images, targets)` followed by `forward(images, targets, features=..., proposals=soften_proposals)`

@@ -126,7 +126,11 @@ class _PredictorFn(Function):
             gp = ops.conv_forward(g, pred.fused_dgrad_weight(), 1, 0).view(K_, -1)
             gx = from_nhwc(ops.avgpool_backward(gp, ctx.xshape, relu_of=ctx.relu_of))
             if ctx.relu_of is not None:
-                gx._abr_relu_masked = True
+                # "layer4's final ReLU mask is already applied" travels as a TOKEN bound to this very storage and version: if the autograd
+                # engine accumulates another consumer's gradient into the tensor (in place: the version moves; out of place: a new tensor
+                # without the attribute), _StageFn.backward no longer finds a matching token and applies the mask itself (idempotent on
+                # this part, required for the other) -- the flag can never outlive the values it describes.
+                gx._abr_relu_masked = (gx.data_ptr(), gx._version)
         ctx.saved = ctx.relu_of = None
         return (gx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
@@ -402,9 +406,16 @@ class ROIBoxHead(nn.Module):
     def forward_joint(self, features, proposals, targets, soften_proposals):
         """training forward (as `forward`) AND the second RoI pass on `soften_proposals` (as `calculate_soften_label`) in one
         trip through the head: -> (forward's 5-tuple, (soften_scores, soften_bboxes, roi_align_features [Ks,1024,7,7]))."""
+        K = self.predictor.num_classes
+        ev = self.loss_evaluator
         with torch.no_grad():
-            proposals = self.loss_evaluator.subsample(proposals, targets)
-        x, raf_det, raf_soft = self.feature_extractor.forward_joint(features, proposals, soften_proposals)
+            if hasattr(proposals, "raw") and getattr(ev, "inject_sampled_inds", None) is None:
+                rois = ev.subsample_fused(proposals, targets, K)["rois"]    # (as `forward`: everything between NMS and ROIAlign stays on the device)
+                proposals = ev._proposals
+            else:
+                proposals = ev.subsample(proposals, targets)
+                rois = proposals
+        x, raf_det, raf_soft = self.feature_extractor.forward_joint(features, rois, soften_proposals)
         fused = self.predictor.forward_fused(x)
         K, R4 = self.predictor.num_classes, 4 * self.predictor.num_bbox_reg_classes
         kd = sum(len(p) for p in proposals)

@@ -273,7 +273,7 @@ typedef struct abr_prep_item {
 } abr_prep_item;
 int abr_conv_prepare_batch(const abr_prep_item* items_host, int n, void* stream);
 /* The library keeps this derived data per (weight address, kind, w_version) -- 36/9 of each wide 3x3 weight, 1.5x of every other bf16x6 weight.  The cache is bounded
- * (least-recently-used entries go when it exceeds ABR_WINO_CACHE_MB, default 8192); abr_conv_cache_clear drops every entry after waiting
+ * (least-recently-used entries go when it exceeds ABR_WINO_CACHE_MB, default 4096); abr_conv_cache_clear drops every entry after waiting
  * for the streams that use them (call it when a model's parameter storage is released or rebuilt), abr_conv_cache_bytes reports its size. */
 int abr_conv_cache_clear(void);
 int64_t abr_conv_cache_bytes(void);

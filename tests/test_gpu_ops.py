@@ -495,16 +495,18 @@ def test_bottleneck_tail_fused(B, H, W):
     float64 (resnet.py:327-346)."""
     from abr_iod_amd import ops
     torch.manual_seed(B * 1000 + H)
+    ops.conv_cache_clear()      # the library caches packed planes per (weight ADDRESS, w_version): fresh tensors may reuse an address
+    ver = 100000 + B * 1000 + H   # ... and every tensor of this test gets a version of its own
     o1 = torch.relu(torch.randn(B, H, W, 64, device="cuda"))
     w2 = torch.randn(64, 3, 3, 64, device="cuda") * 0.06
     w3 = torch.randn(256, 1, 1, 64, device="cuda") * 0.15
     s2, b2 = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.2
     s3, b3 = torch.rand(256, device="cuda") + 0.5, torch.randn(256, device="cuda") * 0.2
     idt = torch.randn(B, H, W, 256, device="cuda")
-    o2 = ops.conv_forward(o1, w2, 1, 1, scale=s2, bias=b2, relu=True, math=ops.MATH_BF16X6, w_version=7)
-    want = ops.conv_forward(o2, w3, 1, 0, scale=s3, bias=b3, residual=idt, relu=True, math=ops.MATH_BF16X6, w_version=7)
+    o2 = ops.conv_forward(o1, w2, 1, 1, scale=s2, bias=b2, relu=True, math=ops.MATH_BF16X6, w_version=ver)
+    want = ops.conv_forward(o2, w3, 1, 0, scale=s3, bias=b3, residual=idt, relu=True, math=ops.MATH_BF16X6, w_version=ver)
     assert ops.bottleneck_tail64_applies(o1, w2, w3, ops.MATH_BF16X6)
-    got = ops.bottleneck_tail64(o1, w2, w3, s2, b2, s3, b3, idt, 7, 7)
+    got = ops.bottleneck_tail64(o1, w2, w3, s2, b2, s3, b3, idt, ver, ver)
     assert torch.equal(got, want)
     assert ops.x6_range_flags(reset=False) == 0
     if H <= 40:
