@@ -25,10 +25,10 @@ import os
 
 from ..utils.comm import get_world_size
 
-# Distillation RoIs through layer4 together with the detection RoIs (GeneralizedRCNN.forward_joint).  Off by default: at the
-# benchmark geometry (4 x 512 RoIs = 1024 tiles of 128x128 = exactly 4 per CU) the extra 256 RoIs break the tile quantisation
-# (1152 tiles -> 5 rounds) and the step gets 0.5 ms SLOWER than two separate passes whose small GEMMs overlap with the side-stream
-# weight gradients anyway; it pays when RoI counts are not already multiples of the CU count.
+# (ABR_JOINT_ROI, below) Distillation RoIs through layer4 together with the detection RoIs (GeneralizedRCNN.forward_joint / forward_finish(...,
+# soften_proposals=)).  Round 1 (fp32 kernels, 2 workgroups per CU) measured it 0.5 ms slower; with the bf16x6 weights-direct kernels (3 workgroups
+# per CU: 288 m-tiles x 16 n-tiles = exactly 6 rounds) the second pass's M = 4096-row launches at ~half the big pass's rate cost more than they
+# fill: ON by default since round 4 (-0.25 ms at B = 4, -0.15 ms at B = 2, same-session A/Bs in MEASUREMENTS.md).
 SOURCE_OVERLAP = os.environ.get("ABR_SOURCE_OVERLAP", "1") != "0"
 # the frozen source model's backbone + RPN head on a stream of their own, NEXT to the target's forward (its many small layer1-3 kernels
 # leave CUs idle that the other model's kernels fill, as the dgrad / wgrad pair does in the backward pass)
@@ -48,7 +48,7 @@ EARLY_PREFETCH = os.environ.get("ABR_EARLY_PREFETCH", "1") != "0"
 # (the reference's setup: both are loaded from the same checkpoint and FREEZE_CONV_BODY_AT = 2 never lets them move), that prefix is the same
 # function of the same batch in both models -- compute it once per batch and feed both.  Verified by comparing the tensors, never assumed.
 SHARE_FROZEN_PREFIX = [os.environ.get("ABR_SHARE_FROZEN_PREFIX", "0") != "0"]
-JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "0") != "0"
+JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "1") != "0"
 
 
 class TrainerState(object):
@@ -414,7 +414,10 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
 
     enqueue_prefetch()
     optimizer.zero_grad()                                                                                  # :142
-    _arm_overlap(optimizer, [det_pooled, roi_align_features_target if need_source else None], feature_target)
+    # tensors whose gradients together say "every kernel of layer4's + the predictor's backward is queued": the pooled inputs of the RoI passes
+    # (the joint pass has ONE pooled input for both RoI sets; its distillation-RoI output gets ARD's gradient much earlier and must not count)
+    head_inputs = [det_pooled] if getattr(det_pooled, "_abr_joint_pool", False) else [det_pooled, roi_align_features_target if need_source else None]
+    _arm_overlap(optimizer, head_inputs, feature_target)
     losses.backward()                                                                                      # :144-145 (amp O0 = identity)
     optimizer.step()                                                                                       # :146 (+ RCCL all-reduce)
     scheduler.step()                                                                                       # :147

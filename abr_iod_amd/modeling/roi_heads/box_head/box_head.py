@@ -52,6 +52,41 @@ def convert_to_roi_format(boxes):
     return torch.cat([ids, concat], dim=1)
 
 
+class _JointPoolFn(Function):
+    """ROIAlign of the detection RoIs (even bins: all layer4's stride-2 1x1 convs read) and of the distillation RoIs (all 7x7 bins: ARD reads
+    them) with the rows layer4 sees written side by side into ONE [Kd + Ks, 4, 4, C] tensor -- no concatenation copy of the detection part.
+    -> (joint logical [Kd+Ks,C,4,4], soft logical [Ks,C,7,7])."""
+
+    @staticmethod
+    def forward(ctx, feat, det_rois, soft_rois, output_size, spatial_scale, sampling_ratio):
+        ph, pw = output_size if isinstance(output_size, (tuple, list)) else (output_size, output_size)
+        fh = as_nhwc(feat)
+        Kd, Ks, C_ = det_rois.shape[0], soft_rois.shape[0], fh.shape[-1]
+        pho, pwo = -(-ph // 2), -(-pw // 2)
+        joint = torch.empty((Kd + Ks, pho, pwo, C_), dtype=fh.dtype, device=fh.device)
+        ops.roi_align_forward(fh, det_rois, spatial_scale, ph, pw, sampling_ratio, 2, out=joint[:Kd])
+        soft = ops.roi_align_forward(fh, soft_rois, spatial_scale, ph, pw, sampling_ratio, 1)
+        joint[Kd:].copy_(soft[:, ::2, ::2, :])
+        ctx.save_for_backward(det_rois, soft_rois)
+        ctx.geom = (ph, pw, spatial_scale, sampling_ratio, tuple(fh.shape), Kd)
+        return from_nhwc(joint), from_nhwc(soft)
+
+    @staticmethod
+    def backward(ctx, g_joint, g_soft):
+        det_rois, soft_rois = ctx.saved_tensors
+        ph, pw, scale, sr, (B, H, W, C_), Kd = ctx.geom
+        gj = as_nhwc(g_joint).contiguous()
+        if g_soft is None:
+            gs = torch.zeros((soft_rois.shape[0], ph, pw, C_), dtype=gj.dtype, device=gj.device)
+        else:
+            gs = as_nhwc(g_soft)
+            gs = gs.clone() if gs.is_contiguous() else gs.contiguous()     # (never write into autograd's own gradient tensor)
+        gs[:, ::2, ::2, :] += gj[Kd:]            # layer4's gradient reaches the even bins of the distillation RoIs
+        g = ops.roi_align_backward(gj[:Kd], det_rois, scale, ph, pw, sr, B, H, W, C_, 2)
+        g = ops.roi_align_backward(gs, soft_rois, scale, ph, pw, sr, B, H, W, C_, 1, out=g)
+        return from_nhwc(g), None, None, None, None, None
+
+
 class Pooler(nn.Module):
     def __init__(self, output_size, scales, sampling_ratio):
         super().__init__()
@@ -90,10 +125,14 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
         them) and then sub-sampled the way layer4's stride-2 1x1 convs would.  -> (head features [Kd+Ks,2048,4,4], detection
         pooled [Kd,1024,4,4], distillation pooled [Ks,1024,7,7])"""
         assert self.resolution % 2 == 1 and list(self.head.layer4)[0].stride == 2
-        det = self.pooler(x, det_proposals, bin_step=2)
-        soft = self.pooler(x, soft_proposals, bin_step=1)
-        joint = from_nhwc(torch.cat([as_nhwc(det), as_nhwc(soft)[:, ::2, ::2, :]], 0))
-        return self.head(joint, first_stride=1), det, soft
+        det_rois = det_proposals if torch.is_tensor(det_proposals) else convert_to_roi_format(det_proposals)
+        soft_rois = soft_proposals if torch.is_tensor(soft_proposals) else convert_to_roi_format(soft_proposals)
+        al = self.pooler.poolers[0]
+        joint, soft = _JointPoolFn.apply(x[0], det_rois, soft_rois, al.output_size, al.spatial_scale, al.sampling_ratio)
+        # (second value: the tensor whose gradient marks "layer4's backward is queued" for the gradient exchange hooks, engine/trainer.py::_arm_overlap:
+        #  with the joint pass that is `joint` itself -- `soft` receives ARD's gradient long before layer4 has run its backward)
+        joint._abr_joint_pool = True
+        return self.head(joint, first_stride=1), joint, soft
 
 
 # ------------------------------------------------------------------------------------------------ predictor

@@ -19,14 +19,17 @@ def _empty(shape, like, dtype=_f32):
 
 
 # ----------------------------------------------------------------------------------------------- ROIAlign
-def roi_align_forward(feat, rois, spatial_scale, ph, pw, sampling_ratio, bin_step=1):
-    """feat [B,H,W,C], rois [K,5] -> [K, ceil(ph/step), ceil(pw/step), C]"""
+def roi_align_forward(feat, rois, spatial_scale, ph, pw, sampling_ratio, bin_step=1, out=None):
+    """feat [B,H,W,C], rois [K,5] -> [K, ceil(ph/step), ceil(pw/step), C] (written into `out`, a contiguous tensor of that shape, when given)"""
     L.require_cuda(feat, rois)
     feat, rois = L.f32c(feat), L.f32c(rois)
     B, H, W, Ch = feat.shape
     K = rois.shape[0]
     pho, pwo = -(-ph // bin_step), -(-pw // bin_step)
-    out = _empty((K, pho, pwo, Ch), feat)
+    if out is None:
+        out = _empty((K, pho, pwo, Ch), feat)
+    else:
+        assert tuple(out.shape) == (K, pho, pwo, Ch) and out.is_contiguous() and out.dtype == _f32
     L.check(L.lib().abr_roi_align_forward(L.ptr(feat), L.ptr(rois), K, B, Ch, H, W, float(spatial_scale), ph, pw,
                                           sampling_ratio, bin_step, L.NHWC, L.ptr(out), L.stream()), "roi_align_forward")
     return out
