@@ -90,6 +90,7 @@ struct ConvP {
     int wp_nblocks;        // 32-row blocks in one packed matrix
     unsigned* x6_flags;      // bf16x6: device word of the range guard (abr::x6_flags_ptr)
     int64_t w_version;       // abr_conv_desc::w_version (0 = nothing derived from w may be cached)
+    int nprod;               // 6 = bf16x6 (exact three-way split, six products); 1 = ABR_MATH_BF16 on the same kernels: plane 0 of both operands, one product
 };
 
 
@@ -826,13 +827,18 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
 // PLAIN: 1x1, stride 1, no padding (every GEMM but the strided 1x1s and the direct 3x3s; all 36 x n Winograd GEMMs): row m of A is x + m * Cin, the
 // k-tile advances through the load's scalar offset -- no per-row address / halo arithmetic in the MFMA loop (it was 36 VALU instructions per k-tile,
 // four of them quarter-rate 32-bit multiplies the compiler rematerialised the offsets with).
-template <int BM, int BN, int WM, int WN, bool PLAIN>
+// NP: products per multiply-add.  6 = the bf16x6 arithmetic; 1 = ABR_MATH_BF16 (both operands ROUNDED to bf16, one product): the SAME kernel reading
+// plane 0 of the packed weights and keeping only the first plane of the activation split -- a third of the LDS and weight-fragment traffic and a sixth
+// of the MFMAs, with the tile shapes, the weights-direct operand path and the epilogue of the default arithmetic (round 4; the round-1 bf16 kernels
+// converted fp32 operands of BOTH sides in the loop and ran the step 20 % slower than bf16x6).
+template <int BM, int BN, int WM, int WN, bool PLAIN, int NP = 6>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_x6w_kernel(const ConvP p, const float* __restrict__ x_,
                                                                                                         float* __restrict__ out_) {
     const float* x = x_;
     float* out = out_;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int NA = BM / 32;
+    constexpr int NPL = NP == 1 ? 1 : 3;   // operand planes in use
     extern __shared__ __attribute__((aligned(16))) float smem[];
     abr::prof_stamp_begin(p.prof_ts);
     __bf16* As = reinterpret_cast<__bf16*>(smem);  // [3][BM][LDX]
@@ -885,7 +891,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 ra[NA];
-    u32x4 fbr[2][TN][3];   // [step of the k-tile][n-block][plane]
+    u32x4 fbr[2][TN][NPL];   // [step of the k-tile][n-block][plane]
     auto load_a = [&](int kt) {
         const int k0 = kt * BKX;
         if constexpr (PLAIN) {
@@ -909,7 +915,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
         for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) fbr[u][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rwp, (int)bo[j], (ks * 3 + pl) * 1024, 0);
+            for (int pl = 0; pl < NPL; pl++) fbr[u][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rwp, (int)bo[j], (ks * 3 + pl) * 1024, 0);
     };
     // range guard: the A rows are inspected by the workgroups of the first n-tile column; the weights were inspected when they were packed
     const bool chk_a = p.x6_flags && tile_n == 0;
@@ -933,8 +939,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             uint2 o0, o1, o2;
             x6_split4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), o0, o1, o2);
             *reinterpret_cast<uint2*>(dst) = o0;
-            *reinterpret_cast<uint2*>(dst + BM * LDX) = o1;
-            *reinterpret_cast<uint2*>(dst + 2 * BM * LDX) = o2;
+            if constexpr (NP != 1) {
+                *reinterpret_cast<uint2*>(dst + BM * LDX) = o1;
+                *reinterpret_cast<uint2*>(dst + 2 * BM * LDX) = o2;
+            }
         }
     };
 
@@ -952,18 +960,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     auto compute_tile = [&](int kt_next) {   // kt_next < nk: the B fragments of that tile are requested as this tile's are consumed
 #pragma unroll
         for (int u = 0; u < BKX / 16; u++) {
-            bf16x8 fa[TM][3], fb[TN][3];
+            bf16x8 fa[TM][NPL], fb[TN][NPL];
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * BM * LDX + i * 32 * LDX + u * 16);
+                for (int pl = 0; pl < NPL; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * BM * LDX + i * 32 * LDX + u * 16);
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) fb[j][pl] = *reinterpret_cast<const bf16x8*>(&fbr[u][j][pl]);
-            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};   // (A plane, B plane) of the six products, smallest first
+                for (int pl = 0; pl < NPL; pl++) fb[j][pl] = *reinterpret_cast<const bf16x8*>(&fbr[u][j][pl]);
+            constexpr int pa[6] = {NP == 1 ? 0 : 2, 0, 1, 1, 0, 0}, pb[6] = {0, NP == 1 ? 0 : 2, 1, 0, 1, 0};   // (A plane, B plane) of the products, smallest first
 #pragma unroll
-            for (int t = 0; t < 6; t++)
+            for (int t = 0; t < NP; t++)
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -1294,30 +1302,34 @@ static int x6_pack(const float* w, int64_t rows, int K, void* planes, hipStream_
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_x6w(const ConvP& p, const float* x, float* out, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int NP>
+int launch_x6w_np(const ConvP& p, const float* x, float* out, hipStream_t st) {
     ConvP q = p;
     q.tiles_m = (p.M + BM - 1) / BM;
     q.tiles_n = (p.Cout + BN - 1) / BN;
     q.tiles_pb = q.tiles_m * q.tiles_n;
     if (q.nbatch < 1) q.nbatch = 1;
     q.n_full = q.tiles_pb * q.nbatch; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
-    q.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
-    constexpr size_t lds_op = sizeof(__bf16) * 3 * BM * LDX;
+    q.x6_flags = (NP != 1 && abr::x6_guard_enabled()) ? abr::x6_flags_ptr() : nullptr;   // (rounding to bf16 is defined for every finite value: no guard)
+    constexpr size_t lds_op = sizeof(__bf16) * (NP == 1 ? 1 : 3) * BM * LDX;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
     const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
     const bool plain = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
-    auto kern = plain ? conv_igemm_x6w_kernel<BM, BN, WM, WN, true> : conv_igemm_x6w_kernel<BM, BN, WM, WN, false>;
+    auto kern = plain ? conv_igemm_x6w_kernel<BM, BN, WM, WN, true, NP> : conv_igemm_x6w_kernel<BM, BN, WM, WN, false, NP>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x6w_kernel<BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x6w_kernel<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x6w_kernel<BM, BN, WM, WN, true, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x6w_kernel<BM, BN, WM, WN, false, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    constexpr int prof_id = BM == 128 ? (BN == 128 ? abr::PROF_X6W_128x128 : abr::PROF_X6W_128x64) : abr::PROF_X6W_64x64;
+    constexpr int prof_id = NP == 1 ? abr::PROF_IGEMM_BF16 : (BM == 128 ? (BN == 128 ? abr::PROF_X6W_128x128 : abr::PROF_X6W_128x64) : abr::PROF_X6W_64x64);
     q.prof_ts = abr::prof_stamp_slot(prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
     kern<<<(unsigned)(q.tiles_pb * q.nbatch), 256, lds, st>>>(q, x, out);
     return 0;
+}
+template <int BM, int BN, int WM, int WN>
+int launch_x6w(const ConvP& p, const float* x, float* out, hipStream_t st) {
+    return p.nprod == 1 ? launch_x6w_np<BM, BN, WM, WN, 1>(p, x, out, st) : launch_x6w_np<BM, BN, WM, WN, 6>(p, x, out, st);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1715,7 +1727,23 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16 || d->math == ABR_MATH_BF16X6, "conv_forward: unknown math mode");
     p.math = d->math;
     if (p.math == ABR_MATH_BF16X6 && p.Cin % BKX != 0) p.math = ABR_MATH_F32;   // the 4-channel stem: fp32 MFMA
+    p.nprod = 6;
     if (d->math == ABR_MATH_BF16 && p.Cin % BKH == 0) {   // (the 4-channel stem has no 64-wide k-tile: it stays fp32)
+        // Round 4: with a weight version the bf16 mode runs on the weights-direct kernels of the default arithmetic, single product (NP = 1): plane 0
+        // of the packed weights (the cache entry bf16x6 uses) IS bf16(w), the first plane of the activation split IS bf16(x).  3x3 convs stay
+        // direct (a Winograd transform of rounded operands is a different, less accurate function than the mode's definition).
+        static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
+        static const bool bf16_wd = !(getenv("ABR_BF16_WEIGHTS_DIRECT") && atoi(getenv("ABR_BF16_WEIGHTS_DIRECT")) == 0);
+        const void* planes = d->w_planes;
+        if (!planes && p.w_version && direct_on && bf16_wd && p.Cin % BKX == 0)
+            planes = abr::derived_cached(w, abr::DERIVED_X6_PLANES, p.wp_bytes, p.w_version, st, [&](void* buf) { return x6_pack(w, d->Cout, p.K, buf, st); });
+        if (planes && direct_on && bf16_wd) {
+            p.w_planes = planes;
+            p.nprod = 1;
+            dispatch_igemm_x6(p, x, w, out, st);
+            ABR_CHECK_LAUNCH("conv_forward (bf16, weights-direct)");
+            return ABR_OK;
+        }
         dispatch_igemm_bf16(p, x, w, out, st);
         ABR_CHECK_LAUNCH("conv_forward (bf16)");
         return ABR_OK;
@@ -1761,6 +1789,7 @@ static void convp_from_desc(const abr_conv_desc* d, ConvP& p) {
     p.x_bytes = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * 4); p.w_bytes = (unsigned)((int64_t)d->Cout * p.K * 4);
     p.d_howo.init((unsigned)(p.Ho * p.Wo)); p.d_wo.init((unsigned)p.Wo); p.d_cin.init((unsigned)p.Cin); p.d_s.init((unsigned)p.S);
     p.math = d->math;
+    p.nprod = 6;
     p.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
     p.prof_ts = nullptr;
 }
@@ -1824,7 +1853,8 @@ extern "C" int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, 
             ABR_REQUIRE(abr::wino_u_cached(w, Cout, Cin, w_version, st) != nullptr, "conv_prepare_weights: no memory for the Winograd-domain weights");
         }
         ABR_CHECK_LAUNCH("conv_prepare_weights");
-    } else if (math == ABR_MATH_BF16X6 && direct_on && Cin % BKX == 0 && x6_packed_bytes(Cout, K) < (int64_t)0xFFFFFFF0) {
+    } else if ((math == ABR_MATH_BF16X6 || (math == ABR_MATH_BF16 && Cin % BKH == 0)) && direct_on && Cin % BKX == 0 &&
+               x6_packed_bytes(Cout, K) < (int64_t)0xFFFFFFF0) {
         void* pl = abr::derived_cached(w, abr::DERIVED_X6_PLANES, (size_t)x6_packed_bytes(Cout, K), w_version, st, [&](void* buf) { return x6_pack(w, Cout, K, buf, st); });
         ABR_REQUIRE(pl != nullptr, "conv_prepare_weights: no memory for the packed weight planes");
         ABR_CHECK_LAUNCH("conv_prepare_weights");
@@ -1925,7 +1955,8 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
             u_total += (size_t)36 * Cout * Cin;
             return 0;
         }
-        if (math == ABR_MATH_BF16X6 && direct_on && Cin % BKX == 0 && x6_packed_bytes(Cout, K) < (int64_t)0xFFFFFFF0) {
+        if ((math == ABR_MATH_BF16X6 || (math == ABR_MATH_BF16 && Cin % BKH == 0)) && direct_on && Cin % BKX == 0 &&
+            x6_packed_bytes(Cout, K) < (int64_t)0xFFFFFFF0) {   // (the bf16 mode reads plane 0 of the same packed planes)
             void* tok = nullptr;
             void* planes = abr::derived_acquire(w, abr::DERIVED_X6_PLANES, (size_t)x6_packed_bytes(Cout, K), ver, st, &tok);
             if (!planes) return 1;

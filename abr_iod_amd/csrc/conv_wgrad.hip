@@ -469,6 +469,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgP p, const
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int MRX = 32;
 
+// NP = 6: the bf16x6 arithmetic.  NP = 1: ABR_MATH_BF16 (operands rounded to bf16, one product) on the same loop: one plane per operand in LDS.
+template <int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_wgrad_x6_kernel(const WgP p, const float* __restrict__ x_, const float* __restrict__ gy_,
                                                              float* __restrict__ dw_) {
     const float* x = x_;
@@ -477,8 +479,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     extern __shared__ __attribute__((aligned(16))) float smem[];
     abr::prof_stamp_begin(p.prof_ts);
     constexpr int PL = (MRX / 8) * 128 * 4;              // dwords per plane: [4 octets][4 j][32 q] chunks of 4 dwords
-    unsigned* Gs = reinterpret_cast<unsigned*>(smem);    // [3][PL]
-    unsigned* As = Gs + 3 * PL;                          // [3][PL]
+    constexpr int NPL = NP == 1 ? 1 : 3;                 // operand planes in use
+    unsigned* Gs = reinterpret_cast<unsigned*>(smem);    // [NPL][PL]
+    unsigned* As = Gs + NPL * PL;                        // [NPL][PL]
 
     const unsigned bid = abr::xcd_remap(blockIdx.x, gridDim.x);
     // workgroup -> (row slice, output tile): the output tile is the FAST index, so the workgroups one XCD runs side by side (a
@@ -577,8 +580,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
                 o2[pp] = *reinterpret_cast<const unsigned*>(&h2);
             }
             *reinterpret_cast<u32x4*>(st_base + j * 128) = o0;
-            *reinterpret_cast<u32x4*>(st_base + j * 128 + PL) = o1;
-            *reinterpret_cast<u32x4*>(st_base + j * 128 + 2 * PL) = o2;
+            if constexpr (NP != 1) {
+                *reinterpret_cast<u32x4*>(st_base + j * 128 + PL) = o1;
+                *reinterpret_cast<u32x4*>(st_base + j * 128 + 2 * PL) = o2;
+            }
         }
     };
 
@@ -597,9 +602,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     auto compute_tile = [&]() {
 #pragma unroll
         for (int s = 0; s < MRX / 16; s++) {
-            bf16x8 G[2][3], A[2][3];   // [column sub-tile][plane]
+            bf16x8 G[2][NPL], A[2][NPL];   // [column sub-tile][plane]
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++)
+            for (int pl = 0; pl < NPL; pl++)
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     G[t][pl] = *reinterpret_cast<const bf16x8*>(g_rd + pl * PL + (s * 8 + t) * 128);
@@ -607,9 +612,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
                 }
             // the six products of a step (smallest terms first for every accumulator) interleaved over the four accumulators: no MFMA
             // waits on the result of the one issued just before it (as in conv_igemm_x6w_kernel)
-            constexpr int pg[6] = {2, 0, 1, 1, 0, 0}, pa[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int pg[6] = {NP == 1 ? 0 : 2, 0, 1, 1, 0, 0}, pa[6] = {0, NP == 1 ? 0 : 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int t = 0; t < 6; t++)
+            for (int t = 0; t < NP; t++)
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -731,21 +736,24 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
                                   (int)(sizeof(float) * 2 * MR * (TN_ + TK_)));
         attr_set = true;
     }
-    if (p.math == ABR_MATH_BF16X6) {   // same split plan (MRX == MR), three-plane LDS
+    if (p.math == ABR_MATH_BF16X6 || p.math == ABR_MATH_BF16) {   // same split plan (MRX == MR), three-plane (bf16: one-plane) LDS
         static bool attr6 = false;
-        const size_t lds6 = sizeof(unsigned) * 3 * (MRX / 2) * (TN_ + TK_);
+        const bool one = p.math == ABR_MATH_BF16;   // round 4: the bf16 mode on the bf16x6 kernel's loader / LDS image, single product
+        const size_t lds6 = sizeof(unsigned) * (one ? 1 : 3) * (MRX / 2) * (TN_ + TK_);
         if (!attr6) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(sizeof(unsigned) * 3 * (MRX / 2) * (TN_ + TK_)));
             attr6 = true;
         }
         p.map4 = 1;
-        p.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
+        p.x6_flags = (!one && abr::x6_guard_enabled()) ? abr::x6_flags_ptr() : nullptr;
         // Timed with a HIP-event pair, not with in-kernel stamps: a kernel trace's duration of these kernels includes the write-back of the
         // parked partial tiles at kernel end, which first-workgroup-in / last-workgroup-out stamps miss by ~10 % (the raw event figure is
         // within 3 % of rocprofv3's here; for the forward / dgrad kernels it is the stamps that agree, within 2.5 %).
         p.prof_ts = nullptr;
         const int rec6 = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
-        conv_wgrad_x6_kernel<<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
+        if (one) conv_wgrad_x6_kernel<1><<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
+        else conv_wgrad_x6_kernel<6><<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
         abr::prof_stop(abr::as_stream(stream), rec6);
         wgrad_reduce(p, tiles, dw, abr::as_stream(stream));
         return;
@@ -813,9 +821,16 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     static const int tile_fast = !(getenv("ABR_WGRAD_TILE_FAST") && atoi(getenv("ABR_WGRAD_TILE_FAST")) == 0);
     p.tile_fast = tile_fast;
     p.math = d->math == ABR_MATH_BF16X6 ? ABR_MATH_BF16X6 : ABR_MATH_F32;   // (x6 handles any Cin % 4 == 0: no k-tile constraint here)
+    static const bool bf16_on_x6 = !(getenv("ABR_BF16_WEIGHTS_DIRECT") && atoi(getenv("ABR_BF16_WEIGHTS_DIRECT")) == 0);
     hipStream_t st = abr::as_stream(stream);
     ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16 || d->math == ABR_MATH_BF16X6, "conv_wgrad: unknown math mode");
     if (d->math == ABR_MATH_BF16 && d->Cin % 64 == 0) {   // same layer set as the bf16 forward (the stem stays fp32)
+        if (bf16_on_x6) {   // round 4: the loader-transposed LDS image and split plan of the default arithmetic, one product (direct form: no Winograd)
+            p.math = ABR_MATH_BF16;
+            launch_wgrad(p, x, gy, dw, stream);
+            ABR_CHECK_LAUNCH("conv_wgrad (bf16 on the x6 loop)");
+            return ABR_OK;
+        }
         launch_wgrad_bf16(p, x, gy, dw, stream);
         ABR_CHECK_LAUNCH("conv_wgrad (bf16)");
         return ABR_OK;

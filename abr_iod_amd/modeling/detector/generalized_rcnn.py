@@ -65,8 +65,16 @@ class GeneralizedRCNN(nn.Module):
         # guarded by a hardware range check (ops.x6_range_flags; engine/trainer.py falls back to "f32" when it trips) -- or "f32" =
         # v_mfma_f32_32x32x2_f32.  ABR_CONV_MATH overrides the default.
         self.conv_math = "f32"
-        if cfg.DTYPE == "float32" and os.environ.get("ABR_CONV_MATH", DEFAULT_CONV_MATH) == "bf16x6":
+        want_x6 = os.environ.get("ABR_CONV_MATH", DEFAULT_CONV_MATH) == "bf16x6"
+        if cfg.DTYPE == "float32" and want_x6:
             self.set_conv_math("bf16x6")
+        elif cfg.DTYPE == "bfloat16" and want_x6 and os.environ.get("ABR_BF16_SCOPE", "backbone") != "all":
+            # "bf16 MFMA backbone" (configs[4]): layer1-3 contract in bf16, EVERYTHING ELSE in the default arithmetic -- until round 4 the RPN head and
+            # layer4 of this mode were left on the fp32 MFMA kernels (round 1's default), which is what made the mode 20 % slower than bf16x6
+            from ..backbone.resnet import set_conv_math
+            set_conv_math(self.rpn, ops.MATH_BF16X6)
+            set_conv_math(self.roi_heads, ops.MATH_BF16X6)
+            self.conv_math = "bf16x6"      # (the range guard of engine/trainer.py watches the bf16x6 part)
         self.flat = None
 
     def set_conv_math(self, name):

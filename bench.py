@@ -338,7 +338,7 @@ def main():
     B = a.batch_per_gpu
     if a.math == "bf16-all":
         os.environ["ABR_BF16_SCOPE"] = "all"
-    os.environ["ABR_CONV_MATH"] = "bf16x6" if a.math == "bf16x6" else "f32"
+    os.environ["ABR_CONV_MATH"] = "f32" if a.math == "f32" else "bf16x6"   # (--math bf16: bf16 backbone, the default arithmetic everywhere else)
     dist_type, feat, alpha, beta, gamma = TASKS[a.task]
     n_old_cls, n_new_cls = {"15-5": (15, 5), "10-10": (10, 10), "10-5": (10, 5), "19-1": (19, 1)}[a.task]
     cfg_s, cfg_t = make_cfgs(a.task, dist_type=dist_type, feat=feat, alpha=alpha, beta=beta, gamma=gamma, ims_per_batch=B * world,
@@ -445,7 +445,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
             "dtype": "f32" if a.math == "f32" else "f32 (tensors, accumulation and error bound; contractions via an exact 3-term bf16 split of both "
                                                    "operands, 6 cross products on the bf16 matrix cores, range-guarded)"
-            if a.math == "bf16x6" else "bf16 MFMA operands / f32 accumulate / f32 tensors ({}); f32 elsewhere".format(
+            if a.math == "bf16x6" else "bf16 MFMA operands / f32 accumulate / f32 tensors ({}); the fp32-accurate bf16x6 contractions elsewhere".format(
                 "backbone layer1-3" if a.math == "bf16" else "backbone, RPN head, layer4"),
             "config": {"workload": "BASELINE.json {}: task {} ABR step, --feat {} --dist_type {} (alpha {}, beta {}, gamma {}), "
                                    "R50-C4, {}, 512 RoIs/img + 64 distillation RoIs/img, source+target models, gradient all-reduce + SGD step".format(
