@@ -372,6 +372,8 @@ class ResNet(nn.Module):
             x, done = prefix
         for i, name in enumerate(self.stages):
             x = done[i] if i < len(done) else run_stage(x, list(getattr(self, name)))
+            if i >= len(done) and torch.is_grad_enabled():
+                ops.mark("target " + name + " forward done")
             if self.return_features[name]:
                 outputs.append(x)
             backbone_features.append(x)

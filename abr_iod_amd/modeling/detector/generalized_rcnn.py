@@ -147,6 +147,7 @@ class GeneralizedRCNN(nn.Module):
         (train_incremental.py:89-95 as forward_joint does it); the result is then (the 8-tuple, the second call's 3-tuple)."""
         features, targets = state["features"], state["targets"]
         (proposals, proposal_losses), anchors, rpn_output = self.rpn.forward_finish(state["rpn"])
+        ops.mark("proposal selection joined (main stream resumes)")
         second = None
         if soften_proposals is not None:
             (x, result, soften_results, detector_losses, roi_align_features), (t_scores, t_bboxes, mask_logits, t_raf) = \
@@ -154,6 +155,7 @@ class GeneralizedRCNN(nn.Module):
             second = ((t_scores, t_bboxes), mask_logits, t_raf)
         else:
             x, result, soften_results, detector_losses, roi_align_features = self.roi_heads(features, proposals, targets)
+        ops.mark("RoI targets + ROIAlign + layer4 + predictor + box losses done")
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)

@@ -58,14 +58,16 @@ class _JointPoolFn(Function):
     -> (joint logical [Kd+Ks,C,4,4], soft logical [Ks,C,7,7])."""
 
     @staticmethod
-    def forward(ctx, feat, det_rois, soft_rois, output_size, spatial_scale, sampling_ratio):
+    def forward(ctx, feat, det_rois, soft_rois, output_size, spatial_scale, sampling_ratio, soft_ready=None):
+        """soft_ready: the distillation RoIs' all-bin pooling [Ks,ph,pw,C] when the caller computed it already (it depends on the features and the
+        SOURCE's proposals only: ROIBoxHead.forward_joint issues it before the main stream starts waiting for the target's own proposals)"""
         ph, pw = output_size if isinstance(output_size, (tuple, list)) else (output_size, output_size)
         fh = as_nhwc(feat)
         Kd, Ks, C_ = det_rois.shape[0], soft_rois.shape[0], fh.shape[-1]
         pho, pwo = -(-ph // 2), -(-pw // 2)
         joint = torch.empty((Kd + Ks, pho, pwo, C_), dtype=fh.dtype, device=fh.device)
         ops.roi_align_forward(fh, det_rois, spatial_scale, ph, pw, sampling_ratio, 2, out=joint[:Kd])
-        soft = ops.roi_align_forward(fh, soft_rois, spatial_scale, ph, pw, sampling_ratio, 1)
+        soft = soft_ready if soft_ready is not None else ops.roi_align_forward(fh, soft_rois, spatial_scale, ph, pw, sampling_ratio, 1)
         joint[Kd:].copy_(soft[:, ::2, ::2, :])
         ctx.save_for_backward(det_rois, soft_rois)
         ctx.geom = (ph, pw, spatial_scale, sampling_ratio, tuple(fh.shape), Kd)
@@ -84,7 +86,7 @@ class _JointPoolFn(Function):
         gs[:, ::2, ::2, :] += gj[Kd:]            # layer4's gradient reaches the even bins of the distillation RoIs
         g = ops.roi_align_backward(gj[:Kd], det_rois, scale, ph, pw, sr, B, H, W, C_, 2)
         g = ops.roi_align_backward(gs, soft_rois, scale, ph, pw, sr, B, H, W, C_, 1, out=g)
-        return from_nhwc(g), None, None, None, None, None
+        return from_nhwc(g), None, None, None, None, None, None
 
 
 class Pooler(nn.Module):
@@ -119,16 +121,28 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
         return x, roi_align_features
 
 
-    def forward_joint(self, x, det_proposals, soft_proposals):
+    def pool_soft_early(self, x, soft_proposals):
+        """the distillation RoIs' pooling, ahead of the detection RoIs' (see _JointPoolFn.forward): -> (RoI table, pooled [Ks,7,7,C] NHWC)"""
+        soft_rois = soft_proposals if torch.is_tensor(soft_proposals) else convert_to_roi_format(soft_proposals)
+        al = self.pooler.poolers[0]
+        ph, pw = al.output_size if isinstance(al.output_size, (tuple, list)) else (al.output_size, al.output_size)
+        with torch.no_grad():
+            pooled = ops.roi_align_forward(as_nhwc(x[0]), soft_rois, al.spatial_scale, ph, pw, al.sampling_ratio, 1)
+        return soft_rois, pooled
+
+    def forward_joint(self, x, det_proposals, soft_proposals, soft_early=None):
         """Detection RoIs and the source model's distillation RoIs through ONE layer4 pass (they share weights and are independent
         rows of every GEMM): the detection RoIs are pooled on the even bins only, the distillation RoIs on all 7x7 bins (ARD reads
         them) and then sub-sampled the way layer4's stride-2 1x1 convs would.  -> (head features [Kd+Ks,2048,4,4], detection
         pooled [Kd,1024,4,4], distillation pooled [Ks,1024,7,7])"""
         assert self.resolution % 2 == 1 and list(self.head.layer4)[0].stride == 2
         det_rois = det_proposals if torch.is_tensor(det_proposals) else convert_to_roi_format(det_proposals)
-        soft_rois = soft_proposals if torch.is_tensor(soft_proposals) else convert_to_roi_format(soft_proposals)
+        soft_rois, soft_ready = soft_early if soft_early is not None else (
+            soft_proposals if torch.is_tensor(soft_proposals) else convert_to_roi_format(soft_proposals), None)
         al = self.pooler.poolers[0]
-        joint, soft = _JointPoolFn.apply(x[0], det_rois, soft_rois, al.output_size, al.spatial_scale, al.sampling_ratio)
+        ops.mark("RoI targets done (ROIAlign starts)")
+        joint, soft = _JointPoolFn.apply(x[0], det_rois, soft_rois, al.output_size, al.spatial_scale, al.sampling_ratio, soft_ready)
+        ops.mark("ROIAlign done (layer4 starts)")
         # (second value: the tensor whose gradient marks "layer4's backward is queued" for the gradient exchange hooks, engine/trainer.py::_arm_overlap:
         #  with the joint pass that is `joint` itself -- `soft` receives ARD's gradient long before layer4 has run its backward)
         joint._abr_joint_pool = True
@@ -447,6 +461,9 @@ class ROIBoxHead(nn.Module):
         trip through the head: -> (forward's 5-tuple, (soften_scores, soften_bboxes, roi_align_features [Ks,1024,7,7]))."""
         K = self.predictor.num_classes
         ev = self.loss_evaluator
+        # the distillation RoIs' pooling needs the features and the SOURCE's proposals only: issued before the main stream starts waiting for the
+        # target's own proposal selection (inside subsample_fused), it runs in that wait instead of behind it
+        soft_early = self.feature_extractor.pool_soft_early(features, soften_proposals) if features[0].is_cuda else None
         with torch.no_grad():
             if hasattr(proposals, "raw") and getattr(ev, "inject_sampled_inds", None) is None:
                 rois = ev.subsample_fused(proposals, targets, K)["rois"]    # (as `forward`: everything between NMS and ROIAlign stays on the device)
@@ -454,7 +471,7 @@ class ROIBoxHead(nn.Module):
             else:
                 proposals = ev.subsample(proposals, targets)
                 rois = proposals
-        x, raf_det, raf_soft = self.feature_extractor.forward_joint(features, rois, soften_proposals)
+        x, raf_det, raf_soft = self.feature_extractor.forward_joint(features, rois, soften_proposals, soft_early=soft_early)
         fused = self.predictor.forward_fused(x)
         K, R4 = self.predictor.num_classes, 4 * self.predictor.num_bbox_reg_classes
         kd = sum(len(p) for p in proposals)

@@ -311,6 +311,27 @@ def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, ma
     return out
 
 
+# Main-stream timeline of the UN-PROFILED step (tools/step_marks.py): with ABR_STEP_MARKS=1 `mark(name)` records an event on the current stream at
+# a handful of points of the step (a kernel trace slows the host enough to change what the device waits for; events do not).  Off: a no-op.
+STEP_MARKS = os.environ.get("ABR_STEP_MARKS", "0") != "0"
+_marks = []
+
+
+def mark(name):
+    if STEP_MARKS and torch.cuda.is_available():
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        _marks.append((name, ev))
+
+
+def take_marks():
+    """[(name, ms since the first mark)] of the marks recorded since the last call (synchronises)"""
+    torch.cuda.synchronize()
+    out = [(n, _marks[0][1].elapsed_time(e)) for n, e in _marks] if _marks else []
+    del _marks[:]
+    return out
+
+
 FUSE_TAIL64 = os.environ.get("ABR_FUSE_TAIL64", "1") != "0"
 
 
