@@ -171,9 +171,10 @@ def test_train_step_losses_and_grads_vs_oracle(step_state):
     assert checked == 52, checked  # the reference's 52 trainable tensors
     print("worst relative gradient error", worst)
     # ReLU masks are discontinuous: an activation that is +1e-7 on one side and -1e-7 on the other flips a whole gradient path,
-    # so element-wise max error is bounded loosely (2e-2 of the tensor's max |g|) and the L2 error tightly (5e-3).
+    # so the bounds are 3x the worst values MEASURED over all configurations and both arithmetics (profiles/r04_fullsize_parity.log: max-rel 1.09e-3,
+    # l2-rel 2.95e-4): element-wise 3.5e-3 of the tensor's max |g|, 1e-3 in L2.
     for name, rel, rel_l2 in report:
-        assert rel <= 2e-2 and rel_l2 <= 5e-3, f"grad {name}: max-rel {rel}, l2-rel {rel_l2}"
+        assert rel <= 3.5e-3 and rel_l2 <= 1e-3, f"grad {name}: max-rel {rel}, l2-rel {rel_l2}"
 
 
 def test_sparse_pool_equals_full_pool(step_state):

@@ -133,7 +133,8 @@ def test_full_size_step_matches_reference(gold, name):
         return
     # ---- BACKWARD at the benchmark geometry, in the benchmarked arithmetic (bf16x6 is the default): the gradient of the step's total
     # w.r.t. all 52 trainable tensors against autograd on the torch-CPU oracle (oracle/model_ref.py; ROIAlign backward from oracle.c) run on
-    # the SAME reference draws.  The reference itself has no CPU backward (csrc/ROIAlign.h:44).  Bounds as in tests/test_gpu_e2e.py.
+    # the SAME reference draws.  The reference itself has no CPU backward (csrc/ROIAlign.h:44).  Bounds as in tests/test_gpu_e2e.py: 3x the worst
+    # values measured (profiles/r04_fullsize_parity.log).
     from abr_iod_amd import ops
     from abr_iod_amd.modeling.backbone.resnet import Conv2d
     from e2e_common import oracle_full_size_step
@@ -164,4 +165,4 @@ def test_full_size_step_matches_reference(gold, name):
     assert len(report) == 52, len(report)
     print(f"[{name}] full-size gradients vs oracle: worst max-rel {max(r[1] for r in report):.2e}, worst l2-rel {max(r[2] for r in report):.2e}")
     for pname, rel, rel_l2 in report:
-        assert rel <= 2e-2 and rel_l2 <= 5e-3, f"grad {pname}: max-rel {rel}, l2-rel {rel_l2}"
+        assert rel <= 3.5e-3 and rel_l2 <= 1e-3, f"grad {pname}: max-rel {rel}, l2-rel {rel_l2}"
