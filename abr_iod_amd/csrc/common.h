@@ -140,6 +140,8 @@ void prof_stop(hipStream_t st, int rec);
 // for this launch, or nullptr when the launch is not sampled.  The kernel calls prof_stamp_begin / prof_stamp_end with it.  No event pair,
 // so no dispatch bubble in front of the kernel, and the duration is the one a kernel trace reports (first wave in to last wave out).
 unsigned long long* prof_stamp_slot(int id, double work);
+// algorithmic HBM bytes of the launch just counted under `id` (what the kernel must move at least: every operand and the output once)
+void prof_add_bytes(int id, double bytes);
 // Only the first / last 512 workgroups of the (1-D) grid stamp: workgroups are dispatched in blockIdx order, so the first one in is among
 // the former and the last one out among the latter -- and a 9000-workgroup grid does not send 18000 atomics to two addresses (which
 // stretched short sampled launches by 7 %).

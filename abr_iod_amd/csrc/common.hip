@@ -27,6 +27,7 @@ static unsigned g_every = 1;
 static unsigned g_seen[32] = {0};          // per kernel id: launches since the last abr_prof_step_begin
 static unsigned g_step = 0;                // steps begun since abr_prof_begin
 static double g_all_launches[32] = {0}, g_all_work[32] = {0};   // every launch between begin and end, bracketed or not
+static double g_all_bytes[32] = {0};   // ALGORITHMIC HBM bytes of those launches (operands + output + fused residual / mask, each once)
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 bool prof_enabled() { return g_prof; }
@@ -61,6 +62,9 @@ unsigned long long* prof_stamp_slot(int id, double work) {
     g_recs.push_back(r);
     return g_ts + 2 * (size_t)r.slot;
 }
+void prof_add_bytes(int id, double bytes) {
+    if (g_prof && id >= 0 && id < 32) g_all_bytes[id] += bytes;
+}
 void prof_stop(hipStream_t st, int rec) {
     if (rec >= 0) (void)hipEventRecord(g_recs[rec].b, st);
 }
@@ -82,12 +86,17 @@ extern "C" int abr_prof_begin(void) {
     abr::g_ts_used = 0;
     abr::g_prof = true;
     abr::g_step = 0;
-    for (int i = 0; i < 32; i++) abr::g_all_launches[i] = abr::g_all_work[i] = 0.0;
+    for (int i = 0; i < 32; i++) abr::g_all_launches[i] = abr::g_all_work[i] = abr::g_all_bytes[i] = 0.0;
     return ABR_OK;
 }
 // out[id*2 + {0,1}] = {launches, total work} of EVERY launch since abr_prof_begin (sampled or not): the executed flops of a step
 extern "C" int abr_prof_totals(double* out, int n_ids) {
     for (int i = 0; i < n_ids && i < 32; i++) { out[2 * i] = abr::g_all_launches[i]; out[2 * i + 1] = abr::g_all_work[i]; }
+    return ABR_OK;
+}
+// out[id] = algorithmic HBM bytes of EVERY launch of kernel id since abr_prof_begin (see abr_prof_totals for the launch counts)
+extern "C" int abr_prof_bytes(double* out, int n_ids) {
+    for (int i = 0; i < n_ids && i < 32; i++) out[i] = abr::g_all_bytes[i];
     return ABR_OK;
 }
 extern "C" int abr_prof_set_mask(uint32_t mask, int every_nth) {

@@ -1324,6 +1324,11 @@ int launch_x6w_np(const ConvP& p, const float* x, float* out, hipStream_t st) {
     }
     constexpr int prof_id = NP == 1 ? abr::PROF_IGEMM_BF16 : (BM == 128 ? (BN == 128 ? abr::PROF_X6W_128x128 : abr::PROF_X6W_128x64) : abr::PROF_X6W_64x64);
     q.prof_ts = abr::prof_stamp_slot(prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
+    {   // algorithmic bytes: the input once (its own size, not the im2col's), the packed weights, the output, a fused residual / mask
+        const double in_b = q.nbatch > 1 ? 4.0 * (double)p.M * p.K * q.nbatch : 4.0 * (double)p.B * p.H * p.W * p.Cin;
+        const double out_b = 4.0 * (double)p.M * p.Cout * q.nbatch;
+        abr::prof_add_bytes(prof_id, in_b + (NP == 1 ? 2.0 : 6.0) * (double)p.Cout * p.K * q.nbatch + out_b * (1.0 + (p.residual ? 1.0 : 0.0) + (p.mask ? 1.0 : 0.0)));
+    }
     kern<<<(unsigned)(q.tiles_pb * q.nbatch), 256, lds, st>>>(q, x, out);
     return 0;
 }
@@ -1826,6 +1831,7 @@ extern "C" int abr_conv_tail64_forward(const abr_conv_desc* d2, const abr_conv_d
         attr_set = true;
     }
     p.prof_ts = abr::prof_stamp_slot(abr::PROF_X6W_TAIL64, 2.0 * (double)p.M * ((double)p.Cout * p.K + (double)q.Cout * q.K));
+    abr::prof_add_bytes(abr::PROF_X6W_TAIL64, 4.0 * (double)p.M * (64.0 + 256.0 * (q.residual ? 2.0 : 1.0)) + 6.0 * (64.0 * 576.0 + 256.0 * 64.0));
     conv_tail64_x6w_kernel<<<(unsigned)p.tiles_m, 256, kTail64Lds, st>>>(p, q, x, out);
     ABR_CHECK_LAUNCH("conv_tail64_forward");
     return ABR_OK;

@@ -752,6 +752,8 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
         // within 3 % of rocprofv3's here; for the forward / dgrad kernels it is the stamps that agree, within 2.5 %).
         p.prof_ts = nullptr;
         const int rec6 = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
+        // algorithmic bytes: x and gy once (x at its own size for a direct 3x3), dw written once
+        abr::prof_add_bytes(abr::PROF_WGRAD_BF16, 4.0 * nb * ((double)p.M * p.Cout + (p.plain ? (double)p.M * p.K : (double)p.B * p.H * p.W * p.Cin) + (double)p.Cout * p.K));
         if (one) conv_wgrad_x6_kernel<1><<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
         else conv_wgrad_x6_kernel<6><<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
         abr::prof_stop(abr::as_stream(stream), rec6);

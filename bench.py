@@ -88,8 +88,21 @@ def _peak_of(name):
     return PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
 
 
+class _Totals(dict):
+    """abr_prof_totals' rows + `alg_bytes` (abr_prof_bytes of the same profiled region)"""
+    alg_bytes = {}
+
+
 def _tf(fl, ms):
     return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0
+
+
+def _alg_bytes_per_launch(kernel, totals, math, alg):
+    """algorithmic HBM bytes per launch of `kernel` over every launch of the profiled region (abr_prof_bytes / abr_prof_totals), or None"""
+    name = kernel.replace("_x6_kernel", "_bf16_kernel") if (math == "bf16x6" and kernel == "conv_wgrad_x6_kernel") else kernel
+    b = alg.get(name) or alg.get(kernel)
+    n = (totals.get(kernel) or (0, 0))[0]
+    return int(b / n) if b and n else None
 
 
 def prof_rows(prof, totals, steps, math, event_overhead_ms=0.0):
@@ -127,6 +140,7 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0, serialised=None):
     flops to the wall clock.  The top row by time fills the contract's fields."""
     if not prof or not any(r[1] + r[4] > 0 for r in prof if "roi_align" not in r[0]):
         return {"bound": "mfma", "note": "no conv launch was sampled"}
+    alg = getattr(totals, "alg_bytes", {})
     rows, totals = prof_rows(prof, totals, a.steps, a.math, event_overhead_ms)
     top = rows[0]
     traffic, traffic_src = _pmc_traffic(top["kernel"])
@@ -136,6 +150,11 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0, serialised=None):
     peak_step = PEAK_FP32_MFMA_TFLOPS if a.math == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if a.math == "bf16x6" else None
     r = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": top["peak"], "unit": "TFLOP/s", "frac": top["frac"],
          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+         # the algorithmic bytes of the same kernel's launches, counted live by the library (every operand and the output once, + a fused
+         # residual / mask read): traffic / traffic_algorithmic = how much of the HBM-side traffic is re-reads
+         "traffic_algorithmic": _alg_bytes_per_launch(top["kernel"], totals, a.math, alg),
+         "traffic_over_algorithmic": (round(traffic / _alg_bytes_per_launch(top["kernel"], totals, a.math, alg), 3)
+                                      if traffic and _alg_bytes_per_launch(top["kernel"], totals, a.math, alg) else None),
          "launches": "every launch position of the step sampled equally often over the timed region (1 launch in {} per step, rotating; "
                      "exclusive and stream-overlapped launches alike)".format(1 if a.time_all_kernels else max(d for d in range(1, 11) if a.steps % d == 0)),
          "flops_counted": "executed multiply-adds x2 of each launch (a Winograd F(4x4,3x3) conv executes 1/4 of its algorithmic MACs)",
@@ -145,7 +164,9 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0, serialised=None):
                    "weight-gradient kernels, whose traced duration includes the end-of-kernel write-back of their parked partial "
                    "tiles (that gap subtracted per launch)".format(round(event_overhead_ms * 1e3, 1)),
          "kernels_by_time": rows[:2],
-         "all_conv_kernels": {x["kernel"]: {k: x[k] for k in ("launches_per_step", "avg_launch_ms", "ms_per_step", "gflop_per_launch", "achieved", "frac")}
+         "all_conv_kernels": {x["kernel"]: dict({k: x[k] for k in ("launches_per_step", "avg_launch_ms", "ms_per_step", "gflop_per_launch", "achieved", "frac")},
+                                                algorithmic_mb_per_launch=(round(_alg_bytes_per_launch(x["kernel"], totals, a.math, alg) / 1e6, 1)
+                                                                           if _alg_bytes_per_launch(x["kernel"], totals, a.math, alg) else None))
                               for x in rows},
          "whole_step": {"executed_gflop": round(exec_flops_step / 1e9, 1), "executed_tflops": round(exec_flops_step / step_s / 1e12, 2),
                         "algorithmic_gflop": round(alg_flops_step / 1e9, 1), "algorithmic_tflops": round(alg_flops_step / step_s / 1e12, 2),
@@ -248,6 +269,10 @@ def read_prof(_lib):
     tot = (ctypes.c_double * (2 * len(PROF_NAMES)))()
     _lib.check(_lib.lib().abr_prof_totals(ctypes.cast(tot, ctypes.c_void_p), len(PROF_NAMES)), "prof_totals")
     totals = {PROF_NAMES[i]: (tot[2 * i], tot[2 * i + 1]) for i in range(len(PROF_NAMES))}   # (launches, flops) of ALL launches
+    by = (ctypes.c_double * len(PROF_NAMES))()
+    _lib.check(_lib.lib().abr_prof_bytes(ctypes.cast(by, ctypes.c_void_p), len(PROF_NAMES)), "prof_bytes")
+    totals = _Totals(totals)
+    totals.alg_bytes = {PROF_NAMES[i]: by[i] for i in range(len(PROF_NAMES))}   # algorithmic HBM bytes of ALL launches per kernel id (same region)
     ov = ctypes.c_double(0.0)
     _lib.check(_lib.lib().abr_prof_event_overhead_ms(ctypes.cast(ctypes.byref(ov), ctypes.c_void_p), _lib.stream()), "prof_event_overhead_ms")
     return prof, totals, float(ov.value)
