@@ -138,11 +138,21 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t* __restri
         uint64_t acc[SW];
 #pragma unroll
         for (int w = 0; w < SW; w++) acc[w] = 0ull;
-        for (int k = t; k < cnt; k += nt) {
-            const uint64_t* row = m + (size_t)kept[k] * words + sb * SW;
+        // FOUR kept rows per trip, all their words requested before any is used: with one row per trip every trip waited out an L2 round trip
+        // (the sweep of a late chunk, ~1500 boxes kept, spent most of its 137 us here: 8 dependent round trips per block and thread)
+        for (int k = t; k < cnt; k += 4 * nt) {
+            uint64_t v[4][SW];
 #pragma unroll
-            for (int w = 0; w < SW; w++)
-                if (sb * SW + w < nw) acc[w] |= row[w];
+            for (int u = 0; u < 4; u++) {
+                const int kk = k + u * nt;
+                const uint64_t* row = m + (size_t)kept[kk < cnt ? kk : k] * words + sb * SW;
+#pragma unroll
+                for (int w = 0; w < SW; w++) v[u][w] = (kk < cnt && sb * SW + w < nw) ? row[w] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int w = 0; w < SW; w++) acc[w] |= v[u][w];
         }
 #pragma unroll
         for (int w = 0; w < SW; w++) {
@@ -152,10 +162,24 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t* __restri
     };
     // the diagonal words of block `sb` (rows of block sb) and the words of block sb for the rows of block sb-1 -> LDS, by threads [t, t + nt)
     auto stage = [&](int sb, int t, int nt, int buf, bool with_nxt) {
-        for (int e = t; e < SW * SW * 64; e += nt) {
+        // every word of a thread's (up to six) entries is requested before the first is parked: one L2 round trip per block instead of six
+        constexpr int NE = (SW * SW * 64 + 191) / 192;
+        uint64_t vd[NE], vn[NE];
+#pragma unroll
+        for (int j = 0; j < NE; j++) {
+            const int e = t + j * nt;
             const int l = e & 63, w = (e >> 6) % SW, q = e / (64 * SW);
-            s_diag[buf * SW * SW * 64 + e] = w >= q ? ld(sb * 64 * SW + 64 * q + l, sb, w) : 0ull;
-            if (with_nxt) s_nxt[buf * SW * SW * 64 + e] = ld((sb - 1) * 64 * SW + 64 * q + l, sb, w);
+            const bool in = e < SW * SW * 64;
+            vd[j] = (in && w >= q) ? ld(sb * 64 * SW + 64 * q + l, sb, w) : 0ull;
+            vn[j] = (in && with_nxt) ? ld((sb - 1) * 64 * SW + 64 * q + l, sb, w) : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < NE; j++) {
+            const int e = t + j * nt;
+            if (e < SW * SW * 64) {
+                s_diag[buf * SW * SW * 64 + e] = vd[j];
+                if (with_nxt) s_nxt[buf * SW * SW * 64 + e] = vn[j];
+            }
         }
     };
     // ---- prologue: removed(sb0) from the boxes kept in the earlier chunks, and block sb0's diagonal words
