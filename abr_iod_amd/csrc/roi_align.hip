@@ -467,7 +467,10 @@ __global__ __launch_bounds__(256) void roi_tile_lists_kernel(const RoiRect* __re
     if (threadIdx.x == 0) counts[lid] = base;
 }
 
-template <int PO>  // PO = compile-time bound on PHo and PWo (4 for bin_step=2 on 7x7, 8 otherwise)
+// NS > 1 (round 4): the workgroup is NS waves on the SAME 256 channels, wave s walking list entries s, s + NS, ... -- a tile's list (~100 RoIs at
+// 512 RoIs per image) is a chain of dependent L2 round trips per entry (weights, then gradient rows), and the kernel's time was the longest chain;
+// the partial sums meet in LDS and are added in wave order (fixed order: still deterministic).  blockDim.x = 64 NS.
+template <int PO, int NS = 1>  // PO = compile-time bound on PHo and PWo (4 for bin_step=2 on 7x7, 8 otherwise)
 __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* __restrict__ grad, int K, int C, int H, int W, int Wp,
                                                                     int PHo, int PWo, const float* __restrict__ Wy,
                                                                     const float* __restrict__ Wx, const RoiRect* __restrict__ rect,
@@ -478,7 +481,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
     const int xt = blockIdx.x / cchunks, chunk = blockIdx.x % cchunks;
     const int y = blockIdx.y, b = blockIdx.z;
     const int x0 = xt * kXT;
-    const int cv = chunk * (int)blockDim.x + threadIdx.x;
+    const int ws = NS > 1 ? (int)(threadIdx.x >> 6) : 0;                       // which share of the list this wave walks
+    const int cv = NS > 1 ? chunk * 64 + (int)(threadIdx.x & 63) : chunk * (int)blockDim.x + (int)threadIdx.x;
     const bool c_ok = cv < C / 4;
     float4 acc[kXT];
 #pragma unroll
@@ -493,10 +497,10 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
     // full wait, ~8 dependent L2 round trips per entry), and the NEXT entry's RoI index is fetched while this one is being accumulated.
     if constexpr (PO <= 4) {
     constexpr int PC = PO, JB = PO;   // (PO == 4 here: 64 registers of gradient vectors, 32 scalar column weights)
-    int r_next = n_row > 0 ? row_list[0] : 0;
-    for (int e = 0; e < n_row; e++) {
+    int r_next = n_row > ws ? row_list[ws] : 0;
+    for (int e = ws; e < n_row; e += NS) {
         const int r = __builtin_amdgcn_readfirstlane(r_next);   // every entry is a RoI of this image that touches this row and these pixels
-        if (e + 1 < n_row) r_next = row_list[e + 1];
+        if (e + NS < n_row) r_next = row_list[e + NS];
         const float* wyr = Wy + (size_t)r * PHo * H + y;
         const float* g = grad + (size_t)r * PHo * PWo * C + cv * 4;
         const float* wxr = Wx + (size_t)r * PWo * Wp + x0;
@@ -556,10 +560,10 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
     // 8 bins per axis (all-bin pooling of the 64-RoI distillation passes): the batched form above would need 8 x 8 gradient vectors and 64
     // uniform weights live at once and spills (1.08 vs 0.80 ms on 2048 RoIs); here ONE bin row's vectors are requested together (column
     // indices past PWo clamped: their weight is zero), then the next row's, and the column weights come two bin columns at a time
-    int r_next = n_row > 0 ? row_list[0] : 0;
-    for (int e = 0; e < n_row; e++) {
+    int r_next = n_row > ws ? row_list[ws] : 0;
+    for (int e = ws; e < n_row; e += NS) {
         const int r = __builtin_amdgcn_readfirstlane(r_next);
-        if (e + 1 < n_row) r_next = row_list[e + 1];
+        if (e + NS < n_row) r_next = row_list[e + NS];
         const float* wyr = Wy + (size_t)r * PHo * H + y;
         const float* g = grad + (size_t)r * PHo * PWo * C + cv * 4;
         const float* wxr = Wx + (size_t)r * PWo * Wp + x0;
@@ -605,6 +609,23 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
                 }
         }
     }
+    }
+    if constexpr (NS > 1) {   // partial sums of waves 1 .. NS-1 -> LDS; wave 0 adds them in wave order
+        __shared__ float4 part[NS - 1][kXT][64];
+        const int lane = threadIdx.x & 63;
+        if (ws > 0) {
+#pragma unroll
+            for (int i = 0; i < kXT; i++) part[ws - 1][i][lane] = acc[i];
+        }
+        __syncthreads();
+        if (ws > 0) return;
+#pragma unroll
+        for (int s2 = 0; s2 < NS - 1; s2++)
+#pragma unroll
+            for (int i = 0; i < kXT; i++) {
+                const float4 v = part[s2][i][lane];
+                acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+            }
     }
     if (!c_ok) return;
 #pragma unroll
@@ -824,14 +845,25 @@ extern "C" int abr_roi_align_backward_gather(const float* grad, const float* roi
     // one wave per workgroup (64 lanes x 16 B = 256 channels): four times the workgroups of a 256-thread block, so that the dependent
     // chain of each (list entry -> weights -> gradient rows) has more neighbours to hide behind (ABR_ROIALIGN_BWD_TB=256: round 2's blocks)
     static const int tb = getenv("ABR_ROIALIGN_BWD_TB") ? atoi(getenv("ABR_ROIALIGN_BWD_TB")) : 64;
-    const int TB = (tb == 64 || tb == 128 || tb == 256) ? tb : 64;
-    const int cchunks = (C / 4 + TB - 1) / TB;
-    dim3 grid((unsigned)(n_xt * cchunks), (unsigned)H, (unsigned)B);
+    // ABR_ROIALIGN_BWD_SPLIT (default 4; 1 = round 3's one wave per list): waves per workgroup sharing a tile's RoI list (see the kernel)
+    static const int ns = getenv("ABR_ROIALIGN_BWD_SPLIT") ? atoi(getenv("ABR_ROIALIGN_BWD_SPLIT")) : 4;
     const int rec = abr::prof_start(st, abr::PROF_ROIALIGN_BWD, 0.0);
-    if (PHo <= 4 && PWo <= 4)
-        roi_align_bwd_gather_kernel<4><<<grid, TB, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
-    else
-        roi_align_bwd_gather_kernel<8><<<grid, TB, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
+    if (ns == 4) {
+        const int cchunks = (C / 4 + 63) / 64;
+        dim3 grid((unsigned)(n_xt * cchunks), (unsigned)H, (unsigned)B);
+        if (PHo <= 4 && PWo <= 4)
+            roi_align_bwd_gather_kernel<4, 4><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
+        else
+            roi_align_bwd_gather_kernel<8, 4><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
+    } else {
+        const int TB = (tb == 64 || tb == 128 || tb == 256) ? tb : 64;
+        const int cchunks = (C / 4 + TB - 1) / TB;
+        dim3 grid((unsigned)(n_xt * cchunks), (unsigned)H, (unsigned)B);
+        if (PHo <= 4 && PWo <= 4)
+            roi_align_bwd_gather_kernel<4><<<grid, TB, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
+        else
+            roi_align_bwd_gather_kernel<8><<<grid, TB, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
+    }
     abr::prof_stop(st, rec);
     ABR_CHECK_LAUNCH("roi_align_backward_gather");
     return ABR_OK;

@@ -176,3 +176,14 @@ def test_bucketed_overlapped_allreduce_equals_one_allreduce():
         for r in results:
             assert torch.equal(torch.from_numpy(r), want)
 
+
+
+def test_modelled_ring_time_of_the_gradient_buckets():
+    """solver/grad_reducer.py::modelled_ring_allreduce_ms (printed per bucket in bench.py's N > 1 line as a PLANNING figure): zero for one rank, 2 (w - 1) / w
+    of the bytes over min(7, w - 1) links of 153 GB/s plus 8 us per ring step otherwise; monotone in bytes; the 33 MB backbone bucket at w = 8 is ~0.17 ms."""
+    from abr_iod_amd.solver.grad_reducer import modelled_ring_allreduce_ms as f
+    assert f(33_000_000, 1) == 0.0
+    t8 = f(33_000_000, 8)
+    want = 2 * 7 / 8 * 33e6 / (153e9 * 7) * 1e3 + 2 * 7 * 8e-3
+    assert abs(t8 - want) < 1e-9 and 0.1 < t8 < 0.3
+    assert f(66_000_000, 8) > t8 > f(33_000_000, 2) * 0 and f(33_000_000, 2) > f(1_000_000, 2)
