@@ -1001,6 +1001,179 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// conv_igemm_x6wk_kernel: the weights-direct bf16x6 GEMM for SMALL grids with LONG K (layer3's conv1 and the dgrad of its conv3: 9576 x 256 x
+// 1024 = 600 tiles of 64 x 64 on 256 CUs, 32 k-tiles each).  Such a launch is a handful of workgroups per CU walking a long chain of k-tiles,
+// every link of it a global load -> split -> LDS -> barrier -> MFMA round trip of ~1.4 us against 0.2 us of MFMA work (52 us per conv, a
+// quarter of the MFMA-bound time).  Here the FOUR WAVES of a workgroup split K instead of the tile: wave w owns k-tiles w, w + 4, ... of the whole
+// 64 x 64 tile (2 x 2 accumulators), with its own operand planes in LDS (15 KB) -- so the main loop has NO workgroup barrier at all (a wave
+// reading what it wrote needs only its own lgkmcnt), the chain is a quarter as long, and four independent chains share each SIMD set.  The four
+// partial tiles meet in LDS once, wave w adds the partials of block w in wave order (fixed order: deterministic) and runs the usual epilogue.
+// PLAIN addressing only (1x1, stride 1, no padding).  Summation order differs from the k-sequential kernels by the 4-way interleave.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr size_t kX6wkLds = 4 * 16384;
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_igemm_x6wk_kernel(const ConvP p, const float* __restrict__ x,
+                                                                                                       float* __restrict__ out) {
+    constexpr int BM = 64, NA = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    abr::prof_stamp_begin(p.prof_ts);
+    const int tile = (int)abr::xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* region = reinterpret_cast<char*>(smem) + wave * 16384;          // this wave's 16 KB: operand planes [3][64][LDX], later partials / staging
+    __bf16* As = reinterpret_cast<__bf16*>(region);
+    const int kq = lane & 7, t8 = lane >> 3;
+    const int srow = (t8 & ~5) | ((t8 & 1) << 2) | ((t8 >> 2) & 1);       // conflict-free ds_write_b64 rows (see the x6w kernel)
+    constexpr unsigned kOOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_planes), 0, p.wp_bytes, 0x00020000);
+    unsigned a_voff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int m = m0 + srow + 8 * i;
+        a_voff[i] = m < p.M ? (unsigned)(m * p.Cin + kq * 4) * 4u : kOOB;
+    }
+    const int KS = p.K / 16;
+    unsigned bo[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int nb = n0 / 32 + j;
+        bo[j] = nb < p.wp_nblocks ? (unsigned)(((size_t)nb * KS * 3 * 64 + lane) * 16) : kOOB;
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[NA];
+    u32x4 fbr[2][2][3];
+    auto load_a = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)a_voff[i], kt * BKX * 4, 0);
+    };
+    auto load_b = [&](int kt, int u) {
+        const int ks = kt * 2 + u;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) fbr[u][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rwp, (int)bo[j], (ks * 3 + pl) * 1024, 0);
+    };
+    const bool chk_a = p.x6_flags && tile_n == 0;
+    unsigned bmin = 0xFFFFFFFFu;
+    float nonfin = 0.f;
+    auto store_a = [&]() {
+        if (chk_a) {
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+                const u32x4 v = ra[i];
+                const unsigned b0 = (v.x << 1) - 1u, b1 = (v.y << 1) - 1u, b2 = (v.z << 1) - 1u, b3 = (v.w << 1) - 1u;
+                bmin = min(min(bmin, min(b0, b1)), min(b2, b3));
+                nonfin = fmaf(__uint_as_float(v.x), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.y), 0.f, nonfin);
+                nonfin = fmaf(__uint_as_float(v.z), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.w), 0.f, nonfin);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const u32x4 v = ra[i];
+            __bf16* dst = As + (srow + 8 * i) * LDX + kq * 4;
+            uint2 o0, o1, o2;
+            x6_split4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), o0, o1, o2);
+            *reinterpret_cast<uint2*>(dst) = o0;
+            *reinterpret_cast<uint2*>(dst + BM * LDX) = o1;
+            *reinterpret_cast<uint2*>(dst + 2 * BM * LDX) = o2;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const __bf16* a_frag = As + l31 * LDX + lh * 8;
+    const int nk = p.K / BKX;
+    constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+    auto compute_tile = [&](int kt_next) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * BM * LDX + i * 32 * LDX + u * 16);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) fb[j][pl] = *reinterpret_cast<const bf16x8*>(&fbr[u][j][pl]);
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa[t]], fb[j][pb[t]], acc[i][j], 0, 0, 0);
+            if (kt_next < nk) load_b(kt_next, u);
+            if (u == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // this wave's k-tiles: wave, wave + 4, ...  (LDS traffic of one wave is ordered: the fragment reads behind the stores need no barrier, only the
+    // wave's own lgkmcnt, which the compiler tracks; the stores of tile t + 4 behind the reads of tile t likewise)
+    int kt = wave;
+    if (kt < nk) {
+        load_b(kt, 0);
+        load_b(kt, 1);
+        load_a(kt);
+        store_a();
+        for (; kt + 4 < nk; kt += 4) {
+            load_a(kt + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(kt + 4);
+            store_a();
+        }
+        compute_tile(nk);
+    }
+    if (chk_a) abr::x6_report(bmin, nonfin, p.x6_flags);
+    // ---- the four partial tiles meet: every wave parks its accumulators in its own region (lane-linear: conflict-free), wave w adds block w's
+    float* part = reinterpret_cast<float*>(region);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) part[((i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    __syncthreads();
+    f32x16 sum[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float v = smem[(0 * 4096) + (wave * 16 + r) * 64 + lane];
+        v += smem[(1 * 4096) + (wave * 16 + r) * 64 + lane];
+        v += smem[(2 * 4096) + (wave * 16 + r) * 64 + lane];
+        v += smem[(3 * 4096) + (wave * 16 + r) * 64 + lane];
+        sum[0][0][r] = v;
+    }
+    __syncthreads();   // every partial has been read: the regions become the epilogue's staging
+    epilogue_rows<1, 1>(p, sum, reinterpret_cast<float*>(region), m0 + (wave >> 1) * 32, n0 + (wave & 1) * 32, lane, out);
+    abr::prof_stamp_end(p.prof_ts);
+}
+
+static int launch_x6wk(const ConvP& p, const float* x, float* out, hipStream_t st) {
+    ConvP q = p;
+    q.tiles_m = (p.M + 63) / 64;
+    q.tiles_n = (p.Cout + 63) / 64;
+    q.tiles_pb = q.tiles_m * q.tiles_n;
+    q.nbatch = 1;
+    q.n_full = q.tiles_pb; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
+    q.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x6wk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX6wkLds);
+        attr_set = true;
+    }
+    q.prof_ts = abr::prof_stamp_slot(abr::PROF_X6W_64x64, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
+    abr::prof_add_bytes(abr::PROF_X6W_64x64, 4.0 * (double)p.M * p.K + 6.0 * (double)p.Cout * p.K +
+                                                 4.0 * (double)p.M * p.Cout * (1.0 + (p.residual ? 1.0 : 0.0) + (p.mask ? 1.0 : 0.0)));
+    conv_igemm_x6wk_kernel<<<(unsigned)q.tiles_pb, 256, kX6wkLds, st>>>(q, x, out);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Fused TAIL of a 64-wide bottleneck that has no backward pass (the frozen stem's layer1, run by BOTH models every step):
 //     o2  = relu(bn2(conv3x3(o1)))          150000 x 64 x 576   -- conv_igemm_x6w_kernel<128,64,2,2,false>'s main loop, unchanged
 //     out = relu(bn3(conv1x1(o2)) + idt)    150000 x 256 x 64   -- the same products in the same order as the stand-alone launch
@@ -1624,6 +1797,20 @@ static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, fl
     else if (p.Cout > 64 && t128 * 10 >= (int64_t)t128_min10 * cus) tile = 1;
     else if (t12864 * 10 >= (int64_t)t12864_min10 * cus || p.Cout <= 64) tile = 2;
     else tile = 3;
+    // small grid + long K + plain addressing: the intra-workgroup split-K form (conv_igemm_x6wk_kernel).  OPT-IN (ABR_X6_SPLITK=1, read per call):
+    // stand-alone it wins on grids of up to two tiles per CU, inside the training step it changes nothing (B = 2: 13.04 vs 13.04 ms, B = 4: 22.55 vs
+    // 22.50 ms) and its summation order differs from every other bf16x6 kernel's in the last bits -- not worth a default.
+    const char* sk_env = getenv("ABR_X6_SPLITK");
+    const bool splitk_on = sk_env && atoi(sk_env) != 0;
+    static const int splitk_mink = getenv("ABR_X6_SPLITK_MINK") ? atoi(getenv("ABR_X6_SPLITK_MINK")) : 512;
+    if (wd && splitk_on && p.nprod == 6 && nb == 1 && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && !p.scatter && p.K >= splitk_mink &&
+        p.K % BKX == 0 && (int64_t)((p.M + 63) / 64) * ((p.Cout + 63) / 64) <= 2L * cus) {
+        // (measured, tools/dbg/splitk_time.py: 4788x256x1024 36.9 -> 31.7 us, 2048x512x2048 47.4 -> 36.8, 4096x512x2048 60.9 -> 56.4, 9576x76x1024
+        //  31.8 -> 28.3; from ~2.3 tiles per CU on -- 9576x256x1024: 45.0 -> 47.3 -- the k-sequential kernels win: those launches are bound by
+        //  VALU + MFMA issue per SIMD (a 64-wide tile splits every A element once per 64 columns), not by the length of the chain)
+        launch_x6wk(p, x, out, st);
+        return;
+    }
     if (wd) {
         // Wave layouts chosen so that every weight fragment (global -> registers) is fetched by as few waves as possible: the 128x128 tile as four
         // waves of 128 x 32 (2x2 waves of 64 x 64 fetched each fragment twice; the A fragments, LDS reads, double instead: +1.3 % alone, -0.19 ms
