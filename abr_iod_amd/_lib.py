@@ -52,6 +52,7 @@ _SIGS = {
     "abr_prof_end": (_i, [_vp, _i]),
     "abr_prof_totals": (_i, [_vp, _i]),
     "abr_prof_bytes": (_i, [_vp, _i]),
+    "abr_prof_clocks": (_i, [_vp, _i]),
     "abr_prof_event_overhead_ms": (_i, [_vp, _vp]),
     "abr_prof_step_begin": (_i, []),
     "abr_conv_prepare_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp]),

@@ -137,18 +137,30 @@ bool prof_enabled();
 int prof_start(hipStream_t st, int id, double work);  // returns record index (or -1)
 void prof_stop(hipStream_t st, int rec);
 // Per-launch timing WITHOUT events for kernels that stamp themselves: returns a device {first start, last end} slot (wall_clock64 ticks)
-// for this launch, or nullptr when the launch is not sampled.  The kernel calls prof_stamp_begin / prof_stamp_end with it.  No event pair,
+// (+ two words for workgroup 0's clocks) for this launch, or nullptr when the launch is not sampled.  The kernel calls prof_stamp_begin / prof_stamp_end with it.  No event pair,
 // so no dispatch bubble in front of the kernel, and the duration is the one a kernel trace reports (first wave in to last wave out).
 unsigned long long* prof_stamp_slot(int id, double work);
+// a slot for an EVENT-timed launch (record index of prof_start): only workgroup 0's clock words are read back
+unsigned long long* prof_clock_slot(int rec);
 // algorithmic HBM bytes of the launch just counted under `id` (what the kernel must move at least: every operand and the output once)
 void prof_add_bytes(int id, double bytes);
 // Only the first / last 512 workgroups of the (1-D) grid stamp: workgroups are dispatched in blockIdx order, so the first one in is among
 // the former and the last one out among the latter -- and a 9000-workgroup grid does not send 18000 atomics to two addresses (which
 // stretched short sampled launches by 7 %).
+// Slot words 2 / 3: workgroup 0's own run in SHADER cycles (s_memtime) and in wall ticks (s_memrealtime, 100 MHz): their ratio is the clock the
+// chip sustained under this kernel (DVFS: MI355X_MICROARCH.md "DVFS give-back").  Held in the slot between begin and end: no registers.
 __device__ __forceinline__ void prof_stamp_begin(unsigned long long* ts) {
     if (ts && threadIdx.x == 0 && blockIdx.x < 512u) atomicMin(ts, (unsigned long long)wall_clock64());
+    if (ts && threadIdx.x == 0 && blockIdx.x == 0u) {
+        ts[2] = (unsigned long long)clock64();
+        ts[3] = (unsigned long long)wall_clock64();
+    }
 }
 __device__ __forceinline__ void prof_stamp_end(unsigned long long* ts) {
+    if (ts && threadIdx.x == 0 && blockIdx.x == 0u) {
+        ts[2] = (unsigned long long)clock64() - ts[2];
+        ts[3] = (unsigned long long)wall_clock64() - ts[3];
+    }
     if (ts && blockIdx.x + 512u >= gridDim.x) {
         __builtin_amdgcn_s_waitcnt(0);   // this wave's stores have landed: a kernel trace's duration includes them
         if (threadIdx.x == 0) atomicMax(ts + 1, (unsigned long long)wall_clock64());

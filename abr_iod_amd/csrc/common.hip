@@ -16,9 +16,10 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-struct ProfRec { hipEvent_t a, b; double work; int id; bool overlapped; int slot; };   // slot >= 0: self-stamped launch (no events)
+struct ProfRec { hipEvent_t a, b; double work; int id; bool overlapped; int slot; int clk = -1; };   // clk >= 0: event-timed launch with a clocks-only slot   // slot >= 0: self-stamped launch (no events)
 constexpr int kMaxStampSlots = 1 << 16;
-static unsigned long long* g_ts = nullptr;   // device [kMaxStampSlots][2] = {first start, last end} in wall_clock64 ticks
+static unsigned long long* g_ts = nullptr;   // device [kMaxStampSlots][4] = {first start, last end} in wall_clock64 ticks, workgroup 0's {shader cycles, wall ticks}
+static double g_clk[32][2] = {{0}};          // per kernel id: sums of the latter two over the sampled launches (filled by abr_prof_end)
 static int g_ts_used = 0;
 static bool g_prof = false;
 static bool g_overlap = false;
@@ -60,7 +61,12 @@ unsigned long long* prof_stamp_slot(int id, double work) {
     if (g_ts_used >= kMaxStampSlots) return nullptr;
     ProfRec r{nullptr, nullptr, work, id, g_overlap, g_ts_used++};
     g_recs.push_back(r);
-    return g_ts + 2 * (size_t)r.slot;
+    return g_ts + 4 * (size_t)r.slot;
+}
+unsigned long long* prof_clock_slot(int rec) {
+    if (rec < 0 || !g_ts || g_ts_used >= kMaxStampSlots) return nullptr;
+    g_recs[rec].clk = g_ts_used++;
+    return g_ts + 4 * (size_t)g_recs[rec].clk;
 }
 void prof_add_bytes(int id, double bytes) {
     if (g_prof && id >= 0 && id < 32) g_all_bytes[id] += bytes;
@@ -76,17 +82,17 @@ extern "C" int abr_prof_step_begin(void) {
     return ABR_OK;
 }
 extern "C" int abr_prof_begin(void) {
-    if (!abr::g_ts && hipMalloc(&abr::g_ts, sizeof(unsigned long long) * 2 * abr::kMaxStampSlots) != hipSuccess) abr::g_ts = nullptr;
+    if (!abr::g_ts && hipMalloc(&abr::g_ts, sizeof(unsigned long long) * 4 * abr::kMaxStampSlots) != hipSuccess) abr::g_ts = nullptr;
     if (abr::g_ts) {   // start = all ones (atomicMin), end = 0 (atomicMax)
         (void)hipDeviceSynchronize();
-        (void)hipMemset2D(abr::g_ts, 16, 0xFF, 8, abr::kMaxStampSlots);
-        (void)hipMemset2D(abr::g_ts + 1, 16, 0x00, 8, abr::kMaxStampSlots);
+        (void)hipMemset2D(abr::g_ts, 32, 0xFF, 8, abr::kMaxStampSlots);
+        (void)hipMemset2D(abr::g_ts + 1, 32, 0x00, 24, abr::kMaxStampSlots);
         (void)hipDeviceSynchronize();
     }
     abr::g_ts_used = 0;
     abr::g_prof = true;
     abr::g_step = 0;
-    for (int i = 0; i < 32; i++) abr::g_all_launches[i] = abr::g_all_work[i] = abr::g_all_bytes[i] = 0.0;
+    for (int i = 0; i < 32; i++) abr::g_all_launches[i] = abr::g_all_work[i] = abr::g_all_bytes[i] = abr::g_clk[i][0] = abr::g_clk[i][1] = 0.0;
     return ABR_OK;
 }
 // out[id*2 + {0,1}] = {launches, total work} of EVERY launch since abr_prof_begin (sampled or not): the executed flops of a step
@@ -97,6 +103,12 @@ extern "C" int abr_prof_totals(double* out, int n_ids) {
 // out[id] = algorithmic HBM bytes of EVERY launch of kernel id since abr_prof_begin (see abr_prof_totals for the launch counts)
 extern "C" int abr_prof_bytes(double* out, int n_ids) {
     for (int i = 0; i < n_ids && i < 32; i++) out[i] = abr::g_all_bytes[i];
+    return ABR_OK;
+}
+// out[id*2 + {0,1}] = {shader cycles, milliseconds} that workgroup 0 of the SAMPLED self-stamping launches of kernel id ran, summed by the
+// last abr_prof_end: cycles / ms / 1e6 = the clock (GHz) the chip sustained under that kernel
+extern "C" int abr_prof_clocks(double* out, int n_ids) {
+    for (int i = 0; i < n_ids && i < 32; i++) { out[2 * i] = abr::g_clk[i][0]; out[2 * i + 1] = abr::g_clk[i][1]; }
     return ABR_OK;
 }
 extern "C" int abr_prof_set_mask(uint32_t mask, int every_nth) {
@@ -117,7 +129,7 @@ extern "C" int abr_prof_end(double* out, int n_ids) {
     double ticks_per_ms = 1e5;   // wall_clock64: 100 MHz unless the device says otherwise
     if (abr::g_ts_used > 0) {
         (void)hipDeviceSynchronize();
-        ts.resize(2 * (size_t)abr::g_ts_used);
+        ts.resize(4 * (size_t)abr::g_ts_used);
         if (hipMemcpy(ts.data(), abr::g_ts, ts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) ts.clear();
         int dev = 0, khz = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0)
@@ -125,8 +137,12 @@ extern "C" int abr_prof_end(double* out, int n_ids) {
     }
     for (auto& r : abr::g_recs) {
         if (r.slot >= 0) {   // self-stamped launch
-            if ((size_t)(2 * r.slot + 1) < ts.size() && r.id < n_ids) {
-                const unsigned long long t0 = ts[2 * r.slot], t1 = ts[2 * r.slot + 1];
+            if ((size_t)(4 * r.slot + 3) < ts.size() && r.id < n_ids) {
+                const unsigned long long t0 = ts[4 * r.slot], t1 = ts[4 * r.slot + 1], cyc = ts[4 * r.slot + 2], wall = ts[4 * r.slot + 3];
+                if (r.id < 32 && wall > 100ull && wall < (1ull << 40) && cyc < (1ull << 48)) {   // workgroup 0 ran >= 1 us: a usable clock ratio
+                    abr::g_clk[r.id][0] += (double)cyc;
+                    abr::g_clk[r.id][1] += (double)wall / ticks_per_ms;
+                }
                 if (t1 > t0 && t0 != ~0ull) {
                     double* o = out + r.id * 6 + (r.overlapped ? 3 : 0);
                     o[0] += 1.0;
@@ -135,6 +151,13 @@ extern "C" int abr_prof_end(double* out, int n_ids) {
                 }
             }
             continue;
+        }
+        if (r.clk >= 0 && (size_t)(4 * r.clk + 3) < ts.size() && r.id < 32) {   // event-timed launch that carried a clocks-only slot
+            const unsigned long long cyc = ts[4 * r.clk + 2], wall = ts[4 * r.clk + 3];
+            if (wall > 100ull && wall < (1ull << 40) && cyc < (1ull << 48)) {
+                abr::g_clk[r.id][0] += (double)cyc;
+                abr::g_clk[r.id][1] += (double)wall / ticks_per_ms;
+            }
         }
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.id < n_ids) {

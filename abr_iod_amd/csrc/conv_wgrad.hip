@@ -750,8 +750,8 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
         // Timed with a HIP-event pair, not with in-kernel stamps: a kernel trace's duration of these kernels includes the write-back of the
         // parked partial tiles at kernel end, which first-workgroup-in / last-workgroup-out stamps miss by ~10 % (the raw event figure is
         // within 3 % of rocprofv3's here; for the forward / dgrad kernels it is the stamps that agree, within 2.5 %).
-        p.prof_ts = nullptr;
         const int rec6 = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
+        p.prof_ts = abr::prof_clock_slot(rec6);
         // algorithmic bytes: x and gy once (x at its own size for a direct 3x3), dw written once
         abr::prof_add_bytes(abr::PROF_WGRAD_BF16, 4.0 * nb * ((double)p.M * p.Cout + (p.plain ? (double)p.M * p.K : (double)p.B * p.H * p.W * p.Cin) + (double)p.Cout * p.K));
         if (one) conv_wgrad_x6_kernel<1><<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
@@ -760,8 +760,8 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
         wgrad_reduce(p, tiles, dw, abr::as_stream(stream));
         return;
     }
-    p.prof_ts = nullptr;
     const int rec = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
+    p.prof_ts = abr::prof_clock_slot(rec);
     if (sb) conv_wgrad_kernel<true><<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
     else conv_wgrad_kernel<false><<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
     abr::prof_stop(abr::as_stream(stream), rec);
@@ -791,8 +791,8 @@ static void launch_wgrad_bf16(WgP p, const float* x, const float* gy, float* dw,
     p.mt_per_split = (m_tiles + splits - 1) / splits;
     wgrad_plan_reduction(p, tiles, abr::as_stream(stream));
     const size_t lds = sizeof(unsigned) * (MRH / 2) * (TN_ + TK_);
-    p.prof_ts = nullptr;
     const int rec = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
+    p.prof_ts = abr::prof_clock_slot(rec);
     conv_wgrad_bf16_kernel<<<(unsigned)(tiles * splits), 256, lds, abr::as_stream(stream)>>>(p, x, gy, dw);
     abr::prof_stop(abr::as_stream(stream), rec);
     wgrad_reduce(p, tiles, dw, abr::as_stream(stream));

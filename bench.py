@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMG_ARD = 1304.0   # algorithmic conv/linear FLOPs of one ARD training image
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense
+PEAK_CLOCK_GHZ = 2.4             # same guide: the clock both peaks are quoted at
 PROF_NAMES = ["conv_igemm_kernel<128,128>", "conv_igemm_kernel<128,64>", "conv_igemm_kernel<64,64>", "conv_igemm_kernel<128,64,small_c>",
               "conv_wgrad_kernel", "roi_align_fwd", "roi_align_bwd", "conv_igemm_bf16_kernel", "conv_wgrad_bf16_kernel",
               "conv_igemm_x6_kernel<128,128>", "conv_igemm_x6_kernel<128,64>", "conv_igemm_x6_kernel<64,64>",
@@ -91,6 +92,7 @@ def _peak_of(name):
 class _Totals(dict):
     """abr_prof_totals' rows + `alg_bytes` (abr_prof_bytes of the same profiled region)"""
     alg_bytes = {}
+    clocks = {}
 
 
 def _tf(fl, ms):
@@ -133,6 +135,15 @@ def prof_rows(prof, totals, steps, math, event_overhead_ms=0.0):
     return rows, totals
 
 
+def _add_clocks(rows, clocks):
+    """sustained shader clock under each self-stamping kernel (abr_prof_clocks), and the row's fraction of the peak AT that clock"""
+    for x in rows:
+        cyc, ms = clocks.get(x["kernel"]) or clocks.get(x["kernel"].replace("_x6_kernel", "_bf16_kernel")) or (0.0, 0.0)
+        if cyc > 0 and ms > 0:
+            x["sustained_clock_ghz"] = round(cyc / ms / 1e6, 3)
+            x["frac_at_sustained_clock"] = round(x["frac"] * PEAK_CLOCK_GHZ / x["sustained_clock_ghz"], 4)
+
+
 def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0, serialised=None):
     """The `roofline` object.  `kernels_by_time` / `all_conv_kernels`: one row per conv kernel and template instance, timed INSIDE the
     step (other streams' kernels share the CUs: durations are stretched); `serialised`: the same rows from a short re-run of the step with
@@ -141,7 +152,9 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0, serialised=None):
     if not prof or not any(r[1] + r[4] > 0 for r in prof if "roi_align" not in r[0]):
         return {"bound": "mfma", "note": "no conv launch was sampled"}
     alg = getattr(totals, "alg_bytes", {})
+    clocks = getattr(totals, "clocks", {})
     rows, totals = prof_rows(prof, totals, a.steps, a.math, event_overhead_ms)
+    _add_clocks(rows, clocks)
     top = rows[0]
     traffic, traffic_src = _pmc_traffic(top["kernel"])
     step_s = elapsed / a.steps
@@ -150,6 +163,9 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0, serialised=None):
     peak_step = PEAK_FP32_MFMA_TFLOPS if a.math == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if a.math == "bf16x6" else None
     r = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": top["peak"], "unit": "TFLOP/s", "frac": top["frac"],
          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+         # `peak` is priced at the 2.4 GHz maximum clock; under matrix-core load the chip clocks to its power budget (MI355X_MICROARCH.md, "DVFS
+         # give-back").  sustained_clock_ghz = workgroup 0's own s_memtime cycles / s_memrealtime time over the sampled launches
+         "sustained_clock_ghz": top.get("sustained_clock_ghz"), "frac_at_sustained_clock": top.get("frac_at_sustained_clock"),
          # the algorithmic bytes of the same kernel's launches, counted live by the library (every operand and the output once, + a fused
          # residual / mask read): traffic / traffic_algorithmic = how much of the HBM-side traffic is re-reads
          "traffic_algorithmic": _alg_bytes_per_launch(top["kernel"], totals, a.math, alg),
@@ -164,7 +180,7 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0, serialised=None):
                    "weight-gradient kernels, whose traced duration includes the end-of-kernel write-back of their parked partial "
                    "tiles (that gap subtracted per launch)".format(round(event_overhead_ms * 1e3, 1)),
          "kernels_by_time": rows[:2],
-         "all_conv_kernels": {x["kernel"]: dict({k: x[k] for k in ("launches_per_step", "avg_launch_ms", "ms_per_step", "gflop_per_launch", "achieved", "frac")},
+         "all_conv_kernels": {x["kernel"]: dict({k: x[k] for k in ("launches_per_step", "avg_launch_ms", "ms_per_step", "gflop_per_launch", "achieved", "frac", "sustained_clock_ghz") if k in x},
                                                 algorithmic_mb_per_launch=(round(_alg_bytes_per_launch(x["kernel"], totals, a.math, alg) / 1e6, 1)
                                                                            if _alg_bytes_per_launch(x["kernel"], totals, a.math, alg) else None))
                               for x in rows},
@@ -273,6 +289,10 @@ def read_prof(_lib):
     _lib.check(_lib.lib().abr_prof_bytes(ctypes.cast(by, ctypes.c_void_p), len(PROF_NAMES)), "prof_bytes")
     totals = _Totals(totals)
     totals.alg_bytes = {PROF_NAMES[i]: by[i] for i in range(len(PROF_NAMES))}   # algorithmic HBM bytes of ALL launches per kernel id (same region)
+    ck = (ctypes.c_double * (2 * len(PROF_NAMES)))()
+    _lib.check(_lib.lib().abr_prof_clocks(ctypes.cast(ck, ctypes.c_void_p), len(PROF_NAMES)), "prof_clocks")
+    # (shader cycles, ms) of workgroup 0 of the sampled launches per kernel id: the clock the chip sustained under that kernel
+    totals.clocks = {PROF_NAMES[i]: (ck[2 * i], ck[2 * i + 1]) for i in range(len(PROF_NAMES))}
     ov = ctypes.c_double(0.0)
     _lib.check(_lib.lib().abr_prof_event_overhead_ms(ctypes.cast(ctypes.byref(ov), ctypes.c_void_p), _lib.stream()), "prof_event_overhead_ms")
     return prof, totals, float(ov.value)
@@ -445,9 +465,11 @@ def main():
             finally:
                 fold_streams(False, optimizer)
             srows, _ = prof_rows(sprof, stot, SER_STEPS, a.math, sov)
+            _add_clocks(srows, getattr(stot, "clocks", {}))
             serialised = {"steps": SER_STEPS, "ms_per_step": round(1e3 * es / SER_STEPS, 3),
                           "conv_kernel_ms_per_step": round(sum(x["ms_per_step"] for x in srows), 3),
-                          "kernels": {x["kernel"]: {k: x[k] for k in ("launches_per_step", "avg_launch_ms", "ms_per_step", "gflop_per_launch", "achieved", "peak", "frac")}
+                          "kernels": {x["kernel"]: {k: x[k] for k in ("launches_per_step", "avg_launch_ms", "ms_per_step", "gflop_per_launch", "achieved", "peak", "frac",
+                                                                         "sustained_clock_ghz", "frac_at_sustained_clock") if k in x}
                                       for x in srows},
                           "note": "every stream of the step folded into one, every conv launch timed (informational re-run behind the timed region)"}
     rccl_ranks = 1

@@ -61,6 +61,9 @@ int abr_prof_totals(double* out_host, int n_ids);
 /* out[id] = ALGORITHMIC HBM bytes (every operand and the output once, + a fused residual / mask read) of every launch of kernel id since
  * abr_prof_begin: next to the PMC traffic of the same kernel it says how much of the traffic is re-reads (bench.py: roofline.traffic_algorithmic) */
 int abr_prof_bytes(double* out_host, int n_ids);
+/* out[id*2 + {0,1}] = {shader cycles (s_memtime), milliseconds (s_memrealtime)} that workgroup 0 of the sampled self-stamping launches of kernel
+   id ran, summed by the last abr_prof_end: cycles / ms / 1e6 = the clock in GHz the chip sustained under that kernel (it clocks to its power budget) */
+int abr_prof_clocks(double* out_host, int n_ids);
 /* median duration (ms) of an event pair around an EMPTY kernel on a busy stream: the share of an event-bracketed duration that is
  * dispatch gap, not kernel; bench.py subtracts it from its live per-launch durations (synchronises the stream) */
 int abr_prof_event_overhead_ms(double* out_host, void* stream);
