@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Soak / race check of the overlapped training step at FULL size.  The learning rate is 0, so the weights never move and every visit of a
+batch must reproduce the losses and the 33 M gradients of its first visit -- while everything that moves WHEN kernels run stays live: the SGD
+kernel still runs and bumps the weight versions (so the derived-weight caches are refilled on the preparation stream every step), the
+next batch's source forward + frozen prefix is prefetched into the backward pass, the batches alternate between three image shapes (scratch
+pools regrow, tile counts change), weight gradients run on their side streams.  A missing stream dependency shows up as a gradient that differs
+between two visits by more than the accumulation-order noise of the few atomically accumulated sums.  Also prints the allocator's high-water
+mark at intervals (a leak shows as growth after the first cycle).   GPU box: python tools/soak.py [--steps 600]"""
+import argparse
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from abr_iod_amd.engine import train_step  # noqa: E402
+from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch  # noqa: E402
+from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=600)
+ap.add_argument("--tol", type=float, default=2e-5, help="allowed ||g - g_first|| / ||g_first|| between two visits of a batch")
+a = ap.parse_args()
+
+cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, ims_per_batch=4, base_lr=0.0)
+ms, mt = build_models(cfg_s, cfg_t, seed=0)
+opt = make_optimizer(cfg_t, mt)
+sch = make_lr_scheduler(cfg_t, opt)
+shapes = [(4, 600, 1000), (4, 600, 600), (2, 800, 1333), (4, 600, 1000), (3, 512, 800)]
+batches = [synthetic_batch(b, h, w, seed=100 + i, label_range=(16, 21)) for i, (b, h, w) in enumerate(shapes)]
+p0 = mt.flat.params.detach().clone()
+first = {}
+worst = 0.0
+worst_loss = 0.0
+bad = []
+for it in range(a.steps):
+    k = it % len(batches)
+    images, targets = batches[k]
+    torch.manual_seed(1000 + k)
+    random.seed(1000 + k)
+    ld, total = train_step(ms, mt, images, targets, opt, sch, cfg_t, next_images=batches[(it + 1) % len(batches)][0])
+    g = mt.flat.grads.detach().clone()
+    losses = torch.stack([v.detach().reshape(()) for _, v in sorted(ld.items())]).clone()
+    if k not in first:
+        first[k] = (g, losses, float(g.norm()))
+        continue
+    g0, l0, n0 = first[k]
+    if it % 7 == 0 or it + len(batches) >= a.steps:      # (a full-size comparison every step would serialise the host with the device)
+        rel = float((g - g0).norm()) / max(n0, 1e-30)
+        dl = float(((losses - l0).abs() / l0.abs().clamp_min(1.0)).max())
+        worst, worst_loss = max(worst, rel), max(worst_loss, dl)
+        if not (rel <= a.tol and dl <= 1e-5 and bool(torch.isfinite(g).all())):
+            bad.append((it, k, rel, dl))
+    if it % 100 == 0:
+        print("step %5d  worst gradient rel. distance so far %.2e, worst loss rel. difference %.2e, allocator high-water %.2f GB" % (
+            it, worst, worst_loss, torch.cuda.max_memory_allocated() / 2 ** 30), flush=True)
+torch.cuda.synchronize()
+moved = float((mt.flat.params - p0).abs().max())
+print("%d steps over %d batches %s: worst gradient rel. distance to the first visit %.2e (tolerance %.0e), worst loss rel. difference %.2e, "
+      "parameters moved by %.1e (lr = 0), allocator high-water %.2f GB, reserved %.2f GB" % (
+          a.steps, len(batches), shapes, worst, a.tol, worst_loss, moved, torch.cuda.max_memory_allocated() / 2 ** 30, torch.cuda.memory_reserved() / 2 ** 30))
+if bad:
+    print("MISMATCHES (step, batch, gradient rel. distance, loss rel. difference):", bad[:20])
+    sys.exit(1)
+print("OK")
