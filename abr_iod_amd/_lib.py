@@ -163,7 +163,12 @@ def ptr(t):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw handle of torch's CURRENT stream on the current device.  torch.cuda.current_stream().cuda_stream builds a Stream object through
+    three layers of Python (~9 us: 1.3 ms of host time per training step over ~150 launches); the two C calls below are ~0.3 us"""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except (AttributeError, RuntimeError):      # (private names moved, or the runtime is not initialised yet)
+        return torch.cuda.current_stream().cuda_stream
 
 
 def require_cuda(*tensors):

@@ -250,9 +250,23 @@ class _StageFn(Function):
         return (from_nhwc(g) if g is not None else None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
+def _stage_params(blocks):
+    """the parameters of a stage's blocks, in module order.  Walking the module tree (nn.Module.parameters) costs ~40 us per stage call and the
+    step makes ~25 of them; a block's parameter OBJECTS never change (flatten_parameters re-homes their .data), so the list is kept on the
+    first block, keyed by the identity of the blocks it was built for"""
+    if not blocks:
+        return []
+    key = tuple(id(b) for b in blocks)
+    cached = blocks[0].__dict__.get("_stage_params_cache")
+    if cached is None or cached[0] != key:
+        cached = (key, [p for b in blocks for p in b.parameters()])
+        blocks[0].__dict__["_stage_params_cache"] = cached
+    return cached[1]
+
+
 def run_stage(x, blocks, first_stride=None, need_dx=True):
     """x logical [B,C,H,W] -> logical output; differentiable when any block parameter requires grad."""
-    params = [p for b in blocks for p in b.parameters()]
+    params = _stage_params(blocks)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         out = _StageFn.apply(x, blocks, first_stride, need_dx and x.requires_grad, *params)
         out._abr_relu_output = True      # (a bottleneck ends in a ReLU: consumers may fuse its backward into theirs, see _PredictorFn)
@@ -329,13 +343,21 @@ class ResNet(nn.Module):
             for p in m.parameters():
                 p.requires_grad = False
 
+    def _trains(self, name):
+        """does stage `name` ("stem", "layer1", ...) hold a trainable parameter?  (parameter lists kept: see _stage_params)"""
+        cache = self.__dict__.setdefault("_stage_param_lists", {})
+        ps = cache.get(name)
+        if ps is None:
+            ps = cache[name] = list(getattr(self, name).parameters())
+        return any(p.requires_grad for p in ps)
+
     def frozen_stage_names(self):
         """names of the leading stages without trainable parameters (what frozen_prefix computes after the stem), or None when the stem trains"""
-        if any(p.requires_grad for p in self.stem.parameters()):
+        if self._trains("stem"):
             return None
         names = []
         for name in self.stages:
-            if any(p.requires_grad for p in getattr(self, name).parameters()):
+            if self._trains(name):
                 break
             names.append(name)
         return names
@@ -344,13 +366,13 @@ class ResNet(nn.Module):
         """The stem and the leading stages whose parameters are all frozen (FREEZE_CONV_BODY_AT = 2: stem + layer1), run without autograd:
         their outputs do not depend on the optimiser, so the trainer may compute them for the NEXT batch while the current backward pass
         runs.  Returns (x, stage outputs so far) or None when the stem itself trains."""
-        if any(p.requires_grad for p in self.stem.parameters()):
+        if self._trains("stem"):
             return None
         with torch.no_grad():
             x = self.stem(x)
             done = []
             for name in self.stages:
-                if any(p.requires_grad for p in getattr(self, name).parameters()):
+                if self._trains(name):
                     break
                 x = run_stage(x, list(getattr(self, name)))
                 done.append(x)
@@ -358,7 +380,7 @@ class ResNet(nn.Module):
 
     def forward(self, x, prefix=None):
         """`prefix`: the result of frozen_prefix() on the same input (the same values the inline path computes)"""
-        if torch.is_grad_enabled() and x.requires_grad and self.frozen_prefix is not None and not any(p.requires_grad for p in self.stem.parameters()):
+        if torch.is_grad_enabled() and x.requires_grad and self.frozen_prefix is not None and not self._trains("stem"):
             # the frozen stem / stages run without autograd (their kernels have no backward): a gradient w.r.t. the IMAGE would silently be
             # dropped.  The reference's training loop never asks for one (images come from the data loader); fail loudly instead.
             raise NotImplementedError("gradients with respect to the input image are not implemented: the frozen stem (FREEZE_CONV_BODY_AT >= 1) "

@@ -381,6 +381,34 @@ def conv_prepare_batch(entries):
     L.check(L.lib().abr_conv_prepare_batch(C.cast(arr, C.c_void_p), len(entries), L.stream()), "conv_prepare_batch")
 
 
+class PreparedBatch(object):
+    """conv_prepare_batch with its table built ONCE: the weights live in the model's flat storage, the dgrad copies and the folded FrozenBN
+    scales in buffers their modules keep, so every pointer of an entry is fixed from step to step and only w_version moves.  `entries` as for
+    conv_prepare_batch, with a CALLABLE in the version slot (read at every run).  `still_valid()` re-reads the pointers (a re-homed weight, a
+    re-fused scale or another math mode means: rebuild)."""
+
+    def __init__(self, entries):
+        self.n = len(entries)
+        self.arr = (L.PrepItem * max(self.n, 1))()
+        self.keep, self.vers, self.sig_src = [], [], []
+        for a, (w, scale, wt, stride, pad, math, ver) in zip(self.arr, entries):
+            Cout, R, S, Cin = w.shape
+            if scale is not None:
+                scale = L.f32c(scale)
+            self.keep.append((w, scale, wt))
+            a.w, a.scale, a.wt = L.ptr(w), L.ptr(scale), L.ptr(wt)
+            a.Cout, a.R, a.S, a.Cin, a.stride, a.pad, a.math = Cout, R, S, Cin, int(stride), int(pad), int(math)
+            self.vers.append(ver)
+        self.ptr = C.cast(self.arr, C.c_void_p)
+
+    def run(self):
+        if not self.n:
+            return
+        for a, ver in zip(self.arr, self.vers):
+            a.w_version = int(ver())
+        L.check(L.lib().abr_conv_prepare_batch(self.ptr, self.n, L.stream()), "conv_prepare_batch")
+
+
 def conv_cache_clear():
     """Drop the library's per-weight derived data (Winograd-domain weights); call when parameter storage is released or rebuilt."""
     L.check(L.lib().abr_conv_cache_clear(), "conv_cache_clear")

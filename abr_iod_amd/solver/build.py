@@ -51,6 +51,7 @@ class FusedSGD(object):
         self._lr = torch.empty(len(self.param_groups), dtype=torch.float32, device=dev)
         self._lr_host = None
         self._steps = 0
+        self._prep_plan = None
         self.reducer = GradReducer(self.flat.grads, self.flat.segments, side_streams=self._grad_writer_streams)
 
     @property
@@ -115,33 +116,53 @@ class FusedSGD(object):
                     # every trainable conv's derived data in a dozen launches (ops.conv_prepare_batch) instead of ~190 (3.2 -> 1.0 ms of host time per step, and
                     # a host-paced train of tiny kernels on a hardware queue the source model's head pass shares).  In the order of first use,
                     # one batch per stage: the next forward pass waits for a stage's data only (the library orders consumers behind the fill of
-                    # THEIR entry); the dgrad copies and what derives from them, first needed ~10 ms later, come last.
+                    # THEIR entry); the dgrad copies and what derives from them, first needed ~10 ms later, come last.  The tables are built
+                    # once (ops.PreparedBatch: every pointer is fixed from step to step) and rebuilt when a module's inputs to them change.
                     from ..modeling.backbone.resnet import _PARAM_VERSION
-                    groups, convs, rest = [], [], []
-                    for m in self._derived:
-                        if hasattr(m, "prep_entries"):
-                            ent = [(conv, scale, stride, pad, math) for conv, scale, stride, pad, math in m.prep_entries()]
-                            key = self._derived_group.get(id(m), "")
-                            if not groups or groups[-1][0] != key:
-                                groups.append((key, []))
-                            groups[-1][1].extend(ent)
-                            if hasattr(m, "prepare_rest"):
-                                rest.append(m.prepare_rest)
-                        else:
-                            rest.append(m.prepare_derived)
-                    for _, ent in groups:    # forward halves, stage by stage
-                        ops.conv_prepare_batch([(conv.weight.detach(), None, None, stride, pad, math, conv.version()) for conv, _, stride, pad, math in ent])
-                    for fn in rest:
+                    plan = self._prep_plan
+                    if plan is None or plan["signature"] != self._prep_signature():
+                        plan = self._prep_plan = self._build_prep_plan()
+                    for b in plan["forward"]:    # forward halves, stage by stage
+                        b.run()
+                    for fn in plan["rest"]:
                         fn()
-                    allent = [e for _, ent in groups for e in ent]
-                    ops.conv_prepare_batch([(conv.weight.detach(), scale, conv.dgrad_buffer(), stride, pad, math, conv.version())
-                                            for conv, scale, stride, pad, math in allent])
-                    for conv, _, _, _, _ in allent:
+                    plan["backward"].run()
+                    for conv in plan["convs"]:
                         conv._wt_version = _PARAM_VERSION[0]
                 else:
                     for m in self._derived:
                         m.prepare_derived()
             ops.prep_done(prep)
+
+    def _prep_signature(self):
+        """what the cached preparation tables were built from: the modules' entries (conv, FrozenBN scale tensor, geometry, math mode), the
+        weights' and dgrad buffers' addresses"""
+        sig = []
+        for m in self._derived:
+            if hasattr(m, "prep_entries"):
+                for conv, scale, stride, pad, math in m.prep_entries():
+                    sig.append((id(conv), conv.weight.data_ptr(), id(scale), conv.dgrad_buffer().data_ptr(), stride, pad, math))
+        return tuple(sig)
+
+    def _build_prep_plan(self):
+        groups, rest = [], []
+        for m in self._derived:
+            if hasattr(m, "prep_entries"):
+                ent = list(m.prep_entries())
+                key = self._derived_group.get(id(m), "")
+                if not groups or groups[-1][0] != key:
+                    groups.append((key, []))
+                groups[-1][1].extend(ent)
+                if hasattr(m, "prepare_rest"):
+                    rest.append(m.prepare_rest)
+            else:
+                rest.append(m.prepare_derived)
+        allent = [e for _, ent in groups for e in ent]
+        forward = [ops.PreparedBatch([(conv.weight.detach(), None, None, stride, pad, math, conv.version) for conv, _, stride, pad, math in ent])
+                   for _, ent in groups]
+        backward = ops.PreparedBatch([(conv.weight.detach(), scale, conv.dgrad_buffer(), stride, pad, math, conv.version)
+                                      for conv, scale, stride, pad, math in allent])
+        return dict(signature=self._prep_signature(), forward=forward, rest=rest, backward=backward, convs=[e[0] for e in allent])
 
     def _reference_params(self):
         """(name, parameter, offset into the flat buffer, Conv2d module or None) for every trainable tensor, in the
