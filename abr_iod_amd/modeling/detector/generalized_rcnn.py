@@ -147,7 +147,7 @@ class GeneralizedRCNN(nn.Module):
         (train_incremental.py:89-95 as forward_joint does it); the result is then (the 8-tuple, the second call's 3-tuple)."""
         features, targets = state["features"], state["targets"]
         (proposals, proposal_losses), anchors, rpn_output = self.rpn.forward_finish(state["rpn"])
-        ops.mark("proposal selection joined (main stream resumes)")
+        ops.mark("RPN finish returned (the selection is still in flight on its stream: the RoI targets join it)")
         second = None
         if soften_proposals is not None:
             (x, result, soften_results, detector_losses, roi_align_features), (t_scores, t_bboxes, mask_logits, t_raf) = \

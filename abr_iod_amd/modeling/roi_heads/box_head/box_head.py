@@ -140,7 +140,7 @@ class ResNet50Conv5ROIFeatureExtractor(nn.Module):
         soft_rois, soft_ready = soft_early if soft_early is not None else (
             soft_proposals if torch.is_tensor(soft_proposals) else convert_to_roi_format(soft_proposals), None)
         al = self.pooler.poolers[0]
-        ops.mark("RoI targets done (ROIAlign starts)")
+        ops.mark("distillation RoIs pooled, proposal selection joined, RoI targets done (detection ROIAlign starts)")
         joint, soft = _JointPoolFn.apply(x[0], det_rois, soft_rois, al.output_size, al.spatial_scale, al.sampling_ratio, soft_ready)
         ops.mark("ROIAlign done (layer4 starts)")
         # (second value: the tensor whose gradient marks "layer4's backward is queued" for the gradient exchange hooks, engine/trainer.py::_arm_overlap:
