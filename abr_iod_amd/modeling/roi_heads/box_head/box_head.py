@@ -52,6 +52,9 @@ def convert_to_roi_format(boxes):
     return torch.cat([ids, concat], dim=1)
 
 
+_DBG_SLEEP_ROI_TARGETS = int(os.environ.get("ABR_DBG_SLEEP_ROI_TARGETS", "0"))   # spin cycles in front of the RoI targets (probe only)
+
+
 class _JointPoolFn(Function):
     """ROIAlign of the detection RoIs (even bins: all layer4's stride-2 1x1 convs read) and of the distillation RoIs (all 7x7 bins: ARD reads
     them) with the rows layer4 sees written side by side into ONE [Kd + Ks, 4, 4, C] tensor -- no concatenation copy of the detection part.
@@ -342,6 +345,8 @@ class FastRCNNLossComputation(object):
         BATCH_SIZE_PER_IMAGE rows; rows past the number actually drawn (only when an image has fewer candidates than that) are
         padding with label -1, which the loss kernels skip.  Returns the dict of device tensors; `self._proposals` are BoxList VIEWS of it."""
         props, scores, keep, n_keep, sizes = lazy.raw()
+        if _DBG_SLEEP_ROI_TARGETS:
+            torch.cuda._sleep(_DBG_SLEEP_ROI_TARGETS)        # (criticality probe: tools/dbg/critical_probe.sh)
         R = self.fg_bg_sampler.batch_size_per_image
         t = ops.roi_head_targets(props, scores, keep, n_keep, [g.bbox for g in targets], [g.get_field("labels") for g in targets],
                                  self.proposal_matcher.high_threshold, self.proposal_matcher.low_threshold, self.box_coder.weights, R,

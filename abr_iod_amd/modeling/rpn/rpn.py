@@ -59,6 +59,9 @@ PROPOSALS_SIDE_STREAM = os.environ.get("ABR_PROPOSAL_STREAM", "1") != "0"
 FUSED_ROI_TARGETS = os.environ.get("ABR_FUSED_ROI_TARGETS", "1") != "0"
 
 
+_DBG_SLEEP_PROPOSALS = int(os.environ.get("ABR_DBG_SLEEP_PROPOSALS", "0"))   # spin cycles in front of the training selection (probe only)
+
+
 class LazyProposals(object):
     """The training selector's output before anything has been read back: the decoded score-sorted boxes, the NMS keep lists and
     their device-resident counts (RPNPostProcessor.launch).  The box head consumes it as is (ROIBoxHead.forward ->
@@ -361,6 +364,8 @@ class RPNPostProcessor(nn.Module):
         side = ops.side_stream((fused.device.index, tag))
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            if _DBG_SLEEP_PROPOSALS and self.training:
+                torch.cuda._sleep(_DBG_SLEEP_PROPOSALS)      # (criticality probe: tools/dbg/critical_probe.sh)
             pending = self.launch(anchors, fused, num_anchors)
         fused.record_stream(side)
         pending["stream"] = side
