@@ -67,6 +67,7 @@ struct ConvP {
     int out_H, out_W, out_sh, out_sw;
     int relu, scatter;
     int tiles_m, tiles_n;
+    int ngroup;    // weights-direct kernels: > 0 = tiles ordered n-group-major, `ngroup` n-tile columns at a time (see launch_x6w_np); 0 = m-major
     FastDiv d_howo, d_wo, d_cin, d_s;
     const float* scale;
     const float* bias;
@@ -850,7 +851,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         tile -= bt * p.tiles_pb;
         x += bt * p.a_bs; out += bt * p.o_bs; wp += bt * p.wp_bs;
     }
-    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+    int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+    if (p.ngroup > 0) {
+        // n-group-major: `ngroup` n-tile columns at a time, all their m-tiles, n fastest inside the group.  An XCD's contiguous tile range
+        // (abr::xcd_remap) then stays on a few weight columns whose packed planes fit its L2 -- the weight fragments, which go global -> registers
+        // and are what the MFMAs wait for first, are L2 hits -- and streams the activation rows (prefetched a k-tile ahead) past them.
+        const int per = p.tiles_m * p.ngroup;
+        const int ng = tile / per, rem = tile - ng * per;
+        const int gn = min(p.ngroup, p.tiles_n - ng * p.ngroup);   // (the last group may be narrower)
+        tile_m = rem / gn;
+        tile_n = ng * p.ngroup + rem - tile_m * gn;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -1483,6 +1494,17 @@ int launch_x6w_np(const ConvP& p, const float* x, float* out, hipStream_t st) {
     q.tiles_pb = q.tiles_m * q.tiles_n;
     if (q.nbatch < 1) q.nbatch = 1;
     q.n_full = q.tiles_pb * q.nbatch; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
+    {   // tile order: weights that do not fit an XCD's L2 (4 MB) are walked a few n-tile columns at a time (<= ~3 MB of planes), every m-tile of
+        // those columns before the next group; lab (tools/x6lab/flab.hip -DGN=): 32768x2048x512 0.336-0.342 -> 0.322 ms, x1024 0.627-0.631 -> 0.618; library
+        // (with its epilogue): 36864x2048x512 504 -> 495 us, x2048x1024 782 -> 768, x1024x2048 737 -> 728; shapes with <= 4 columns or weights that fit: unchanged.
+        // ABR_X6_NGROUP: 0 = always m-major (rounds 2-3), n > 0 = force groups of n columns
+        static const int forced = getenv("ABR_X6_NGROUP") ? atoi(getenv("ABR_X6_NGROUP")) : -1;
+        const double col_bytes = (double)BN * (double)p.K * (NP == 1 ? 2.0 : 6.0);
+        int g = 0;
+        if (forced >= 0) g = forced;
+        else if (col_bytes * q.tiles_n > 3.0 * 1048576.0) g = col_bytes <= 1.6 * 1048576.0 ? 4 : (col_bytes <= 3.2 * 1048576.0 ? 2 : 0);   // (measured: tools/dbg/ngroup_time.py)
+        q.ngroup = (g > 0 && g < q.tiles_n) ? g : 0;
+    }
     q.x6_flags = (NP != 1 && abr::x6_guard_enabled()) ? abr::x6_flags_ptr() : nullptr;   // (rounding to bf16 is defined for every finite value: no guard)
     constexpr size_t lds_op = sizeof(__bf16) * (NP == 1 ? 1 : 3) * BM * LDX;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
@@ -1904,7 +1926,7 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     ABR_REQUIRE((p.Ho - 1) * p.out_sh < p.out_H && (p.Wo - 1) * p.out_sw < p.out_W, "conv_forward: scatter out of range");
     p.relu = d->relu;
     p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.mask = d->mask;
-    p.tiles_m = p.tiles_n = 0;
+    p.tiles_m = p.tiles_n = 0; p.ngroup = 0;
     p.nbatch = 1; p.tiles_pb = 0; p.a_bs = p.w_bs = p.o_bs = 0;
     p.v_out = d->wino_v;
     p.w_version = d->w_version;
@@ -1971,7 +1993,7 @@ static void convp_from_desc(const abr_conv_desc* d, ConvP& p) {
     p.out_H = d->Ho; p.out_W = d->Wo; p.out_sh = p.out_sw = 1; p.scatter = 0;
     p.relu = d->relu;
     p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.mask = d->mask;
-    p.tiles_m = (p.M + 127) / 128; p.tiles_n = 1;
+    p.tiles_m = (p.M + 127) / 128; p.tiles_n = 1; p.ngroup = 0;
     p.nbatch = 1; p.tiles_pb = p.tiles_m; p.a_bs = p.w_bs = p.o_bs = 0;
     p.n_full = p.tiles_m; p.split = 1; p.ws = nullptr; p.cnt = nullptr;
     p.v_out = nullptr;

@@ -105,7 +105,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int tiles_n = N / BN;
     const unsigned nblk = gridDim.x, q_ = nblk / 8, r_ = nblk % 8, xcd = blockIdx.x % 8, pos = blockIdx.x / 8;
     const int tile = (int)((xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + pos);
+#ifndef GN
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+#else
+    // n-group-major order: GN n-tile columns at a time, all m-tiles of them, n fastest inside the group: an XCD's contiguous tile range stays on
+    // FEW weight columns (their planes stay in its L2) and streams the activation rows past them
+    const int tiles_m_ = M / BM;
+    const int ng = tile / (tiles_m_ * GN), rem = tile % (tiles_m_ * GN);
+    const int tile_m = rem / GN, tile_n = ng * GN + rem % GN;
+#endif
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int kq = tid & 7, srow = tid >> 3;
