@@ -62,15 +62,26 @@ __device__ __forceinline__ float box_iou(const float4 g, const float4 b) {
 }
 
 // pass 1: per-gt maximum IoU over all boxes (needed only for Matcher.set_low_quality_matches_, matcher.py:83-112)
-__global__ void gt_max_iou_kernel(const float* __restrict__ boxes, int n, const float* __restrict__ gt, int G,
+// maximum over a 256-thread workgroup (all threads call; s_m: 4 floats).  ONE atomic per workgroup and ground-truth box then goes to the
+// shared word: with one per WAVE, the ~560 waves of the RPN call queued on a handful of addresses (80 us for 35 910 anchors x 5 boxes)
+__device__ __forceinline__ float block_max_256(float m, float* s_m) {
+    m = abr::wave_max(m);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+}
+
+__global__ __launch_bounds__(256) void gt_max_iou_kernel(const float* __restrict__ boxes, int n, const float* __restrict__ gt, int G,
                                   unsigned* __restrict__ rowmax) {
+    __shared__ float s_m[4];
     for (int g = 0; g < G; g++) {
         const float4 gb = reinterpret_cast<const float4*>(gt)[g];
         float m = 0.f;
         for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
             m = fmaxf(m, box_iou(gb, reinterpret_cast<const float4*>(boxes)[j]));
-        m = abr::wave_max(m);
-        if ((threadIdx.x & 63) == 0) atomicMax(rowmax + g, __float_as_uint(m));  // IoU >= 0: bit pattern is monotone
+        m = block_max_256(m, s_m);
+        if (threadIdx.x == 0) atomicMax(rowmax + g, __float_as_uint(m));  // IoU >= 0: bit pattern is monotone
     }
 }
 
@@ -261,8 +272,9 @@ __global__ void gather_proposals_kernel(const float* __restrict__ props, const f
 // ---------------------------------------------------------------------------------------------------------------------------------
 // RPN training targets for the whole batch (abr_rpn_targets_batched): the anchors are shared by the images (same feature-map size), the
 // GT boxes and the visibility masks are per image.  Same arithmetic as gt_max_iou_kernel / match_encode_kernel, blockIdx.y = image.
-__global__ void gt_max_iou_batched_kernel(const float* __restrict__ boxes, int n, const float* const* __restrict__ gt_ptrs,
+__global__ __launch_bounds__(256) void gt_max_iou_batched_kernel(const float* __restrict__ boxes, int n, const float* const* __restrict__ gt_ptrs,
                                           const int32_t* __restrict__ n_gt, int g_max, unsigned* __restrict__ rowmax) {
+    __shared__ float s_m[4];
     const int i = blockIdx.y;
     const float* gt = gt_ptrs[i];
     const int G = n_gt[i];
@@ -271,8 +283,8 @@ __global__ void gt_max_iou_batched_kernel(const float* __restrict__ boxes, int n
         float m = 0.f;
         for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
             m = fmaxf(m, box_iou(gb, reinterpret_cast<const float4*>(boxes)[j]));
-        m = abr::wave_max(m);
-        if ((threadIdx.x & 63) == 0) atomicMax(rowmax + (size_t)i * g_max + g, __float_as_uint(m));
+        m = block_max_256(m, s_m);
+        if (threadIdx.x == 0) atomicMax(rowmax + (size_t)i * g_max + g, __float_as_uint(m));
     }
 }
 
@@ -406,7 +418,7 @@ extern "C" int abr_match_encode(const float* boxes, int n, const float* gt, cons
         ABR_REQUIRE(workspace && workspace_bytes >= abr_match_workspace_bytes(n, G), "match_encode: workspace too small");
         rowmax = (unsigned*)workspace;
         if (hipMemsetAsync(rowmax, 0, 4 * (size_t)G, st) != hipSuccess) return ABR_E_LAUNCH;
-        gt_max_iou_kernel<<<std::min(abr::cdiv(n, 256), 512u), 256, 0, st>>>(boxes, n, gt, G, rowmax);
+        gt_max_iou_kernel<<<std::min(abr::cdiv(n, 1024), 64u), 256, 0, st>>>(boxes, n, gt, G, rowmax);
     }
     match_encode_kernel<<<abr::cdiv(n, 256), 256, 0, st>>>(boxes, n, gt, gt_labels, G, vis, hi, lo, allow_low_quality, rowmax,
                                                            wx, wy, ww, wh, matched, labels_f32, labels_i64, reg_targets);
@@ -463,7 +475,7 @@ extern "C" int abr_rpn_targets_batched(const float* anchors, int n, int N, const
     hipStream_t st = abr::as_stream(stream);
     unsigned* rowmax = (unsigned*)workspace;
     if (hipMemsetAsync(rowmax, 0, 4 * (size_t)N * g_max, st) != hipSuccess) return ABR_E_LAUNCH;
-    gt_max_iou_batched_kernel<<<dim3(std::min(abr::cdiv(n, 256), 256u), N), 256, 0, st>>>(anchors, n, gt_ptrs, n_gt, g_max, rowmax);
+    gt_max_iou_batched_kernel<<<dim3(std::min(abr::cdiv(n, 1024), 64u), N), 256, 0, st>>>(anchors, n, gt_ptrs, n_gt, g_max, rowmax);
     rpn_match_batched_kernel<<<dim3(abr::cdiv(n, 256), N), 256, 0, st>>>(anchors, n, gt_ptrs, n_gt, g_max, vis_ptrs, hi, lo, rowmax, wx, wy, ww, wh,
                                                                           labels, reg_targets);
     ABR_CHECK_LAUNCH("rpn_targets_batched");

@@ -466,6 +466,39 @@ def test_fused_sampler():
     assert hits[labels[1] < 1].sum() == 0
 
 
+@pytest.mark.parametrize("n", [3000, 8192, 8193, 36000])
+def test_fused_sampler_draw_is_the_k_smallest_keys(n):
+    """The draw is defined (csrc/sampler.hip): every candidate of a class gets the 32-bit key hash(seed, image, index); the k smallest keys
+    (ties by index) are taken and written in ascending index order.  Restated in numpy and compared exactly, for both workgroup sizes
+    (n <= 8192: 256 threads, above: 1024) and per-wave ranges that do not divide n."""
+    from abr_iod_amd import ops
+    rng = np.random.default_rng(n)
+    N, batch, max_pos, seed = 3, 256, 128, 987654321
+    labels = rng.integers(-1, 2, (N, n)).astype(np.float32)      # ~1/3 each: ignored / negative / positive
+    labels[1, rng.permutation(n)[: n - 50]] = -1                  # an image with fewer candidates than the quota
+    pos, neg, counts = ops.sample_pos_neg(T(labels), batch, max_pos, seed=seed)
+    pos, neg, counts = pos.cpu().numpy(), neg.cpu().numpy(), counts.cpu().numpy()
+
+    def keys(img, idx):
+        with np.errstate(over="ignore"):
+            z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * ((np.uint64(img) << np.uint64(32)) | idx.astype(np.uint64)) + np.uint64(0x632BE59BD9B4E019)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        return ((z >> np.uint64(16)) & np.uint64(0xFFFFFFFF)).astype(np.int64)
+
+    for i in range(N):
+        p_all, n_all = np.nonzero(labels[i] >= 1)[0], np.nonzero(labels[i] == 0)[0]
+        k_pos = min(len(p_all), max_pos)
+        k_neg = min(len(n_all), batch - k_pos)
+        assert tuple(counts[i]) == (k_pos, k_neg)
+        for cand, k, got in ((p_all, k_pos, pos[i]), (n_all, k_neg, neg[i])):
+            order = np.lexsort((cand, keys(i, cand)))             # by key, ties by index
+            want = np.sort(cand[order[:k]])
+            assert np.array_equal(got[:k], want), (n, i, k)
+            assert (got[k:] == -1).all()
+
+
 def test_topk_sigmoid_matches_torch():
     """fused sigmoid + sorted top-k == torch.sigmoid(...).topk(sorted=True) (values exact up to 1 ulp of expf, order identical
     wherever scores differ; ties resolved by ascending index)."""
