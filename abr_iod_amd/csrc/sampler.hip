@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int NT_BIG = 1024;   // RPN anchors (143 640 labels per image)
+constexpr int NT_BIG = 1024;   // RPN anchors (35 910 labels per image at 600x1000, 63 000 at 800x1333)
 constexpr int NT_SMALL = 256;  // box-head candidates (~2000 per image): this launch sits on the step's chain between NMS and ROIAlign; four waves
                                // keep its ~20 workgroup barriers (radix select) cheap
 
