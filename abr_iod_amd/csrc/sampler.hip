@@ -251,8 +251,14 @@ extern "C" int abr_sample_pos_neg(const void* labels, int labels_are_int64, int 
     ABR_REQUIRE(labels && pos_idx && neg_idx && counts, "sample_pos_neg: null pointer");
     hipStream_t st = abr::as_stream(stream);
     const bool small = n <= 8192;
-    const int has_top = n <= 60000;                      // one LDS byte per candidate (static arrays + this stay under the default 64 KB)
+    const int has_top = n <= 150000;                     // one LDS byte per candidate (160 KB per compute unit; the large request is enabled below)
     const size_t lds = has_top ? (size_t)((n + 15) & ~15) : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel<float, NT_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 150016);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel<int64_t, NT_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 150016);
+        attr_set = true;
+    }
 #define ABR_SAMPLE_LAUNCH(T, NTHR) sample_kernel<T, NTHR><<<N, NTHR, lds, st>>>((const T*)labels, n, stride, batch_size, max_pos, seed, first_image, \
                                                                                 index_offset_per_image, pos_idx, neg_idx, counts, has_top)
     if (labels_are_int64) { if (small) ABR_SAMPLE_LAUNCH(int64_t, NT_SMALL); else ABR_SAMPLE_LAUNCH(int64_t, NT_BIG); }

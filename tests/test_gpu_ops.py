@@ -466,11 +466,12 @@ def test_fused_sampler():
     assert hits[labels[1] < 1].sum() == 0
 
 
-@pytest.mark.parametrize("n", [3000, 8192, 8193, 36000])
+@pytest.mark.parametrize("n", [3000, 8192, 8193, 36000, 63000, 70000, 151000])
 def test_fused_sampler_draw_is_the_k_smallest_keys(n):
     """The draw is defined (csrc/sampler.hip): every candidate of a class gets the 32-bit key hash(seed, image, index); the k smallest keys
     (ties by index) are taken and written in ascending index order.  Restated in numpy and compared exactly, for both workgroup sizes
-    (n <= 8192: 256 threads, above: 1024) and per-wave ranges that do not divide n."""
+    (n <= 8192: 256 threads, above: 1024), per-wave ranges that do not divide n, more than 64 visits per lane (70000: the labels are re-read) and
+    more candidates than the LDS byte cache holds (151000: every pass hashes)."""
     from abr_iod_amd import ops
     rng = np.random.default_rng(n)
     N, batch, max_pos, seed = 3, 256, 128, 987654321
