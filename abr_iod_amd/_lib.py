@@ -32,6 +32,9 @@ class ConvDesc(C.Structure):
         ("wino_v", _vp),
         ("w_planes", _vp),
         ("w_version", _i64),
+        ("x_amax", _vp), ("x_amax_epoch", C.c_uint32),
+        ("gy_amax", _vp), ("gy_amax_epoch", C.c_uint32),
+        ("out_amax", _vp), ("out_amax_epoch", C.c_uint32),
     ]
 
 
@@ -66,6 +69,9 @@ _SIGS = {
     "abr_loss_sum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "abr_loss_sum_backward": (_i, [_vp, _i, _vp, _vp, _vp]),
     "abr_gather_proposals": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "abr_h3_amax_alloc": (_i, [_vp, _vp]),
+    "abr_h3_amax": (_i, [_vp, _i64, _vp, C.c_uint32, _vp]),
+    "abr_h3_range_stats": (_i, [_vp, _i, _vp]),
     "abr_x6_range_flags": (_i, [_vp, _i, _vp]),
     "abr_x6_range_flags_async": (_i, [_vp, _vp]),
     "abr_x6_range_flags_to_device": (_i, [_vp, _vp]),

@@ -69,20 +69,23 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Off by default.
 enum ProfId { PROF_IGEMM_128x128 = 0, PROF_IGEMM_128x64, PROF_IGEMM_64x64, PROF_IGEMM_SMALLC, PROF_WGRAD, PROF_ROIALIGN_FWD,
               PROF_ROIALIGN_BWD, PROF_IGEMM_BF16, PROF_WGRAD_BF16,
-              PROF_X6_128x128, PROF_X6_128x64, PROF_X6_64x64, PROF_X6W_128x128, PROF_X6W_128x64, PROF_X6W_64x64, PROF_X6W_TAIL64, PROF_COUNT };   // (ids are positions in bench.py's PROF_NAMES)
+              PROF_X6_128x128, PROF_X6_128x64, PROF_X6_64x64, PROF_X6W_128x128, PROF_X6W_128x64, PROF_X6W_64x64, PROF_X6W_TAIL64,
+              PROF_H3W_128x128, PROF_H3W_128x64, PROF_H3W_64x64, PROF_WGRAD_H3, PROF_COUNT };   // (ids are positions in bench.py's PROF_NAMES)
 // Winograd F(4x4,3x3) transform kernels (conv_winograd.hip); the batched GEMM between them is launched by conv_igemm.hip
-int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, hipStream_t st);
+struct AmaxRef;
+// `amax` (optional, here and below): the kernel also writes max |value it stored| into that amax word (f16x3 consumers read it)
+int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, hipStream_t st, const AmaxRef* amax = nullptr);
 int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st);
 int wino_output_transform(const float* M, int B, int H, int W, int N, const float* scale, const float* bias, int relu, const float* mask,
-                          float* out, hipStream_t st);
-int wino_outgrad_transform(const float* gy, int B, int H, int W, int N, float* Mg, hipStream_t st);
+                          float* out, hipStream_t st, const AmaxRef* amax = nullptr);
+int wino_outgrad_transform(const float* gy, int B, int H, int W, int N, float* Mg, hipStream_t st, const AmaxRef* amax = nullptr);
 int wino_wgrad_inverse(const float* dU, int N, int C, const float* scale, float* dw, hipStream_t st);
 float* wino_ws(hipStream_t st, size_t floats);
 // cached Winograd-domain weights U [36][N][C] of the tensor at `w` (abr_conv_desc::w_version != 0), transformed on `st` when (w, version)
 // has not been seen; nullptr = no memory (transform into scratch instead)
 float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t st);
 // the cache behind it, for every kind of data derived from a weight tensor (conv_winograd.hip): `fill(buf)` writes `bytes` on `st` (0 = ok)
-enum DerivedKind { DERIVED_WINO_U = 0, DERIVED_X6_PLANES = 1, DERIVED_WINO_U_X6_PLANES = 2 };
+enum DerivedKind { DERIVED_WINO_U = 0, DERIVED_X6_PLANES = 1, DERIVED_WINO_U_X6_PLANES = 2, DERIVED_H3_PLANES = 3, DERIVED_WINO_U_H3_PLANES = 4 };
 void* derived_cached(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, const std::function<int(void*)>& fill);
 // The same in two halves, for fills that are launched together (abr_conv_prepare_batch): derived_acquire returns the entry's buffer and, when the
 // entry does not hold `version` yet, a token (the refill is already ordered behind the entry's readers); the caller fills every such buffer on `st`
@@ -103,6 +106,7 @@ struct PrepJob {
 };
 int prep_transpose_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);   // conv_igemm.hip
 int prep_pack_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);        // conv_igemm.hip
+int prep_pack_h3_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);     // conv_igemm.hip (f16x3 planes: one workgroup per 32-row block)
 int prep_wino_u_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);      // conv_winograd.hip (C % 4 == 0 jobs only)
 __device__ __forceinline__ int prep_find_job(const PrepJob* jobs, int njobs, int block) {
     int lo = 0, hi = njobs - 1;
@@ -124,6 +128,90 @@ __device__ __forceinline__ void x6_report(unsigned bmin, float nonfin, unsigned*
     if (bmin < kX6TinyB) f |= ABR_X6_FLAG_TINY;       // a non-zero operand below 2^-110: its low bf16 planes leave the normal range
     if (nonfin != nonfin) f |= ABR_X6_FLAG_NONFINITE;  // inf / nan operand: inf - inf poisons the low planes (NaN where fp32 gives inf)
     if (f) atomicOr(flags, f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// f16x3 arithmetic (ABR_MATH_F16X3, round 5): x = s (h0 + h1), h0 = fp16(x / s), h1 = fp16(x / s - h0), s = the power of two that puts the
+// tensor's (weight row's) largest magnitude in [2^14, 2^15); x w = s_x s_w (h0 g0 + h0 g1 + h1 g0), three exact products per multiply-add on
+// v_mfma_f32_32x32x16_f16, fp32 accumulation.  The operand's amax travels in an AMAX WORD: 64 bits = (epoch << 32) | bits of a non-negative
+// float, written with ONE 64-bit atomic max per workgroup by whatever kernel produces the tensor; a later epoch always wins, so a word is
+// re-used without ever being cleared, and a reader that finds another epoch than the one it was told knows the word is not its tensor's.
+// Words come from a zero-initialised device ring owned by the library (h3_amax_alloc).
+// ------------------------------------------------------------------------------------------------------------------------
+struct AmaxRef {
+    unsigned long long* word;   // nullptr = none
+    unsigned epoch;
+};
+constexpr unsigned kH3RangeBinades = 18;   // elements below amax * 2^-18 keep an ABSOLUTE accuracy of 2^-40 amax instead of 2^-22 relative
+AmaxRef h3_amax_alloc();                   // a fresh (word, epoch) of the ring; word == nullptr: no device memory
+// max |x| of n floats into `ref` (one pass over x; the fallback for tensors whose producer did not emit its amax)
+int h3_amax_reduce(const float* x, int64_t n, AmaxRef ref, hipStream_t st);
+// amax refs of tensors the LIBRARY wrote and will read back through a caller-held buffer (a Winograd-domain input kept for the weight gradient)
+void h3_amax_remember(const void* tensor, AmaxRef ref);
+AmaxRef h3_amax_recall(const void* tensor);
+
+// bits of the amax in `word` if it carries `epoch`, else 0xFFFFFFFF (stale: the caller raises ABR_H3_FLAG_STALE and treats it as 0)
+__device__ __forceinline__ unsigned h3_amax_load(const unsigned long long* word, unsigned epoch) {
+    const unsigned long long v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned)(v >> 32) == epoch ? (unsigned)v : 0xFFFFFFFFu;
+}
+// (s, 1 / s) for an amax given by its bits; a non-finite amax gives s = 1 (the caller flags it)
+__device__ __forceinline__ void h3_scales(unsigned amax_bits, float& s, float& inv_s) {
+    int e = (int)(amax_bits >> 23);
+    if (amax_bits == 0u || e >= 255) { s = 1.f; inv_s = 1.f; return; }
+    e = e < 15 ? 15 : e;                                  // amax < 2^-112: the scale stops following (operands then sit lower in fp16's range)
+    s = __uint_as_float((unsigned)(e - 14) << 23);        // amax / s in [2^14, 2^15)
+    inv_s = __uint_as_float((unsigned)(268 - e) << 23);
+}
+// block-wide max of a non-negative (or NaN) per-thread value given by its BITS, sent to the amax word by one atomic (all threads of the
+// workgroup call it; blockDim.x a multiple of 64, <= 1024)
+__device__ __forceinline__ void h3_amax_emit(unsigned long long* word, unsigned epoch, unsigned local_bits) {
+    __shared__ unsigned sm[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local_bits = max(local_bits, (unsigned)__shfl_xor((int)local_bits, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = local_bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = sm[0];
+        for (unsigned i = 1; i < (blockDim.x >> 6); i++) m = max(m, sm[i]);
+        // Thousands of workgroups, one word: an atomic per workgroup would queue on one address (~12 ns each: a 9000-workgroup launch of 45 us
+        // stretched to 150).  The word is read first and the atomic skipped when it already holds this epoch with at least this value -- a stale
+        // read can only be SMALLER than the truth (the max grows monotonically inside an epoch), so skipping is always safe.
+        const unsigned long long mine = ((unsigned long long)epoch << 32) | m;
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mine) atomicMax(word, mine);
+    }
+}
+// two-term fp16 split of a pair of fp32 values: four v_fma_mix (h0 = f16(x * inv_s), h1 = f16(fma(x, inv_s, -h0)): both exact before the one
+// rounding to fp16); o0 / o1 = the pair's h0 / h1 as packed halves
+__device__ __forceinline__ void h3_split2(const float a, const float b, const float inv_s, unsigned& o0, unsigned& o1) {
+    unsigned h0, h1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h0) : "v"(a), "v"(inv_s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h0) : "v"(b), "v"(inv_s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(h1) : "v"(a), "v"(inv_s), "v"(h0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(h1) : "v"(b), "v"(inv_s), "v"(h0));
+    o0 = h0; o1 = h1;
+}
+// Range report of an f16x3 operand (one call per inspecting WAVE, all lanes): nsmall = this lane's count of non-zero elements more than 18
+// binades below the amax (h3_small_threshold), inspected = elements this wave looked at.  Flags as in include/abr_iod_hip.h; the two counts are
+// added to the device statistics behind abr_h3_range_stats.
+constexpr int kH3StatSlots = 256;     // the small-element counts are spread over this many words (one address would serialise the atomics)
+unsigned long long* h3_stats_ptr();   // device [kH3StatSlots] partial counts of small elements
+void h3_stats_inspected(double n);    // host-side count of inspected operand elements (the launch functions know it)
+__device__ __forceinline__ unsigned h3_small_threshold(unsigned amax_bits) {   // compare (bits << 1) - 1 of an element against this (zeros map to 0xFFFFFFFF)
+    const unsigned e = amax_bits >> 23;
+    return (e >= 255u || e <= kH3RangeBinades) ? 0u : ((e - kH3RangeBinades) << 24);
+}
+__device__ __forceinline__ void h3_report(unsigned amax_bits, unsigned nsmall, unsigned* flags, unsigned long long* stats) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nsmall += (unsigned)__shfl_xor((int)nsmall, o, 64);
+    if ((threadIdx.x & 63) != 0) return;
+    unsigned f = 0;
+    if (amax_bits == 0xFFFFFFFFu) f |= ABR_H3_FLAG_STALE;
+    else if ((amax_bits >> 23) >= 255u) f |= ABR_X6_FLAG_NONFINITE;
+    else if (nsmall) f |= ABR_H3_FLAG_SMALL;
+    if (f && (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & f) != f) atomicOr(flags, f);   // (the bits are sticky: set once)
+    if (stats && nsmall) atomicAdd(stats + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (kH3StatSlots - 1)), (unsigned long long)nsmall);
 }
 
 // x - y as ONE v_sub_f32: the exact-split residuals must not be packed into v_pk_add_f32 (slow beside MFMAs, MI355X_MICROARCH.md)

@@ -3,6 +3,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -246,6 +248,105 @@ extern "C" int abr_x6_range_flags_to_device(uint32_t* out_device, void* stream) 
         abr::set_error("x6_range_flags_to_device: copy failed");
         return ABR_E_LAUNCH;
     }
+    return ABR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- f16x3: amax words (common.h)
+namespace {
+__global__ __launch_bounds__(256) void h3_amax_kernel(const float* __restrict__ x, int64_t n, unsigned long long* word, unsigned epoch) {
+    unsigned m = 0;
+    const int64_t n4 = n >> 2;
+    const uint4* x4 = reinterpret_cast<const uint4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = x4[i];
+        m = max(max(m, max(v.x & 0x7FFFFFFFu, v.y & 0x7FFFFFFFu)), max(v.z & 0x7FFFFFFFu, v.w & 0x7FFFFFFFu));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(x[(n4 << 2) + threadIdx.x]) & 0x7FFFFFFFu);
+    abr::h3_amax_emit(word, epoch, m);
+}
+std::mutex g_amax_mu;
+unsigned long long* g_amax_ring = nullptr;
+uint64_t g_amax_count = 0;
+std::map<const void*, abr::AmaxRef> g_amax_map;
+}  // namespace
+namespace abr {
+static std::mutex g_h3_stats_mu;
+static double g_h3_inspected = 0.0;
+unsigned long long* h3_stats_ptr() {
+    static unsigned long long* p = nullptr;
+    std::lock_guard<std::mutex> g(g_h3_stats_mu);
+    if (!p) {
+        if (hipMalloc(&p, kH3StatSlots * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(p, 0, kH3StatSlots * sizeof(unsigned long long));
+    }
+    return p;
+}
+void h3_stats_inspected(double n) {
+    std::lock_guard<std::mutex> g(g_h3_stats_mu);
+    g_h3_inspected += n;
+}
+AmaxRef h3_amax_alloc() {
+    std::lock_guard<std::mutex> g(g_amax_mu);
+    if (!g_amax_ring) {
+        if (hipMalloc(&g_amax_ring, (size_t)ABR_H3_AMAX_RING * 8) != hipSuccess) { g_amax_ring = nullptr; return AmaxRef{nullptr, 0}; }
+        (void)hipMemset(g_amax_ring, 0, (size_t)ABR_H3_AMAX_RING * 8);
+    }
+    const uint64_t c = g_amax_count++;
+    // epochs grow with every allocation, so a word's later owner always outranks its earlier ones in the 64-bit max (0 is never used: a cleared
+    // word carries no epoch); 2^32 allocations ~ 10^7 training steps
+    return AmaxRef{g_amax_ring + c % ABR_H3_AMAX_RING, (unsigned)(c + 1)};
+}
+int h3_amax_reduce(const float* x, int64_t n, AmaxRef ref, hipStream_t st) {
+    if (!ref.word) return 1;
+    const int64_t blocks = std::min<int64_t>(std::max<int64_t>((n / 4 + 255) / 256, 1), 2048);
+    h3_amax_kernel<<<(unsigned)blocks, 256, 0, st>>>(x, n, ref.word, ref.epoch);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+void h3_amax_remember(const void* tensor, AmaxRef ref) {
+    std::lock_guard<std::mutex> g(g_amax_mu);
+    if (g_amax_map.size() > 4096) g_amax_map.clear();   // (refs older than the ring are dead anyway)
+    g_amax_map[tensor] = ref;
+}
+AmaxRef h3_amax_recall(const void* tensor) {
+    std::lock_guard<std::mutex> g(g_amax_mu);
+    auto it = g_amax_map.find(tensor);
+    if (it == g_amax_map.end() || g_amax_count - (uint64_t)it->second.epoch >= (uint64_t)ABR_H3_AMAX_RING) return AmaxRef{nullptr, 0};
+    return it->second;
+}
+}  // namespace abr
+extern "C" int abr_h3_amax_alloc(uint64_t** word_out, uint32_t* epoch_out) {
+    ABR_REQUIRE(word_out && epoch_out, "h3_amax_alloc: null pointer");
+    const abr::AmaxRef r = abr::h3_amax_alloc();
+    ABR_REQUIRE(r.word, "h3_amax_alloc: no device memory");
+    *word_out = reinterpret_cast<uint64_t*>(r.word);
+    *epoch_out = r.epoch;
+    return ABR_OK;
+}
+extern "C" int abr_h3_range_stats(uint64_t* out_host, int reset, void* stream) {
+    ABR_REQUIRE(out_host, "h3_range_stats: null pointer");
+    unsigned long long* p = abr::h3_stats_ptr();
+    ABR_REQUIRE(p, "h3_range_stats: no device memory");
+    hipStream_t st = abr::as_stream(stream);
+    unsigned long long slots[abr::kH3StatSlots];
+    if (hipMemcpyAsync(slots, p, sizeof slots, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        abr::set_error("h3_range_stats: read-back failed");
+        return ABR_E_LAUNCH;
+    }
+    unsigned long long small = 0;
+    for (int i = 0; i < abr::kH3StatSlots; i++) small += slots[i];
+    out_host[0] = small;
+    {
+        std::lock_guard<std::mutex> g(abr::g_h3_stats_mu);
+        out_host[1] = (uint64_t)abr::g_h3_inspected;
+        if (reset) abr::g_h3_inspected = 0.0;
+    }
+    if (reset) (void)hipMemsetAsync(p, 0, sizeof slots, st);
+    return ABR_OK;
+}
+extern "C" int abr_h3_amax(const float* x, int64_t n, uint64_t* word, uint32_t epoch, void* stream) {
+    ABR_REQUIRE(word && n >= 0 && (n == 0 || x), "h3_amax: bad args");
+    ABR_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "h3_amax: x must be 16-byte aligned");
+    ABR_REQUIRE(abr::h3_amax_reduce(x, n, abr::AmaxRef{reinterpret_cast<unsigned long long*>(word), epoch}, abr::as_stream(stream)) == 0, "h3_amax: launch failed");
     return ABR_OK;
 }
 

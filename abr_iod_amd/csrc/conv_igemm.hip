@@ -91,13 +91,25 @@ struct ConvP {
     int wp_nblocks;        // 32-row blocks in one packed matrix
     unsigned* x6_flags;      // bf16x6: device word of the range guard (abr::x6_flags_ptr)
     int64_t w_version;       // abr_conv_desc::w_version (0 = nothing derived from w may be cached)
-    int nprod;               // 6 = bf16x6 (exact three-way split, six products); 1 = ABR_MATH_BF16 on the same kernels: plane 0 of both operands, one product
+    int nprod;               // 6 = bf16x6 (exact three-way split, six products); 1 = ABR_MATH_BF16 on the same kernels: plane 0 of both operands, one product;
+                             // 3 = ABR_MATH_F16X3 (two-term fp16 split, three products: common.h)
+    // f16x3: the A operand's amax word (scale of its split), the per-row scales of the packed weight planes (folded into the epilogue's column
+    // scale; batched mode: Cout per batch), and -- any arithmetic -- the amax word the epilogue feeds with max |out|
+    const unsigned long long* a_amax;
+    unsigned a_epoch;
+    const float* w_scales;
+    unsigned long long* out_amax;
+    unsigned out_epoch;
+    unsigned long long* h3_stats;   // f16x3 range statistics (abr::h3_stats_ptr) or nullptr
 };
 
 
+// Returns the bits of max |value stored| by this thread (for the output's amax word).  wsc / sa (f16x3): per-column scales of the packed weight
+// planes and the A operand's scale -- both powers of two, multiplied into the column scale, so the result equals scaling the accumulators first.
 template <int TM, int TN>
-__device__ __forceinline__ void epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][TN], float* ep, int m_base, int n_base, int lane,
-                                              float* __restrict__ out) {
+__device__ __forceinline__ unsigned epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][TN], float* ep, int m_base, int n_base, int lane,
+                                                  float* __restrict__ out, const float* __restrict__ wsc = nullptr, const float sa = 1.f) {
+    unsigned amax_bits = 0;
     // one 32-row block of the wave tile at a time: the staging slice is 32 x (WC + EPAD) floats per wave (8.7 KB at WC = 64), so
     // the whole workgroup needs 34.8 KB -- it fits the single-buffered operand LDS as well as the double-buffered one.
     constexpr int WC = TN * 32, EP = WC + EPAD;
@@ -107,15 +119,22 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][
     const int c4 = (lane % LPR) * 4;
     const int ncol = n_base + c4;
     const bool vec_ok = (p.Cout % 4 == 0) && (ncol + 3 < p.Cout);
-    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), bi4 = make_float4(0.f, 0.f, 0.f, 0.f), lo4 = make_float4(1.f, 1.f, 1.f, 1.f);
     if (ncol < p.Cout) {
         float* s_ = reinterpret_cast<float*>(&sc4);
+        float* l_ = reinterpret_cast<float*>(&lo4);
         float* b_ = reinterpret_cast<float*>(&bi4);
 #pragma unroll
         for (int e = 0; e < 4; e++)
             if (ncol + e < p.Cout) {
                 if (p.scale) s_[e] = p.scale[ncol + e];
                 if (p.bias) b_[e] = p.bias[ncol + e];
+                if (wsc) {   // f16x3: two exact power-of-two steps, the smaller factor first -- their PRODUCT, or the accumulator times the
+                             // larger one, could leave fp32's range although neither the accumulator nor the result does
+                    const float ws = wsc[ncol + e];
+                    l_[e] = fminf(sa, ws);
+                    s_[e] *= fmaxf(sa, ws);
+                }
             }
     }
 #pragma unroll
@@ -140,6 +159,7 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][
                 row_off = (size_t)m * p.Cout;
             }
             float4 v = *reinterpret_cast<const float4*>(ep + row * EP + c4);
+            if (wsc) { v.x *= lo4.x; v.y *= lo4.y; v.z *= lo4.z; v.w *= lo4.w; }
             v.x = v.x * sc4.x + bi4.x; v.y = v.y * sc4.y + bi4.y; v.z = v.z * sc4.z + bi4.z; v.w = v.w * sc4.w + bi4.w;
             float* o = out + row_off + ncol;
             if (vec_ok) {
@@ -157,6 +177,9 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][
                     v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f; v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
                 }
                 *reinterpret_cast<float4*>(o) = v;
+                if (p.out_amax)
+                    amax_bits = max(max(amax_bits, max(__float_as_uint(v.x) & 0x7FFFFFFFu, __float_as_uint(v.y) & 0x7FFFFFFFu)),
+                                    max(__float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu));
             } else {
                 const float* vv = reinterpret_cast<const float*>(&v);
 #pragma unroll
@@ -167,10 +190,12 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][
                     if (p.relu) t = fmaxf(t, 0.f);
                     if (p.mask) t = p.mask[row_off + ncol + e] > 0.f ? t : 0.f;
                     o[e] = t;
+                    amax_bits = max(amax_bits, __float_as_uint(t) & 0x7FFFFFFFu);
                 }
             }
         }
     }
+    return amax_bits;
 }
 
 // SMALL_C: Cin is not a multiple of 32 (the 3->4 padded stem): (r,s,c) is derived per 16 B slot.
@@ -414,7 +439,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
     // ~0.9 TB/s effective, 20-25 % of the kernel at K <= 1024).  Instead each wave transposes its TM*32 x TN*32 tile through its
     // own slice of the (now idle) operand LDS and streams whole rows: 16 B per lane, 128-256 B contiguous per row, with the
     // residual / mask read the same way.  Waves only touch their own slice, so no workgroup barrier is needed here.
-    epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    const unsigned ob = epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    if (p.out_amax) abr::h3_amax_emit(p.out_amax, p.out_epoch, ob);
     abr::prof_stamp_end(p.prof_ts);
 }
 
@@ -430,6 +456,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
 // fp32 sources), not by the matrix pipe.
 // ------------------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -591,7 +618,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvP p, con
         compute_tile(kt & 1);
     }
     __syncthreads();  // the epilogue reuses the operand LDS
-    epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    const unsigned ob = epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    if (p.out_amax) abr::h3_amax_emit(p.out_amax, p.out_epoch, ob);
     abr::prof_stamp_end(p.prof_ts);
 }
 
@@ -807,7 +835,8 @@ __global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const
     compute_tile();
     if (chk_a | chk_b) abr::x6_report(bmin, nonfin, p.x6_flags);
     __syncthreads();  // the epilogue reuses the operand LDS
-    epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    const unsigned ob = epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    if (p.out_amax) abr::h3_amax_emit(p.out_amax, p.out_epoch, ob);
     abr::prof_stamp_end(p.prof_ts);
 }
 
@@ -839,15 +868,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     float* out = out_;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int NA = BM / 32;
-    constexpr int NPL = NP == 1 ? 1 : 3;   // operand planes in use
+    constexpr bool H3 = NP == 3;           // ABR_MATH_F16X3: two fp16 planes per operand, three products (common.h)
+    constexpr int NPL = NP == 1 ? 1 : (H3 ? 2 : 3);   // operand planes in use
+    constexpr int NPW = H3 ? 2 : 3;        // planes per k-step in the packed weights (the bf16 mode reads plane 0 of the bf16x3 packing)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     abr::prof_stamp_begin(p.prof_ts);
     __bf16* As = reinterpret_cast<__bf16*>(smem);  // [3][BM][LDX]
 
     int tile = (int)abr::xcd_remap(blockIdx.x, gridDim.x);
     const char* wp = reinterpret_cast<const char*>(p.w_planes);
+    int wsc_bt = 0;
     if (p.nbatch > 1) {
         const int bt = tile / p.tiles_pb;
+        wsc_bt = bt;
         tile -= bt * p.tiles_pb;
         x += bt * p.a_bs; out += bt * p.o_bs; wp += bt * p.wp_bs;
     }
@@ -898,7 +931,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int nb = (n0 + wn * (TN * 32)) / 32 + j;
-        bo[j] = nb < p.wp_nblocks ? (unsigned)(((size_t)nb * KS * 3 * 64 + lane) * 16) : kOOB;
+        bo[j] = nb < p.wp_nblocks ? (unsigned)(((size_t)nb * KS * NPW * 64 + lane) * 16) : kOOB;
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 ra[NA];
@@ -926,13 +959,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
         for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int pl = 0; pl < NPL; pl++) fbr[u][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rwp, (int)bo[j], (ks * 3 + pl) * 1024, 0);
+            for (int pl = 0; pl < NPL; pl++) fbr[u][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rwp, (int)bo[j], (ks * NPW + pl) * 1024, 0);
     };
     // range guard: the A rows are inspected by the workgroups of the first n-tile column; the weights were inspected when they were packed
     const bool chk_a = p.x6_flags && tile_n == 0;
     unsigned bmin = 0xFFFFFFFFu;
     float nonfin = 0.f;
+    // f16x3: the scale of the A operand's split from its amax word (every workgroup reads the same 8 bytes)
+    unsigned a_bits = 0;
+    float sa = 1.f, inv_sa = 1.f;
+    if constexpr (H3) {
+        a_bits = abr::h3_amax_load(p.a_amax, p.a_epoch);
+        abr::h3_scales(a_bits, sa, inv_sa);
+    }
+    const unsigned small_thr = H3 ? abr::h3_small_threshold(a_bits) : 0u;
+    unsigned nsmall = 0;
     auto store_a = [&]() {
+        if constexpr (H3) {
+            if (chk_a) {
+#pragma unroll
+                for (int i = 0; i < NA; i++) {
+                    const u32x4 v = ra[i];
+                    nsmall += (unsigned)(((v.x << 1) - 1u) < small_thr) + (unsigned)(((v.y << 1) - 1u) < small_thr) + (unsigned)(((v.z << 1) - 1u) < small_thr) +
+                              (unsigned)(((v.w << 1) - 1u) < small_thr);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+                const u32x4 v = ra[i];
+                __bf16* dst = As + (srow + 32 * i) * LDX + kq * 4;
+                uint2 o0, o1;
+                abr::h3_split2(__uint_as_float(v.x), __uint_as_float(v.y), inv_sa, o0.x, o1.x);
+                abr::h3_split2(__uint_as_float(v.z), __uint_as_float(v.w), inv_sa, o0.y, o1.y);
+                *reinterpret_cast<uint2*>(dst) = o0;
+                *reinterpret_cast<uint2*>(dst + BM * LDX) = o1;
+            }
+            return;
+        }
         if (chk_a) {
 #pragma unroll
             for (int i = 0; i < NA; i++) {
@@ -980,13 +1043,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             for (int j = 0; j < TN; j++)
 #pragma unroll
                 for (int pl = 0; pl < NPL; pl++) fb[j][pl] = *reinterpret_cast<const bf16x8*>(&fbr[u][j][pl]);
-            constexpr int pa[6] = {NP == 1 ? 0 : 2, 0, 1, 1, 0, 0}, pb[6] = {0, NP == 1 ? 0 : 2, 1, 0, 1, 0};   // (A plane, B plane) of the products, smallest first
+            constexpr int pa[6] = {NP == 1 ? 0 : (H3 ? 1 : 2), 0, H3 ? 0 : 1, 1, 0, 0}, pb[6] = {0, NP == 1 ? 0 : (H3 ? 1 : 2), H3 ? 0 : 1, 0, 1, 0};   // (A plane, B plane) of the products, smallest first
 #pragma unroll
             for (int t = 0; t < NP; t++)
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
-                    for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa[t]], fb[j][pb[t]], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; j++) {
+                        if constexpr (H3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][pa[t]]), __builtin_bit_cast(f16x8, fb[j][pb[t]]), acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa[t]], fb[j][pb[t]], acc[i][j], 0, 0, 0);
+                    }
             if (kt_next < nk) load_b(kt_next, u);
             if (u == 0) __builtin_amdgcn_sched_barrier(0);   // keeps step 0's refill ahead of step 1's MFMAs (lab7: +3 %)
         }
@@ -1005,9 +1071,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         __syncthreads();
     }
     compute_tile(nk);
-    if (chk_a) abr::x6_report(bmin, nonfin, p.x6_flags);
+    if constexpr (H3) {
+        if (chk_a) abr::h3_report(a_bits, nsmall, p.x6_flags, p.h3_stats);
+    } else {
+        if (chk_a) abr::x6_report(bmin, nonfin, p.x6_flags);
+    }
     __syncthreads();  // the epilogue reuses the operand LDS
-    epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
+    const float* wsc = nullptr;
+    if constexpr (H3) wsc = p.w_scales + (p.nbatch > 1 ? (size_t)wsc_bt * p.Cout : 0);
+    const unsigned ob = epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out, wsc, sa);
+    if (p.out_amax) abr::h3_amax_emit(p.out_amax, p.out_epoch, ob);
     abr::prof_stamp_end(p.prof_ts);
 }
 
@@ -1160,7 +1233,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         sum[0][0][r] = v;
     }
     __syncthreads();   // every partial has been read: the regions become the epilogue's staging
-    epilogue_rows<1, 1>(p, sum, reinterpret_cast<float*>(region), m0 + (wave >> 1) * 32, n0 + (wave & 1) * 32, lane, out);
+    const unsigned ob = epilogue_rows<1, 1>(p, sum, reinterpret_cast<float*>(region), m0 + (wave >> 1) * 32, n0 + (wave & 1) * 32, lane, out);
+    if (p.out_amax) abr::h3_amax_emit(p.out_amax, p.out_epoch, ob);
     abr::prof_stamp_end(p.prof_ts);
 }
 
@@ -1486,6 +1560,82 @@ static int x6_pack(const float* w, int64_t rows, int K, void* planes, hipStream_
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// f16x3 weight planes: fp32 matrix [rows][K] (K % 16 == 0) -> per-row scale s_n (the power of two with rowmax / s_n in [2^14, 2^15)), two
+// fragment-packed fp16 planes g0 = fp16(w / s_n), g1 = fp16(w / s_n - g0) in the order the MFMA consumes them -- chunk (nb, ks, pl) = 64 lanes x
+// 16 B at byte (((nb * K/16 + ks) * 2 + pl) * 64 + lane) * 16, lane l holding row nb*32 + (l & 31), k = ks*16 + (l >> 5)*8 .. +8 -- and, BEHIND the
+// planes (at byte rows32 * K * 4), the scales s_n as rows32 floats (padded rows: zeros, scale 1).  One workgroup = one 32-row block: a first
+// pass over its K columns finds the row maxima, a second one (L2 hits) splits and stores.  A non-finite weight raises ABR_X6_FLAG_NONFINITE.
+// ------------------------------------------------------------------------------------------------------------------------
+static int64_t h3_planes_bytes(int64_t rows, int64_t K) { return (rows + 31) / 32 * 32 * K * 4; }
+__device__ __forceinline__ size_t h3_planes_bytes_dev(int rows, int K) { return (size_t)((rows + 31) / 32 * 32) * (size_t)K * 4; }
+static int64_t h3_packed_bytes(int64_t rows, int64_t K) { return h3_planes_bytes(rows, K) + (rows + 31) / 32 * 32 * 4; }
+
+__device__ __forceinline__ void h3_pack_block(const float* __restrict__ w, int rows, int K, int nb, uint4* __restrict__ planes, float* __restrict__ scales,
+                                              unsigned* flags) {
+    __shared__ float t[32][68];
+    __shared__ unsigned rmax[32];
+    const int tid = threadIdx.x;
+    if (tid < 32) rmax[tid] = 0u;
+    __syncthreads();
+    const int r0 = tid >> 4, c = (tid & 15) * 4;   // rows r0, r0 + 16; 64 columns per pass
+    unsigned m[2] = {0u, 0u};
+    for (int k0 = 0; k0 < K; k0 += 64)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int row = nb * 32 + r0 + 16 * h;
+            if (row < rows && k0 + c < K) {
+                const uint4 v = *reinterpret_cast<const uint4*>(w + (size_t)row * K + k0 + c);
+                m[h] = max(max(m[h], max(v.x & 0x7FFFFFFFu, v.y & 0x7FFFFFFFu)), max(v.z & 0x7FFFFFFFu, v.w & 0x7FFFFFFFu));
+            }
+        }
+    atomicMax(&rmax[r0], m[0]);
+    atomicMax(&rmax[r0 + 16], m[1]);
+    __syncthreads();
+    if (tid < 32) {
+        float sc, inv;
+        abr::h3_scales(rmax[tid], sc, inv);
+        scales[nb * 32 + tid] = sc;
+        if (flags && (rmax[tid] >> 23) >= 255u) atomicOr(flags, ABR_X6_FLAG_NONFINITE);
+    }
+    const int ksl = tid >> 6, lane = tid & 63;
+    float sc, inv;
+    abr::h3_scales(rmax[lane & 31], sc, inv);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int r = r0 + 16 * h, row = nb * 32 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows && k0 + c < K) v = *reinterpret_cast<const float4*>(w + (size_t)row * K + k0 + c);
+            *reinterpret_cast<float4*>(&t[r][c]) = v;
+        }
+        __syncthreads();
+        const int ks = k0 / 16 + ksl;
+        if (ks * 16 >= K) continue;
+        const float* src = &t[lane & 31][ksl * 16 + (lane >> 5) * 8];
+        unsigned h0[4], h1[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) abr::h3_split2(src[2 * e], src[2 * e + 1], inv, h0[e], h1[e]);
+        const size_t ch = ((size_t)nb * (K / 16) + ks) * 2;
+        planes[ch * 64 + lane] = make_uint4(h0[0], h0[1], h0[2], h0[3]);
+        planes[(ch + 1) * 64 + lane] = make_uint4(h1[0], h1[1], h1[2], h1[3]);
+    }
+}
+__global__ __launch_bounds__(256) void h3_pack_kernel(const float* __restrict__ w, int rows, int K, uint4* __restrict__ planes, unsigned* flags) {
+    h3_pack_block(w, rows, K, blockIdx.x, planes, reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + h3_planes_bytes_dev(rows, K)), flags);
+}
+__global__ __launch_bounds__(256) void h3_pack_multi_kernel(const abr::PrepJob* __restrict__ jobs, int njobs, unsigned* flags) {
+    const int j = abr::prep_find_job(jobs, njobs, blockIdx.x);
+    const abr::PrepJob jb = jobs[j];
+    uint4* planes = reinterpret_cast<uint4*>(jb.dst);
+    h3_pack_block(jb.src, jb.a, jb.b, blockIdx.x - jb.first_block, planes, reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + h3_planes_bytes_dev(jb.a, jb.b)), flags);
+}
+static int h3_pack(const float* w, int64_t rows, int K, void* planes, hipStream_t st) {
+    h3_pack_kernel<<<(unsigned)((rows + 31) / 32), 256, 0, st>>>(w, (int)rows, K, reinterpret_cast<uint4*>(planes), abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 template <int BM, int BN, int WM, int WN, int NP>
 int launch_x6w_np(const ConvP& p, const float* x, float* out, hipStream_t st) {
     ConvP q = p;
@@ -1499,14 +1649,16 @@ int launch_x6w_np(const ConvP& p, const float* x, float* out, hipStream_t st) {
         // (with its epilogue): 36864x2048x512 504 -> 495 us, x2048x1024 782 -> 768, x1024x2048 737 -> 728; shapes with <= 4 columns or weights that fit: unchanged.
         // ABR_X6_NGROUP: 0 = always m-major (rounds 2-3), n > 0 = force groups of n columns
         static const int forced = getenv("ABR_X6_NGROUP") ? atoi(getenv("ABR_X6_NGROUP")) : -1;
-        const double col_bytes = (double)BN * (double)p.K * (NP == 1 ? 2.0 : 6.0);
+        const double col_bytes = (double)BN * (double)p.K * (NP == 1 ? 2.0 : (NP == 3 ? 4.0 : 6.0));
         int g = 0;
         if (forced >= 0) g = forced;
         else if (col_bytes * q.tiles_n > 3.0 * 1048576.0) g = col_bytes <= 1.6 * 1048576.0 ? 4 : (col_bytes <= 3.2 * 1048576.0 ? 2 : 0);   // (measured: tools/dbg/ngroup_time.py)
         q.ngroup = (g > 0 && g < q.tiles_n) ? g : 0;
     }
     q.x6_flags = (NP != 1 && abr::x6_guard_enabled()) ? abr::x6_flags_ptr() : nullptr;   // (rounding to bf16 is defined for every finite value: no guard)
-    constexpr size_t lds_op = sizeof(__bf16) * (NP == 1 ? 1 : 3) * BM * LDX;
+    q.h3_stats = (NP == 3 && q.x6_flags) ? abr::h3_stats_ptr() : nullptr;
+    if (q.h3_stats) abr::h3_stats_inspected((double)q.tiles_m * BM * (double)p.K * q.nbatch);   // (the first n-tile column's workgroups inspect their A rows)
+    constexpr size_t lds_op = sizeof(__bf16) * (NP == 1 ? 1 : (NP == 3 ? 2 : 3)) * BM * LDX;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
     const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
     const bool plain = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
@@ -1517,19 +1669,22 @@ int launch_x6w_np(const ConvP& p, const float* x, float* out, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x6w_kernel<BM, BN, WM, WN, false, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    constexpr int prof_id = NP == 1 ? abr::PROF_IGEMM_BF16 : (BM == 128 ? (BN == 128 ? abr::PROF_X6W_128x128 : abr::PROF_X6W_128x64) : abr::PROF_X6W_64x64);
+    constexpr int prof_id = NP == 1 ? abr::PROF_IGEMM_BF16
+                            : NP == 3 ? (BM == 128 ? (BN == 128 ? abr::PROF_H3W_128x128 : abr::PROF_H3W_128x64) : abr::PROF_H3W_64x64)
+                                      : (BM == 128 ? (BN == 128 ? abr::PROF_X6W_128x128 : abr::PROF_X6W_128x64) : abr::PROF_X6W_64x64);
     q.prof_ts = abr::prof_stamp_slot(prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
     {   // algorithmic bytes: the input once (its own size, not the im2col's), the packed weights, the output, a fused residual / mask
         const double in_b = q.nbatch > 1 ? 4.0 * (double)p.M * p.K * q.nbatch : 4.0 * (double)p.B * p.H * p.W * p.Cin;
         const double out_b = 4.0 * (double)p.M * p.Cout * q.nbatch;
-        abr::prof_add_bytes(prof_id, in_b + (NP == 1 ? 2.0 : 6.0) * (double)p.Cout * p.K * q.nbatch + out_b * (1.0 + (p.residual ? 1.0 : 0.0) + (p.mask ? 1.0 : 0.0)));
+        abr::prof_add_bytes(prof_id, in_b + (NP == 1 ? 2.0 : (NP == 3 ? 4.0 : 6.0)) * (double)p.Cout * p.K * q.nbatch + out_b * (1.0 + (p.residual ? 1.0 : 0.0) + (p.mask ? 1.0 : 0.0)));
     }
     kern<<<(unsigned)(q.tiles_pb * q.nbatch), 256, lds, st>>>(q, x, out);
     return 0;
 }
 template <int BM, int BN, int WM, int WN>
 int launch_x6w(const ConvP& p, const float* x, float* out, hipStream_t st) {
-    return p.nprod == 1 ? launch_x6w_np<BM, BN, WM, WN, 1>(p, x, out, st) : launch_x6w_np<BM, BN, WM, WN, 6>(p, x, out, st);
+    return p.nprod == 1 ? launch_x6w_np<BM, BN, WM, WN, 1>(p, x, out, st)
+                        : (p.nprod == 3 ? launch_x6w_np<BM, BN, WM, WN, 3>(p, x, out, st) : launch_x6w_np<BM, BN, WM, WN, 6>(p, x, out, st));
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1803,7 +1958,7 @@ static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, fl
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * nb;
     const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64) * nb;
     static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
-    const bool wd = p.w_planes != nullptr && direct_on;
+    const bool wd = p.w_planes != nullptr && (direct_on || p.nprod == 3);   // (f16x3 has no in-kernel weight split: always weights-direct)
     static const int force = getenv("ABR_X6_TILE") ? atoi(getenv("ABR_X6_TILE")) : 0;   // experiments: 1 = 128x128, 2 = 128x64, 3 = 64x64
     static const int force_maxk = getenv("ABR_X6_TILE_MAXK") ? atoi(getenv("ABR_X6_TILE_MAXK")) : 1 << 30;
     // Short-K convs (K <= 256: the 1x1 convs of layer1-3 and their dgrads) take 64x64 tiles whatever the grid size: alone they are
@@ -1856,7 +2011,11 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
     // Winograd-domain weights: from the per-weight cache when the caller vouches for (w, w_version), else transformed into scratch.
     // bf16x6: the cached form is U's fragment-packed bf16x3 planes (36 matrices of Cout x Cin back to back: Cout % 32 == 0 makes the
     // 36 * Cout rows pack as ONE matrix whose 32-row blocks never straddle two batches), fed to the weights-direct kernel.
+    // f16x3: the same with two fp16 planes and one scale per row of U (h3_pack_kernel); without a weight version U is transformed and packed
+    // into scratch on every call.
     static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
+    const bool h3 = p.math == ABR_MATH_F16X3;
+    if (h3 && p.Cout % 32 != 0) return false;
     const void* Up = nullptr;
     if (p.math == ABR_MATH_BF16X6 && p.w_version && direct_on && p.Cout % 32 == 0) {
         Up = abr::derived_cached(w, abr::DERIVED_WINO_U_X6_PLANES, (size_t)x6_packed_bytes((int64_t)36 * p.Cout, p.Cin), p.w_version, st, [&](void* buf) {
@@ -1865,15 +2024,36 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
             return x6_pack(Uf, (int64_t)36 * p.Cout, p.Cin, buf, st);
         });
     }
-    float* Uc = (!Up && p.w_version) ? abr::wino_u_cached(w, p.Cout, p.Cin, p.w_version, st) : nullptr;
+    const size_t h3_up_floats = h3 ? (size_t)h3_packed_bytes((int64_t)36 * p.Cout, p.Cin) / 4 : 0;
+    if (h3 && p.w_version) {
+        Up = abr::derived_cached(w, abr::DERIVED_WINO_U_H3_PLANES, h3_up_floats * 4, p.w_version, st, [&](void* buf) {
+            float* Uf = abr::wino_ws(st, nU);
+            if (!Uf || abr::wino_weight_transform(w, p.Cout, p.Cin, Uf, st)) return 1;
+            return h3_pack(Uf, (int64_t)36 * p.Cout, p.Cin, buf, st);
+        });
+        if (!Up) return false;
+    }
+    float* Uc = (!Up && !h3 && p.w_version) ? abr::wino_u_cached(w, p.Cout, p.Cin, p.w_version, st) : nullptr;
     const bool have_u = Uc || Up;
-    float* ws = abr::wino_ws(st, (p.v_out ? 0 : nV) + (have_u ? 0 : nU) + nM);
+    const size_t h3_extra = (h3 && !Up) ? h3_up_floats : 0;   // f16x3 without a version: fp32 U AND its planes live in scratch
+    float* ws = abr::wino_ws(st, (p.v_out ? 0 : nV) + (have_u ? 0 : nU) + nM + h3_extra);
     if (!ws) return false;
     float* V = p.v_out ? p.v_out : ws;
     float* U = Uc ? Uc : ws + (p.v_out ? 0 : nV);
     float* Mm = ws + (p.v_out ? 0 : nV) + (have_u ? 0 : nU);
     if (!have_u && abr::wino_weight_transform(w, p.Cout, p.Cin, U, st)) return false;
-    if (abr::wino_input_transform(x, p.B, p.H, p.W, p.Cin, V, st)) return false;
+    if (h3 && !Up) {
+        void* planes = Mm + nM;
+        if (h3_pack(U, (int64_t)36 * p.Cout, p.Cin, planes, st)) return false;
+        Up = planes;
+    }
+    abr::AmaxRef v_ref{nullptr, 0};
+    if (h3) {
+        v_ref = abr::h3_amax_alloc();
+        if (!v_ref.word) return false;
+        if (p.v_out) abr::h3_amax_remember(p.v_out, v_ref);   // the weight gradient reads V back through the caller's buffer
+    }
+    if (abr::wino_input_transform(x, p.B, p.H, p.W, p.Cin, V, st, h3 ? &v_ref : nullptr)) return false;
     ConvP g = p;
     g.B = (int)T; g.H = g.W = 1; g.R = g.S = 1; g.stride = 1; g.pad = 0; g.Ho = g.Wo = 1;
     g.M = (int)T; g.K = p.Cin;
@@ -1883,10 +2063,18 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
     g.x_bytes = (unsigned)(T * p.Cin * 4); g.w_bytes = (unsigned)((int64_t)p.Cout * p.Cin * 4);
     g.nbatch = 36; g.a_bs = (long)T * p.Cin; g.w_bs = (long)p.Cout * p.Cin; g.o_bs = (long)T * p.Cout;
     g.v_out = nullptr;
-    g.w_planes = Up; g.wp_bytes = (unsigned)x6_packed_bytes(p.Cout, p.Cin); g.wp_bs = (long)x6_packed_bytes(p.Cout, p.Cin); g.wp_nblocks = p.Cout / 32;
-    if (p.math == ABR_MATH_BF16X6) dispatch_igemm_x6(g, V, U, Mm, st);
+    g.out_amax = nullptr;   // (the conv's output is written by the output transform)
+    if (h3) {
+        g.w_planes = Up; g.wp_bytes = (unsigned)h3_planes_bytes(p.Cout, p.Cin); g.wp_bs = (long)h3_planes_bytes(p.Cout, p.Cin); g.wp_nblocks = p.Cout / 32;
+        g.w_scales = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Up) + h3_planes_bytes((int64_t)36 * p.Cout, p.Cin));
+        g.a_amax = v_ref.word; g.a_epoch = v_ref.epoch;
+    } else {
+        g.w_planes = Up; g.wp_bytes = (unsigned)x6_packed_bytes(p.Cout, p.Cin); g.wp_bs = (long)x6_packed_bytes(p.Cout, p.Cin); g.wp_nblocks = p.Cout / 32;
+    }
+    if (p.math == ABR_MATH_BF16X6 || h3) dispatch_igemm_x6(g, V, U, Mm, st);
     else dispatch_igemm(g, V, U, Mm, st);
-    return abr::wino_output_transform(Mm, p.B, p.H, p.W, p.Cout, p.scale, p.bias, p.relu, p.mask, out, st) == 0;
+    const abr::AmaxRef o_ref{p.out_amax, p.out_epoch};
+    return abr::wino_output_transform(Mm, p.B, p.H, p.W, p.Cout, p.scale, p.bias, p.relu, p.mask, out, st, p.out_amax ? &o_ref : nullptr) == 0;
 }
 
 static int wino_min_c() {
@@ -1938,10 +2126,25 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
     p.d_howo.init((unsigned)(p.Ho * p.Wo)); p.d_wo.init((unsigned)p.Wo); p.d_cin.init((unsigned)p.Cin); p.d_s.init((unsigned)p.S);
     hipStream_t st = abr::as_stream(stream);
-    ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16 || d->math == ABR_MATH_BF16X6, "conv_forward: unknown math mode");
+    ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16 || d->math == ABR_MATH_BF16X6 || d->math == ABR_MATH_F16X3, "conv_forward: unknown math mode");
     p.math = d->math;
-    if (p.math == ABR_MATH_BF16X6 && p.Cin % BKX != 0) p.math = ABR_MATH_F32;   // the 4-channel stem: fp32 MFMA
+    if ((p.math == ABR_MATH_BF16X6 || p.math == ABR_MATH_F16X3) && p.Cin % BKX != 0) p.math = ABR_MATH_F32;   // the 4-channel stem: fp32 MFMA
     p.nprod = 6;
+    p.a_amax = nullptr; p.a_epoch = 0; p.w_scales = nullptr;
+    p.out_amax = reinterpret_cast<unsigned long long*>(d->out_amax); p.out_epoch = d->out_amax_epoch;   // (every kernel's epilogue feeds it)
+    if (p.math == ABR_MATH_F16X3) {
+        // the A operand's amax: the caller's word (written by the tensor's producer), else reduced here
+        abr::AmaxRef ar{reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(d->x_amax)), d->x_amax_epoch};
+        if (!ar.word) {
+            ar = abr::h3_amax_alloc();
+            ABR_REQUIRE(ar.word && abr::h3_amax_reduce(x, (int64_t)d->B * d->H * d->W * d->Cin, ar, st) == 0, "conv_forward (f16x3): amax reduction failed");
+        }
+        p.a_amax = ar.word; p.a_epoch = ar.epoch;
+        p.nprod = 3;
+        p.w_planes = nullptr;
+        ABR_REQUIRE(h3_planes_bytes(d->Cout, p.K) < (int64_t)0xFFFFFFF0, "conv_forward: weight tensor too large for 32-bit buffer offsets");
+        p.wp_bytes = (unsigned)h3_planes_bytes(d->Cout, p.K);
+    }
     if (d->math == ABR_MATH_BF16 && p.Cin % BKH == 0) {   // (the 4-channel stem has no 64-wide k-tile: it stays fp32)
         // Round 4: with a weight version the bf16 mode runs on the weights-direct kernels of the default arithmetic, single product (NP = 1): plane 0
         // of the packed weights (the cache entry bf16x6 uses) IS bf16(w), the first plane of the activation split IS bf16(x).  3x3 convs stay
@@ -1972,7 +2175,19 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
             return ABR_OK;
         }
     }
-    if (p.math == ABR_MATH_BF16X6) {
+    if (p.math == ABR_MATH_F16X3) {
+        // packed fp16 planes + row scales of (w, w_version) from the library's cache, or packed into this stream's scratch for a one-off call
+        const size_t pb = (size_t)h3_packed_bytes(d->Cout, p.K);
+        const void* planes = p.w_version ? abr::derived_cached(w, abr::DERIVED_H3_PLANES, pb, p.w_version, st, [&](void* buf) { return h3_pack(w, d->Cout, p.K, buf, st); }) : nullptr;
+        if (!planes) {
+            void* scratch = abr::wino_ws(st, pb / 4);
+            ABR_REQUIRE(scratch && h3_pack(w, d->Cout, p.K, scratch, st) == 0, "conv_forward (f16x3): no memory for the weight planes");
+            planes = scratch;
+        }
+        p.w_planes = planes;
+        p.w_scales = reinterpret_cast<const float*>(reinterpret_cast<const char*>(planes) + h3_planes_bytes(d->Cout, p.K));
+        dispatch_igemm_x6(p, x, w, out, st);
+    } else if (p.math == ABR_MATH_BF16X6) {
         // weights-direct kernel: the packed planes of (w, w_version) come from the library's cache (filled here on a miss: one small launch)
         if (!p.w_planes && p.w_version)
             p.w_planes = abr::derived_cached(w, abr::DERIVED_X6_PLANES, p.wp_bytes, p.w_version, st, [&](void* buf) { return x6_pack(w, d->Cout, p.K, buf, st); });
@@ -2056,7 +2271,18 @@ extern "C" int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, 
     // the same predicate as abr_conv_forward's Winograd branch (residual / scatter never occur on the convs that prepare)
     if (wino_min_c() > 0 && math != ABR_MATH_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && Cin % BK == 0 && Cout % 4 == 0 &&
         Cin >= wino_min_c() && Cout >= 128) {
-        if (math == ABR_MATH_BF16X6 && direct_on && Cout % 32 == 0) {
+        if (math == ABR_MATH_F16X3 && Cout % 32 == 0) {
+            const size_t nU = (size_t)36 * Cout * Cin;
+            void* up = abr::derived_cached(w, abr::DERIVED_WINO_U_H3_PLANES, (size_t)h3_packed_bytes((int64_t)36 * Cout, Cin), w_version, st, [&](void* buf) {
+                float* Uf = abr::wino_ws(st, nU);
+                if (!Uf || abr::wino_weight_transform(w, Cout, Cin, Uf, st)) return 1;
+                return h3_pack(Uf, (int64_t)36 * Cout, Cin, buf, st);
+            });
+            ABR_REQUIRE(up != nullptr, "conv_prepare_weights: no memory for the packed Winograd-domain weights");
+        } else if (math == ABR_MATH_F16X3) {
+            void* pl = abr::derived_cached(w, abr::DERIVED_H3_PLANES, (size_t)h3_packed_bytes(Cout, K), w_version, st, [&](void* buf) { return h3_pack(w, Cout, K, buf, st); });
+            ABR_REQUIRE(pl != nullptr, "conv_prepare_weights: no memory for the packed weight planes");
+        } else if (math == ABR_MATH_BF16X6 && direct_on && Cout % 32 == 0) {
             const size_t nU = (size_t)36 * Cout * Cin;
             void* up = abr::derived_cached(w, abr::DERIVED_WINO_U_X6_PLANES, (size_t)x6_packed_bytes((int64_t)36 * Cout, Cin), w_version, st, [&](void* buf) {
                 float* Uf = abr::wino_ws(st, nU);
@@ -2067,6 +2293,10 @@ extern "C" int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, 
         } else {
             ABR_REQUIRE(abr::wino_u_cached(w, Cout, Cin, w_version, st) != nullptr, "conv_prepare_weights: no memory for the Winograd-domain weights");
         }
+        ABR_CHECK_LAUNCH("conv_prepare_weights");
+    } else if (math == ABR_MATH_F16X3 && Cin % BKX == 0 && h3_planes_bytes(Cout, K) < (int64_t)0xFFFFFFF0) {
+        void* pl = abr::derived_cached(w, abr::DERIVED_H3_PLANES, (size_t)h3_packed_bytes(Cout, K), w_version, st, [&](void* buf) { return h3_pack(w, Cout, K, buf, st); });
+        ABR_REQUIRE(pl != nullptr, "conv_prepare_weights: no memory for the packed weight planes");
         ABR_CHECK_LAUNCH("conv_prepare_weights");
     } else if ((math == ABR_MATH_BF16X6 || (math == ABR_MATH_BF16 && Cin % BKH == 0)) && direct_on && Cin % BKX == 0 &&
                x6_packed_bytes(Cout, K) < (int64_t)0xFFFFFFF0) {
@@ -2081,6 +2311,11 @@ namespace abr {
 int prep_transpose_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st) {
     if (njobs <= 0 || blocks <= 0) return 0;
     dgrad_weights_multi_kernel<<<(unsigned)blocks, 256, 0, st>>>(jobs_dev, njobs);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int prep_pack_h3_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st) {
+    if (njobs <= 0 || blocks <= 0) return 0;
+    h3_pack_multi_kernel<<<(unsigned)blocks, 256, 0, st>>>(jobs_dev, njobs, abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int prep_pack_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st) {
@@ -2131,7 +2366,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
     static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
     std::lock_guard<std::mutex> lock(g_prep_mu);
     PrepTables& T = g_prep_tables[st];
-    std::vector<abr::PrepJob> tj, uj, pj;        // transposes, Winograd weight transforms, packings
+    std::vector<abr::PrepJob> tj, uj, pj, hj;    // transposes, Winograd weight transforms, bf16x3 packings, f16x3 packings
     std::vector<void*> tokens;
     // every early return between the acquires below and derived_commit releases the tokens (entries left pending would never be evictable and
     // would repack on every later call)
@@ -2141,7 +2376,13 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
     } token_guard{tokens};
     std::vector<size_t> u_off;                    // per uj entry: offset (floats) of its U inside the scratch
     size_t u_total = 0;
-    int tb = 0, ub = 0, pb = 0;                   // workgroups of the three launches
+    int tb = 0, ub = 0, pb = 0, hb = 0;           // workgroups of the four launches
+    auto add_pack_h3 = [&](const float* src, int64_t rows, int K, void* dst) {
+        abr::PrepJob j{};
+        j.src = src; j.dst = dst; j.a = (int)rows; j.b = K; j.gx = 1; j.gy = (int)((rows + 31) / 32); j.first_block = hb;
+        hb += j.gy;
+        hj.push_back(j);
+    };
     auto add_pack = [&](const float* src, int64_t rows, int K, void* dst) {
         abr::PrepJob j{};
         j.src = src; j.dst = dst; j.a = (int)rows; j.b = K; j.gx = (K + 63) / 64; j.gy = (int)((rows + 31) / 32); j.first_block = pb;
@@ -2153,9 +2394,11 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
         const int K = R * S * Cin;
         if (wino_min_c() > 0 && math != ABR_MATH_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && Cin % BK == 0 && Cout % 4 == 0 &&
             Cin >= wino_min_c() && Cout >= 128) {
-            if (!(math == ABR_MATH_BF16X6 && direct_on && Cout % 32 == 0 && Cin % 4 == 0)) return 1;
+            const bool h3 = math == ABR_MATH_F16X3;
+            if (!(((math == ABR_MATH_BF16X6 && direct_on) || h3) && Cout % 32 == 0 && Cin % 4 == 0)) return 1;
             void* tok = nullptr;
-            void* planes = abr::derived_acquire(w, abr::DERIVED_WINO_U_X6_PLANES, (size_t)x6_packed_bytes((int64_t)36 * Cout, Cin), ver, st, &tok);
+            void* planes = h3 ? abr::derived_acquire(w, abr::DERIVED_WINO_U_H3_PLANES, (size_t)h3_packed_bytes((int64_t)36 * Cout, Cin), ver, st, &tok)
+                              : abr::derived_acquire(w, abr::DERIVED_WINO_U_X6_PLANES, (size_t)x6_packed_bytes((int64_t)36 * Cout, Cin), ver, st, &tok);
             if (!planes) return 1;
             if (!tok) return 0;   // already there
             tokens.push_back(tok);
@@ -2165,9 +2408,17 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
             uj.push_back(j);
             u_off.push_back(u_total);
             // the packing job reads the fp32 U from the scratch: its src is patched in once the scratch address is known
-            add_pack(reinterpret_cast<const float*>(u_total), (int64_t)36 * Cout, Cin, planes);
-            pj.back().c = 1;   // src is a scratch offset
+            if (h3) { add_pack_h3(reinterpret_cast<const float*>(u_total), (int64_t)36 * Cout, Cin, planes); hj.back().c = 1; }
+            else { add_pack(reinterpret_cast<const float*>(u_total), (int64_t)36 * Cout, Cin, planes); pj.back().c = 1; }   // c = 1: src is a scratch offset
             u_total += (size_t)36 * Cout * Cin;
+            return 0;
+        }
+        if (math == ABR_MATH_F16X3) {
+            if (!(Cin % BKX == 0 && h3_planes_bytes(Cout, K) < (int64_t)0xFFFFFFF0)) return 0;
+            void* tok = nullptr;
+            void* planes = abr::derived_acquire(w, abr::DERIVED_H3_PLANES, (size_t)h3_packed_bytes(Cout, K), ver, st, &tok);
+            if (!planes) return 1;
+            if (tok) { tokens.push_back(tok); add_pack_h3(w, Cout, K, planes); }
             return 0;
         }
         if ((math == ABR_MATH_BF16X6 || (math == ABR_MATH_BF16 && Cin % BKH == 0)) && direct_on && Cin % BKX == 0 &&
@@ -2195,7 +2446,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
             if (derive(it.wt, it.Cin, it.R, it.S, it.Cout, 1, it.R - 1 - it.pad, it.math, it.w_version)) single_bwd.push_back(i);
         }
     }
-    const size_t njobs = tj.size() + uj.size() + pj.size();
+    const size_t njobs = tj.size() + uj.size() + pj.size() + hj.size();
     if (njobs) {
         if (T.u_floats < u_total) {
             if (T.u_scratch) { (void)hipStreamSynchronize(st); (void)hipFree(T.u_scratch); T.u_scratch = nullptr; T.u_floats = 0; }
@@ -2205,6 +2456,8 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
         for (size_t k = 0; k < uj.size(); k++) uj[k].dst = T.u_scratch + u_off[k];
         for (auto& j : pj)
             if (j.c == 1) { j.src = T.u_scratch + reinterpret_cast<size_t>(j.src); j.c = 0; }
+        for (auto& j : hj)
+            if (j.c == 1) { j.src = T.u_scratch + reinterpret_cast<size_t>(j.src); j.c = 0; }
         size_t first = 0;
         ABR_REQUIRE(prep_ring_take(T, njobs, &first), "conv_prepare_batch: no memory for the job tables");
         abr::PrepJob* h = T.host + first;
@@ -2212,6 +2465,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
         std::copy(tj.begin(), tj.end(), h);
         std::copy(uj.begin(), uj.end(), h + tj.size());
         std::copy(pj.begin(), pj.end(), h + tj.size() + uj.size());
+        std::copy(hj.begin(), hj.end(), h + tj.size() + uj.size() + pj.size());
         ABR_REQUIRE(hipMemcpyAsync(d, h, njobs * sizeof(abr::PrepJob), hipMemcpyHostToDevice, st) == hipSuccess, "conv_prepare_batch: table upload failed");
         hipEvent_t up = nullptr;
         if (hipEventCreateWithFlags(&up, hipEventDisableTiming) == hipSuccess) {
@@ -2221,6 +2475,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
         int bad = abr::prep_transpose_multi(d, (int)tj.size(), tb, st);
         bad |= abr::prep_wino_u_multi(d + tj.size(), (int)uj.size(), ub, st);
         bad |= abr::prep_pack_multi(d + tj.size() + uj.size(), (int)pj.size(), pb, st);
+        bad |= abr::prep_pack_h3_multi(d + tj.size() + uj.size() + pj.size(), (int)hj.size(), hb, st);
         ABR_REQUIRE(!bad, "conv_prepare_batch: launch failed");
         abr::derived_commit(tokens.data(), (int)tokens.size(), st);
         token_guard.committed = true;

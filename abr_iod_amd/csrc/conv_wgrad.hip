@@ -30,6 +30,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int TN_ = 128;  // dW tile rows  (cout)
 constexpr int TK_ = 128;  // dW tile cols  (r,s,cin)
@@ -72,7 +73,22 @@ struct WgP {
     float* ws;
     int final_store;             // the reduction stores (dw = sum: the Winograd-domain dU, never zero-filled) instead of dw += sum
     int map4;                    // accumulator interleave of conv_wgrad_x6_kernel (n = n0 + 4 i + 2 wm + tm) instead of n0 + wm*64 + 2 i + tm
+    // ABR_MATH_F16X3: the amax words of the two operands (their split scales; dW = s_gy s_x * sum); null otherwise
+    const unsigned long long* gy_amax;
+    const unsigned long long* x_amax;
+    unsigned gy_epoch, x_epoch;
+    unsigned long long* h3_stats;   // f16x3 range statistics (abr::h3_stats_ptr) or nullptr
 };
+
+// f16x3: the factors s_gy, s_x the accumulators carry (1, 1 in every other arithmetic); applied one after the other: their PRODUCT could leave
+// fp32's normal range although neither the sum nor the result does
+__device__ __forceinline__ float2 wg_operand_scale(const WgP& p) {
+    if (!p.gy_amax) return make_float2(1.f, 1.f);
+    float sg, ig, sx, ix;
+    abr::h3_scales(abr::h3_amax_load(p.gy_amax, p.gy_epoch), sg, ig);
+    abr::h3_scales(abr::h3_amax_load(p.x_amax, p.x_epoch), sx, ix);
+    return make_float2(sg, sx);
+}
 
 typedef f32x16 wg_f32x16;
 
@@ -81,7 +97,7 @@ typedef f32x16 wg_f32x16;
 constexpr unsigned kPartBytes = 16u * 256u * 16u;   // one partial tile (128 x 128 fp32), thread-major: quad (t,c) of thread tid at (t*4+c)*4096 + tid*16
 
 __device__ __forceinline__ void wgrad_store_tile(const WgP& p, const float (&v)[4], int tm, int tn, int c, int n0, int k0, int wm, int wn, int l31, int lh,
-                                                 bool store, float* __restrict__ dw) {
+                                                 bool store, float* __restrict__ dw, const float2 osc = make_float2(1.f, 1.f)) {
     const int k = p.map4 ? k0 + 4 * l31 + 2 * wn + tn : k0 + wn * 64 + 2 * l31 + tn;
     if (k >= p.K) return;
 #pragma unroll
@@ -90,9 +106,10 @@ __device__ __forceinline__ void wgrad_store_tile(const WgP& p, const float (&v)[
         const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int n = p.map4 ? n0 + 4 * i + 2 * wm + tm : n0 + wm * 64 + 2 * i + tm;
         if (n >= p.Cout) continue;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        if (store) dw[(size_t)n * p.K + k] = v[e] * sc;
-        else unsafeAtomicAdd(dw + (size_t)n * p.K + k, v[e] * sc);   // dw += (other launches may add to the same dw)
+        const float sc = (p.scale ? p.scale[n] : 1.f) * fmaxf(osc.x, osc.y);   // (osc: powers of two -- the same value as scaling the sum first;
+        const float val = (v[e] * fminf(osc.x, osc.y)) * sc;                 //  the smaller factor first: conv_igemm.hip::epilogue_rows)
+        if (store) dw[(size_t)n * p.K + k] = val;
+        else unsafeAtomicAdd(dw + (size_t)n * p.K + k, val);   // dw += (other launches may add to the same dw)
     }
 }
 
@@ -109,13 +126,14 @@ __device__ __forceinline__ void wgrad_finish(const WgP& p, f32x16 (&acc)[2][2], 
             }
         return;   // (the caller stamps the end: wgrad_finish is the kernel's last statement)
     }
+    const float2 osc = wg_operand_scale(p);
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const f32x16& a = acc[t >> 1][t & 1];
             const float v[4] = {a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]};
-            wgrad_store_tile(p, v, t >> 1, t & 1, c, n0, k0, wm, wn, l31, lh, p.overwrite != 0, dw);
+            wgrad_store_tile(p, v, t >> 1, t & 1, c, n0, k0, wm, wn, l31, lh, p.overwrite != 0, dw, osc);
         }
 }
 
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgP p, float* _
     const int n0 = (tile % p.tiles_n) * TN_, k0 = (tile / p.tiles_n) * TK_;
     const float v[4] = {sum.x, sum.y, sum.z, sum.w};
     const int t = quad >> 2, c = quad & 3;
-    wgrad_store_tile(p, v, t >> 1, t & 1, c, n0, k0, wave >> 1, wave & 1, lane & 31, lane >> 5, p.final_store != 0, dw);
+    wgrad_store_tile(p, v, t >> 1, t & 1, c, n0, k0, wave >> 1, wave & 1, lane & 31, lane >> 5, p.final_store != 0, dw, wg_operand_scale(p));
 }
 
 // SB: single-buffered operand LDS (two barriers per stage, 32 KB instead of 64 KB -> a third resident workgroup per CU)
@@ -470,6 +488,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgP p, const
 constexpr int MRX = 32;
 
 // NP = 6: the bf16x6 arithmetic.  NP = 1: ABR_MATH_BF16 (operands rounded to bf16, one product) on the same loop: one plane per operand in LDS.
+// NP = 3: ABR_MATH_F16X3 (two fp16 planes per operand, scaled by the operand's amax word; three products on v_mfma_f32_32x32x16_f16).
 template <int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_wgrad_x6_kernel(const WgP p, const float* __restrict__ x_, const float* __restrict__ gy_,
                                                              float* __restrict__ dw_) {
@@ -479,7 +498,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     extern __shared__ __attribute__((aligned(16))) float smem[];
     abr::prof_stamp_begin(p.prof_ts);
     constexpr int PL = (MRX / 8) * 128 * 4;              // dwords per plane: [4 octets][4 j][32 q] chunks of 4 dwords
-    constexpr int NPL = NP == 1 ? 1 : 3;                 // operand planes in use
+    constexpr bool H3 = NP == 3;
+    constexpr int NPL = NP == 1 ? 1 : (H3 ? 2 : 3);      // operand planes in use
     unsigned* Gs = reinterpret_cast<unsigned*>(smem);    // [NPL][PL]
     unsigned* As = Gs + NPL * PL;                        // [NPL][PL]
 
@@ -557,7 +577,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         nonfin = fmaf(__uint_as_float(v.z), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.w), 0.f, nonfin);
     };
     unsigned* const st_base = (is_x ? As : Gs) + (oct * 4 * 32 + q) * 4;   // chunk (oct, j, q) at + j * 128 dwords
+    unsigned op_bits = 0;            // f16x3: this wave's operand's amax and the scale of its split
+    float op_s = 1.f, op_inv = 1.f;
+    if constexpr (H3) {
+        op_bits = is_x ? abr::h3_amax_load(p.x_amax, p.x_epoch) : abr::h3_amax_load(p.gy_amax, p.gy_epoch);
+        abr::h3_scales(op_bits, op_s, op_inv);
+    }
+    const unsigned small_thr = H3 ? abr::h3_small_threshold(op_bits) : 0u;
+    unsigned nsmall = 0;
     auto store_tile = [&]() {
+        if constexpr (H3) {
+            if (chk) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const u32x4 v = rr[i];
+                    nsmall += (unsigned)(((v.x << 1) - 1u) < small_thr) + (unsigned)(((v.y << 1) - 1u) < small_thr) + (unsigned)(((v.z << 1) - 1u) < small_thr) +
+                              (unsigned)(((v.w << 1) - 1u) < small_thr);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                u32x4 o0, o1;
+#pragma unroll
+                for (int pp = 0; pp < 4; pp++) {
+                    unsigned a0, a1;
+                    abr::h3_split2(__uint_as_float(rr[2 * pp][j]), __uint_as_float(rr[2 * pp + 1][j]), op_inv, a0, a1);
+                    o0[pp] = a0; o1[pp] = a1;
+                }
+                *reinterpret_cast<u32x4*>(st_base + j * 128) = o0;
+                *reinterpret_cast<u32x4*>(st_base + j * 128 + PL) = o1;
+            }
+            return;
+        }
         if (chk) {
 #pragma unroll
             for (int i = 0; i < 8; i++) inspect(rr[i]);
@@ -612,13 +663,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
                 }
             // the six products of a step (smallest terms first for every accumulator) interleaved over the four accumulators: no MFMA
             // waits on the result of the one issued just before it (as in conv_igemm_x6w_kernel)
-            constexpr int pg[6] = {NP == 1 ? 0 : 2, 0, 1, 1, 0, 0}, pa[6] = {0, NP == 1 ? 0 : 2, 1, 0, 1, 0};
+            constexpr int pg[6] = {NP == 1 ? 0 : (H3 ? 1 : 2), 0, H3 ? 0 : 1, 1, 0, 0}, pa[6] = {0, NP == 1 ? 0 : (H3 ? 1 : 2), H3 ? 0 : 1, 0, 1, 0};
 #pragma unroll
             for (int t = 0; t < NP; t++)
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][pg[t]], A[j][pa[t]], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; j++) {
+                        if constexpr (H3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, G[i][pg[t]]), __builtin_bit_cast(f16x8, A[j][pa[t]]), acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G[i][pg[t]], A[j][pa[t]], acc[i][j], 0, 0, 0);
+                    }
         }
     };
     if (mt0 < mt1) {
@@ -636,7 +690,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         }
         compute_tile();
     }
-    if (chk) abr::x6_report(bmin, nonfin, p.x6_flags);
+    if constexpr (H3) {
+        if (chk) abr::h3_report(op_bits, nsmall, p.x6_flags, p.h3_stats);
+    } else {
+        if (chk) abr::x6_report(bmin, nonfin, p.x6_flags);
+    }
 
     wgrad_finish(p, acc, n0, k0, wm, wn, l31, lh, tid, gtile, split, dw);
     abr::prof_stamp_end(p.prof_ts);
@@ -736,10 +794,11 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
                                   (int)(sizeof(float) * 2 * MR * (TN_ + TK_)));
         attr_set = true;
     }
-    if (p.math == ABR_MATH_BF16X6 || p.math == ABR_MATH_BF16) {   // same split plan (MRX == MR), three-plane (bf16: one-plane) LDS
+    if (p.math == ABR_MATH_BF16X6 || p.math == ABR_MATH_BF16 || p.math == ABR_MATH_F16X3) {   // same split plan (MRX == MR), three-plane (bf16: one-plane, f16x3: two-plane) LDS
         static bool attr6 = false;
         const bool one = p.math == ABR_MATH_BF16;   // round 4: the bf16 mode on the bf16x6 kernel's loader / LDS image, single product
-        const size_t lds6 = sizeof(unsigned) * (one ? 1 : 3) * (MRX / 2) * (TN_ + TK_);
+        const bool h3 = p.math == ABR_MATH_F16X3;
+        const size_t lds6 = sizeof(unsigned) * (one ? 1 : (h3 ? 2 : 3)) * (MRX / 2) * (TN_ + TK_);
         if (!attr6) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(sizeof(unsigned) * 3 * (MRX / 2) * (TN_ + TK_)));
@@ -747,14 +806,18 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
         }
         p.map4 = 1;
         p.x6_flags = (!one && abr::x6_guard_enabled()) ? abr::x6_flags_ptr() : nullptr;
+        p.h3_stats = (h3 && p.x6_flags) ? abr::h3_stats_ptr() : nullptr;
+        if (p.h3_stats) abr::h3_stats_inspected((double)nb * p.M * ((double)p.Cout + (double)p.K));   // gy by the first k-tile column, x by the first n-tile row
         // Timed with a HIP-event pair, not with in-kernel stamps: a kernel trace's duration of these kernels includes the write-back of the
         // parked partial tiles at kernel end, which first-workgroup-in / last-workgroup-out stamps miss by ~10 % (the raw event figure is
         // within 3 % of rocprofv3's here; for the forward / dgrad kernels it is the stamps that agree, within 2.5 %).
-        const int rec6 = abr::prof_start(abr::as_stream(stream), abr::PROF_WGRAD_BF16, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
+        const int pid6 = h3 ? abr::PROF_WGRAD_H3 : abr::PROF_WGRAD_BF16;
+        const int rec6 = abr::prof_start(abr::as_stream(stream), pid6, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * nb);
         p.prof_ts = abr::prof_clock_slot(rec6);
         // algorithmic bytes: x and gy once (x at its own size for a direct 3x3), dw written once
-        abr::prof_add_bytes(abr::PROF_WGRAD_BF16, 4.0 * nb * ((double)p.M * p.Cout + (p.plain ? (double)p.M * p.K : (double)p.B * p.H * p.W * p.Cin) + (double)p.Cout * p.K));
-        if (one) conv_wgrad_x6_kernel<1><<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
+        abr::prof_add_bytes(pid6, 4.0 * nb * ((double)p.M * p.Cout + (p.plain ? (double)p.M * p.K : (double)p.B * p.H * p.W * p.Cin) + (double)p.Cout * p.K));
+        if (h3) conv_wgrad_x6_kernel<3><<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
+        else if (one) conv_wgrad_x6_kernel<1><<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
         else conv_wgrad_x6_kernel<6><<<(unsigned)(tiles * splits), 256, lds6, abr::as_stream(stream)>>>(p, x, gy, dw);
         abr::prof_stop(abr::as_stream(stream), rec6);
         wgrad_reduce(p, tiles, dw, abr::as_stream(stream));
@@ -820,12 +883,22 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     p.nbatch = 1; p.tiles_pb = 0; p.x_bs = p.gy_bs = p.dw_bs = 0; p.overwrite = 0;
     p.ws = nullptr; p.final_store = 0; p.map4 = 0;
     p.x6_flags = nullptr;
+    p.gy_amax = p.x_amax = nullptr; p.gy_epoch = p.x_epoch = 0; p.h3_stats = nullptr;
     static const int tile_fast = !(getenv("ABR_WGRAD_TILE_FAST") && atoi(getenv("ABR_WGRAD_TILE_FAST")) == 0);
     p.tile_fast = tile_fast;
-    p.math = d->math == ABR_MATH_BF16X6 ? ABR_MATH_BF16X6 : ABR_MATH_F32;   // (x6 handles any Cin % 4 == 0: no k-tile constraint here)
+    p.math = (d->math == ABR_MATH_BF16X6 || d->math == ABR_MATH_F16X3) ? d->math : ABR_MATH_F32;   // (x6 / h3 handle any Cin % 4 == 0: no k-tile constraint here)
     static const bool bf16_on_x6 = !(getenv("ABR_BF16_WEIGHTS_DIRECT") && atoi(getenv("ABR_BF16_WEIGHTS_DIRECT")) == 0);
     hipStream_t st = abr::as_stream(stream);
-    ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16 || d->math == ABR_MATH_BF16X6, "conv_wgrad: unknown math mode");
+    ABR_REQUIRE(d->math == ABR_MATH_F32 || d->math == ABR_MATH_BF16 || d->math == ABR_MATH_BF16X6 || d->math == ABR_MATH_F16X3, "conv_wgrad: unknown math mode");
+    const bool h3 = p.math == ABR_MATH_F16X3;
+    // f16x3: amax words of the two operands -- the caller's (written by the producers of x / gy), else reduced here
+    abr::AmaxRef gy_ref{reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(d->gy_amax)), d->gy_amax_epoch};
+    abr::AmaxRef x_ref{reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(d->x_amax)), d->x_amax_epoch};
+    auto need_ref = [&](abr::AmaxRef& r, const float* t, int64_t n) -> bool {
+        if (r.word) return true;
+        r = abr::h3_amax_alloc();
+        return r.word && abr::h3_amax_reduce(t, n, r, st) == 0;
+    };
     if (d->math == ABR_MATH_BF16 && d->Cin % 64 == 0) {   // same layer set as the bf16 forward (the stem stays fp32)
         if (bf16_on_x6) {   // round 4: the loader-transposed LDS image and split plan of the default arithmetic, one product (direct form: no Winograd)
             p.math = ABR_MATH_BF16;
@@ -851,8 +924,17 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
         if (ws) {
             float* V = vin ? vin : ws;
             float *Mg = ws + (vin ? 0 : nV), *dU = Mg + nM;
-            int bad = vin ? 0 : abr::wino_input_transform(x, d->B, d->H, d->W, d->Cin, V, st);
-            bad |= abr::wino_outgrad_transform(gy, d->B, d->H, d->W, d->Cout, Mg, st);
+            // f16x3: the GEMM's operands are V and Mg: their amax words come from the transforms (a kept V: from the forward pass's, else reduced)
+            abr::AmaxRef v_ref{nullptr, 0}, m_ref{nullptr, 0};
+            if (h3) {
+                if (vin) v_ref = abr::h3_amax_recall(vin);
+                else v_ref = abr::h3_amax_alloc();
+                m_ref = abr::h3_amax_alloc();
+                ABR_REQUIRE(m_ref.word && (vin || v_ref.word), "conv_wgrad (f16x3): no amax words");
+                if (vin && !v_ref.word) ABR_REQUIRE(need_ref(v_ref, vin, (int64_t)nV), "conv_wgrad (f16x3): amax reduction failed");
+            }
+            int bad = vin ? 0 : abr::wino_input_transform(x, d->B, d->H, d->W, d->Cin, V, st, h3 ? &v_ref : nullptr);
+            bad |= abr::wino_outgrad_transform(gy, d->B, d->H, d->W, d->Cout, Mg, st, h3 ? &m_ref : nullptr);
             // enough output tiles to fill the chip without splitting the tile axis -> each workgroup owns its dU tile and writes
             // it directly; otherwise split-M with atomics into a zeroed dU
             int32_t info[3];
@@ -873,6 +955,7 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
                 g.tiles_n = (g.Cout + TN_ - 1) / TN_; g.tiles_k = (g.K + TK_ - 1) / TK_;
                 g.x_bytes = (unsigned)(T * d->Cin * 4); g.gy_bytes = (unsigned)(T * d->Cout * 4);
                 g.nbatch = 36; g.x_bs = (long)T * d->Cin; g.gy_bs = (long)T * d->Cout; g.dw_bs = (long)d->Cout * d->Cin;
+                if (h3) { g.x_amax = v_ref.word; g.x_epoch = v_ref.epoch; g.gy_amax = m_ref.word; g.gy_epoch = m_ref.epoch; }
                 launch_wgrad(g, V, Mg, dU, stream);
                 bad = abr::wino_wgrad_inverse(dU, d->Cout, d->Cin, d->scale, dw, st);
             }
@@ -880,6 +963,10 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
             ABR_CHECK_LAUNCH("conv_wgrad (winograd)");
             return ABR_OK;
         }
+    }
+    if (h3) {
+        ABR_REQUIRE(need_ref(gy_ref, gy, (int64_t)p.M * d->Cout) && need_ref(x_ref, x, (int64_t)d->B * d->H * d->W * d->Cin), "conv_wgrad (f16x3): amax reduction failed");
+        p.gy_amax = gy_ref.word; p.gy_epoch = gy_ref.epoch; p.x_amax = x_ref.word; p.x_epoch = x_ref.epoch;
     }
     launch_wgrad(p, x, gy, dw, stream);
     ABR_CHECK_LAUNCH("conv_wgrad");

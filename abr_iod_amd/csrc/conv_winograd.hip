@@ -105,8 +105,17 @@ __device__ __forceinline__ void bt6(const T d0, const T d1, const T d2, const T 
 
 // grid-stride over (tile, channel group); consecutive threads = consecutive channel groups (coalesced 1 KB per wave at V = 4)
 template <int V>
+__device__ __forceinline__ unsigned vabs_max(unsigned m, vf<V> a) {
+#pragma unroll
+    for (int i = 0; i < V; i++) m = max(m, __float_as_uint(a.v[i]) & 0x7FFFFFFFu);
+    return m;
+}
+
+// amax / epoch (optional): max |V| goes to that amax word (one atomic per workgroup): the f16x3 GEMMs scale their A operand by it
+template <int V>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int B, int H, int W, int C, int th_n, int tw_n,
-                                                         float* __restrict__ Vo) {
+                                                         float* __restrict__ Vo, unsigned long long* amax, unsigned epoch) {
+    unsigned am = 0;
     typedef vf<V> f2;
     const int64_t T = (int64_t)B * th_n * tw_n;
     const int C2 = C / V;
@@ -141,8 +150,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
             bt6(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], tcol[i][4], tcol[i][5], v0, v1, v2, v3, v4, v5);
             float* o = Vo + ((int64_t)(6 * i) * T + t) * C + c;
             vst(o, v0); vst(o + ps, v1); vst(o + 2 * ps, v2); vst(o + 3 * ps, v3); vst(o + 4 * ps, v4); vst(o + 5 * ps, v5);
+            if (amax) am = vabs_max(vabs_max(vabs_max(vabs_max(vabs_max(vabs_max(am, v0), v1), v2), v3), v4), v5);
         }
     }
+    if (amax) abr::h3_amax_emit(amax, epoch, am);
 }
 
 // G (6x3) on a 3-vector
@@ -228,8 +239,9 @@ __device__ __forceinline__ void at4(const T m0, const T m1, const T m2, const T 
 template <int V>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mm, int B, int H, int W, int N, int th_n, int tw_n,
                                                           const float* __restrict__ scale, const float* __restrict__ bias, int relu,
-                                                          const float* __restrict__ mask, float* __restrict__ out) {
+                                                          const float* __restrict__ mask, float* __restrict__ out, unsigned long long* amax, unsigned epoch) {
     typedef vf<V> f2;
+    unsigned am = 0;
     const int64_t T = (int64_t)B * th_n * tw_n;
     const int N2 = N / V;
     const int64_t total = T * N2;
@@ -283,9 +295,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                     for (int e = 0; e < V; e++) v.v[e] = mk[i][j].v[e] > 0.f ? v.v[e] : 0.f;
                 }
                 vst(out + o, v);
+                if (amax) am = vabs_max(am, v);
             }
         }
     }
+    if (amax) abr::h3_amax_emit(amax, epoch, am);
 }
 
 // A (6x4) on a 4-vector: the transpose of at4's matrix
@@ -302,8 +316,9 @@ __device__ __forceinline__ void a6(const T y0, const T y1, const T y2, const T y
 // weight gradient, step 1: gy [B,H,W,N] -> Mg [36][T][N] = A dY A^T per 4x4 output tile (zeros beyond the image)
 template <int V>
 __global__ __launch_bounds__(256) void wino_outgrad_kernel(const float* __restrict__ gy, int B, int H, int W, int N, int th_n, int tw_n,
-                                                           float* __restrict__ Mg) {
+                                                           float* __restrict__ Mg, unsigned long long* amax, unsigned epoch) {
     typedef vf<V> f2;
+    unsigned am = 0;
     const int64_t T = (int64_t)B * th_n * tw_n;
     const int N2 = N / V;
     const int64_t total = T * N2;
@@ -330,8 +345,10 @@ __global__ __launch_bounds__(256) void wino_outgrad_kernel(const float* __restri
             a6(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], v0, v1, v2, v3, v4, v5);
             float* o = Mg + ((int64_t)(6 * i) * T + t) * N + n;
             vst(o, v0); vst(o + ps, v1); vst(o + 2 * ps, v2); vst(o + 3 * ps, v3); vst(o + 4 * ps, v4); vst(o + 5 * ps, v5);
+            if (amax) am = vabs_max(vabs_max(vabs_max(vabs_max(vabs_max(vabs_max(am, v0), v1), v2), v3), v4), v5);
         }
     }
+    if (amax) abr::h3_amax_emit(amax, epoch, am);
 }
 
 // G^T (3x6) on a 6-vector
@@ -391,12 +408,14 @@ static inline bool wide(int64_t tiles, int C) {
     return C % 4 == 0 && tiles * (C / 4) >= (int64_t)256 * 4 * 256;
 }
 
-int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, hipStream_t st) {
+int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, hipStream_t st, const AmaxRef* amax) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
+    unsigned long long* aw = amax ? amax->word : nullptr;
+    const unsigned ae = amax ? amax->epoch : 0u;
     // (measured: the input transform is never faster with 16 B accesses -- 0.95 ms / step at V = 2 against 1.07 mixed and 1.13 at V = 4)
     static const bool in4 = getenv("ABR_WINO_VEC") && atoi(getenv("ABR_WINO_VEC")) == 4;
-    if (in4 && C % 4 == 0) wino_input_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (C / 4)), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V);
-    else wino_input_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (C / 2)), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V);
+    if (in4 && C % 4 == 0) wino_input_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (C / 4)), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V, aw, ae);
+    else wino_input_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (C / 2)), 256, 0, st>>>(x, B, H, W, C, th_n, tw_n, V, aw, ae);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -413,19 +432,23 @@ int prep_wino_u_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_
 }
 
 int wino_output_transform(const float* Mm, int B, int H, int W, int N, const float* scale, const float* bias, int relu, const float* mask,
-                          float* out, hipStream_t st) {
+                          float* out, hipStream_t st, const AmaxRef* amax) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
+    unsigned long long* aw = amax ? amax->word : nullptr;
+    const unsigned ae = amax ? amax->epoch : 0u;
     if (wide((int64_t)B * th_n * tw_n, N))
-        wino_output_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (N / 4)), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out);
+        wino_output_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (N / 4)), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out, aw, ae);
     else
-        wino_output_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out);
+        wino_output_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(Mm, B, H, W, N, th_n, tw_n, scale, bias, relu, mask, out, aw, ae);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-int wino_outgrad_transform(const float* gy, int B, int H, int W, int N, float* Mg, hipStream_t st) {
+int wino_outgrad_transform(const float* gy, int B, int H, int W, int N, float* Mg, hipStream_t st, const AmaxRef* amax) {
     const int th_n = (H + 3) / 4, tw_n = (W + 3) / 4;
-    if (wide((int64_t)B * th_n * tw_n, N)) wino_outgrad_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (N / 4)), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg);
-    else wino_outgrad_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg);
+    unsigned long long* aw = amax ? amax->word : nullptr;
+    const unsigned ae = amax ? amax->epoch : 0u;
+    if (wide((int64_t)B * th_n * tw_n, N)) wino_outgrad_kernel<4><<<grid_for((int64_t)B * th_n * tw_n * (N / 4)), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg, aw, ae);
+    else wino_outgrad_kernel<2><<<grid_for((int64_t)B * th_n * tw_n * (N / 2)), 256, 0, st>>>(gy, B, H, W, N, th_n, tw_n, Mg, aw, ae);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

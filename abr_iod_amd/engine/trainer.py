@@ -142,7 +142,7 @@ def _x6_guard(model_source, model_target, log=None):
     arithmetic for them would silently cost 25 % of the throughput for nothing.  It is logged once; ABR_X6_STRICT=1 switches on it too.
 
     Under data parallelism the flag is MAX-reduced over the ranks first, so that every rank switches at the same step."""
-    if getattr(model_target, "conv_math", "f32") != "bf16x6":
+    if getattr(model_target, "conv_math", "f32") not in ("bf16x6", "f16x3"):
         return
     from .. import ops
     st = trainer_state(model_target)
@@ -153,6 +153,19 @@ def _x6_guard(model_source, model_target, log=None):
     if not flags:
         return
     logger = log or logging.getLogger("abr_iod_amd.trainer")
+    if flags & ops.H3_FLAG_STALE:
+        raise RuntimeError("f16x3: a kernel was handed an amax word that did not carry the epoch it was told (abr_iod_amd.ops amax tags): "
+                           "the results of that launch are wrong -- a bug in the host plumbing, not in the data")
+    if flags & ops.H3_FLAG_SMALL:
+        # f16x3, informational: operand elements more than 18 binades below their tensor's amax keep an ABSOLUTE accuracy of 2^-40 amax
+        # (ops.h3_range_stats counts them); logged once
+        if not getattr(st, "h3_small_logged", False):
+            st.h3_small_logged = True
+            logger.info("f16x3: operand elements more than 18 binades below their tensor's largest magnitude seen; each keeps an absolute "
+                        "accuracy of 2^-40 of that magnitude (ops.h3_range_stats() counts them)")
+        flags &= ~ops.H3_FLAG_SMALL
+        if not flags:
+            return
     if (flags & ops.X6_FLAG_TINY) and not (flags & ops.X6_FLAG_NONFINITE) and not X6_STRICT:
         if not st.x6_tiny_logged:
             st.x6_tiny_logged = True
@@ -160,7 +173,7 @@ def _x6_guard(model_source, model_target, log=None):
                         "absolute error below 2^-119 x the other operand -- staying on the bf16 matrix cores (ABR_X6_STRICT=1 would switch)")
         return
     what = " + ".join(n for b, n in ((ops.X6_FLAG_TINY, "non-zero operand below 2^-110"), (ops.X6_FLAG_NONFINITE, "inf/nan operand")) if flags & b)
-    logger.warning("bf16x6 range guard tripped ({}): switching both models to the fp32 MFMA kernels from the next step on; the last two "
+    logger.warning("bf16x6 / f16x3 range guard tripped ({}): switching both models to the fp32 MFMA kernels from the next step on; the last two "
                    "updates were computed with operands outside the exact-split domain and are not redone".format(what))
     for m in (model_source, model_target):
         if m is not None and hasattr(m, "set_conv_math"):

@@ -24,8 +24,10 @@ class _ROIAlign(Function):
         ctx.output_size = _pair(output_size)
         ctx.spatial_scale, ctx.sampling_ratio, ctx.bin_step = spatial_scale, sampling_ratio, bin_step
         ctx.input_shape = input.size()
-        out = ops.roi_align_forward(as_nhwc(input), roi, spatial_scale, ctx.output_size[0], ctx.output_size[1],
+        xin = as_nhwc(input)
+        out = ops.roi_align_forward(xin, roi, spatial_scale, ctx.output_size[0], ctx.output_size[1],
                                     sampling_ratio, bin_step)
+        ops.amax_carry_bound(out, xin)   # pooled values are averages of bilinear samples: bounded by the feature map's amax (f16x3 scales)
         return from_nhwc(out)
 
     @staticmethod

@@ -64,23 +64,27 @@ class GeneralizedRCNN(nn.Module):
         # matrix cores -- each operand split exactly into three bf16 terms, six cross products, fp32 accumulate (csrc/conv_igemm.hip),
         # guarded by a hardware range check (ops.x6_range_flags; engine/trainer.py falls back to "f32" when it trips) -- or "f32" =
         # v_mfma_f32_32x32x2_f32.  ABR_CONV_MATH overrides the default.
+        # "f16x3" (round 5) = the same on a two-term fp16 split with three products, operands scaled by their amax (csrc/common.h).
         self.conv_math = "f32"
-        want_x6 = os.environ.get("ABR_CONV_MATH", DEFAULT_CONV_MATH) == "bf16x6"
+        env_math = os.environ.get("ABR_CONV_MATH", DEFAULT_CONV_MATH)
+        if env_math not in ("f32", "bf16x6", "f16x3"):
+            raise ValueError("ABR_CONV_MATH must be f32, bf16x6 or f16x3, got {!r}".format(env_math))
+        want_x6 = env_math in ("bf16x6", "f16x3")
         if cfg.DTYPE == "float32" and want_x6:
-            self.set_conv_math("bf16x6")
+            self.set_conv_math(env_math)
         elif cfg.DTYPE == "bfloat16" and want_x6 and os.environ.get("ABR_BF16_SCOPE", "backbone") != "all":
             # "bf16 MFMA backbone" (configs[4]): layer1-3 contract in bf16, EVERYTHING ELSE in the default arithmetic -- until round 4 the RPN head and
             # layer4 of this mode were left on the fp32 MFMA kernels (round 1's default), which is what made the mode 20 % slower than bf16x6
             from ..backbone.resnet import set_conv_math
-            set_conv_math(self.rpn, ops.MATH_BF16X6)
-            set_conv_math(self.roi_heads, ops.MATH_BF16X6)
-            self.conv_math = "bf16x6"      # (the range guard of engine/trainer.py watches the bf16x6 part)
+            set_conv_math(self.rpn, ops.MATH_F16X3 if env_math == "f16x3" else ops.MATH_BF16X6)
+            set_conv_math(self.roi_heads, ops.MATH_F16X3 if env_math == "f16x3" else ops.MATH_BF16X6)
+            self.conv_math = env_math      # (the range guard of engine/trainer.py watches the fp32-accurate part)
         self.flat = None
 
     def set_conv_math(self, name):
-        """'f32' or 'bf16x6' for every conv of the backbone, RPN head and layer4 head (takes effect at the next call)"""
+        """'f32', 'bf16x6' or 'f16x3' for every conv of the backbone, RPN head and layer4 head (takes effect at the next call)"""
         from ..backbone.resnet import set_conv_math
-        math = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6}[name]
+        math = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3}[name]
         for m in (self.backbone, self.rpn, self.roi_heads):
             set_conv_math(m, math)
         self.conv_math = name

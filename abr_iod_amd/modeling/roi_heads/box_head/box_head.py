@@ -72,6 +72,8 @@ class _JointPoolFn(Function):
         ops.roi_align_forward(fh, det_rois, spatial_scale, ph, pw, sampling_ratio, 2, out=joint[:Kd])
         soft = soft_ready if soft_ready is not None else ops.roi_align_forward(fh, soft_rois, spatial_scale, ph, pw, sampling_ratio, 1)
         joint[Kd:].copy_(soft[:, ::2, ::2, :])
+        ops.amax_carry_bound(joint, fh)   # pooled values are averages of bilinear samples: bounded by the feature map's amax (f16x3 scales)
+        ops.amax_carry_bound(soft, fh)
         ctx.save_for_backward(det_rois, soft_rois)
         ctx.geom = (ph, pw, spatial_scale, sampling_ratio, tuple(fh.shape), Kd)
         return from_nhwc(joint), from_nhwc(soft)

@@ -56,10 +56,12 @@ def roi_align_backward(grad, rois, spatial_scale, ph, pw, sampling_ratio, B, H, 
         L.check(L.lib().abr_roi_align_backward_gather(L.ptr(grad), L.ptr(rois), K, B, Ch, H, W, float(spatial_scale), ph, pw,
                                                       sampling_ratio, bin_step, int(acc), L.ptr(out), L.ptr(ws), ws.numel(),
                                                       L.stream()), "roi_align_backward_gather")
+        amax_drop(out)
         return out
     L.check(L.lib().abr_roi_align_backward(L.ptr(grad), L.ptr(rois), K, B, Ch, H, W, float(spatial_scale), ph, pw,
                                            sampling_ratio, bin_step, L.NHWC, int(acc), L.ptr(out), L.stream()),
             "roi_align_backward")
+    amax_drop(out)
     return out
 
 
@@ -201,8 +203,86 @@ def bce_logits_gather(x, y, idx, gscale=1.0, want_grad=False, yidx=None, denom_d
 
 
 # ----------------------------------------------------------------------------------------------- conv
-MATH_F32, MATH_BF16, MATH_BF16X6 = 0, 1, 2   # abr_conv_desc::math (include/abr_iod_hip.h)
+MATH_F32, MATH_BF16, MATH_BF16X6, MATH_F16X3 = 0, 1, 2, 3   # abr_conv_desc::math (include/abr_iod_hip.h)
 X6_FLAG_TINY, X6_FLAG_NONFINITE = 1, 2       # ABR_X6_FLAG_*
+H3_FLAG_SMALL, H3_FLAG_STALE = 4, 8          # ABR_H3_FLAG_*
+
+# ---- f16x3 (MATH_F16X3): amax words.  A tensor's amax word (include/abr_iod_hip.h, abr_conv_desc) rides on the torch.Tensor OBJECT the producing
+# op returned, as `_abr_amax` = (word address, epoch, data_ptr, tensor version, allocation count): valid only while that object still names the
+# same bytes (same storage address, no in-place write since) and the library's ring has not wrapped past it.  A consumer that finds no valid tag
+# lets the library reduce the tensor itself (one extra pass over it: always correct).  ABR_H3_TAGS=0: never tag (every consumer reduces).
+H3_TAGS = os.environ.get("ABR_H3_TAGS", "1") != "0"
+_AMAX_RING = 65536
+_amax_count = [0]
+amax_reductions = [0, 0]   # (calls, bytes) of amax_compute: operands whose producer did not emit an amax word (bench.py reports them per step)
+
+
+def amax_new():
+    """a fresh amax word of the library's ring: (address, epoch)"""
+    w, e = C.c_void_p(0), C.c_uint32(0)
+    L.check(L.lib().abr_h3_amax_alloc(C.byref(w), C.byref(e)), "h3_amax_alloc")
+    _amax_count[0] += 1
+    return int(w.value), int(e.value)
+
+
+def amax_tag(t, word, epoch, stream=None):
+    """remember that `word` (epoch) holds max |t| -- called by the op that just produced t with that word as its out_amax.  stream: the word
+    was written by a reduction queued on that stream AFTER t was produced (amax_compute): only consumers on the same stream are ordered
+    behind it; a producer's own word (stream=None) is as ordered as the tensor's bytes."""
+    t._abr_amax = (word, epoch, t.data_ptr(), t._version, _amax_count[0], stream)
+    return t
+
+
+def amax_of(t):
+    """(word, epoch) of t's amax if t still carries a valid tag, else (None, 0)"""
+    tag = getattr(t, "_abr_amax", None)
+    if (tag is not None and tag[2] == t.data_ptr() and tag[3] == t._version and _amax_count[0] - tag[4] < _AMAX_RING // 4
+            and (tag[5] is None or tag[5] == L.stream())):
+        return tag[0], tag[1]
+    return None, 0
+
+
+def amax_carry(dst, src):
+    """dst is another view of exactly src's elements (permute / reshape of the whole tensor): it inherits the tag"""
+    tag = getattr(src, "_abr_amax", None)
+    if tag is not None and tag[2] == dst.data_ptr() and dst.numel() == src.numel():
+        dst._abr_amax = (tag[0], tag[1], tag[2], dst._version, tag[4], tag[5])
+    return dst
+
+
+def amax_carry_bound(dst, src):
+    """dst holds a subset / masked copy of src's values in fresh memory: src's amax is an upper bound of dst's"""
+    w, e = amax_of(src)
+    if w is not None:
+        dst._abr_amax = (w, e, dst.data_ptr(), dst._version, src._abr_amax[4], src._abr_amax[5])
+    return dst
+
+
+def amax_drop(t):
+    """t was written in place by a raw kernel: whatever tag it carried no longer describes it"""
+    if getattr(t, "_abr_amax", None) is not None:
+        t._abr_amax = None
+    return t
+
+
+def amax_compute(t):
+    """reduce max |t| into a fresh word on the current stream and tag t with it"""
+    t = L.f32c(t)
+    w, e = amax_new()
+    st = L.stream()
+    L.check(L.lib().abr_h3_amax(L.ptr(t), t.numel(), w, e, st), "h3_amax")
+    amax_reductions[0] += 1
+    amax_reductions[1] += t.numel() * 4
+    return amax_tag(t, w, e, st)
+
+
+def h3_range_stats(reset=True):
+    """(operand elements more than 18 binades below their tensor's amax, operand elements inspected) by the f16x3 kernels since the last
+    reset (abr_h3_range_stats).  Synchronises the current stream."""
+    import ctypes
+    v = (ctypes.c_uint64 * 2)(0, 0)
+    L.check(L.lib().abr_h3_range_stats(ctypes.cast(v, ctypes.c_void_p), int(bool(reset)), L.stream()), "h3_range_stats")
+    return int(v[0]), int(v[1])
 
 
 def x6_range_flags(reset=True):
@@ -293,21 +373,38 @@ def wino_v_alloc(x, w, stride, pad, math=MATH_F32):
 
 
 def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, mask=None, relu=False,
-                 out=None, out_hw=None, out_stride=(1, 1), math=MATH_F32, wino_v=None, w_planes=None, w_version=0):
+                 out=None, out_hw=None, out_stride=(1, 1), math=MATH_F32, wino_v=None, w_planes=None, w_version=0, emit_amax=None):
     """x [B,H,W,Cin] NHWC, w [Cout,R,S,Cin] OHWI -> [B,Ho,Wo,Cout] (or scattered into `out` [B,out_H,out_W,Cout]).
-    math=MATH_BF16: operands rounded to bf16 inside the kernel, bf16 MFMA, fp32 accumulate (fp32 tensors in and out)."""
+    math=MATH_BF16: operands rounded to bf16 inside the kernel, bf16 MFMA, fp32 accumulate (fp32 tensors in and out).
+    math=MATH_F16X3: x's amax word is taken from its tag when it has one (else the library reduces x first); emit_amax (default: under
+    MATH_F16X3) makes the kernel's epilogue write the output's amax word, and the result is tagged with it -- not when the conv accumulates
+    into a caller's `out` that already holds other pixels (a scattered second pass), whose amax the epilogue cannot know."""
     L.require_cuda(x, w)
-    x, w = L.f32c(x), L.f32c(w)
-    d = conv_desc(x.shape, w.shape, stride, pad, scale, bias, residual, mask, relu, out_hw, out_stride, math)
+    xc, w = L.f32c(x), L.f32c(w)
+    d = conv_desc(xc.shape, w.shape, stride, pad, scale, bias, residual, mask, relu, out_hw, out_stride, math)
     d.wino_v = L.ptr(wino_v)
     d.w_planes = L.ptr(w_planes)   # MATH_BF16X6: the caller's own pack_weights(w) planes (else the library packs (w, w_version) itself)
     d.w_version = int(w_version)   # non-zero: the library may keep data derived from (w, w_version): Winograd-domain weights, packed bf16x3 planes
+    if math == MATH_F16X3:
+        aw, ae = amax_of(x) if xc is x else (None, 0)
+        if aw is None and H3_TAGS:
+            aw, ae = amax_of(amax_compute(xc))
+        d.x_amax, d.x_amax_epoch = aw, ae
+    fresh = out is None
     if out is None:
         if out_hw is not None:
             out = torch.zeros((d.B, d.out_H, d.out_W, d.Cout), dtype=_f32, device=x.device)
         else:
-            out = _empty((d.B, d.Ho, d.Wo, d.Cout), x)
-    L.check(L.lib().abr_conv_forward(C.byref(d), L.ptr(x), L.ptr(w), L.ptr(out), L.stream()), "conv_forward")
+            out = _empty((d.B, d.Ho, d.Wo, d.Cout), xc)
+    if emit_amax is None:
+        emit_amax = math == MATH_F16X3
+    emit_amax = bool(emit_amax) and H3_TAGS and (fresh or out is residual) and d.out_sh == 1 and d.out_sw == 1
+    if emit_amax:
+        ow, oe = amax_new()
+        d.out_amax, d.out_amax_epoch = ow, oe
+    L.check(L.lib().abr_conv_forward(C.byref(d), L.ptr(xc), L.ptr(w), L.ptr(out), L.stream()), "conv_forward")
+    if emit_amax:
+        amax_tag(out, ow, oe)
     return out
 
 
@@ -418,13 +515,25 @@ def conv_cache_bytes():
     return int(L.lib().abr_conv_cache_bytes())
 
 
-def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino_v=None):
-    """dw [Cout,R,S,Cin] += scale * gy^T im2col(x) (fp32 atomics; caller zeroes dw once per step)"""
+def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino_v=None, amax_refs=None):
+    """dw [Cout,R,S,Cin] += scale * gy^T im2col(x) (fp32 atomics; caller zeroes dw once per step).  MATH_F16X3: the amax words of x and
+    gy come from their tags (else the library reduces the operand first); amax_refs = ((word, epoch) of x, of gy) taken by the caller on
+    the stream that produced the operands (conv_wgrad_async)."""
     L.require_cuda(x, gy, dw)
-    x, gy = L.f32c(x), L.f32c(gy)
-    d = conv_desc(x.shape, dw.shape, stride, pad, scale=scale, math=math)
+    xc, gyc = L.f32c(x), L.f32c(gy)
+    d = conv_desc(xc.shape, dw.shape, stride, pad, scale=scale, math=math)
     d.wino_v = L.ptr(wino_v)
-    L.check(L.lib().abr_conv_wgrad(C.byref(d), L.ptr(x), L.ptr(gy), L.ptr(dw), L.stream()), "conv_wgrad")
+    if math == MATH_F16X3:
+        if xc is x:
+            d.x_amax, d.x_amax_epoch = amax_refs[0] if amax_refs else amax_of(x)
+        if gyc is gy:
+            d.gy_amax, d.gy_amax_epoch = amax_refs[1] if amax_refs else amax_of(gy)
+        if H3_TAGS:   # (reduced here rather than inside the call so that a second consumer of the same tensor finds the tag)
+            if not d.x_amax and wino_v is None:
+                d.x_amax, d.x_amax_epoch = amax_of(amax_compute(xc))
+            if not d.gy_amax:
+                d.gy_amax, d.gy_amax_epoch = amax_of(amax_compute(gyc))
+    L.check(L.lib().abr_conv_wgrad(C.byref(d), L.ptr(xc), L.ptr(gyc), L.ptr(dw), L.stream()), "conv_wgrad")
     return dw
 
 
@@ -531,9 +640,19 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino
     _wg_seq["n"] += 1
     if WGRAD_MAIN_TAIL and _wg_seq["last_total"] and _wg_seq["n"] > _wg_seq["last_total"] - WGRAD_MAIN_TAIL:
         return conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v)   # (same stream as its producers: nothing to order)
+    refs = None
+    if math == MATH_F16X3 and H3_TAGS and x.is_contiguous() and gy.is_contiguous():
+        # operands without an amax word get one HERE, on the stream that produced them: the dgrad that follows on this stream shares gy's, and
+        # the side stream (ordered behind this point by wait_stream) is handed both -- a word reduced on the side stream would not be ordered
+        # before this stream's later readers
+        if wino_v is None and amax_of(x)[0] is None:
+            amax_compute(x)
+        if amax_of(gy)[0] is None:
+            amax_compute(gy)
+        refs = (amax_of(x), amax_of(gy))
     side.wait_stream(cur)  # x, gy (and the zeroed gradient buffer) are produced on the current stream
     with torch.cuda.stream(side):
-        conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v)
+        conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v, amax_refs=refs)
     if wino_v is not None:
         wino_v.record_stream(side)
     x.record_stream(side)  # the caching allocator must not recycle them for the main stream while the side kernel reads
@@ -639,6 +758,8 @@ def relu_backward(g, y, inplace=False):
     g = L.f32c(g)
     out = g if inplace else torch.empty_like(g)
     L.check(L.lib().abr_relu_backward(L.ptr(g), L.ptr(y), g.numel(), L.ptr(out), L.stream()), "relu_backward")
+    if not inplace:
+        amax_carry_bound(out, g)   # (masking only removes elements: g's amax stays an upper bound, which is all a split scale needs)
     return out
 
 
@@ -648,6 +769,7 @@ def relu_backward_(g, y):
 
 def add_(a, b):
     L.check(L.lib().abr_add_inplace(L.ptr(a), L.ptr(b), a.numel(), L.stream()), "add_inplace")
+    amax_drop(a)
     return a
 
 
@@ -690,6 +812,7 @@ def scale_(x, s=1.0, s_dev=None):
     if x is None:
         return None
     L.check(L.lib().abr_scale_inplace(L.ptr(x), x.numel(), float(s), L.ptr(s_dev), L.stream()), "scale_inplace")
+    amax_drop(x)
     return x
 
 

@@ -30,7 +30,8 @@ PEAK_CLOCK_GHZ = 2.4             # same guide: the clock both peaks are quoted a
 PROF_NAMES = ["conv_igemm_kernel<128,128>", "conv_igemm_kernel<128,64>", "conv_igemm_kernel<64,64>", "conv_igemm_kernel<128,64,small_c>",
               "conv_wgrad_kernel", "roi_align_fwd", "roi_align_bwd", "conv_igemm_bf16_kernel", "conv_wgrad_bf16_kernel",
               "conv_igemm_x6_kernel<128,128>", "conv_igemm_x6_kernel<128,64>", "conv_igemm_x6_kernel<64,64>",
-              "conv_igemm_x6w_kernel<128,128>", "conv_igemm_x6w_kernel<128,64>", "conv_igemm_x6w_kernel<64,64>", "conv_tail64_x6w_kernel"]
+              "conv_igemm_x6w_kernel<128,128>", "conv_igemm_x6w_kernel<128,64>", "conv_igemm_x6w_kernel<64,64>", "conv_tail64_x6w_kernel",
+              "conv_igemm_x6w_kernel<128,128,NP=3>", "conv_igemm_x6w_kernel<128,64,NP=3>", "conv_igemm_x6w_kernel<64,64,NP=3>", "conv_wgrad_x6_kernel<3>"]
 # (positions = abr::ProfId in csrc/common.h.  One row per TEMPLATE INSTANCE of the bf16x6 implicit GEMM, named as rocprofv3 names them
 #  (`conv_igemm_x6w_kernel<128, 128, 1, 4, true>` ...: x6w = the weights-direct form, x6 = the form that splits the weight tile per workgroup),
 #  so every row's fraction can be recomputed from profiles/ alone.  id 8 is the
@@ -84,6 +85,8 @@ def _pmc_traffic(kernel):
 
 
 def _peak_of(name):
+    if "NP=3" in name or name.endswith("<3>"):
+        return round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1)   # f16x3: three fp16 MFMA products (bf16 rate) per fp32 multiply-add
     if "_x6_" in name or "_x6w_" in name:
         return round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)   # six bf16 MFMA products per fp32 multiply-add
     return PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
@@ -160,7 +163,8 @@ def roofline(prof, totals, a, elapsed, event_overhead_ms=0.0, serialised=None):
     step_s = elapsed / a.steps
     exec_flops_step = sum(v[1] for k, v in totals.items() if "roi_align" not in k) / a.steps
     alg_flops_step = GFLOP_PER_IMG_ARD * 1e9 * a.batch_per_gpu
-    peak_step = PEAK_FP32_MFMA_TFLOPS if a.math == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if a.math == "bf16x6" else None
+    peak_step = (PEAK_FP32_MFMA_TFLOPS if a.math == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if a.math == "bf16x6"
+                 else round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1) if a.math == "f16x3" else None)
     r = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": top["peak"], "unit": "TFLOP/s", "frac": top["frac"],
          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
          # `peak` is priced at the 2.4 GHz maximum clock; under matrix-core load the chip clocks to its power budget (MI355X_MICROARCH.md, "DVFS
@@ -317,7 +321,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the short informational re-run on the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--math", choices=["f32", "bf16", "bf16-all", "bf16x6"], default="bf16x6",
+    ap.add_argument("--math", choices=["f32", "bf16", "bf16-all", "bf16x6", "f16x3"], default="bf16x6",
                     help="bf16x6 (default): fp32 tensors, fp32 accumulation, fp32 error bound -- every contraction operand is split EXACTLY into "
                          "three bf16 terms and the six leading cross products run on the bf16 matrix cores (range-guarded; admitted by "
                          "tests/test_gpu_x6_admission.py).  f32 = the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32).  bf16 = BASELINE.json "
@@ -383,7 +387,7 @@ def main():
     B = a.batch_per_gpu
     if a.math == "bf16-all":
         os.environ["ABR_BF16_SCOPE"] = "all"
-    os.environ["ABR_CONV_MATH"] = "f32" if a.math == "f32" else "bf16x6"   # (--math bf16: bf16 backbone, the default arithmetic everywhere else)
+    os.environ["ABR_CONV_MATH"] = a.math if a.math in ("f32", "f16x3") else "bf16x6"   # (--math bf16: bf16 backbone, the default arithmetic everywhere else)
     dist_type, feat, alpha, beta, gamma = TASKS[a.task]
     n_old_cls, n_new_cls = {"15-5": (15, 5), "10-10": (10, 10), "10-5": (10, 5), "19-1": (19, 1)}[a.task]
     cfg_s, cfg_t = make_cfgs(a.task, dist_type=dist_type, feat=feat, alpha=alpha, beta=beta, gamma=gamma, ims_per_batch=B * world,
@@ -490,7 +494,9 @@ def main():
             "metric": "training images/sec (R50-C4 Faster R-CNN + ARD)", "value": round(value, 3), "unit": "img/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-            "dtype": "f32" if a.math == "f32" else "f32 (tensors, accumulation and error bound; contractions via an exact 3-term bf16 split of both "
+            "dtype": "f32" if a.math == "f32" else "f32 (tensors, accumulation and error bound; contractions via a 2-term fp16 split of both operands scaled by "
+                                                   "their amax, 3 cross products on the fp16 matrix cores: f16x3)" if a.math == "f16x3"
+            else "f32 (tensors, accumulation and error bound; contractions via an exact 3-term bf16 split of both "
                                                    "operands, 6 cross products on the bf16 matrix cores, range-guarded)"
             if a.math == "bf16x6" else "bf16 MFMA operands / f32 accumulate / f32 tensors ({}); the fp32-accurate bf16x6 contractions elsewhere".format(
                 "backbone layer1-3" if a.math == "bf16" else "backbone, RPN head, layer4"),
@@ -511,10 +517,16 @@ def main():
             "conv_math_at_end": getattr(model_target, "conv_math", None),   # "f32" here = the range guard took the run off the bf16x6 kernels
             "math": a.math,
         }
-        if a.math == "bf16x6":
+        if a.math in ("bf16x6", "f16x3"):
             from abr_iod_amd import ops as _o
             fl = _o.x6_range_flags(reset=False)
             out["x6_range_guard"] = {"flags": fl, "tiny_operands_seen": bool(fl & _o.X6_FLAG_TINY), "non_finite_operands_seen": bool(fl & _o.X6_FLAG_NONFINITE)}
+            if a.math == "f16x3":
+                small, seen = _o.h3_range_stats(reset=False)
+                out["x6_range_guard"].update({"stale_amax_word": bool(fl & _o.H3_FLAG_STALE), "operand_elements_inspected": seen,
+                                              "amax_reductions_by_the_host_side": {"calls": _o.amax_reductions[0], "mb": round(_o.amax_reductions[1] / 1e6, 1),
+                                                                                   "note": "whole run (warm-up, timed steps, informational legs): operands whose producer did not emit its amax word"},
+                                              "elements_more_than_18_binades_below_amax": small, "fraction": (small / seen if seen else None)})
         if prof:
             out["roofline"] = roofline(prof, prof_totals, a, elapsed, event_overhead_ms, serialised)
         if world == 1 and not a.no_cpu_baseline:

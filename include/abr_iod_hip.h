@@ -77,6 +77,11 @@ int abr_prof_event_overhead_ms(double* out_host, void* stream);
  * (the Python host does: ops.x6_range_flags, engine/trainer.py). */
 #define ABR_X6_FLAG_TINY 1u
 #define ABR_X6_FLAG_NONFINITE 2u
+/* f16x3 arithmetic (ABR_MATH_F16X3), same flag word: SMALL = an operand holds non-zero elements more than 18 binades below its amax (they keep an
+ * ABSOLUTE accuracy of 2^-40 amax instead of 2^-22 relative: reported, harmless unless a whole reduction consists of them); STALE = an amax word
+ * did not carry the epoch the caller named (a caller bug: the kernel then ran with scale 1); a non-finite amax raises ABR_X6_FLAG_NONFINITE. */
+#define ABR_H3_FLAG_SMALL 4u
+#define ABR_H3_FLAG_STALE 8u
 int abr_x6_range_flags(uint32_t* out_host, int reset, void* stream);
 /* the same word copied to PINNED host memory on `stream` without synchronising (the trainer polls it one step later) */
 int abr_x6_range_flags_async(uint32_t* out_pinned_host, void* stream);
@@ -213,6 +218,7 @@ int abr_bce_logits_gather(const float* x, const float* y, const int64_t* idx, co
 #define ABR_MATH_F32 0
 #define ABR_MATH_BF16 1
 #define ABR_MATH_BF16X6 2
+#define ABR_MATH_F16X3 3
 
 typedef struct {
     int B, H, W, Cin;        /* input  [B,H,W,Cin]  (Cin % 4 == 0) */
@@ -250,7 +256,28 @@ typedef struct {
        floats, or their packed bf16x3 planes under ABR_MATH_BF16X6) and the packed bf16x3 planes of w -- and skips the derivation on later calls (the frozen source model: once; a trainable conv: once per optimiser
        step, shared by its forward passes).  0 = derive it again on every call. */
     int64_t w_version;
+    /* ABR_MATH_F16X3 (round 5): fp32-ACCURATE contractions with THREE products per multiply-add.  Each operand is written x = s (h0 + h1) with
+       h0 = fp16(x / s), h1 = fp16(x / s - h0) and s = the power of two that puts the operand's largest magnitude in [2^14, 2^15) -- per tensor
+       for activations / gradients, per output channel for weights (folded into the epilogue) -- and x w = s_x s_w (h0 g0 + h0 g1 + h1 g0) runs on
+       v_mfma_f32_32x32x16_f16 with fp32 accumulation.  Representation error <= 2^-22 |x| for |x| >= 2^-18 amax (2^-40 amax below), random-signed:
+       the result meets the fp32-MFMA error bound on tensors whose reductions are not made of such elements only (tests/test_gpu_f16x3_admission.py).
+       The amax of an activation tensor lives in an AMAX WORD (abr_h3_amax_alloc): the producing kernel writes it (out_amax: any abr_conv_forward,
+       whatever its math), the consuming kernel reads it (x_amax; gy_amax for abr_conv_wgrad).  A NULL x_amax / gy_amax makes the call reduce the
+       operand itself first (one extra pass over it: correct, slower). */
+    const uint64_t* x_amax;   uint32_t x_amax_epoch;
+    const uint64_t* gy_amax;  uint32_t gy_amax_epoch;
+    uint64_t* out_amax;       uint32_t out_amax_epoch;
 } abr_conv_desc;
+
+/* An amax word of the library's zero-initialised device ring and the epoch to use with it (see abr_conv_desc).  A word is handed out again after
+ * ABR_H3_AMAX_RING allocations; by then its tensor must be gone (a reader naming an older epoch raises ABR_H3_FLAG_STALE). */
+#define ABR_H3_AMAX_RING 65536
+int abr_h3_amax_alloc(uint64_t** word_out, uint32_t* epoch_out);
+/* Range statistics of the f16x3 kernels since the last reset: out_host[0] = operand elements seen more than 18 binades below their tensor's amax
+ * (non-zero), out_host[1] = operand elements inspected (every element of an activation / gradient operand once per GEMM).  Synchronises `stream`. */
+int abr_h3_range_stats(uint64_t* out_host, int reset, void* stream);
+/* *word = (epoch << 32) | bits(max |x[i]|) for n floats on `stream` (what a producer kernel's epilogue writes for free) */
+int abr_h3_amax(const float* x, int64_t n, uint64_t* word, uint32_t epoch, void* stream);
 
 int abr_conv_forward(const abr_conv_desc* d_host, const float* x, const float* w, float* out, void* stream);
 /* The tail of a 64-wide bottleneck WITHOUT a backward pass (maskrcnn_benchmark/modeling/backbone/resnet.py:327-346 for the frozen layer1:
