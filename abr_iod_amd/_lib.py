@@ -72,6 +72,7 @@ _SIGS = {
     "abr_h3_amax_alloc": (_i, [_vp, _vp]),
     "abr_h3_amax": (_i, [_vp, _i64, _vp, C.c_uint32, _vp]),
     "abr_h3_range_stats": (_i, [_vp, _i, _vp]),
+    "abr_h3_range_stats_to_device": (_i, [_vp, _i, _vp]),
     "abr_x6_range_flags": (_i, [_vp, _i, _vp]),
     "abr_x6_range_flags_async": (_i, [_vp, _vp]),
     "abr_x6_range_flags_to_device": (_i, [_vp, _vp]),

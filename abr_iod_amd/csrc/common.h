@@ -193,8 +193,8 @@ __device__ __forceinline__ void h3_split2(const float a, const float b, const fl
     o0 = h0; o1 = h1;
 }
 // Range report of an f16x3 operand (one call per inspecting WAVE, all lanes): nsmall = this lane's count of non-zero elements more than 18
-// binades below the amax (h3_small_threshold), inspected = elements this wave looked at.  Flags as in include/abr_iod_hip.h; the two counts are
-// added to the device statistics behind abr_h3_range_stats.
+// binades below the amax (h3_small_threshold).  Flags as in include/abr_iod_hip.h (conditions somebody must act on); the count goes to the
+// device statistics behind abr_h3_range_stats (data with such elements is ordinary: a Gaussian tensor of a million elements has a few).
 constexpr int kH3StatSlots = 256;     // the small-element counts are spread over this many words (one address would serialise the atomics)
 unsigned long long* h3_stats_ptr();   // device [kH3StatSlots] partial counts of small elements
 void h3_stats_inspected(double n);    // host-side count of inspected operand elements (the launch functions know it)
@@ -209,7 +209,6 @@ __device__ __forceinline__ void h3_report(unsigned amax_bits, unsigned nsmall, u
     unsigned f = 0;
     if (amax_bits == 0xFFFFFFFFu) f |= ABR_H3_FLAG_STALE;
     else if ((amax_bits >> 23) >= 255u) f |= ABR_X6_FLAG_NONFINITE;
-    else if (nsmall) f |= ABR_H3_FLAG_SMALL;
     if (f && (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & f) != f) atomicOr(flags, f);   // (the bits are sticky: set once)
     if (stats && nsmall) atomicAdd(stats + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (kH3StatSlots - 1)), (unsigned long long)nsmall);
 }

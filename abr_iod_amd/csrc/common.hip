@@ -343,6 +343,34 @@ extern "C" int abr_h3_range_stats(uint64_t* out_host, int reset, void* stream) {
     if (reset) (void)hipMemsetAsync(p, 0, sizeof slots, st);
     return ABR_OK;
 }
+namespace {
+__global__ void h3_stats_sum_kernel(unsigned long long* slots, unsigned long long inspected, int reset, unsigned long long* out) {
+    unsigned long long v = slots[threadIdx.x];
+    if (reset) slots[threadIdx.x] = 0;
+    __shared__ unsigned long long sm[abr::kH3StatSlots];
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = abr::kH3StatSlots / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sm[0]; out[1] = inspected; }
+}
+}  // namespace
+extern "C" int abr_h3_range_stats_to_device(uint64_t* out_device, int reset, void* stream) {
+    ABR_REQUIRE(out_device, "h3_range_stats_to_device: null pointer");
+    unsigned long long* p = abr::h3_stats_ptr();
+    ABR_REQUIRE(p, "h3_range_stats_to_device: no device memory");
+    unsigned long long inspected;
+    {
+        std::lock_guard<std::mutex> g(abr::g_h3_stats_mu);
+        inspected = (unsigned long long)abr::g_h3_inspected;
+        if (reset) abr::g_h3_inspected = 0.0;
+    }
+    h3_stats_sum_kernel<<<1, abr::kH3StatSlots, 0, abr::as_stream(stream)>>>(p, inspected, reset, reinterpret_cast<unsigned long long*>(out_device));
+    ABR_CHECK_LAUNCH("h3_range_stats_to_device");
+    return ABR_OK;
+}
 extern "C" int abr_h3_amax(const float* x, int64_t n, uint64_t* word, uint32_t epoch, void* stream) {
     ABR_REQUIRE(word && n >= 0 && (n == 0 || x), "h3_amax: bad args");
     ABR_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "h3_amax: x must be 16-byte aligned");

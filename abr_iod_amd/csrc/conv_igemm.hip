@@ -2087,7 +2087,8 @@ extern "C" int64_t abr_conv_wino_v_floats(const abr_conv_desc* d) {
     static const bool wino_wgrad = !(getenv("ABR_WINOGRAD_WGRAD") && atoi(getenv("ABR_WINOGRAD_WGRAD")) == 0);
     const bool scatter = !((d->out_H <= 0 || d->out_H == d->Ho) && (d->out_W <= 0 || d->out_W == d->Wo) && d->out_sh <= 1 && d->out_sw <= 1);
     const bool ok = wino_wgrad && wino_min_c() > 0 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && !scatter && !d->residual &&
-                    d->Cin % BK == 0 && d->Cout % 4 == 0 && d->Cin >= wino_min_c() && d->Cout >= 128;
+                    d->Cin % BK == 0 && d->Cout % 4 == 0 && d->Cin >= wino_min_c() && d->Cout >= 128 &&
+                    (d->math != ABR_MATH_F16X3 || d->Cout % 32 == 0);   // (f16x3 packs U in 32-row blocks: wino_conv)
     if (!ok) return 0;
     const int64_t T = (int64_t)d->B * ((d->H + 3) / 4) * ((d->W + 3) / 4);
     if (T * (int64_t)std::max(d->Cin, d->Cout) * 4 >= (int64_t)0x7FFFFFF0) return 0;

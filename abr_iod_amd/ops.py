@@ -205,7 +205,7 @@ def bce_logits_gather(x, y, idx, gscale=1.0, want_grad=False, yidx=None, denom_d
 # ----------------------------------------------------------------------------------------------- conv
 MATH_F32, MATH_BF16, MATH_BF16X6, MATH_F16X3 = 0, 1, 2, 3   # abr_conv_desc::math (include/abr_iod_hip.h)
 X6_FLAG_TINY, X6_FLAG_NONFINITE = 1, 2       # ABR_X6_FLAG_*
-H3_FLAG_SMALL, H3_FLAG_STALE = 4, 8          # ABR_H3_FLAG_*
+H3_FLAG_STALE = 8                            # ABR_H3_FLAG_STALE
 
 # ---- f16x3 (MATH_F16X3): amax words.  A tensor's amax word (include/abr_iod_hip.h, abr_conv_desc) rides on the torch.Tensor OBJECT the producing
 # op returned, as `_abr_amax` = (word address, epoch, data_ptr, tensor version, allocation count): valid only while that object still names the
@@ -334,6 +334,30 @@ class X6RangeWatch(object):
         x6_range_flags(reset=True)    # synchronises the stream: the pending copy has landed
         self._event = None
         self._host.zero_()
+
+    def poll_h3_stats(self, reduce_over_ranks=False):
+        """f16x3: enqueue an asynchronous read of (small operand elements, inspected operand elements) since the previous call (the device
+        counters are reset by the read; SUM over the ranks first under data parallelism) and return the PREVIOUS read's pair, or None while
+        none has landed.  No host stall."""
+        seen = None
+        ev = getattr(self, "_h3_event", None)
+        if ev is not None and reduce_over_ranks:
+            ev.synchronize()   # (every rank reads the same poll: see poll())
+        if ev is not None and ev.query():
+            seen = (int(self._h3_host[0].item()), int(self._h3_host[1].item()))
+            self._h3_event = ev = None
+        if ev is None:
+            if getattr(self, "_h3_dev", None) is None:
+                self._h3_dev = torch.zeros(2, dtype=torch.int64, device="cuda")
+                self._h3_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+            L.check(L.lib().abr_h3_range_stats_to_device(self._h3_dev.data_ptr(), 1, L.stream()), "h3_range_stats_to_device")
+            if reduce_over_ranks:
+                import torch.distributed as dist
+                dist.all_reduce(self._h3_dev, op=dist.ReduceOp.SUM)
+            self._h3_host.copy_(self._h3_dev, non_blocking=True)
+            self._h3_event = torch.cuda.Event()
+            self._h3_event.record()
+        return seen
 
 
 def conv_desc(x_shape, w_shape, stride, pad, scale=None, bias=None, residual=None, mask=None, relu=False,

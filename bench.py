@@ -526,7 +526,8 @@ def main():
                 out["x6_range_guard"].update({"stale_amax_word": bool(fl & _o.H3_FLAG_STALE), "operand_elements_inspected": seen,
                                               "amax_reductions_by_the_host_side": {"calls": _o.amax_reductions[0], "mb": round(_o.amax_reductions[1] / 1e6, 1),
                                                                                    "note": "whole run (warm-up, timed steps, informational legs): operands whose producer did not emit its amax word"},
-                                              "elements_more_than_18_binades_below_amax": small, "fraction": (small / seen if seen else None)})
+                                              "elements_more_than_18_binades_below_amax": small, "fraction": (small / seen if seen else None),
+                                              "fraction_at_the_trainers_last_poll": getattr(_trainer.trainer_state(model_target), "h3_small_fraction", None)})
         if prof:
             out["roofline"] = roofline(prof, prof_totals, a, elapsed, event_overhead_ms, serialised)
         if world == 1 and not a.no_cpu_baseline:

@@ -77,10 +77,9 @@ int abr_prof_event_overhead_ms(double* out_host, void* stream);
  * (the Python host does: ops.x6_range_flags, engine/trainer.py). */
 #define ABR_X6_FLAG_TINY 1u
 #define ABR_X6_FLAG_NONFINITE 2u
-/* f16x3 arithmetic (ABR_MATH_F16X3), same flag word: SMALL = an operand holds non-zero elements more than 18 binades below its amax (they keep an
- * ABSOLUTE accuracy of 2^-40 amax instead of 2^-22 relative: reported, harmless unless a whole reduction consists of them); STALE = an amax word
- * did not carry the epoch the caller named (a caller bug: the kernel then ran with scale 1); a non-finite amax raises ABR_X6_FLAG_NONFINITE. */
-#define ABR_H3_FLAG_SMALL 4u
+/* f16x3 arithmetic (ABR_MATH_F16X3), same flag word: STALE = an amax word did not carry the epoch the caller named (a caller bug: the kernel
+ * then ran with scale 1); a non-finite amax raises ABR_X6_FLAG_NONFINITE.  Operand elements more than 18 binades below their tensor's amax
+ * (they keep an ABSOLUTE accuracy of 2^-40 amax instead of 2^-22 relative) are ordinary and are COUNTED, not flagged: abr_h3_range_stats. */
 #define ABR_H3_FLAG_STALE 8u
 int abr_x6_range_flags(uint32_t* out_host, int reset, void* stream);
 /* the same word copied to PINNED host memory on `stream` without synchronising (the trainer polls it one step later) */
@@ -276,6 +275,9 @@ int abr_h3_amax_alloc(uint64_t** word_out, uint32_t* epoch_out);
 /* Range statistics of the f16x3 kernels since the last reset: out_host[0] = operand elements seen more than 18 binades below their tensor's amax
  * (non-zero), out_host[1] = operand elements inspected (every element of an activation / gradient operand once per GEMM).  Synchronises `stream`. */
 int abr_h3_range_stats(uint64_t* out_host, int reset, void* stream);
+/* the same two numbers written to DEVICE memory on `stream` without synchronising (a training loop copies them out asynchronously, after a SUM
+ * over the ranks under data parallelism: engine/trainer.py::_x6_guard) */
+int abr_h3_range_stats_to_device(uint64_t* out_device, int reset, void* stream);
 /* *word = (epoch << 32) | bits(max |x[i]|) for n floats on `stream` (what a producer kernel's epilogue writes for free) */
 int abr_h3_amax(const float* x, int64_t n, uint64_t* word, uint32_t epoch, void* stream);
 

@@ -19,14 +19,14 @@ def _close(a, b, tol=1e-4):
     return abs(a - b) <= tol * max(1.0, abs(b))
 
 
-CASES = [(n, m) for n in ("15-5", "10-10", "10-5", "finetune") for m in ("bf16x6", "f32")]
+CASES = [(n, m) for n in ("15-5", "10-10", "10-5", "finetune") for m in ("bf16x6", "f16x3", "f32")]
 
 
 @pytest.fixture(scope="module", params=CASES, ids=["{}-{}".format(*c) for c in CASES])
 def step_state(request):
     """Every BASELINE.json configuration (tests/e2e_common.py: finetune = configs[1], 15-5 = configs[2], 10-10 = configs[3],
-    10-5 = configs[4]) in BOTH arithmetics: bf16x6 (the default and the one bench.py reports: fp32-accurate contractions on the bf16
-    matrix cores) and f32 (ABR_CONV_MATH=f32: the fp32 MFMA kernels).  The SAME oracle comparisons at the SAME tolerances hold for all."""
+    10-5 = configs[4]) in EVERY fp32-accurate arithmetic: bf16x6 (exact three-term bf16 split, six products), f16x3 (two-term fp16 split
+    scaled by the operands' amax, three products: round 5) and f32 (ABR_CONV_MATH=f32: the fp32 MFMA kernels).  The SAME oracle comparisons at the SAME tolerances hold for all."""
     import os
     import random
     from e2e_common import CONFIGS, clamp_targets, needs_source
@@ -51,7 +51,7 @@ def step_state(request):
     clamp_targets(targets, 224, 160)   # keep GT inside the small image
     os.environ.pop("ABR_CONV_MATH", None)   # read at model construction only
     from abr_iod_amd import ops
-    want = ops.MATH_BF16X6 if math == "bf16x6" else ops.MATH_F32
+    want = {"bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3, "f32": ops.MATH_F32}[math]
     assert all(m.math == want for m in mt.modules() if hasattr(m, "math"))
     return dict(name=name, cfg_s=cfg_s, cfg_t=cfg_t, ms=ms, mt=mt, images=images, targets=targets, n_old=n_old, dist_type=dist_type,
                 sd_s=reference_state_dict(ms) if ms is not None else None, sd_t=reference_state_dict(mt))

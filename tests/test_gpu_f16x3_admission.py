@@ -14,7 +14,7 @@ this library has,   |err| <= 2^-22 sum|x||w|  +  2^-40 (amax_x sum_k |w_k| + ama
     bf16x6;
   * OUTSIDE it -- exponents spread over 2^+-40 / 2^+-60 inside every reduction (80 / 120 binades: what bf16x6 still takes), a reduction
     made only of elements far below the tensor's amax -- the error must stay within the ABSOLUTE bound above (tested with a factor 2), and
-    the guard counts the elements below the 18 binades (ABR_H3_FLAG_SMALL, ops.h3_range_stats: the trainer reports the fraction and
+    the kernels count the elements below the 18 binades (ops.h3_range_stats: the trainer reads the fraction every few steps and
     leaves the arithmetic for bf16x6 above ABR_H3_MAX_SMALL_FRACTION); inf / nan operands raise ABR_X6_FLAG_NONFINITE, poison their own
     outputs, and the trainer switches the models to the fp32 MFMA kernels; an amax word that does not carry the epoch the caller names
     raises ABR_H3_FLAG_STALE (a plumbing bug, never data).
@@ -100,8 +100,7 @@ def test_in_domain_error_matches_fp32_kernel(name):
     w3 = _rel_err(_wgrad(X, G, ops.MATH_F16X3), d64, dscale)
     print(f"{name}: wgrad    f32 {w32 / EPS:.1f} ulp   f16x3 {w3 / EPS:.1f} ulp")
     assert w3 <= max(2.0 * w32, 8 * EPS), (name, w3, w32)
-    # nothing but the informational SMALL bit may be up (never NONFINITE / STALE / bf16x6's TINY)
-    assert ops.x6_range_flags(reset=True) & ~ops.H3_FLAG_SMALL == 0, name
+    assert ops.x6_range_flags(reset=True) == 0, name
 
 
 @pytest.mark.parametrize("name", OUT_OF_DOMAIN)
@@ -126,7 +125,7 @@ def test_out_of_domain_spread_stays_within_the_absolute_bound(name):
     w32 = _rel_err(_wgrad(X, G, ops.MATH_F32), d64, dscale)
     print(f"{name}: wgrad    f32 {w32 / EPS:.1f} ulp   f16x3 {float((derr / dscale).max()) / EPS:.1f} ulp, {float((derr / (dfloor + 1e-300)).max()):.3f} of the absolute floor")
     assert bool((derr <= max(2.0 * w32, 8 * EPS) * dscale + dfloor).all()), name
-    assert ops.x6_range_flags(reset=True) == ops.H3_FLAG_SMALL
+    assert ops.x6_range_flags(reset=True) == 0
     small, seen = ops.h3_range_stats(reset=True)
     print(f"{name}: {small} of {seen} inspected operand elements more than 18 binades below their amax ({small / seen:.2f})")
     assert small / seen > 0.5
@@ -151,7 +150,7 @@ def test_in_domain_winograd_and_dgrad_paths():
         print(f"winograd 3x3, spread 2^+-{sp}: f32 {e['f32'] / EPS:.1f} ulp, f16x3 {e['h3'] / EPS:.1f} ulp (of sum|x||w|; includes the transforms' own fp32 rounding)")
         assert e["h3"] <= max(2.0 * e["f32"], 8 * EPS)
         assert e["h3 cached"] == e["h3"]
-        assert ops.x6_range_flags(reset=True) & ~ops.H3_FLAG_SMALL == 0
+        assert ops.x6_range_flags(reset=True) == 0
         # input gradient of a 1x1 conv = forward with the transposed weight copy
         w1 = rn(Co, 1, 1, C)
         wt = ops.conv_dgrad_weights(w1, None)
@@ -184,7 +183,7 @@ def test_in_domain_winograd_and_dgrad_paths():
             ew[tag] = float(((dw.double() - d64).abs() / s64w).max())
         print(f"winograd wgrad, spread 2^+-{sp}: f32 {ew['f32'] / EPS:.1f} ulp, f16x3 {ew['h3'] / EPS:.1f} ulp, with the kept V {ew['h3 kept V'] / EPS:.1f}")
         assert ew["h3"] <= max(2.0 * ew["f32"], 8 * EPS) and ew["h3 kept V"] <= max(2.0 * ew["f32"], 8 * EPS), ew
-        assert ops.x6_range_flags(reset=True) & ~ops.H3_FLAG_SMALL == 0
+        assert ops.x6_range_flags(reset=True) == 0
 
 
 def test_amax_from_the_producers_tag_equals_amax_reduced_by_the_library(monkeypatch):
@@ -212,7 +211,7 @@ def test_amax_from_the_producers_tag_equals_amax_reduced_by_the_library(monkeypa
     assert ops.amax_of(h)[0] is not None
     h.mul_(3.0)
     assert ops.amax_of(h)[0] is None
-    assert ops.x6_range_flags(reset=True) & ~ops.H3_FLAG_SMALL == 0
+    assert ops.x6_range_flags(reset=True) == 0
 
 
 def test_reduction_made_of_small_elements_only_is_bounded_absolutely_and_counted():
@@ -231,7 +230,7 @@ def test_reduction_made_of_small_elements_only_is_bounded_absolutely_and_counted
     assert bool(((y - y64).abs() <= bound).all())
     rel_small = _rel_err(y[: M // 2].float(), y64[: M // 2], (x.double().abs() @ w.double().abs().t())[: M // 2])
     print(f"all-small rows: {rel_small / EPS:.0f} ulp relative to their own scale (bounded absolutely instead)")
-    assert ops.x6_range_flags(reset=True) == ops.H3_FLAG_SMALL
+    assert ops.x6_range_flags(reset=True) == 0
     small, seen = ops.h3_range_stats(reset=True)
     assert seen == M * K and M * K // 2 <= small <= M * K // 2 + M * K // 100, (small, seen)
 
@@ -275,14 +274,16 @@ def test_stale_amax_word_raises_the_flag():
     assert ops.x6_range_flags(reset=True) & ops.H3_FLAG_STALE
 
 
-@pytest.mark.parametrize("trip", ["nonfinite", "small"])
-def test_trainer_guard_on_f16x3(trip):
-    """inf / nan operands: both models leave the f16x3 arithmetic for the fp32 MFMA kernels.  Small elements: logged once, no switch."""
+@pytest.mark.parametrize("trip", ["nonfinite", "small", "clean"])
+def test_trainer_guard_on_f16x3(trip, monkeypatch):
+    """inf / nan operands: both models leave the f16x3 arithmetic for the fp32 MFMA kernels.  A large share of operand elements far below
+    their tensor's amax: both models move to bf16x6.  Ordinary data (a fraction of 1e-3): nothing happens."""
     import logging
     import os
     from abr_iod_amd import ops
     from abr_iod_amd.engine import trainer
     from abr_iod_amd.engine.synthetic import build_models, make_cfgs
+    monkeypatch.setattr(trainer, "H3_STATS_EVERY", 1)
     tiny = ["MODEL.RESNETS.STEM_OUT_CHANNELS", 16, "MODEL.RESNETS.RES2_OUT_CHANNELS", 32, "MODEL.RESNETS.WIDTH_PER_GROUP", 8,
             "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 128]
     os.environ["ABR_CONV_MATH"] = "f16x3"
@@ -294,6 +295,7 @@ def test_trainer_guard_on_f16x3(trip):
     assert mt.conv_math == ms.conv_math == "f16x3"
     assert all(m.math == ops.MATH_F16X3 for m in mt.modules() if hasattr(m, "math"))
     ops.x6_range_flags(reset=True)
+    ops.h3_range_stats(reset=True)
     trainer.trainer_state(mt).x6_watch = None
     for _ in range(3):                       # clean steps: nothing happens
         trainer._x6_guard(ms, mt)
@@ -303,19 +305,23 @@ def test_trainer_guard_on_f16x3(trip):
     bad = rn(M, K)
     if trip == "nonfinite":
         bad[5, 7] = float("inf")
-    else:
+    elif trip == "small":
         bad[: M // 2] *= 2.0 ** -25
     _gemm(bad, rn(N, K), ops.MATH_F16X3)
     records = []
     h = logging.Handler(); h.emit = records.append
     log = logging.getLogger("h3test." + trip); log.addHandler(h); log.setLevel(logging.INFO)
-    for _ in range(4):                       # the poll is asynchronous: the flag is seen one or two steps later
+    for _ in range(4):                       # the polls are asynchronous: a flag / a count is seen one or two steps later
         trainer._x6_guard(ms, mt, log)
         torch.cuda.synchronize()
+    if trip == "clean":
+        assert mt.conv_math == ms.conv_math == "f16x3" and not records
+        assert trainer.trainer_state(mt).h3_small_fraction < 0.01
+        return
     if trip == "small":
-        assert mt.conv_math == ms.conv_math == "f16x3"
-        assert len(records) == 1 and "18 binades" in records[0].getMessage() and records[0].levelno == logging.INFO
-        ops.x6_range_flags(reset=True)
+        assert mt.conv_math == ms.conv_math == "bf16x6"
+        assert all(m.math == ops.MATH_BF16X6 for m in mt.modules() if hasattr(m, "math"))
+        assert len(records) == 1 and "18 binades" in records[0].getMessage() and records[0].levelno == logging.WARNING
         return
     assert mt.conv_math == ms.conv_math == "f32"
     assert all(m.math == ops.MATH_F32 for m in mt.modules() if hasattr(m, "math"))

@@ -51,12 +51,12 @@ SCALE_CONVS = [
     (2, 256, 50, 84, 256, 3, 1, 1),      # layer3 3x3: Winograd, 50 = 12 tiles + 2 rows
     (2, 1024, 50, 84, 1024, 3, 1, 1),    # RPN 3x3
 ]
-MATHS = ["bf16x6", "f32"]   # bf16x6 = the default arithmetic, the one bench.py reports; f32 = the fp32 MFMA kernels
+MATHS = ["bf16x6", "f16x3", "f32"]   # bf16x6 = the default arithmetic, the one bench.py reports; f32 = the fp32 MFMA kernels
 
 
 def _math(name):
     from abr_iod_amd import ops
-    return ops.MATH_BF16X6 if name == "bf16x6" else ops.MATH_F32
+    return {"bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3, "f32": ops.MATH_F32}[name]
 
 
 def _case_tensors(case):

@@ -771,12 +771,12 @@ def test_conv_bf16x6_mode_is_fp32_accurate(case):
     assert close(dx, xr.grad.permute(0, 2, 3, 1), tol * 2)
 
 
-@pytest.mark.parametrize("math", ["f32", "bf16x6"])
+@pytest.mark.parametrize("math", ["f32", "bf16x6", "f16x3"])
 def test_winograd_input_transform_is_shared_between_forward_and_wgrad(math):
     """abr_conv_desc::wino_v: the forward pass keeps its Winograd-domain input V and the weight gradient reads it instead of
     transforming x again -- same outputs as the self-contained calls (the gradient call must not even look at x)."""
     from abr_iod_amd import ops
-    m = ops.MATH_BF16X6 if math == "bf16x6" else ops.MATH_F32
+    m = {"bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3, "f32": ops.MATH_F32}[math]
     g = torch.Generator(device="cuda").manual_seed(3)
     for (B, H, W, Cin, Cout) in [(2, 38, 63, 256, 256), (96, 7, 7, 512, 512), (1, 21, 10, 128, 192)]:
         x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
@@ -937,14 +937,14 @@ def test_winograd_weight_cache_follows_w_version():
         assert torch.equal(y_c, y_d)
 
 
-@pytest.mark.parametrize("math", ["f32", "bf16x6"])
+@pytest.mark.parametrize("math", ["f32", "bf16x6", "f16x3"])
 def test_wgrad_split_reduction_is_deterministic_and_accumulates(math):
     """Split-M weight gradients park their partial tiles and a second launch adds them in split order (conv_wgrad.hip::wgrad_reduce_kernel):
     the same call gives bit-identical results every time (the round-1 fp32 atomics did not), `dw +=` still accumulates over calls
     (a weight used twice per step), and the values agree with float64.  Shapes: few output tiles x many rows (the split path),
     direct and Winograd-domain, plus one with a single split (plain stores)."""
     from abr_iod_amd import ops
-    m = ops.MATH_BF16X6 if math == "bf16x6" else ops.MATH_F32
+    m = {"bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3, "f32": ops.MATH_F32}[math]
     g = torch.Generator(device="cuda").manual_seed(5)
     for (B, H, W, Cin, Cout, k, pad) in [(2, 38, 63, 256, 1024, 1, 0), (1, 75, 125, 512, 128, 1, 0), (2, 38, 63, 256, 256, 3, 1), (8, 4, 4, 2048, 512, 1, 0)]:
         x = torch.randn(B, H, W, Cin, device="cuda", generator=g)

@@ -12,10 +12,10 @@ SHAPES = [  # (Cout, R, Cin, stride, pad, with scale)
 ]
 
 
-@pytest.mark.parametrize("math_name", ["bf16x6", "f32"])
+@pytest.mark.parametrize("math_name", ["bf16x6", "f16x3", "f32"])
 def test_batched_weight_preparation_equals_per_tensor_preparation(math_name):
     from abr_iod_amd import ops
-    math = ops.MATH_BF16X6 if math_name == "bf16x6" else ops.MATH_F32
+    math = {"bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3, "f32": ops.MATH_F32}[math_name]
     torch.manual_seed(0)
     ws, entries, wts, scales = [], [], [], []
     for i, (Cout, R, Cin, stride, pad, sc) in enumerate(SHAPES):

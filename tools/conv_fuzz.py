@@ -19,7 +19,7 @@ ap.add_argument("--cases", type=int, default=300)
 ap.add_argument("--seed", type=int, default=0)
 a = ap.parse_args()
 rng = random.Random(a.seed)
-MODES = [("f32", ops.MATH_F32, 1e-4), ("bf16x6", ops.MATH_BF16X6, 1e-4), ("bf16", ops.MATH_BF16, 3e-2)]
+MODES = [("f32", ops.MATH_F32, 1e-4), ("bf16x6", ops.MATH_BF16X6, 1e-4), ("f16x3", ops.MATH_F16X3, 1e-4), ("bf16", ops.MATH_BF16, 3e-2)]
 CH = [4, 8, 12, 16, 20, 32, 36, 48, 64, 76, 96, 100, 128, 160, 192, 256, 320, 512]
 fails, refused, ran = [], {}, 0
 

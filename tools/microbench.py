@@ -83,10 +83,10 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--only", default="")
-    ap.add_argument("--math", choices=["f32", "bf16", "bf16x6"], default="f32")
+    ap.add_argument("--math", choices=["f32", "bf16", "bf16x6", "f16x3"], default="f32")
     ap.add_argument("--convs-only", action="store_true")
     a = ap.parse_args()
-    mth = {"f32": ops.MATH_F32, "bf16": ops.MATH_BF16, "bf16x6": ops.MATH_BF16X6}[a.math]
+    mth = {"f32": ops.MATH_F32, "bf16": ops.MATH_BF16, "bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3}[a.math]
     dev = "cuda"
     print(f"{'layer':10s} {'M':>7s} {'N':>5s} {'K':>5s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
     for name, N, H, W, Cin, Cout, k, s, p in conv_cases(a.batch, a.rois):

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from abr_iod_amd import ops  # noqa: E402
 from microbench import timeit  # noqa: E402
 
-mth = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6}[os.environ.get("PROBE_MATH", "bf16x6")]
+mth = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3}[os.environ.get("PROBE_MATH", "bf16x6")]
 print(f"{'M':>7s} {'N':>5s} {'K':>5s} {'WGs':>5s} | {'us':>7s} {'TF/s':>6s} {'GB/s':>6s}")
 for N in (64, 256, 1024):
     for K in (64, 128, 256, 512, 1024):

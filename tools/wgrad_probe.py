@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from abr_iod_amd import ops  # noqa: E402
 from microbench import timeit  # noqa: E402
 
-mth = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6}[os.environ.get("PROBE_MATH", "bf16x6")]
+mth = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3}[os.environ.get("PROBE_MATH", "bf16x6")]
 print(f"{'M':>7s} {'Cout':>5s} {'K':>5s} | {'us':>7s} {'TF/s':>6s}")
 for Cout, K in ((1024, 256), (256, 1024), (512, 128), (128, 512), (2048, 512)):
     for M in (2048, 4096, 8192, 9576, 16384, 32768, 65536, 131072):
