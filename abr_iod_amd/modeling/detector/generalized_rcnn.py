@@ -28,9 +28,11 @@ from ..rpn.rpn import build_rpn
 from .._flat import flatten_parameters
 
 
-# Default contraction arithmetic: fp32-accurate on the bf16 matrix cores (admitted by tests/test_gpu_x6_admission.py; range-guarded with
-# an automatic fall-back to the fp32 MFMA kernels, engine/trainer.py::_x6_guard).  ABR_CONV_MATH=f32 selects the fp32 MFMA kernels.
-DEFAULT_CONV_MATH = "bf16x6"
+# Default contraction arithmetic (round 5): f16x3 -- fp32-accurate contractions as three fp16 products per multiply-add, operands scaled by their
+# amax (admitted by tests/test_gpu_f16x3_admission.py at the bounds bf16x6 was admitted with; guarded: engine/trainer.py::_x6_guard moves the
+# models to bf16x6 when a large share of the operands leaves its domain and to the fp32 MFMA kernels on inf / nan).  ABR_CONV_MATH=bf16x6 selects
+# rounds 2-4's default (exact three-term bf16 split, six products), ABR_CONV_MATH=f32 the fp32 MFMA kernels.
+DEFAULT_CONV_MATH = "f16x3"
 # source model's distillation proposals gathered from the selector's raw output by one kernel (GeneralizedRCNN._soften_fused)
 FUSED_SOFTEN = os.environ.get("ABR_FUSED_SOFTEN", "1") != "0"
 
@@ -66,6 +68,7 @@ class GeneralizedRCNN(nn.Module):
         # v_mfma_f32_32x32x2_f32.  ABR_CONV_MATH overrides the default.
         # "f16x3" (round 5) = the same on a two-term fp16 split with three products, operands scaled by their amax (csrc/common.h).
         self.conv_math = "f32"
+        self.bf16_backbone = False     # cfg.DTYPE "bfloat16" with the backbone only in bf16: set_conv_math leaves the backbone's arithmetic alone
         env_math = os.environ.get("ABR_CONV_MATH", DEFAULT_CONV_MATH)
         if env_math not in ("f32", "bf16x6", "f16x3"):
             raise ValueError("ABR_CONV_MATH must be f32, bf16x6 or f16x3, got {!r}".format(env_math))
@@ -79,13 +82,16 @@ class GeneralizedRCNN(nn.Module):
             set_conv_math(self.rpn, ops.MATH_F16X3 if env_math == "f16x3" else ops.MATH_BF16X6)
             set_conv_math(self.roi_heads, ops.MATH_F16X3 if env_math == "f16x3" else ops.MATH_BF16X6)
             self.conv_math = env_math      # (the range guard of engine/trainer.py watches the fp32-accurate part)
+            self.bf16_backbone = True
         self.flat = None
 
     def set_conv_math(self, name):
         """'f32', 'bf16x6' or 'f16x3' for every conv of the backbone, RPN head and layer4 head (takes effect at the next call)"""
         from ..backbone.resnet import set_conv_math
         math = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3}[name]
-        for m in (self.backbone, self.rpn, self.roi_heads):
+        # (a "bf16 MFMA backbone" -- configs[4] -- keeps its own arithmetic when the guard moves the rest: rounding to bf16 is defined for every
+        #  finite value, and the mode would otherwise silently stop being what its name says)
+        for m in ((self.rpn, self.roi_heads) if self.bf16_backbone else (self.backbone, self.rpn, self.roi_heads)):
             set_conv_math(m, math)
         self.conv_math = name
 

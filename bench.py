@@ -321,8 +321,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the short informational re-run on the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--math", choices=["f32", "bf16", "bf16-all", "bf16x6", "f16x3"], default="bf16x6",
-                    help="bf16x6 (default): fp32 tensors, fp32 accumulation, fp32 error bound -- every contraction operand is split EXACTLY into "
+    ap.add_argument("--math", choices=["f32", "bf16", "bf16-all", "bf16x6", "f16x3"], default="f16x3",
+                    help="f16x3 (default since round 5): fp32 tensors, fp32 accumulation, fp32 error bound -- every contraction operand is written as two "
+                         "fp16 terms scaled by the operand's amax and the three leading cross products run on the fp16 matrix cores (guarded; admitted by "
+                         "tests/test_gpu_f16x3_admission.py at bf16x6's bounds).  bf16x6 (rounds 2-4's default): fp32 tensors, fp32 accumulation, fp32 error bound -- every contraction operand is split EXACTLY into "
                          "three bf16 terms and the six leading cross products run on the bf16 matrix cores (range-guarded; admitted by "
                          "tests/test_gpu_x6_admission.py).  f32 = the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32).  bf16 = BASELINE.json "
                          "configs[4]'s bf16 MFMA backbone (cfg.DTYPE bfloat16: operands ROUNDED to bf16 in-kernel -- reduced precision, never "
@@ -387,7 +389,7 @@ def main():
     B = a.batch_per_gpu
     if a.math == "bf16-all":
         os.environ["ABR_BF16_SCOPE"] = "all"
-    os.environ["ABR_CONV_MATH"] = a.math if a.math in ("f32", "f16x3") else "bf16x6"   # (--math bf16: bf16 backbone, the default arithmetic everywhere else)
+    os.environ["ABR_CONV_MATH"] = a.math if a.math in ("f32", "f16x3", "bf16x6") else "f16x3"   # (--math bf16: bf16 backbone, the default arithmetic everywhere else)
     dist_type, feat, alpha, beta, gamma = TASKS[a.task]
     n_old_cls, n_new_cls = {"15-5": (15, 5), "10-10": (10, 10), "10-5": (10, 5), "19-1": (19, 1)}[a.task]
     cfg_s, cfg_t = make_cfgs(a.task, dist_type=dist_type, feat=feat, alpha=alpha, beta=beta, gamma=gamma, ims_per_batch=B * world,
@@ -498,7 +500,7 @@ def main():
                                                    "their amax, 3 cross products on the fp16 matrix cores: f16x3)" if a.math == "f16x3"
             else "f32 (tensors, accumulation and error bound; contractions via an exact 3-term bf16 split of both "
                                                    "operands, 6 cross products on the bf16 matrix cores, range-guarded)"
-            if a.math == "bf16x6" else "bf16 MFMA operands / f32 accumulate / f32 tensors ({}); the fp32-accurate bf16x6 contractions elsewhere".format(
+            if a.math == "bf16x6" else "bf16 MFMA operands / f32 accumulate / f32 tensors ({}); the fp32-accurate f16x3 contractions elsewhere".format(
                 "backbone layer1-3" if a.math == "bf16" else "backbone, RPN head, layer4"),
             "config": {"workload": "BASELINE.json {}: task {} ABR step, --feat {} --dist_type {} (alpha {}, beta {}, gamma {}), "
                                    "R50-C4, {}, 512 RoIs/img + 64 distillation RoIs/img, source+target models, gradient all-reduce + SGD step".format(
@@ -532,14 +534,15 @@ def main():
             out["roofline"] = roofline(prof, prof_totals, a, elapsed, event_overhead_ms, serialised)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_target, images, targets, len(cfg_t.MODEL.ROI_BOX_HEAD.NAME_OLD_CLASSES))
-        if world == 1 and a.math == "bf16x6" and not a.no_alt_math:
-            # Informational only, AFTER the timed region above and never part of `value`: the same workload on the fp32 MFMA kernels
-            # (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) -- the arithmetic of round 1's headline, for comparison.
-            os.environ["ABR_CONV_MATH"] = "f32"
+        if world == 1 and a.math in ("bf16x6", "f16x3") and not a.no_alt_math:
+            # Informational only, AFTER the timed region above and never part of `value`: the same workload in the PREVIOUS headline arithmetic --
+            # bf16x6 (rounds 2-4) under --math f16x3, the fp32 MFMA kernels (round 1; v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) under --math bf16x6.
+            alt = "bf16x6" if a.math == "f16x3" else "f32"
+            os.environ["ABR_CONV_MATH"] = alt
             try:
                 ms6, mt6 = build_models(cfg_s, cfg_t, seed=0)
             finally:
-                os.environ["ABR_CONV_MATH"] = "bf16x6"
+                os.environ["ABR_CONV_MATH"] = a.math
             opt6 = make_optimizer(cfg_t, mt6)
             sch6 = make_lr_scheduler(cfg_t, opt6)
             for _ in range(3):
@@ -550,8 +553,8 @@ def main():
                 l6 = train_step(ms6, mt6, images, targets, opt6, sch6, cfg_t)
             torch.cuda.synchronize()
             e6 = time.perf_counter() - t6
-            out["alt_math_f32_mfma"] = {"value": round(B * 10 / e6, 3), "unit": "img/s", "ms_per_step": round(1e3 * e6 / 10, 3), "steps": 10,
-                                        "note": "informational: the same step on the fp32 MFMA kernels (ABR_CONV_MATH=f32); not the reported value",
+            out["alt_math_" + ("bf16x6" if alt == "bf16x6" else "f32_mfma")] = {"value": round(B * 10 / e6, 3), "unit": "img/s", "ms_per_step": round(1e3 * e6 / 10, 3), "steps": 10,
+                                        "note": "informational: the same step with ABR_CONV_MATH={} (the previous headline arithmetic); not the reported value".format(alt),
                                         "final_total_loss": round(float(l6[1].detach()), 5)}
             del ms6, mt6, opt6, sch6, l6
             from abr_iod_amd import ops as _ops

@@ -140,7 +140,7 @@ def test_bf16_mfma_backbone_matches_oracle_on_rounded_operands():
     assert len(maths) == 13 and all(m == ops.MATH_BF16 for m in maths)          # 3 + 4 + 6 bottlenecks
     # everything else runs in the DEFAULT arithmetic (round 4; fp32 MFMA only under ABR_CONV_MATH=f32)
     import os
-    rest = ops.MATH_BF16X6 if os.environ.get("ABR_CONV_MATH", "bf16x6") == "bf16x6" else ops.MATH_F32
+    rest = {"f16x3": ops.MATH_F16X3, "bf16x6": ops.MATH_BF16X6, "f32": ops.MATH_F32}[os.environ.get("ABR_CONV_MATH", "f16x3")]
     assert all(m.math == rest for m in mt.roi_heads.modules() if hasattr(m, "math")) and mt.rpn.head.math == rest
     images, _ = synthetic_batch(2, 192, 256, seed=4)
     with torch.no_grad():

@@ -131,7 +131,7 @@ def test_full_size_step_matches_reference(gold, name):
     assert torch.isfinite(mt.flat.grads).all() and float(mt.flat.grads.abs().sum()) > 0
     if name not in GRAD_CONFIGS:
         return
-    # ---- BACKWARD at the benchmark geometry, in the benchmarked arithmetic (bf16x6 is the default): the gradient of the step's total
+    # ---- BACKWARD at the benchmark geometry, in the benchmarked arithmetic (f16x3 is the default since round 5; ABR_CONV_MATH=bf16x6 re-runs this in rounds 2-4's): the gradient of the step's total
     # w.r.t. all 52 trainable tensors against autograd on the torch-CPU oracle (oracle/model_ref.py; ROIAlign backward from oracle.c) run on
     # the SAME reference draws.  The reference itself has no CPU backward (csrc/ROIAlign.h:44).  Bounds as in tests/test_gpu_e2e.py: 3x the worst
     # values measured (profiles/r04_fullsize_parity.log).
@@ -139,9 +139,9 @@ def test_full_size_step_matches_reference(gold, name):
     from abr_iod_amd.modeling.backbone.resnet import Conv2d
     from e2e_common import oracle_full_size_step
     from abr_iod_amd.modeling.detector.generalized_rcnn import DEFAULT_CONV_MATH
-    assert DEFAULT_CONV_MATH == "bf16x6"
-    if os.environ.get("ABR_CONV_MATH", DEFAULT_CONV_MATH) == "bf16x6":   # the arithmetic bench.py reports
-        assert all(m.math == ops.MATH_BF16X6 for m in mt.modules() if hasattr(m, "math"))
+    assert DEFAULT_CONV_MATH == "f16x3"
+    if os.environ.get("ABR_CONV_MATH", DEFAULT_CONV_MATH) == "f16x3":   # the arithmetic bench.py reports
+        assert all(m.math == ops.MATH_F16X3 for m in mt.modules() if hasattr(m, "math"))
     sd_s = {k: v.cpu() for k, v in reference_state_dict(ms).items()} if ms is not None else None
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8))))
     ref_losses, ref_total, ref_t = oracle_full_size_step(g, name, sd_s, sd_t, images.cpu(), with_grad=True)
