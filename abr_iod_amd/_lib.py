@@ -61,6 +61,7 @@ _SIGS = {
     "abr_conv_prepare_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "abr_conv_prepare_batch": (_i, [_vp, _i, _vp]),
     "abr_conv_cache_clear": (_i, []),
+    "abr_conv_cache_drop_range": (_i, [_vp, _i64]),
     "abr_conv_cache_bytes": (_i64, []),
     "abr_roi_head_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _i, _i, C.c_uint64,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),

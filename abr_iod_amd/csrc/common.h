@@ -117,6 +117,7 @@ __device__ __forceinline__ int prep_find_job(const PrepJob* jobs, int njobs, int
     return lo;
 }
 void derived_cache_clear();
+void derived_cache_drop_range(const void* base, size_t bytes);
 size_t derived_cache_bytes();
 
 // bf16x6 range guard (see abr_x6_range_flags in include/abr_iod_hip.h).  The flag word lives in device memory owned by common.hip.

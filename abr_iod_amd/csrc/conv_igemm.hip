@@ -2500,6 +2500,10 @@ extern "C" int abr_conv_cache_clear(void) {
     abr::derived_cache_clear();
     return ABR_OK;
 }
+extern "C" int abr_conv_cache_drop_range(const void* base, int64_t bytes) {
+    if (base && bytes > 0) abr::derived_cache_drop_range(base, (size_t)bytes);
+    return ABR_OK;
+}
 extern "C" int64_t abr_conv_cache_bytes(void) { return (int64_t)abr::derived_cache_bytes(); }
 
 extern "C" int64_t abr_conv_packed_bytes(int64_t rows, int64_t K) { return rows > 0 && K > 0 && K % 16 == 0 ? x6_packed_bytes(rows, K) : 0; }

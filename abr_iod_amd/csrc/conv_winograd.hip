@@ -609,11 +609,28 @@ float* wino_u_cached(const float* w, int N, int C, int64_t version, hipStream_t 
                                                    [&](void* buf) { return wino_weight_transform(w, N, C, reinterpret_cast<float*>(buf), st); }));
 }
 
+// Entries with a fill token outstanding (derived_acquire .. derived_commit / derived_abandon on another thread) are left alone: their
+// DEntry* is in that thread's hands.  They become droppable once committed.
 void derived_cache_clear() {
     std::lock_guard<std::mutex> lock(g_dcache_mu);
-    for (auto& kv : g_dcache) dcache_drop(kv.second);
-    g_dcache.clear();
-    g_dcache_bytes = 0;
+    for (auto it = g_dcache.begin(); it != g_dcache.end();) {
+        if (it->second.pending) { ++it; continue; }
+        dcache_drop(it->second);
+        it = g_dcache.erase(it);
+    }
+}
+// drop what was derived from tensors inside [base, base + bytes): a model's parameter storage that is going away.  Other models' entries
+// (and their in-flight conv calls on other host threads) are not touched.
+void derived_cache_drop_range(const void* base, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_dcache_mu);
+    const char* lo = reinterpret_cast<const char*>(base);
+    const char* hi = lo + bytes;
+    for (auto it = g_dcache.begin(); it != g_dcache.end();) {
+        const char* k = reinterpret_cast<const char*>(it->first.first);
+        if (k < lo || k >= hi || it->second.pending) { ++it; continue; }
+        dcache_drop(it->second);
+        it = g_dcache.erase(it);
+    }
 }
 size_t derived_cache_bytes() {
     std::lock_guard<std::mutex> lock(g_dcache_mu);

@@ -251,14 +251,20 @@ extern "C" int abr_sample_pos_neg(const void* labels, int labels_are_int64, int 
     ABR_REQUIRE(labels && pos_idx && neg_idx && counts, "sample_pos_neg: null pointer");
     hipStream_t st = abr::as_stream(stream);
     const bool small = n <= 8192;
-    const int has_top = n <= 150000;                     // one LDS byte per candidate (160 KB per compute unit; the large request is enabled below)
-    const size_t lds = has_top ? (size_t)((n + 15) & ~15) : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel<float, NT_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 150016);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel<int64_t, NT_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 150016);
-        attr_set = true;
+    // one LDS byte per candidate (160 KB per compute unit).  The large request has to be granted per device: where it is not (another part, a
+    // failed call) candidate sets beyond the default 64 KB run without the key-byte cache (has_top = 0: the kernel re-hashes instead)
+    static int big_ok[64] = {0};   // per device: 0 = not asked yet, 1 = granted, -1 = refused
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 || dev >= 64 ? 0 : dev;
+    if (big_ok[dev] == 0) {
+        const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel<float, NT_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 150016) == hipSuccess;
+        const bool b = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel<int64_t, NT_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 150016) == hipSuccess;
+        big_ok[dev] = (a && b) ? 1 : -1;
+        (void)hipGetLastError();
     }
+    const int has_top = n <= (big_ok[dev] == 1 ? 150000 : 60000);
+    const size_t lds = has_top ? (size_t)((n + 15) & ~15) : 0;
 #define ABR_SAMPLE_LAUNCH(T, NTHR) sample_kernel<T, NTHR><<<N, NTHR, lds, st>>>((const T*)labels, n, stride, batch_size, max_pos, seed, first_image, \
                                                                                 index_offset_per_image, pos_idx, neg_idx, counts, has_top)
     if (labels_are_int64) { if (small) ABR_SAMPLE_LAUNCH(int64_t, NT_SMALL); else ABR_SAMPLE_LAUNCH(int64_t, NT_BIG); }

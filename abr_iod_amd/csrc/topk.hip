@@ -333,6 +333,9 @@ extern "C" int abr_topk_sigmoid(const float* logits, int64_t img_stride, int N, 
     const int G = 64;
     const int per = ((n + G - 1) / G + KT - 1) / KT * KT;
     const size_t lds_sort = (size_t)CAP * 8, lds_part = (size_t)per * 16;
+    // the partition kernel keeps its slice's keys in LDS beside 16 KB of histogram: beyond 64 KB (n > ~196 k keys per image; the C4 geometries of
+    // this path stay below 63 k) it cannot be launched -- say so instead of returning a launch error
+    ABR_REQUIRE(one_wg || lds_part + 16384 <= 65536, "topk_sigmoid: %d keys per image exceed the partition kernel's LDS (at most 196608; ABR_TOPK_ONE_WG=1 has no such limit)", n);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort);

@@ -258,10 +258,16 @@ def _stage_params(blocks):
         return []
     key = tuple(id(b) for b in blocks)
     cached = blocks[0].__dict__.get("_stage_params_cache")
-    if cached is None or cached[0] != key:
-        cached = (key, [p for b in blocks for p in b.parameters()])
-        blocks[0].__dict__["_stage_params_cache"] = cached
-    return cached[1]
+    if cached is not None and cached[0] == key:
+        # a replaced parameter OBJECT (module.weight = nn.Parameter(...), a swapped sub-module) must not leave a stale list behind: the blocks' direct
+        # conv weights are checked by identity (cheap: 3-4 per block), anything else invalidates through flatten_parameters / _apply
+        ws = cached[2]
+        if all(c.weight is w for c, w in ws):
+            return cached[1]
+    plist = [p for b in blocks for p in b.parameters()]
+    ws = [(m, m.weight) for b in blocks for m in b.modules() if isinstance(m, Conv2d)]
+    blocks[0].__dict__["_stage_params_cache"] = (key, plist, ws)
+    return plist
 
 
 def run_stage(x, blocks, first_stride=None, need_dx=True):
@@ -346,10 +352,11 @@ class ResNet(nn.Module):
     def _trains(self, name):
         """does stage `name` ("stem", "layer1", ...) hold a trainable parameter?  (parameter lists kept: see _stage_params)"""
         cache = self.__dict__.setdefault("_stage_param_lists", {})
-        ps = cache.get(name)
-        if ps is None:
-            ps = cache[name] = list(getattr(self, name).parameters())
-        return any(p.requires_grad for p in ps)
+        ent = cache.get(name)
+        mod = getattr(self, name)
+        if ent is None or ent[0] is not mod or not all(c.weight is w for c, w in ent[2]):   # (rebuilt when a stage module or a conv weight object is replaced)
+            ent = cache[name] = (mod, list(mod.parameters()), [(m, m.weight) for m in mod.modules() if isinstance(m, Conv2d)])
+        return any(p.requires_grad for p in ent[1])
 
     def frozen_stage_names(self):
         """names of the leading stages without trainable parameters (what frozen_prefix computes after the stem), or None when the stem trains"""

@@ -37,11 +37,12 @@ DEFAULT_CONV_MATH = "f16x3"
 FUSED_SOFTEN = os.environ.get("ABR_FUSED_SOFTEN", "1") != "0"
 
 
-def _drop_derived_cache():
-    """weakref finalizer of a model's flat parameter storage (see flatten_parameters)"""
+def _drop_derived_cache(base, nbytes):
+    """weakref finalizer of a model's flat parameter storage (see flatten_parameters): only what was derived from THIS storage goes -- the
+    garbage collector may run this on any thread while another model's conv call is in flight"""
     try:
         from ... import ops
-        ops.conv_cache_clear()
+        ops.conv_cache_drop_range(base, nbytes)
     except Exception:   # never raise from a finalizer
         pass
 
@@ -97,16 +98,17 @@ class GeneralizedRCNN(nn.Module):
 
     # --- storage: one flat fp32 buffer for parameters, one for gradients (RCCL all-reduce + fused SGD work on them)
     def flatten_parameters(self):
-        rebuilt = getattr(self, "flat", None) is not None
+        old = getattr(self, "flat", None)
+        old_range = (old.params.data_ptr(), old.params.numel() * old.params.element_size()) if (old is not None and old.params.is_cuda) else None
         self.flat = flatten_parameters(self)
-        if rebuilt and self.flat.params.is_cuda:
+        if old_range is not None:
             from ... import ops
-            ops.conv_cache_clear()   # the old storage is gone: entries keyed by its addresses would outlive it (and may alias new tensors)
+            ops.conv_cache_drop_range(*old_range)   # the old storage is gone: entries keyed by its addresses would outlive it (and may alias new tensors)
         if self.flat.params.is_cuda:
             # the library keeps packed planes / Winograd-domain copies per weight ADDRESS (raw hipMalloc, outside torch's caching allocator): drop
             # them when this storage dies (a model that is deleted, a long pytest session building model after model), not only when it is rebuilt
             import weakref
-            fin = weakref.finalize(self.flat, _drop_derived_cache)
+            fin = weakref.finalize(self.flat, _drop_derived_cache, self.flat.params.data_ptr(), self.flat.params.numel() * self.flat.params.element_size())
             fin.atexit = False   # not during interpreter shutdown (the runtime may already be gone)
         from ..backbone.resnet import Conv2d, bump_param_version
         bump_param_version()   # new weight storage: nothing derived from an earlier tensor at the same address may be reused

@@ -535,6 +535,11 @@ def conv_cache_clear():
     L.check(L.lib().abr_conv_cache_clear(), "conv_cache_clear")
 
 
+def conv_cache_drop_range(base, nbytes):
+    """Drop the derived data of the weights stored inside [base, base + nbytes) only (abr_conv_cache_drop_range)."""
+    L.check(L.lib().abr_conv_cache_drop_range(int(base), int(nbytes)), "conv_cache_drop_range")
+
+
 def conv_cache_bytes():
     return int(L.lib().abr_conv_cache_bytes())
 

@@ -311,6 +311,10 @@ int abr_conv_prepare_batch(const abr_prep_item* items_host, int n, void* stream)
  * (least-recently-used entries go when it exceeds ABR_WINO_CACHE_MB, default 4096); abr_conv_cache_clear drops every entry after waiting
  * for the streams that use them (call it when a model's parameter storage is released or rebuilt), abr_conv_cache_bytes reports its size. */
 int abr_conv_cache_clear(void);
+/* the same for the entries derived from tensors that live inside [base, base + bytes) only (a model's flat parameter storage that is being
+ * released): entries of other models -- and conv calls in flight on other host threads that hold them -- are not touched.  Both calls skip
+ * entries whose fill is in progress on another thread. */
+int abr_conv_cache_drop_range(const void* base, int64_t bytes);
 int64_t abr_conv_cache_bytes(void);
 /* floats of the Winograd-domain input V = 36 * B*ceil(H/4)*ceil(W/4) * Cin if BOTH abr_conv_forward and abr_conv_wgrad take the
  * Winograd F(4x4,3x3) path for this descriptor (wide stride-1 pad-1 3x3, no residual / scatter, fp32 or bf16x6 math), else 0 */
