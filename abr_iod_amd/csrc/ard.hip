@@ -27,8 +27,9 @@ __device__ __forceinline__ float sumsq4(float acc, const float4 v) {
 template <bool VEC4>
 __global__ __launch_bounds__(1024) void ard_fwd_kernel(const float* __restrict__ f_src, const float* __restrict__ f_tgt,
                                                        int N, int C, int HW, int sHW, int sC, float gamma,
-                                                       float* __restrict__ coef, float* __restrict__ loss_out) {
+                                                       float* __restrict__ coef, float* __restrict__ loss_out, const abr::DetWs ws) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // ms[HW], mt[HW], d2[HW], red[8]
+    float part[2] = {0.f, 0.f};   // this RoI's (afd, pad) terms, in thread 0
     float* ms = sm;
     float* mt = sm + HW;
     float* d2 = sm + 2 * HW;
@@ -96,11 +97,21 @@ __global__ __launch_bounds__(1024) void ard_fwd_kernel(const float* __restrict__
             co[HW + j] = mt[j] * (d2[j] - S / (float)HW);    // d(sum_i |A_t-A_s|)/d m_t[hw]
         }
         if (lane == 0) {
-            const float afd_n = afd / ((float)N * (float)C * (float)HW);
-            const float pad_n = pad / ((float)N * (float)HW);
-            atomicAdd(loss_out + 1, afd_n);
-            atomicAdd(loss_out + 2, pad_n);
-            atomicAdd(loss_out + 0, afd_n + gamma * pad_n);
+            part[0] = afd / ((float)N * (float)C * (float)HW);
+            part[1] = pad / ((float)N * (float)HW);
+            if (!ws.part) {
+                atomicAdd(loss_out + 1, part[0]);
+                atomicAdd(loss_out + 2, part[1]);
+                atomicAdd(loss_out + 0, part[0] + gamma * part[1]);
+            }
+        }
+    }
+    if (ws.part) {   // one RoI per workgroup: the per-RoI terms are added in RoI order by the last workgroup to arrive (deterministic)
+        float tot[2];
+        if (abr::det_sum_last<2>(part, ws, tot) && threadIdx.x == 0) {
+            loss_out[1] = tot[0];
+            loss_out[2] = tot[1];
+            loss_out[0] = tot[0] + gamma * tot[1];
         }
     }
 }
@@ -155,12 +166,13 @@ extern "C" int abr_ard_forward(const float* f_src, const float* f_tgt, int N, in
     if (N == 0) return ABR_OK;
     ABR_REQUIRE(f_src && f_tgt && coef, "ard_forward: null pointer");
     const size_t lds = sizeof(float) * (3 * (size_t)HW + 8);
+    const abr::DetWs ws = abr::det_ws(st, 2 * (size_t)N);
     if (layout == ABR_NHWC && C % 4 == 0)
-        ard_fwd_kernel<true><<<N, 1024, lds, st>>>(f_src, f_tgt, N, C, HW, C, 1, gamma, coef, loss_out);
+        ard_fwd_kernel<true><<<N, 1024, lds, st>>>(f_src, f_tgt, N, C, HW, C, 1, gamma, coef, loss_out, ws);
     else if (layout == ABR_NHWC)
-        ard_fwd_kernel<false><<<N, 1024, lds, st>>>(f_src, f_tgt, N, C, HW, C, 1, gamma, coef, loss_out);
+        ard_fwd_kernel<false><<<N, 1024, lds, st>>>(f_src, f_tgt, N, C, HW, C, 1, gamma, coef, loss_out, ws);
     else
-        ard_fwd_kernel<false><<<N, 1024, lds, st>>>(f_src, f_tgt, N, C, HW, 1, HW, gamma, coef, loss_out);
+        ard_fwd_kernel<false><<<N, 1024, lds, st>>>(f_src, f_tgt, N, C, HW, 1, HW, gamma, coef, loss_out, ws);
     ABR_CHECK_LAUNCH("ard_forward");
     return ABR_OK;
 }

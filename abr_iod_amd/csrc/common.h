@@ -66,6 +66,52 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
     return t;
 }
 
+// Deterministic cross-workgroup sums (round 5: the step reproduces bit for bit).  Every workgroup parks its partial values in a scratch slot,
+// takes a ticket, and the LAST one to arrive adds all partials up in slot order (strided over its threads, then a fixed tree): the result does
+// not depend on which workgroup finishes last.  Replaces fp32 atomicAdd into the loss scalars / bias gradients, whose summation order -- and
+// with it the last bits -- changed from run to run.  det_ws: per-stream ring of scratch (launches on a stream are ordered; a slot is reused
+// thousands of launches later); .part == nullptr: no memory, the kernels fall back to atomics.
+struct DetWs {
+    float* part;
+    unsigned* ticket;   // zero on entry, left zero
+};
+DetWs det_ws(hipStream_t st, size_t nfloats);
+// vals: the workgroup's NV partial values, valid in thread 0.  Returns true in every thread of the last workgroup, with the totals in thread
+// 0's `total`.  1-D or 2-D grids; blockDim.x a multiple of 64, <= 1024.
+template <int NV>
+__device__ __forceinline__ bool det_sum_last(const float (&vals)[NV], const DetWs ws, float (&total)[NV]) {
+    __shared__ int s_last;
+    __shared__ float s_w[16];
+    const unsigned nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) __hip_atomic_store(ws.part + (size_t)bid * NV + j, vals[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop the wait behind the write-back: MI355X_MICROARCH.md)
+        s_last = atomicAdd(ws.ticket, 1u) == nblk - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return false;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *ws.ticket = 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        float a = 0.f;
+        for (unsigned i = threadIdx.x; i < nblk; i += blockDim.x) a += __hip_atomic_load(ws.part + (size_t)i * NV + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a = wave_sum(a);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = a;
+        __syncthreads();
+        float t = 0.f;
+        for (unsigned w = 0; w < (blockDim.x >> 6); w++) t += s_w[w];
+        total[j] = t;
+    }
+    return true;
+}
+
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Off by default.
 enum ProfId { PROF_IGEMM_128x128 = 0, PROF_IGEMM_128x64, PROF_IGEMM_64x64, PROF_IGEMM_SMALLC, PROF_WGRAD, PROF_ROIALIGN_FWD,
               PROF_ROIALIGN_BWD, PROF_IGEMM_BF16, PROF_WGRAD_BF16,

@@ -251,6 +251,28 @@ extern "C" int abr_x6_range_flags_to_device(uint32_t* out_device, void* stream) 
     return ABR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------- deterministic sums (common.h)
+namespace abr {
+DetWs det_ws(hipStream_t st, size_t nfloats) {
+    constexpr size_t kFloats = 1u << 16, kTickets = 4096;
+    struct Ring { float* part = nullptr; unsigned* tick = nullptr; size_t head = 0, thead = 0; };
+    static std::map<hipStream_t, Ring> rings;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (nfloats == 0 || nfloats > kFloats) return DetWs{nullptr, nullptr};
+    Ring& r = rings[st];
+    if (!r.part) {
+        if (hipMalloc(&r.part, kFloats * sizeof(float)) != hipSuccess) { r.part = nullptr; return DetWs{nullptr, nullptr}; }
+        if (hipMalloc(&r.tick, kTickets * sizeof(unsigned)) != hipSuccess) { (void)hipFree(r.part); r.part = nullptr; return DetWs{nullptr, nullptr}; }
+        (void)hipMemset(r.tick, 0, kTickets * sizeof(unsigned));
+    }
+    if (r.head + nfloats > kFloats) r.head = 0;
+    DetWs w{r.part + r.head, r.tick + (r.thead++ % kTickets)};
+    r.head += nfloats;
+    return w;
+}
+}  // namespace abr
+
 // ---------------------------------------------------------------------------------------------------- f16x3: amax words (common.h)
 namespace {
 __global__ __launch_bounds__(256) void h3_amax_kernel(const float* __restrict__ x, int64_t n, unsigned long long* word, unsigned epoch) {

@@ -1847,8 +1847,11 @@ __global__ __launch_bounds__(256) void x6_pack_multi_kernel(const abr::PrepJob* 
     for (int pl = 0; pl < 3; pl++) planes[(c + pl) * 64 + lane] = *reinterpret_cast<const uint4*>(h[pl]);
 }
 
+// part / tickets (round 5): every (column chunk, row chunk) workgroup parks its 64 column sums; the LAST row chunk of a column chunk to arrive adds
+// them in row-chunk order and does db += (one writer per column: deterministic, where the former atomicAdd per workgroup changed the last bits
+// of the bias gradients from run to run).  part == nullptr: atomics.
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ gy, int64_t M, int C, int rows_per_block,
-                                                         float* __restrict__ db) {
+                                                         float* __restrict__ db, float* __restrict__ part, unsigned* __restrict__ tickets) {
     // block = 64 columns x 4 row-lanes; grid.x = column chunks, grid.y = row chunks
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
@@ -1858,9 +1861,36 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     if (c < C)
         for (int64_t r = r0 + rl; r < r1; r += 4) acc += gy[r * C + c];
     __shared__ float sm[4][64];
+    __shared__ int s_last;
     sm[rl][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (rl == 0 && c < C) atomicAdd(db + c, sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    const float mine = sm[0][threadIdx.x & 63] + sm[1][threadIdx.x & 63] + sm[2][threadIdx.x & 63] + sm[3][threadIdx.x & 63];
+    if (!part) {
+        if (rl == 0 && c < C) atomicAdd(db + c, mine);
+        return;
+    }
+    float* slot = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64;
+    if (rl == 0) __hip_atomic_store(slot + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = atomicAdd(tickets + blockIdx.x, 1u) == gridDim.y - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        tickets[blockIdx.x] = 0u;
+    }
+    __syncthreads();
+    float a = 0.f;
+    const float* col = part + (size_t)blockIdx.x * gridDim.y * 64 + (threadIdx.x & 63);
+    for (unsigned y = rl; y < gridDim.y; y += 4) a += __hip_atomic_load(col + (size_t)y * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    sm[rl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rl == 0 && c < C) db[c] += sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
 }  // namespace
@@ -2530,7 +2560,18 @@ extern "C" int abr_bias_grad(const float* gy, int64_t M, int C, float* db, void*
     ABR_REQUIRE(gy, "bias_grad: null pointer");
     const int rows_per_block = 256;
     dim3 grid((C + 63) / 64, (unsigned)((M + rows_per_block - 1) / rows_per_block));
-    bias_grad_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(gy, M, C, rows_per_block, db);
+    // scratch: 64 floats per workgroup + one ticket per column chunk (the ring's ticket array serves as the ticket block: column chunks <= 64 here)
+    abr::DetWs ws = grid.x <= 64 ? abr::det_ws(abr::as_stream(stream), (size_t)grid.x * grid.y * 64) : abr::DetWs{nullptr, nullptr};
+    static std::map<hipStream_t, unsigned*> tick;
+    static std::mutex tick_mu;
+    unsigned* tk = nullptr;
+    if (ws.part) {
+        std::lock_guard<std::mutex> g(tick_mu);
+        unsigned*& t = tick[abr::as_stream(stream)];
+        if (!t && (hipMalloc(&t, 64 * sizeof(unsigned)) != hipSuccess || hipMemset(t, 0, 64 * sizeof(unsigned)) != hipSuccess)) t = nullptr;
+        tk = t;
+    }
+    bias_grad_kernel<<<grid, 256, 0, abr::as_stream(stream)>>>(gy, M, C, rows_per_block, db, tk ? ws.part : nullptr, tk);
     ABR_CHECK_LAUNCH("bias_grad");
     return ABR_OK;
 }

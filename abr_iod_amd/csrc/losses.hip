@@ -48,6 +48,18 @@ __global__ __launch_bounds__(256) void focal_bwd(const float* __restrict__ logit
     }
 }
 
+// Add this workgroup's share `v` (valid in thread 0) to *loss_out: through the deterministic last-arrival sum when there is scratch (the
+// result is then STORED: loss_out need not be zero), else with an atomic (loss_out zeroed by the host).
+__device__ __forceinline__ void loss_add(float v, float* loss_out, const abr::DetWs ws) {
+    if (ws.part) {
+        const float in[1] = {v};
+        float tot[1];
+        if (abr::det_sum_last<1>(in, ws, tot) && threadIdx.x == 0) *loss_out = tot[0];
+    } else if (threadIdx.x == 0) {
+        atomicAdd(loss_out, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // smooth L1 -- layers/smooth_l1_loss.py:6-17
 // ------------------------------------------------------------------------------------------------
@@ -60,7 +72,7 @@ __device__ __forceinline__ float sl1(float d, float beta, float* g) {
 
 __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t n,
                                                          float beta, float scale, float* __restrict__ loss_out,
-                                                         float gscale, float* __restrict__ grad) {
+                                                         float gscale, float* __restrict__ grad, const abr::DetWs ws) {
     __shared__ float sm[4];
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict_
         if (grad) grad[i] = g * gscale * scale;
     }
     acc = abr::block_sum<4>(acc, sm);
-    if (threadIdx.x == 0) atomicAdd(loss_out, acc * scale);
+    loss_add(acc * scale, loss_out, ws);
 }
 
 // x row rows[i], columns col0[i]..col0[i]+3  vs  t row trows[i] (t is [*,4]; trows==NULL -> same row as x)
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(256) void smooth_l1_rows_kernel(const float* __rest
                                                               int n_rows, float beta,
                                                               float scale, const float* __restrict__ denom_dev,
                                                               float* __restrict__ loss_out, float gscale,
-                                                              float* __restrict__ grad) {
+                                                              float* __restrict__ grad, const abr::DetWs ws) {
     __shared__ float sm[4];
     float acc = 0.f;
     if (denom_dev) scale = scale / fmaxf(*denom_dev, 1.f);
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(256) void smooth_l1_rows_kernel(const float* __rest
         if (grad) grad[r * x_cols + c] = g * gscale * scale;
     }
     acc = abr::block_sum<4>(acc, sm);
-    if (threadIdx.x == 0) atomicAdd(loss_out, acc * scale);
+    loss_add(acc * scale, loss_out, ws);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -106,7 +118,7 @@ constexpr int kMaxK = 128;
 // xor-shuffle reductions inside the 8-lane group.
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                           int n, int K, int ldz, int ldg, int inclusive, int n_old, const int* __restrict__ n_valid,
-                                                          float* __restrict__ loss_out, float gscale, float* __restrict__ dz) {
+                                                          float* __restrict__ loss_out, float gscale, float* __restrict__ dz, const abr::DetWs ws) {
     __shared__ float sm[4];
     constexpr int G = 8;
     const int i = blockIdx.x * (256 / G) + threadIdx.x / G, l = threadIdx.x % G;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     }
     if (!live) li = 0.f;
     li = abr::block_sum<4>(li, sm);
-    if (threadIdx.x == 0) atomicAdd(loss_out, li);
+    loss_add(li, loss_out, ws);
 }
 
 __global__ void count_valid_kernel(const int64_t* __restrict__ labels, int n, int* __restrict__ out) {
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restric
                                                            const float* __restrict__ z_t, const float* __restrict__ b_t, int n,
                                                            int ld_zs, int ld_bs, int ld_zt, int ld_bt, int ld_dzt, int ld_dbt,
                                                            int K_old, int K_all, int dist_id, float* __restrict__ loss_out,
-                                                           float gscale, float* __restrict__ d_zt, float* __restrict__ d_bt) {
+                                                           float gscale, float* __restrict__ d_zt, float* __restrict__ d_bt, const abr::DetWs ws) {
     __shared__ float sm[4];
     constexpr int G = 16;
     const int i = blockIdx.x * (256 / G) + threadIdx.x / G, l = threadIdx.x % G;
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restric
     }
     if (!live) li = 0.f;
     li = abr::block_sum<4>(li, sm);
-    if (threadIdx.x == 0) atomicAdd(loss_out, li);
+    loss_add(li, loss_out, ws);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(256) void roi_distill_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bce_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           const int64_t* __restrict__ idx, const int64_t* __restrict__ yidx, int n_idx,
                                                           const float* __restrict__ denom_dev, float* __restrict__ loss_out,
-                                                          float gscale, float* __restrict__ grad) {
+                                                          float gscale, float* __restrict__ grad, const abr::DetWs ws) {
     __shared__ float sm[4];
     float acc = 0.f;
     const float inv = 1.f / (denom_dev ? fmaxf(*denom_dev, 1.f) : (float)n_idx);
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(256) void bce_gather_kernel(const float* __restrict
         if (grad) grad[j] = (1.f / (1.f + expf(-xv)) - yv) * inv * gscale;
     }
     acc = abr::block_sum<4>(acc, sm);
-    if (threadIdx.x == 0) atomicAdd(loss_out, acc * inv);
+    loss_add(acc * inv, loss_out, ws);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -308,18 +320,22 @@ __global__ __launch_bounds__(256) void bce_gather_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // pass 1 of the feature loss: sums of both maps (their means normalise the difference)
 __global__ __launch_bounds__(256) void feat_distill_sums_kernel(const float* __restrict__ s, const float* __restrict__ t, int64_t n,
-                                                                 float* __restrict__ stats) {
+                                                                 float* __restrict__ stats, const abr::DetWs ws) {
     __shared__ float sm[4];
     float a = 0.f, b = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { a += s[i]; b += t[i]; }
     a = abr::block_sum<4>(a, sm);
     b = abr::block_sum<4>(b, sm);
-    if (threadIdx.x == 0) { atomicAdd(stats, a); atomicAdd(stats + 1, b); }
+    if (ws.part) {
+        const float in[2] = {a, b};
+        float tot[2];
+        if (abr::det_sum_last<2>(in, ws, tot) && threadIdx.x == 0) { stats[0] = tot[0]; stats[1] = tot[1]; }
+    } else if (threadIdx.x == 0) { atomicAdd(stats, a); atomicAdd(stats + 1, b); }
 }
 
 // pass 2: loss = mean(max((s - mean s) - (t - mean t), 0)), and the number of positive differences (the mean's share of the gradient)
 __global__ __launch_bounds__(256) void feat_distill_loss_kernel(const float* __restrict__ s, const float* __restrict__ t, int64_t n,
-                                                                 float* __restrict__ stats, float* __restrict__ loss_out) {
+                                                                 float* __restrict__ stats, float* __restrict__ loss_out, const abr::DetWs ws) {
     __shared__ float sm[4];
     const float inv = 1.f / (float)n;
     const float shift = stats[1] * inv - stats[0] * inv;  // d_i = s_i - t_i + (mean t - mean s)
@@ -330,7 +346,11 @@ __global__ __launch_bounds__(256) void feat_distill_loss_kernel(const float* __r
     }
     l = abr::block_sum<4>(l, sm);
     c = abr::block_sum<4>(c, sm);
-    if (threadIdx.x == 0) { atomicAdd(loss_out, l * inv); atomicAdd(stats + 2, c); }
+    if (ws.part) {
+        const float in[2] = {l * inv, c};
+        float tot[2];
+        if (abr::det_sum_last<2>(in, ws, tot) && threadIdx.x == 0) { *loss_out = tot[0]; stats[2] = tot[1]; }
+    } else if (threadIdx.x == 0) { atomicAdd(loss_out, l * inv); atomicAdd(stats + 2, c); }
 }
 
 // pass 3: d loss / d t_j = (1/n) * (mean(mask) - mask_j)
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(256) void rpn_distill_kernel(const float* __restric
                                                            const float* __restrict__ obj_t, const float* __restrict__ reg_t, int ld_ot, int ld_rt,
                                                            int64_t rows, int A, float thr, int use_bbox, float* __restrict__ loss_out,
                                                            float gscale, float* __restrict__ g_obj, float* __restrict__ g_reg, int ld_go,
-                                                           int ld_gr) {
+                                                           int ld_gr, const abr::DetWs ws) {
     __shared__ float sm[4];
     const int64_t n = rows * A;
     const float inv = 1.f / (float)n;
@@ -375,7 +395,7 @@ __global__ __launch_bounds__(256) void rpn_distill_kernel(const float* __restric
         }
     }
     l = abr::block_sum<4>(l, sm);
-    if (threadIdx.x == 0) atomicAdd(loss_out, l * inv);
+    loss_add(l * inv, loss_out, ws);
 }
 
 }  // namespace
@@ -419,8 +439,8 @@ extern "C" int abr_smooth_l1(const float* x, const float* t, int64_t n, float be
     if (int e = zero_loss(loss_out, 1, st, "smooth_l1")) return e;
     if (n == 0) return ABR_OK;
     ABR_REQUIRE(x && t, "smooth_l1: null pointer");
-    smooth_l1_kernel<<<(unsigned)std::min<int64_t>((n + 255) / 256, 1024), 256, 0, st>>>(x, t, n, beta, scale, loss_out,
-                                                                                           gscale, grad);
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 1024);
+    smooth_l1_kernel<<<grid, 256, 0, st>>>(x, t, n, beta, scale, loss_out, gscale, grad, abr::det_ws(st, grid));
     ABR_CHECK_LAUNCH("smooth_l1");
     return ABR_OK;
 }
@@ -433,8 +453,8 @@ extern "C" int abr_smooth_l1_rows(const float* x, int x_cols, const float* t, co
     if (int e = zero_loss(loss_out, 1, st, "smooth_l1_rows")) return e;
     if (n_rows == 0) return ABR_OK;
     ABR_REQUIRE(x && t && rows, "smooth_l1_rows: null pointer");
-    smooth_l1_rows_kernel<<<abr::cdiv((int64_t)n_rows * 4, 256), 256, 0, st>>>(x, x_cols, t, rows, col0, trows, n_rows,
-                                                                                beta, scale, denom_dev, loss_out, gscale, grad);
+    const unsigned grid = abr::cdiv((int64_t)n_rows * 4, 256);
+    smooth_l1_rows_kernel<<<grid, 256, 0, st>>>(x, x_cols, t, rows, col0, trows, n_rows, beta, scale, denom_dev, loss_out, gscale, grad, abr::det_ws(st, grid));
     ABR_CHECK_LAUNCH("smooth_l1_rows");
     return ABR_OK;
 }
@@ -453,7 +473,7 @@ extern "C" int abr_softmax_ce(const float* logits, int ld_logits, const int64_t*
     int* cnt = reinterpret_cast<int*>(loss_out + 1);
     count_valid_kernel<<<1, 256, 0, st>>>(labels, n, cnt);
     softmax_ce_kernel<<<abr::cdiv(n, 32), 256, 0, st>>>(logits, labels, n, K, ld_logits, ld_dlogits, inclusive, n_old, cnt, loss_out, gscale,
-                                                          d_logits);
+                                                          d_logits, abr::det_ws(st, abr::cdiv(n, 32)));
     ABR_CHECK_LAUNCH("softmax_ce");
     return ABR_OK;
 }
@@ -473,7 +493,7 @@ extern "C" int abr_roi_distill(const float* z_s, const float* b_s, const float* 
     ABR_REQUIRE(z_s && b_s && z_t && b_t, "roi_distill: null pointer");
     roi_distill_kernel<<<abr::cdiv(n, 16), 256, 0, st>>>(z_s, b_s, z_t, b_t, n, ld[0], ld[1], ld[2], ld[3], ld[4], ld[5], K_old, K_all, dist_id, loss_out,
                                                            gscale,
-                                                           d_zt, d_bt);
+                                                           d_zt, d_bt, abr::det_ws(st, abr::cdiv(n, 16)));
     ABR_CHECK_LAUNCH("roi_distill");
     return ABR_OK;
 }
@@ -486,7 +506,8 @@ extern "C" int abr_bce_logits_gather(const float* x, const float* y, const int64
     if (int e = zero_loss(loss_out, 1, st, "bce_logits_gather")) return e;
     if (n_idx == 0) return ABR_OK;
     ABR_REQUIRE(x && y && idx, "bce_logits_gather: null pointer");
-    bce_gather_kernel<<<std::min(abr::cdiv(n_idx, 256), 256u), 256, 0, st>>>(x, y, idx, yidx, n_idx, denom_dev, loss_out, gscale, grad);
+    const unsigned grid = std::min(abr::cdiv(n_idx, 256), 256u);
+    bce_gather_kernel<<<grid, 256, 0, st>>>(x, y, idx, yidx, n_idx, denom_dev, loss_out, gscale, grad, abr::det_ws(st, grid));
     ABR_CHECK_LAUNCH("bce_logits_gather");
     return ABR_OK;
 }
@@ -500,8 +521,8 @@ extern "C" int abr_feat_distill(const float* src, const float* tgt, int64_t n, f
     if (n == 0) return ABR_OK;
     ABR_REQUIRE(src && tgt, "feat_distill: null pointer");
     const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
-    feat_distill_sums_kernel<<<grid, 256, 0, st>>>(src, tgt, n, stats3);
-    feat_distill_loss_kernel<<<grid, 256, 0, st>>>(src, tgt, n, stats3, loss_out);
+    feat_distill_sums_kernel<<<grid, 256, 0, st>>>(src, tgt, n, stats3, abr::det_ws(st, 2 * (size_t)grid));
+    feat_distill_loss_kernel<<<grid, 256, 0, st>>>(src, tgt, n, stats3, loss_out, abr::det_ws(st, 2 * (size_t)grid));
     if (d_tgt) feat_distill_grad_kernel<<<grid, 256, 0, st>>>(src, tgt, n, stats3, gscale, d_tgt);
     ABR_CHECK_LAUNCH("feat_distill");
     return ABR_OK;
@@ -516,9 +537,10 @@ extern "C" int abr_rpn_distill(const float* obj_s, const float* reg_s, int ld_ob
     if (rows == 0) return ABR_OK;
     ABR_REQUIRE(obj_s && reg_s && obj_t && reg_t, "rpn_distill: null pointer");
     ABR_REQUIRE((d_obj_t == nullptr) == (d_reg_t == nullptr), "rpn_distill: gradients come together");
-    rpn_distill_kernel<<<(unsigned)std::min<int64_t>((rows * A + 255) / 256, 2048), 256, 0, st>>>(
+    const unsigned grid = (unsigned)std::min<int64_t>((rows * A + 255) / 256, 2048);
+    rpn_distill_kernel<<<grid, 256, 0, st>>>(
         obj_s, reg_s, ld_obj_s, ld_reg_s, obj_t, reg_t, ld_obj_t, ld_reg_t, rows, A, bbox_threshold, use_bbox, loss_out, gscale, d_obj_t,
-        d_reg_t, ld_d_obj, ld_d_reg);
+        d_reg_t, ld_d_obj, ld_d_reg, abr::det_ws(st, grid));
     ABR_CHECK_LAUNCH("rpn_distill");
     return ABR_OK;
 }

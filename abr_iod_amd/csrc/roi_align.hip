@@ -400,24 +400,29 @@ __global__ __launch_bounds__(64) void roi_bwd_tables_kernel(const float* __restr
     for (int i = threadIdx.x; i < PHo * H + PWo * Wp; i += 64) sm[i] = 0.f;
     if (threadIdx.x == 0) { rng[0] = H; rng[1] = -1; rng[2] = W; rng[3] = -1; }
     __syncthreads();
-    for (int t = threadIdx.x; t < PHo * g.gh; t += 64) {
-        const int pi = t / g.gh, iy = t % g.gh;
-        int lo, hi; float wl, wh; bool ok;
-        axis_tap(g.y0, g.bh, g.gh, pi * step, iy, H, &lo, &hi, &wl, &wh, &ok);
-        if (ok) {
-            atomicAdd(&sy[pi * H + lo], wl);
-            atomicAdd(&sy[pi * H + hi], wh);
-            atomicMin(&rng[0], lo); atomicMax(&rng[1], hi);
+    // one thread per bin walks the bin's samples IN ORDER and owns the bin's table row (round 5: the former one-thread-per-sample form added
+    // into the row with LDS float atomics, whose order -- and the tables' last bits, and with them the feature gradient's -- changed from run to run)
+    if (threadIdx.x < PHo) {
+        const int pi = threadIdx.x;
+        for (int iy = 0; iy < g.gh; iy++) {
+            int lo, hi; float wl, wh; bool ok;
+            axis_tap(g.y0, g.bh, g.gh, pi * step, iy, H, &lo, &hi, &wl, &wh, &ok);
+            if (ok) {
+                sy[pi * H + lo] += wl;
+                sy[pi * H + hi] += wh;
+                atomicMin(&rng[0], lo); atomicMax(&rng[1], hi);
+            }
         }
-    }
-    for (int t = threadIdx.x; t < PWo * g.gw; t += 64) {
-        const int pi = t / g.gw, ix = t % g.gw;
-        int lo, hi; float wl, wh; bool ok;
-        axis_tap(g.x0, g.bw, g.gw, pi * step, ix, W, &lo, &hi, &wl, &wh, &ok);
-        if (ok) {
-            atomicAdd(&sx[pi * Wp + lo], wl);
-            atomicAdd(&sx[pi * Wp + hi], wh);
-            atomicMin(&rng[2], lo); atomicMax(&rng[3], hi);
+    } else if (threadIdx.x >= 32 && threadIdx.x < 32 + PWo) {
+        const int pi = threadIdx.x - 32;
+        for (int ix = 0; ix < g.gw; ix++) {
+            int lo, hi; float wl, wh; bool ok;
+            axis_tap(g.x0, g.bw, g.gw, pi * step, ix, W, &lo, &hi, &wl, &wh, &ok);
+            if (ok) {
+                sx[pi * Wp + lo] += wl;
+                sx[pi * Wp + hi] += wh;
+                atomicMin(&rng[2], lo); atomicMax(&rng[3], hi);
+            }
         }
     }
     __syncthreads();

@@ -4,7 +4,8 @@ batch must reproduce the losses and the 33 M gradients of its first visit -- whi
 kernel still runs and bumps the weight versions (so the derived-weight caches are refilled on the preparation stream every step), the
 next batch's source forward + frozen prefix is prefetched into the backward pass, the batches alternate between three image shapes (scratch
 pools regrow, tile counts change), weight gradients run on their side streams.  A missing stream dependency shows up as a gradient that differs
-between two visits by more than the accumulation-order noise of the few atomically accumulated sums.  Also prints the allocator's high-water
+between two visits at all: since round 5 no sum of the step is accumulated with floating-point atomics (losses, bias gradients and the ROIAlign
+weight tables add up in a fixed order), so a revisit must be BIT-IDENTICAL (--tol > 0 restores the former noise allowance).  Also prints the allocator's high-water
 mark at intervals (a leak shows as growth after the first cycle).   GPU box: python tools/soak.py [--steps 600]"""
 import argparse
 import os
@@ -20,7 +21,8 @@ from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer  # noqa: 
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=600)
-ap.add_argument("--tol", type=float, default=2e-5, help="allowed ||g - g_first|| / ||g_first|| between two visits of a batch")
+ap.add_argument("--tol", type=float, default=0.0, help="allowed ||g - g_first|| / ||g_first|| between two visits of a batch (0: bit-identical, "
+                "the default since round 5: every cross-workgroup sum of the step has a fixed order)")
 a = ap.parse_args()
 
 cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, ims_per_batch=4, base_lr=0.0)
@@ -50,7 +52,7 @@ for it in range(a.steps):
         rel = float((g - g0).norm()) / max(n0, 1e-30)
         dl = float(((losses - l0).abs() / l0.abs().clamp_min(1.0)).max())
         worst, worst_loss = max(worst, rel), max(worst_loss, dl)
-        if not (rel <= a.tol and dl <= 1e-5 and bool(torch.isfinite(g).all())):
+        if not (rel <= a.tol and dl <= (1e-5 if a.tol > 0 else 0.0) and bool(torch.isfinite(g).all())):
             bad.append((it, k, rel, dl))
     if it % 100 == 0:
         print("step %5d  worst gradient rel. distance so far %.2e, worst loss rel. difference %.2e, allocator high-water %.2f GB" % (
