@@ -245,7 +245,7 @@ def test_two_ranks_one_image_each_equal_one_rank_two_images():
     g_mean = 0.5 * g0
     rel = float(np.linalg.norm(g_mean - g_single) / np.linalg.norm(g_single))
     print("1x2 vs 2x1: gradient rel-L2", rel, " max-abs", float(np.abs(g_mean - g_single).max()), " |g|max", float(np.abs(g_single).max()))
-    assert rel < 2e-5, rel
+    assert rel < 1e-6, rel   # (measured 2.0e-7: what the different per-rank reduction shapes -- one image's rows vs two -- explain; 2e-5 before round 5)
     # and the SGD update (1/world folded into the kernel) lands on the same parameters
     relp = float(np.linalg.norm(p0 - p_single) / np.linalg.norm(p_single - p_before.cpu().numpy()))
     print("parameter update rel-L2 difference", relp)
