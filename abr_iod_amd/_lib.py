@@ -83,7 +83,15 @@ _SIGS = {
     "abr_roi_align_backward_gather": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "abr_roi_align_taps": (_i, [_vp, _i, _i, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     "abr_nms_workspace_bytes": (_i64, [_i, _i]),
+    "abr_nms_unsorted_workspace_bytes": (_i64, [_i]),
+    "abr_nms": (_i, [_vp, _vp, _i, _f, _i, _vp, _vp, _vp, _i64, _vp]),
+    "abr_sort_scores_max_n": (_i64, []),
+    "abr_sort_scores_desc": (_i, [_vp, _i, _vp, _vp]),
     "abr_nms_sorted_batched": (_i, [_vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _i64, _vp]),
+    "abr_roi_align_forward_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.c_double, _i, _i, _i, _vp, _vp]),
+    "abr_roi_align_backward_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.c_double, _i, _i, _i, _vp, _vp]),
+    "abr_sigmoid_focal_forward_f64": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    "abr_sigmoid_focal_backward_f64": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "abr_sigmoid_focal_forward": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "abr_sigmoid_focal_backward": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "abr_ard_forward": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
@@ -190,4 +198,14 @@ def f32c(t):
     """contiguous fp32 view/copy (the reference kernels call .contiguous() too, ROIAlign_cuda.cu:286)."""
     if t.dtype != torch.float32:
         raise RuntimeError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def fpc(t, like=None):
+    """contiguous float32 / float64 tensor (the two types AT_DISPATCH_FLOATING_TYPES gives the reference's _C entry points); `like`: the
+    tensor whose dtype it must share"""
+    if t.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"expected float32 or float64, got {t.dtype}")
+    if like is not None and t.dtype != like.dtype:
+        raise RuntimeError(f"expected {like.dtype} like the first argument, got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()

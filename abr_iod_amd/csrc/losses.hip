@@ -48,6 +48,40 @@ __global__ __launch_bounds__(256) void focal_bwd(const float* __restrict__ logit
     }
 }
 
+// float64 instantiation (AT_DISPATCH_FLOATING_TYPES, SigmoidFocalLoss_cuda.cu:128,172): the reference's template with T = double keeps its
+// expf / powf / logf calls, i.e. float transcendentals inside double arithmetic; the same expressions here.
+__global__ __launch_bounds__(256) void focal_fwd_f64(const double* __restrict__ logits, const int32_t* __restrict__ targets, int64_t total, int C,
+                                                      float gamma, float alpha, double* __restrict__ losses) {   // (gamma / alpha are `const float` in the reference's template too)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = i / C, d = i % C, t = targets[n];
+        const double c1 = (t == d + 1), c2 = (t >= 0) & (t != d + 1);
+        const double zn = (1.0 - alpha), zp = alpha, x = logits[i];
+        const double p = 1. / (1. + expf((float)-x));
+        const double term1 = powf((float)(1. - p), gamma) * logf((float)fmax(p, (double)FLT_MIN));
+        const double term2 = powf((float)p, gamma) * (-1. * x * (x >= 0) - logf((float)(1. + expf((float)(x - 2. * x * (x >= 0))))));
+        double l = 0.0;
+        l += -c1 * term1 * zp;
+        l += -c2 * term2 * zn;
+        losses[i] = l;
+    }
+}
+__global__ __launch_bounds__(256) void focal_bwd_f64(const double* __restrict__ logits, const int32_t* __restrict__ targets, const double* __restrict__ d_losses,
+                                                      int64_t total, int C, float gamma, float alpha, double* __restrict__ d_logits) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = i / C, d = i % C, t = targets[n];
+        const double c1 = (t == d + 1), c2 = (t >= 0) & (t != d + 1);
+        const double zn = (1.0 - alpha), zp = alpha, x = logits[i];
+        const double p = 1. / (1. + expf((float)-x));
+        const double term1 = powf((float)(1. - p), gamma) * (1. - p - (p * gamma * logf((float)fmax(p, (double)FLT_MIN))));
+        const double term2 = powf((float)p, gamma) *
+                             ((-1. * x * (x >= 0) - logf((float)(1. + expf((float)(x - 2. * x * (x >= 0)))))) * (1. - p) * gamma - p);
+        double g = 0.0;
+        g += -c1 * term1 * zp;
+        g += -c2 * term2 * zn;
+        d_logits[i] = g * d_losses[i];
+    }
+}
+
 // Add this workgroup's share `v` (valid in thread 0) to *loss_out: through the deterministic last-arrival sum when there is scratch (the
 // result is then STORED: loss_out need not be zero), else with an atomic (loss_out zeroed by the host).
 __device__ __forceinline__ void loss_add(float v, float* loss_out, const abr::DetWs ws) {
@@ -421,6 +455,29 @@ extern "C" int abr_sigmoid_focal_backward(const float* logits, const int32_t* ta
     focal_bwd<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, abr::as_stream(stream)>>>(
         logits, targets, d_losses, total, C, gamma, alpha, d_logits);
     ABR_CHECK_LAUNCH("sigmoid_focal_backward");
+    return ABR_OK;
+}
+
+extern "C" int abr_sigmoid_focal_forward_f64(const double* logits, const int32_t* targets, int N, int C, float gamma, float alpha, double* losses,
+                                             void* stream) {
+    ABR_REQUIRE(N >= 0 && C > 0, "sigmoid_focal_forward_f64: bad shape");
+    if (N == 0) return ABR_OK;
+    ABR_REQUIRE(logits && targets && losses, "sigmoid_focal_forward_f64: null pointer");
+    const int64_t total = (int64_t)N * C;
+    focal_fwd_f64<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, abr::as_stream(stream)>>>(logits, targets, total, C, gamma, alpha, losses);
+    ABR_CHECK_LAUNCH("sigmoid_focal_forward_f64");
+    return ABR_OK;
+}
+
+extern "C" int abr_sigmoid_focal_backward_f64(const double* logits, const int32_t* targets, const double* d_losses, int N, int C, float gamma,
+                                              float alpha, double* d_logits, void* stream) {
+    ABR_REQUIRE(N >= 0 && C > 0, "sigmoid_focal_backward_f64: bad shape");
+    if (N == 0) return ABR_OK;
+    ABR_REQUIRE(logits && targets && d_losses && d_logits, "sigmoid_focal_backward_f64: null pointer");
+    const int64_t total = (int64_t)N * C;
+    focal_bwd_f64<<<(unsigned)std::min<int64_t>((total + 255) / 256, 4096), 256, 0, abr::as_stream(stream)>>>(logits, targets, d_losses, total, C, gamma, alpha,
+                                                                                                          d_logits);
+    ABR_CHECK_LAUNCH("sigmoid_focal_backward_f64");
     return ABR_OK;
 }
 

@@ -271,7 +271,85 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const uint64_t* __restri
     if (threadIdx.x == 0) n_keep[img] = total;
 }
 
+// ---- _C.nms(dets, scores, thr) as ONE call on UNSORTED boxes (round 5): rank the scores (abr_sort_scores_desc: the proposal ranking's own key /
+// partition / chunk-sort / merge kernels on order-preserving keys, ties by ascending index = torch.sort(stable, descending)), gather the boxes in
+// that order, mask + sweep as above, then hand back the survivors' ORIGINAL indices in ascending order (nms.cu:127-130, nms_cpu.cpp:66) by
+// marking them in a flag array and compacting it -- no second sort.
+__global__ __launch_bounds__(256) void nms_gather_boxes_kernel(const float4* __restrict__ dets, const int64_t* __restrict__ order, int n, float4* __restrict__ out,
+                                                               int32_t* __restrict__ counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = dets[order[i]];
+    if (i == 0) counts[0] = n;
+}
+__global__ __launch_bounds__(1024) void nms_mark_compact_kernel(const int64_t* __restrict__ order, const int32_t* __restrict__ keep, const int32_t* __restrict__ n_keep,
+                                                                int n, unsigned char* __restrict__ mark, int64_t* __restrict__ out) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int k = n_keep[0];
+    for (int i = threadIdx.x; i < n; i += 1024) mark[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < k; i += 1024) mark[order[keep[i]]] = 1;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i0 = 0; i0 < n; i0 += 1024) {          // ascending index: a running prefix count over 1024-element slabs
+        const int i = i0 + threadIdx.x;
+        const int m = i < n ? mark[i] : 0;
+        const unsigned long long b = __ballot(m);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(b);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        if (m) out[off + before] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; w++) t += s_wave[w]; s_base += t; }
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+extern "C" int abr_sort_scores_desc(const float* scores, int n, int64_t* order, void* stream);   // topk.hip
+extern "C" int64_t abr_sort_scores_max_n(void);
+
+extern "C" int64_t abr_nms_workspace_bytes(int N, int n_max);
+extern "C" int abr_nms_sorted_batched(const float* boxes, const int32_t* counts, int N, int n_max, float thr, int strict_gt, int max_keep, int32_t* keep,
+                                      int32_t* n_keep, void* workspace, int64_t workspace_bytes, void* stream);
+
+extern "C" int64_t abr_nms_unsorted_workspace_bytes(int n) {
+    if (n <= 0) return 64;
+    // order [n] int64, sorted boxes [n] float4, counts, keep [n] int32, marks [n], then the mask workspace
+    return (int64_t)n * 8 + (int64_t)n * 16 + 64 + (((int64_t)n * 4 + 63) & ~63) + (((int64_t)n + 63) & ~63) + abr_nms_workspace_bytes(1, n);
+}
+
+extern "C" int abr_nms(const float* dets, const float* scores, int n, float thr, int strict_gt, int64_t* keep_out, int32_t* n_keep_out, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
+    ABR_REQUIRE(n >= 0 && n_keep_out, "nms: bad args");
+    hipStream_t st = abr::as_stream(stream);
+    if (n == 0) {
+        if (hipMemsetAsync(n_keep_out, 0, sizeof(int32_t), st) != hipSuccess) return ABR_E_LAUNCH;
+        return ABR_OK;
+    }
+    ABR_REQUIRE(dets && scores && keep_out && workspace, "nms: null pointer");
+    ABR_REQUIRE(n <= abr_sort_scores_max_n(), "nms: at most %d boxes per call (the in-LDS merge of the score sort)", (int)abr_sort_scores_max_n());
+    ABR_REQUIRE(workspace_bytes >= abr_nms_unsorted_workspace_bytes(n), "nms: workspace too small");
+    ABR_REQUIRE((reinterpret_cast<uintptr_t>(dets) & 15) == 0, "nms: dets must be 16-byte aligned");
+    char* w = static_cast<char*>(workspace);
+    int64_t* order = reinterpret_cast<int64_t*>(w);                       w += (size_t)n * 8;
+    float4* sorted = reinterpret_cast<float4*>(w);                         w += (size_t)n * 16;
+    int32_t* counts = reinterpret_cast<int32_t*>(w);                       w += 64;
+    int32_t* keep = reinterpret_cast<int32_t*>(w);                         w += ((size_t)n * 4 + 63) & ~(size_t)63;
+    unsigned char* mark = reinterpret_cast<unsigned char*>(w);             w += ((size_t)n + 63) & ~(size_t)63;
+    int rc = abr_sort_scores_desc(scores, n, order, stream);
+    if (rc != ABR_OK) return rc;
+    nms_gather_boxes_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(reinterpret_cast<const float4*>(dets), order, n, sorted, counts);
+    rc = abr_nms_sorted_batched(reinterpret_cast<const float*>(sorted), counts, 1, n, thr, strict_gt, n, keep, n_keep_out, w, abr_nms_workspace_bytes(1, n), stream);
+    if (rc != ABR_OK) return rc;
+    nms_mark_compact_kernel<<<1, 1024, 0, st>>>(order, keep, n_keep_out, n, mark, keep_out);
+    ABR_CHECK_LAUNCH("nms");
+    return ABR_OK;
+}
 
 extern "C" int64_t abr_nms_workspace_bytes(int N, int n_max) {
     const int64_t words = (n_max + 63) / 64;

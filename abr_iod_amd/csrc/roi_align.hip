@@ -689,6 +689,91 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nchw(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// float64 instantiation of the NCHW pair: the reference dispatches float AND double (AT_DISPATCH_FLOATING_TYPES, ROIAlign_cuda.cu:283,329;
+// ROIAlign_cpu.cpp:242).  The same arithmetic with every T = double, as the reference's templates give it: coordinates, weights and the
+// accumulation in double, the (i + .5f) sample offset a float literal converted to T (ROIAlign_cuda.cu:104-109).
+// ---------------------------------------------------------------------------------------------------
+struct RoiGeomD {
+    double y0, x0, bh, bw;
+    int gh, gw, b;
+};
+#pragma clang fp contract(off)
+__device__ __forceinline__ RoiGeomD roi_geom_d(const double* __restrict__ r, double scale, int PH, int PW, int sr) {
+    RoiGeomD g;
+    g.b = (int)r[0];
+    const double sw = r[1] * scale, sh = r[2] * scale, ew = r[3] * scale, eh = r[4] * scale;
+    const double rw = fmax(ew - sw, 1.), rh = fmax(eh - sh, 1.);
+    g.x0 = sw; g.y0 = sh;
+    g.bh = rh / (double)PH;
+    g.bw = rw / (double)PW;
+    g.gh = sr > 0 ? sr : (int)ceil(rh / (double)PH);
+    g.gw = sr > 0 ? sr : (int)ceil(rw / (double)PW);
+    return g;
+}
+struct TapD {
+    int p0, p1, p2, p3;
+    double w0, w1, w2, w3;
+};
+#pragma clang fp contract(off)
+__device__ __forceinline__ TapD make_tap_d(const RoiGeomD& g, int H, int W, int ph, int pw, int iy, int ix) {
+    double y = g.y0 + ph * g.bh + (double)(iy + .5f) * g.bh / (double)g.gh;
+    double x = g.x0 + pw * g.bw + (double)(ix + .5f) * g.bw / (double)g.gw;
+    TapD t;
+    if (y < -1.0 || y > (double)H || x < -1.0 || x > (double)W) {
+        t.p0 = t.p1 = t.p2 = t.p3 = -1;
+        t.w0 = t.w1 = t.w2 = t.w3 = 0.;
+        return t;
+    }
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (double)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (double)xl; } else xh = xl + 1;
+    const double ly = y - yl, lx = x - xl;
+    const double hy = 1. - ly, hx = 1. - lx;
+    t.w0 = hy * hx; t.w1 = hy * lx; t.w2 = ly * hx; t.w3 = ly * lx;
+    t.p0 = yl * W + xl; t.p1 = yl * W + xh; t.p2 = yh * W + xl; t.p3 = yh * W + xh;
+    return t;
+}
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void roi_align_fwd_nchw_f64(const double* __restrict__ feat, const double* __restrict__ rois, int64_t total, int C,
+                                                               int H, int W, double scale, int PH, int PW, int sr, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int pw = i % PW, ph = (i / PW) % PH, c = (i / PW / PH) % C, n = i / PW / PH / C;
+        const RoiGeomD g = roi_geom_d(rois + 5 * (size_t)n, scale, PH, PW, sr);
+        const double* plane = feat + ((size_t)g.b * C + c) * H * W;
+        double acc = 0.;
+        for (int iy = 0; iy < g.gh; iy++)
+            for (int ix = 0; ix < g.gw; ix++) {
+                const TapD t = make_tap_d(g, H, W, ph, pw, iy, ix);
+                if (t.p0 < 0) continue;
+                acc += t.w0 * plane[t.p0] + t.w1 * plane[t.p1] + t.w2 * plane[t.p2] + t.w3 * plane[t.p3];
+            }
+        out[i] = acc / (double)(g.gh * g.gw);
+    }
+}
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void roi_align_bwd_nchw_f64(const double* __restrict__ grad, const double* __restrict__ rois, int64_t total, int C,
+                                                               int H, int W, double scale, int PH, int PW, int sr, double* __restrict__ gfeat) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int pw = i % PW, ph = (i / PW) % PH, c = (i / PW / PH) % C, n = i / PW / PH / C;
+        const RoiGeomD g = roi_geom_d(rois + 5 * (size_t)n, scale, PH, PW, sr);
+        double* plane = gfeat + ((size_t)g.b * C + c) * H * W;
+        const double gv = grad[i];
+        const double count = (double)(g.gh * g.gw);
+        for (int iy = 0; iy < g.gh; iy++)
+            for (int ix = 0; ix < g.gw; ix++) {
+                const TapD t = make_tap_d(g, H, W, ph, pw, iy, ix);
+                if (t.p0 < 0) continue;
+                unsafeAtomicAdd(plane + t.p0, gv * t.w0 / count);
+                unsafeAtomicAdd(plane + t.p1, gv * t.w1 / count);
+                unsafeAtomicAdd(plane + t.p2, gv * t.w2 / count);
+                unsafeAtomicAdd(plane + t.p3, gv * t.w3 / count);
+            }
+    }
+}
+
 __global__ void roi_align_taps_kernel(const float* __restrict__ rois, int K, int H, int W, float scale, int PH, int PW,
                                       int sr, int max_s, int32_t* __restrict__ idx, int32_t* __restrict__ grid) {
     const int64_t total = (int64_t)K * PH * PW * max_s;
@@ -809,6 +894,36 @@ extern "C" int abr_roi_align_backward(const float* grad, const float* rois, int 
         }
     }
     ABR_CHECK_LAUNCH("roi_align_backward");
+    return ABR_OK;
+}
+
+extern "C" int abr_roi_align_forward_f64(const double* feat, const double* rois, int K, int B, int C, int H, int W, double scale, int PH, int PW,
+                                         int sr, double* out, void* stream) {
+    ABR_REQUIRE(K >= 0 && B > 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0, "roi_align_forward_f64: bad shape");
+    if (K == 0) return ABR_OK;
+    ABR_REQUIRE(feat && rois && out, "roi_align_forward_f64: null pointer");
+    const int64_t total = (int64_t)K * C * PH * PW;
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    roi_align_fwd_nchw_f64<<<grid, 256, 0, abr::as_stream(stream)>>>(feat, rois, total, C, H, W, scale, PH, PW, sr, out);
+    ABR_CHECK_LAUNCH("roi_align_forward_f64");
+    return ABR_OK;
+}
+
+extern "C" int abr_roi_align_backward_f64(const double* grad, const double* rois, int K, int B, int C, int H, int W, double scale, int PH, int PW,
+                                          int sr, double* gfeat, void* stream) {
+    ABR_REQUIRE(K >= 0 && B > 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0, "roi_align_backward_f64: bad shape");
+    ABR_REQUIRE(gfeat, "roi_align_backward_f64: null output");
+    hipStream_t st = abr::as_stream(stream);
+    if (hipMemsetAsync(gfeat, 0, sizeof(double) * (size_t)B * C * H * W, st) != hipSuccess) {   // at::zeros, ROIAlign_cuda.cu:316
+        abr::set_error("roi_align_backward_f64: memset failed");
+        return ABR_E_LAUNCH;
+    }
+    if (K == 0) return ABR_OK;
+    ABR_REQUIRE(grad && rois, "roi_align_backward_f64: null pointer");
+    const int64_t total = (int64_t)K * C * PH * PW;
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    roi_align_bwd_nchw_f64<<<grid, 256, 0, st>>>(grad, rois, total, C, H, W, scale, PH, PW, sr, gfeat);
+    ABR_CHECK_LAUNCH("roi_align_backward_f64");
     return ABR_OK;
 }
 

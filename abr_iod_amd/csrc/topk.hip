@@ -23,8 +23,14 @@ namespace {
 constexpr int TT = 1024;
 constexpr int CAP = 16384;  // LDS sort capacity (64-bit words)
 
-__device__ __forceinline__ unsigned score_bits(const float* __restrict__ base, int j, int A, int ld) {
+// raw = 0: the key is the bit pattern of sigmoid(x) (non-negative: orders like the value).  raw = 1 (abr_sort_scores_desc: the score sort of
+// _C.nms): the key orders like x itself for ANY finite float -- sign bit flipped for x >= 0, all bits for x < 0 (-0 sorts below +0, NaNs at the ends)
+__device__ __forceinline__ unsigned score_bits(const float* __restrict__ base, int j, int A, int ld, int raw) {
     const float x = base[(size_t)(j / A) * ld + (j % A)];
+    if (raw) {
+        const unsigned b = __float_as_uint(x);
+        return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    }
     return __float_as_uint(1.f / (1.f + expf(-x)));
 }
 
@@ -35,7 +41,7 @@ constexpr int KT = 256;      // threads of the key kernel
 constexpr int HB = 4096;     // bins of a 12-bit level
 
 __global__ __launch_bounds__(KT) void topk_keys_kernel(const float* __restrict__ logits, int64_t img_stride, int n, int A, int ld, int per,
-                                                       unsigned* __restrict__ keys, int* __restrict__ hist) {
+                                                       unsigned* __restrict__ keys, int* __restrict__ hist, int raw) {
     __shared__ int lh[HB];
     const int img = blockIdx.y;
     for (int i = threadIdx.x; i < HB; i += KT) lh[i] = 0;
@@ -43,7 +49,7 @@ __global__ __launch_bounds__(KT) void topk_keys_kernel(const float* __restrict__
     const float* base = logits + (size_t)img * img_stride;
     const int j0 = blockIdx.x * per, j1 = min(j0 + per, n);
     for (int j = j0 + threadIdx.x; j < j1; j += KT) {
-        const unsigned key = score_bits(base, j, A, ld);
+        const unsigned key = score_bits(base, j, A, ld, raw);
         keys[(size_t)img * n + j] = key;
         atomicAdd(&lh[key >> 20], 1);
     }
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(TT) void topk_select_sort_kernel(const unsigned* __
     }
     for (int j = threadIdx.x; j < k; j += TT) {
         const unsigned long long v = j < filled ? buf[j] : 0ull;
-        scores[(size_t)blockIdx.x * k + j] = __uint_as_float((unsigned)(v >> 32));
+        if (scores) scores[(size_t)blockIdx.x * k + j] = __uint_as_float((unsigned)(v >> 32));
         idx[(size_t)blockIdx.x * k + j] = (int64_t)(~(unsigned)(v & 0xFFFFFFFFu));
     }
 }
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(TT) void topk_merge_emit_kernel(const unsigned long
     if (c * CH >= filled) {
         // (filled < k cannot happen unless the capacity overflowed: then the tail reads as zeros, like the one-workgroup form)
         for (int j = max(filled, c * CH) + threadIdx.x; j < min(k, (c + 1) * CH); j += TT) {
-            scores[(size_t)img * k + j] = 0.f;
+            if (scores) scores[(size_t)img * k + j] = 0.f;
             idx[(size_t)img * k + j] = (int64_t)(~0u);
         }
         return;
@@ -316,12 +322,14 @@ __global__ __launch_bounds__(TT) void topk_merge_emit_kernel(const unsigned long
         rank += lo;
     }
     if (rank < k) {
-        scores[(size_t)img * k + rank] = __uint_as_float((unsigned)(x >> 32));
+        if (scores) scores[(size_t)img * k + rank] = __uint_as_float((unsigned)(x >> 32));
         idx[(size_t)img * k + rank] = (int64_t)(~(unsigned)(x & 0xFFFFFFFFu));
     }
 }
 
 }  // namespace
+
+static int topk_run(const float* logits, int64_t img_stride, int N, int n, int A, int ld, int k, float* scores, int64_t* idx, int raw, void* stream);
 
 extern "C" int abr_topk_sigmoid(const float* logits, int64_t img_stride, int N, int n, int A, int ld, int k, float* scores,
                                 int64_t* idx, void* stream) {
@@ -329,6 +337,19 @@ extern "C" int abr_topk_sigmoid(const float* logits, int64_t img_stride, int N, 
     ABR_REQUIRE(k <= CAP - 1024, "topk_sigmoid: k too large for the in-LDS sort (max 15360)");
     if (N == 0 || k == 0) return ABR_OK;
     ABR_REQUIRE(logits && scores && idx, "topk_sigmoid: null pointer");
+    return topk_run(logits, img_stride, N, n, A, ld, k, scores, idx, 0, stream);
+}
+
+extern "C" int64_t abr_sort_scores_max_n(void) { return CAP - 1024; }
+
+extern "C" int abr_sort_scores_desc(const float* scores, int n, int64_t* order, void* stream) {
+    ABR_REQUIRE(n >= 0 && n <= CAP - 1024, "sort_scores_desc: at most 15360 scores");
+    if (n == 0) return ABR_OK;
+    ABR_REQUIRE(scores && order, "sort_scores_desc: null pointer");
+    return topk_run(scores, n, 1, n, 1, 1, n, nullptr, order, 1, stream);
+}
+
+static int topk_run(const float* logits, int64_t img_stride, int N, int n, int A, int ld, int k, float* scores, int64_t* idx, int raw, void* stream) {
     static const bool one_wg = getenv("ABR_TOPK_ONE_WG") && atoi(getenv("ABR_TOPK_ONE_WG")) != 0;   // round 3's one-workgroup-per-image phase 2 (A/B)
     const int G = 64;
     const int per = ((n + G - 1) / G + KT - 1) / KT * KT;
@@ -377,7 +398,7 @@ extern "C" int abr_topk_sigmoid(const float* logits, int64_t img_stride, int N, 
         keys = reinterpret_cast<unsigned*>(b);
     }
     const unsigned slices = (unsigned)((n + per - 1) / per);
-    topk_keys_kernel<<<dim3(slices, (unsigned)N), KT, 0, st>>>(logits, img_stride, n, A, ld, per, keys, hist);
+    topk_keys_kernel<<<dim3(slices, (unsigned)N), KT, 0, st>>>(logits, img_stride, n, A, ld, per, keys, hist, raw);
     if (one_wg) {
         topk_select_sort_kernel<<<N, TT, lds_sort, st>>>(keys, hist, n, k, scores, idx);
     } else {

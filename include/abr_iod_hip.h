@@ -109,6 +109,13 @@ int abr_roi_align_backward(const float* grad, const float* rois, int K, int B, i
                            float spatial_scale, int PH, int PW, int sampling_ratio, int bin_step,
                            int layout, int accumulate, float* grad_feat, void* stream);
 
+/* The float64 instantiations of the reference's dispatch (AT_DISPATCH_FLOATING_TYPES: csrc/cuda/ROIAlign_cuda.cu:283,329, csrc/cpu/ROIAlign_cpu.cpp:242):
+ * NCHW tensors, every T of the reference's templates = double.  grad_feat is zero-filled by the callee (at::zeros, :316). */
+int abr_roi_align_forward_f64(const double* feat, const double* rois, int K, int B, int C, int H, int W, double spatial_scale, int PH, int PW,
+                              int sampling_ratio, double* out, void* stream);
+int abr_roi_align_backward_f64(const double* grad, const double* rois, int K, int B, int C, int H, int W, double spatial_scale, int PH, int PW,
+                               int sampling_ratio, double* grad_feat, void* stream);
+
 /* Same result as abr_roi_align_backward(layout=ABR_NHWC) without atomics: every feature pixel gathers from the RoIs that
  * cover it (two kernels: per-RoI separable weight tables, then one coalesced write per dFeat element, deterministic order).
  * workspace: abr_roi_align_backward_ws_bytes(...) bytes.  This is the form the training step uses. */
@@ -135,12 +142,28 @@ int abr_nms_sorted_batched(const float* boxes, const int32_t* counts, int N, int
                            int strict_gt, int max_keep, int32_t* keep, int32_t* n_keep,
                            void* workspace, int64_t workspace_bytes, void* stream);
 
+/* _C.nms on UNSORTED boxes in one call (round 5; abr_iod_amd/_C.py::nms): descending stable score sort (abr_sort_scores_desc: the proposal
+ * ranking's own kernels on order-preserving keys), greedy suppression as above, survivors' ORIGINAL indices in ascending order (nms.cu:127-130).
+ *   dets [n,4] xyxy fp32 (16-byte aligned), scores [n] fp32, n <= abr_sort_scores_max_n() (15360); keep_out [n] int64, *n_keep_out int32 (device);
+ *   workspace: abr_nms_unsorted_workspace_bytes(n) bytes. */
+int64_t abr_nms_unsorted_workspace_bytes(int n);
+int abr_nms(const float* dets, const float* scores, int n, float thr, int strict_gt, int64_t* keep_out, int32_t* n_keep_out, void* workspace,
+            int64_t workspace_bytes, void* stream);
+/* order[i] = index of the i-th largest score (ties: ascending index -- torch.sort(descending=True, stable=True)); any finite fp32 */
+int64_t abr_sort_scores_max_n(void);
+int abr_sort_scores_desc(const float* scores, int n, int64_t* order, void* stream);
+
 /* _C.sigmoid_focalloss_forward / _backward   csrc/SigmoidFocalLoss.h:10-41 -> csrc/cuda/SigmoidFocalLoss_cuda.cu:20-101
  * logits [N,C] fp32, targets [N] int32 (0 = background, -1 = ignore, c>=1 = class c), losses/d_logits [N,C]. */
 int abr_sigmoid_focal_forward(const float* logits, const int32_t* targets, int N, int C, float gamma,
                               float alpha, float* losses, void* stream);
 int abr_sigmoid_focal_backward(const float* logits, const int32_t* targets, const float* d_losses, int N,
                                int C, float gamma, float alpha, float* d_logits, void* stream);
+/* the float64 instantiations (AT_DISPATCH_FLOATING_TYPES, SigmoidFocalLoss_cuda.cu:128,172): T = double with the template's own float gamma /
+ * alpha and expf / powf / logf calls */
+int abr_sigmoid_focal_forward_f64(const double* logits, const int32_t* targets, int N, int C, float gamma, float alpha, double* losses, void* stream);
+int abr_sigmoid_focal_backward_f64(const double* logits, const int32_t* targets, const double* d_losses, int N, int C, float gamma, float alpha,
+                                   double* d_logits, void* stream);
 
 /* =====================================================================================================
  * 2. Distillation + detector losses (ATen elementwise/reduction chains in the reference)
