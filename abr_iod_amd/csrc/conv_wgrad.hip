@@ -78,6 +78,11 @@ struct WgP {
     const unsigned long long* x_amax;
     unsigned gy_epoch, x_epoch;
     unsigned long long* h3_stats;   // f16x3 range statistics (abr::h3_stats_ptr) or nullptr
+    // round 5: with tickets the partial tiles are summed by the LAST workgroup of each output tile to arrive (in split order, its own partial
+    // included: the same sum whoever is last) instead of by a wgrad_reduce_kernel launch behind every split launch (41 launches per step).
+    // One counter per output tile, zero on entry, left zero.  nullptr: the reduction kernel follows.
+    unsigned* tickets;
+    unsigned ws_bytes;              // extent of `ws` for the coherent buffer accesses
 };
 
 // f16x3: the factors s_gy, s_x the accumulators carry (1, 1 in every other arithmetic); applied one after the other: their PRODUCT could leave
@@ -115,7 +120,7 @@ __device__ __forceinline__ void wgrad_store_tile(const WgP& p, const float (&v)[
 
 __device__ __forceinline__ void wgrad_finish(const WgP& p, f32x16 (&acc)[2][2], int n0, int k0, int wm, int wn, int l31, int lh, int tid,
                                              int gtile, int split, float* __restrict__ dw) {
-    if (p.ws) {   // park the partial sums; wgrad_reduce_kernel adds them up
+    if (p.ws && !p.tickets) {   // park the partial sums; wgrad_reduce_kernel adds them up
         float4* dst = reinterpret_cast<float4*>(reinterpret_cast<char*>(p.ws) + ((size_t)gtile * p.splits + split) * kPartBytes) + tid;
 #pragma unroll
         for (int t = 0; t < 4; t++)
@@ -125,6 +130,52 @@ __device__ __forceinline__ void wgrad_finish(const WgP& p, f32x16 (&acc)[2][2], 
                 dst[(t * 4 + c) * 256] = make_float4(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
             }
         return;   // (the caller stamps the end: wgrad_finish is the kernel's last statement)
+    }
+    if (p.ws) {
+        // park through system-coherent buffer stores (written through the XCD-local L2: no cache maintenance around the ticket, as in
+        // conv_igemm_kernel's split-K), take the tile's ticket; the last arrival re-reads ALL partials in split order and finishes the tile
+        constexpr int kCoherent = 0x11;   // sc0 | sc1
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, p.ws_bytes, 0x00020000);
+        const unsigned my_off = (unsigned)(((size_t)gtile * p.splits + split) * kPartBytes) + (unsigned)tid * 16u;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const f32x16& a = acc[t >> 1][t & 1];
+                const u32x4 v = {__float_as_uint(a[4 * c]), __float_as_uint(a[4 * c + 1]), __float_as_uint(a[4 * c + 2]), __float_as_uint(a[4 * c + 3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rws, (int)(my_off + (unsigned)(t * 4 + c) * 4096u), 0, kCoherent);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // = wait for this wave's stores
+        __syncthreads();
+        __shared__ int s_last;
+        if (tid == 0) s_last = atomicAdd(p.tickets + gtile, 1u) == (unsigned)p.splits - 1u;
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) p.tickets[gtile] = 0u;
+        const float2 osc = wg_operand_scale(p);
+        const unsigned base = (unsigned)((size_t)gtile * p.splits * kPartBytes) + (unsigned)tid * 16u;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                int q = 0;
+                for (; q + 4 <= p.splits; q += 4) {   // four loads in flight; the additions stay in split order
+                    u32x4 v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(base + (unsigned)(q + e) * kPartBytes + (unsigned)(t * 4 + c) * 4096u), 0, kCoherent);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { sum.x += __uint_as_float(v[e].x); sum.y += __uint_as_float(v[e].y); sum.z += __uint_as_float(v[e].z); sum.w += __uint_as_float(v[e].w); }
+                }
+                for (; q < p.splits; q++) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(base + (unsigned)q * kPartBytes + (unsigned)(t * 4 + c) * 4096u), 0, kCoherent);
+                    sum.x += __uint_as_float(v.x); sum.y += __uint_as_float(v.y); sum.z += __uint_as_float(v.z); sum.w += __uint_as_float(v.w);
+                }
+                const float vv[4] = {sum.x, sum.y, sum.z, sum.w};
+                wgrad_store_tile(p, vv, t >> 1, t & 1, c, n0, k0, wm, wn, l31, lh, p.final_store != 0, dw, osc);
+            }
+        return;
     }
     const float2 osc = wg_operand_scale(p);
 #pragma unroll
@@ -723,15 +774,40 @@ static float* wgrad_scratch(hipStream_t st, size_t units) {
     return w.ws;
 }
 
+// per-stream ticket counters of the in-kernel reduction (one per output tile; zeroed once, the kernels leave them zero)
+static unsigned* wgrad_tickets(hipStream_t st, int tiles) {
+    constexpr int kMaxTiles = 8192;
+    // OPT-IN (ABR_WGRAD_INKERNEL_REDUCE=1).  Measured in the step (same session, two rounds): 19.38 ms with it against 18.62 with the reduction
+    // kernel -- the write-through stores of the 64 KB partial tiles and the last arrival's 16 x splits coherent loads cost more than the 41
+    // short launches they replace, which run beside other streams' kernels anyway.  Results are identical either way.
+    static const bool on = getenv("ABR_WGRAD_INKERNEL_REDUCE") && atoi(getenv("ABR_WGRAD_INKERNEL_REDUCE")) != 0;
+    if (!on || tiles > kMaxTiles) return nullptr;
+    static std::map<hipStream_t, unsigned*> pool;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    unsigned*& t = pool[st];
+    if (!t) {
+        if (hipMalloc(&t, kMaxTiles * sizeof(unsigned)) != hipSuccess) { t = nullptr; return nullptr; }
+        (void)hipMemset(t, 0, kMaxTiles * sizeof(unsigned));
+    }
+    return t;
+}
+
 // fills p.ws for a split launch (left null -> the kernel falls back to atomics; the caller must then have zeroed a final_store dw)
 static void wgrad_plan_reduction(WgP& p, int tiles, hipStream_t st) {
     p.ws = nullptr;
+    p.tickets = nullptr;
+    p.ws_bytes = 0;
     if (p.splits <= 1) { if (p.final_store) p.overwrite = 1; return; }
     if (wgrad_ticket_enabled()) p.ws = wgrad_scratch(st, (size_t)tiles * p.splits);
+    if (p.ws && (size_t)tiles * p.splits * 65536 < (size_t)0x7FFFFFF0) {
+        p.tickets = wgrad_tickets(st, tiles);
+        p.ws_bytes = (unsigned)((size_t)tiles * p.splits * 65536);
+    }
 }
 
 static void wgrad_reduce(const WgP& p, int tiles, float* dw, hipStream_t st) {
-    if (p.ws) wgrad_reduce_kernel<<<(unsigned)tiles * 16u, 256, 0, st>>>(p, dw);
+    if (p.ws && !p.tickets) wgrad_reduce_kernel<<<(unsigned)tiles * 16u, 256, 0, st>>>(p, dw);
 }
 
 // split choice + launch for one (possibly batched) weight-gradient GEMM described by p (tiles_n / tiles_k / M / K filled in)
@@ -884,6 +960,7 @@ extern "C" int abr_conv_wgrad(const abr_conv_desc* d, const float* x, const floa
     p.ws = nullptr; p.final_store = 0; p.map4 = 0;
     p.x6_flags = nullptr;
     p.gy_amax = p.x_amax = nullptr; p.gy_epoch = p.x_epoch = 0; p.h3_stats = nullptr;
+    p.tickets = nullptr; p.ws_bytes = 0;
     static const int tile_fast = !(getenv("ABR_WGRAD_TILE_FAST") && atoi(getenv("ABR_WGRAD_TILE_FAST")) == 0);
     p.tile_fast = tile_fast;
     p.math = (d->math == ABR_MATH_BF16X6 || d->math == ABR_MATH_F16X3) ? d->math : ABR_MATH_F32;   // (x6 / h3 handle any Cin % 4 == 0: no k-tile constraint here)
