@@ -152,7 +152,7 @@ struct PrepJob {
 };
 int prep_transpose_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);   // conv_igemm.hip
 int prep_pack_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);        // conv_igemm.hip
-int prep_pack_h3_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);     // conv_igemm.hip (f16x3 planes: one workgroup per 32-row block)
+int prep_pack_h3_multi(const PrepJob* jobs_dev, int njobs, int blocks, int scale_blocks, hipStream_t st);     // conv_igemm.hip (f16x3 planes: one workgroup per 32-row block)
 int prep_wino_u_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);      // conv_winograd.hip (C % 4 == 0 jobs only)
 __device__ __forceinline__ int prep_find_job(const PrepJob* jobs, int njobs, int block) {
     int lo = 0, hi = njobs - 1;

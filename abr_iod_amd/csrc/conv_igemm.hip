@@ -1571,68 +1571,85 @@ static int64_t h3_planes_bytes(int64_t rows, int64_t K) { return (rows + 31) / 3
 __device__ __forceinline__ size_t h3_planes_bytes_dev(int rows, int K) { return (size_t)((rows + 31) / 32 * 32) * (size_t)K * 4; }
 static int64_t h3_packed_bytes(int64_t rows, int64_t K) { return h3_planes_bytes(rows, K) + (rows + 31) / 32 * 32 * 4; }
 
-__device__ __forceinline__ void h3_pack_block(const float* __restrict__ w, int rows, int K, int nb, uint4* __restrict__ planes, float* __restrict__ scales,
-                                              unsigned* flags) {
-    __shared__ float t[32][68];
-    __shared__ unsigned rmax[32];
-    const int tid = threadIdx.x;
-    if (tid < 32) rmax[tid] = 0u;
-    __syncthreads();
-    const int r0 = tid >> 4, c = (tid & 15) * 4;   // rows r0, r0 + 16; 64 columns per pass
-    unsigned m[2] = {0u, 0u};
-    for (int k0 = 0; k0 < K; k0 += 64)
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int row = nb * 32 + r0 + 16 * h;
-            if (row < rows && k0 + c < K) {
-                const uint4 v = *reinterpret_cast<const uint4*>(w + (size_t)row * K + k0 + c);
-                m[h] = max(max(m[h], max(v.x & 0x7FFFFFFFu, v.y & 0x7FFFFFFFu)), max(v.z & 0x7FFFFFFFu, v.w & 0x7FFFFFFFu));
-            }
+// Two launches (round 5b: one workgroup per 32-row block walking all of K twice took 16-20 us per weight, 110 us for a model's table, on the
+// path of the next step's first convs): the row scales by one wave per row, then the split by one workgroup per (32-row block, 64 columns).
+__device__ __forceinline__ void h3_rowscale_row(const float* __restrict__ w, int rows, int K, int row, float* __restrict__ scales, unsigned* flags) {
+    const int lane = threadIdx.x & 63;
+    unsigned m = 0u;
+    if (row < rows) {
+        const uint4* r4 = reinterpret_cast<const uint4*>(w + (size_t)row * K);
+        for (int k = lane; k < K / 4; k += 64) {
+            const uint4 v = r4[k];
+            m = max(max(m, max(v.x & 0x7FFFFFFFu, v.y & 0x7FFFFFFFu)), max(v.z & 0x7FFFFFFFu, v.w & 0x7FFFFFFFu));
         }
-    atomicMax(&rmax[r0], m[0]);
-    atomicMax(&rmax[r0 + 16], m[1]);
-    __syncthreads();
-    if (tid < 32) {
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if (lane == 0) {
         float sc, inv;
-        abr::h3_scales(rmax[tid], sc, inv);
-        scales[nb * 32 + tid] = sc;
-        if (flags && (rmax[tid] >> 23) >= 255u) atomicOr(flags, ABR_X6_FLAG_NONFINITE);
-    }
-    const int ksl = tid >> 6, lane = tid & 63;
-    float sc, inv;
-    abr::h3_scales(rmax[lane & 31], sc, inv);
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int r = r0 + 16 * h, row = nb * 32 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < rows && k0 + c < K) v = *reinterpret_cast<const float4*>(w + (size_t)row * K + k0 + c);
-            *reinterpret_cast<float4*>(&t[r][c]) = v;
-        }
-        __syncthreads();
-        const int ks = k0 / 16 + ksl;
-        if (ks * 16 >= K) continue;
-        const float* src = &t[lane & 31][ksl * 16 + (lane >> 5) * 8];
-        unsigned h0[4], h1[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) abr::h3_split2(src[2 * e], src[2 * e + 1], inv, h0[e], h1[e]);
-        const size_t ch = ((size_t)nb * (K / 16) + ks) * 2;
-        planes[ch * 64 + lane] = make_uint4(h0[0], h0[1], h0[2], h0[3]);
-        planes[(ch + 1) * 64 + lane] = make_uint4(h1[0], h1[1], h1[2], h1[3]);
+        abr::h3_scales(m, sc, inv);
+        scales[row] = sc;                       // (padded rows: amax 0 -> scale 1)
+        if (flags && (m >> 23) >= 255u) atomicOr(flags, ABR_X6_FLAG_NONFINITE);
     }
 }
-__global__ __launch_bounds__(256) void h3_pack_kernel(const float* __restrict__ w, int rows, int K, uint4* __restrict__ planes, unsigned* flags) {
-    h3_pack_block(w, rows, K, blockIdx.x, planes, reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + h3_planes_bytes_dev(rows, K)), flags);
+__device__ __forceinline__ void h3_pack_chunk(const float* __restrict__ w, int rows, int K, int nb, int k0, uint4* __restrict__ planes,
+                                              const float* __restrict__ scales) {
+    __shared__ float t[32][68];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int r = (tid >> 4) + 16 * h, c = (tid & 15) * 4, row = nb * 32 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows && k0 + c < K) v = *reinterpret_cast<const float4*>(w + (size_t)row * K + k0 + c);
+        *reinterpret_cast<float4*>(&t[r][c]) = v;
+    }
+    __syncthreads();
+    const int ksl = tid >> 6, lane = tid & 63, ks = k0 / 16 + ksl;
+    if (ks * 16 >= K) return;
+    const float inv = 1.f / scales[nb * 32 + (lane & 31)];   // (a power of two: exact)
+    const float* src = &t[lane & 31][ksl * 16 + (lane >> 5) * 8];
+    unsigned h0[4], h1[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) abr::h3_split2(src[2 * e], src[2 * e + 1], inv, h0[e], h1[e]);
+    const size_t ch = ((size_t)nb * (K / 16) + ks) * 2;
+    planes[ch * 64 + lane] = make_uint4(h0[0], h0[1], h0[2], h0[3]);
+    planes[(ch + 1) * 64 + lane] = make_uint4(h1[0], h1[1], h1[2], h1[3]);
 }
-__global__ __launch_bounds__(256) void h3_pack_multi_kernel(const abr::PrepJob* __restrict__ jobs, int njobs, unsigned* flags) {
+__global__ __launch_bounds__(256) void h3_rowscale_kernel(const float* __restrict__ w, int rows, int K, uint4* __restrict__ planes, unsigned* flags) {
+    const int rows32 = (rows + 31) / 32 * 32;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < rows32) h3_rowscale_row(w, rows, K, row, reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + h3_planes_bytes_dev(rows, K)), flags);
+}
+__global__ __launch_bounds__(256) void h3_pack_kernel(const float* __restrict__ w, int rows, int K, uint4* __restrict__ planes) {
+    h3_pack_chunk(w, rows, K, blockIdx.y, blockIdx.x * 64, planes, reinterpret_cast<const float*>(reinterpret_cast<const char*>(planes) + h3_planes_bytes_dev(rows, K)));
+}
+// the same over a TABLE of matrices (abr_conv_prepare_batch): jobs[j].c = first workgroup of job j in the row-scale launch, .first_block in the pack launch
+__device__ __forceinline__ int prep_find_job_c(const abr::PrepJob* jobs, int njobs, int block) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].c <= block) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void h3_rowscale_multi_kernel(const abr::PrepJob* __restrict__ jobs, int njobs, unsigned* flags) {
+    const int j = prep_find_job_c(jobs, njobs, blockIdx.x);
+    const abr::PrepJob jb = jobs[j];
+    const int rows32 = (jb.a + 31) / 32 * 32;
+    const int row = (blockIdx.x - jb.c) * 4 + (threadIdx.x >> 6);
+    if (row < rows32) h3_rowscale_row(jb.src, jb.a, jb.b, row, reinterpret_cast<float*>(reinterpret_cast<char*>(jb.dst) + h3_planes_bytes_dev(jb.a, jb.b)), flags);
+}
+__global__ __launch_bounds__(256) void h3_pack_multi_kernel(const abr::PrepJob* __restrict__ jobs, int njobs) {
     const int j = abr::prep_find_job(jobs, njobs, blockIdx.x);
     const abr::PrepJob jb = jobs[j];
+    const int lb = blockIdx.x - jb.first_block;
     uint4* planes = reinterpret_cast<uint4*>(jb.dst);
-    h3_pack_block(jb.src, jb.a, jb.b, blockIdx.x - jb.first_block, planes, reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + h3_planes_bytes_dev(jb.a, jb.b)), flags);
+    h3_pack_chunk(jb.src, jb.a, jb.b, lb / jb.gx, (lb % jb.gx) * 64, planes, reinterpret_cast<const float*>(reinterpret_cast<const char*>(planes) + h3_planes_bytes_dev(jb.a, jb.b)));
 }
 static int h3_pack(const float* w, int64_t rows, int K, void* planes, hipStream_t st) {
-    h3_pack_kernel<<<(unsigned)((rows + 31) / 32), 256, 0, st>>>(w, (int)rows, K, reinterpret_cast<uint4*>(planes), abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr);
+    const unsigned rb = (unsigned)((rows + 31) / 32);
+    h3_rowscale_kernel<<<rb * 8u, 256, 0, st>>>(w, (int)rows, K, reinterpret_cast<uint4*>(planes), abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr);
+    h3_pack_kernel<<<dim3((unsigned)((K + 63) / 64), rb), 256, 0, st>>>(w, (int)rows, K, reinterpret_cast<uint4*>(planes));
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -2000,7 +2017,7 @@ static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, fl
     static const int t12864_min10 = getenv("ABR_X6_T12864_MIN10") ? atoi(getenv("ABR_X6_T12864_MIN10")) : 20;
     int tile;   // 1 = 128x128, 2 = 128x64, 3 = 64x64
     if (force && p.K <= force_maxk && nb == 1) tile = force;
-    else if (shortk > 0 && p.K <= shortk && nb == 1) tile = 3;
+    else if (shortk > 0 && p.K <= shortk && nb == 1 && p.nprod != 3) tile = 3;   // (f16x3: the grid-size rule alone is 0.1 ms per step better -- same-session A/B, two rounds: 18.23 vs 18.34)
     else if (p.Cout > 64 && t128 * 10 >= (int64_t)t128_min10 * cus) tile = 1;
     else if (t12864 * 10 >= (int64_t)t12864_min10 * cus || p.Cout <= 64) tile = 2;
     else tile = 3;
@@ -2344,9 +2361,10 @@ int prep_transpose_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStre
     dgrad_weights_multi_kernel<<<(unsigned)blocks, 256, 0, st>>>(jobs_dev, njobs);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
-int prep_pack_h3_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st) {
+int prep_pack_h3_multi(const PrepJob* jobs_dev, int njobs, int blocks, int scale_blocks, hipStream_t st) {
     if (njobs <= 0 || blocks <= 0) return 0;
-    h3_pack_multi_kernel<<<(unsigned)blocks, 256, 0, st>>>(jobs_dev, njobs, abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr);
+    h3_rowscale_multi_kernel<<<(unsigned)scale_blocks, 256, 0, st>>>(jobs_dev, njobs, abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr);
+    h3_pack_multi_kernel<<<(unsigned)blocks, 256, 0, st>>>(jobs_dev, njobs);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int prep_pack_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st) {
@@ -2407,11 +2425,14 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
     } token_guard{tokens};
     std::vector<size_t> u_off;                    // per uj entry: offset (floats) of its U inside the scratch
     size_t u_total = 0;
-    int tb = 0, ub = 0, pb = 0, hb = 0;           // workgroups of the four launches
+    int tb = 0, ub = 0, pb = 0, hb = 0, hsb = 0;  // workgroups of the launches (hsb: the f16x3 row-scale launch)
+    std::vector<int> h_scale_first;               // per hj entry: its first workgroup in the row-scale launch (stored in PrepJob::c once the sources are patched)
     auto add_pack_h3 = [&](const float* src, int64_t rows, int K, void* dst) {
         abr::PrepJob j{};
-        j.src = src; j.dst = dst; j.a = (int)rows; j.b = K; j.gx = 1; j.gy = (int)((rows + 31) / 32); j.first_block = hb;
-        hb += j.gy;
+        j.src = src; j.dst = dst; j.a = (int)rows; j.b = K; j.gx = (K + 63) / 64; j.gy = (int)((rows + 31) / 32); j.first_block = hb;
+        hb += j.gx * j.gy;
+        h_scale_first.push_back(hsb);
+        hsb += j.gy * 8;
         hj.push_back(j);
     };
     auto add_pack = [&](const float* src, int64_t rows, int K, void* dst) {
@@ -2487,8 +2508,10 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
         for (size_t k = 0; k < uj.size(); k++) uj[k].dst = T.u_scratch + u_off[k];
         for (auto& j : pj)
             if (j.c == 1) { j.src = T.u_scratch + reinterpret_cast<size_t>(j.src); j.c = 0; }
-        for (auto& j : hj)
-            if (j.c == 1) { j.src = T.u_scratch + reinterpret_cast<size_t>(j.src); j.c = 0; }
+        for (size_t k = 0; k < hj.size(); k++) {
+            if (hj[k].c == 1) hj[k].src = T.u_scratch + reinterpret_cast<size_t>(hj[k].src);
+            hj[k].c = h_scale_first[k];
+        }
         size_t first = 0;
         ABR_REQUIRE(prep_ring_take(T, njobs, &first), "conv_prepare_batch: no memory for the job tables");
         abr::PrepJob* h = T.host + first;
@@ -2506,7 +2529,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
         int bad = abr::prep_transpose_multi(d, (int)tj.size(), tb, st);
         bad |= abr::prep_wino_u_multi(d + tj.size(), (int)uj.size(), ub, st);
         bad |= abr::prep_pack_multi(d + tj.size() + uj.size(), (int)pj.size(), pb, st);
-        bad |= abr::prep_pack_h3_multi(d + tj.size() + uj.size() + pj.size(), (int)hj.size(), hb, st);
+        bad |= abr::prep_pack_h3_multi(d + tj.size() + uj.size() + pj.size(), (int)hj.size(), hb, hsb, st);
         ABR_REQUIRE(!bad, "conv_prepare_batch: launch failed");
         abr::derived_commit(tokens.data(), (int)tokens.size(), st);
         token_guard.committed = true;

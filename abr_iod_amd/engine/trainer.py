@@ -213,7 +213,11 @@ def _arm_overlap(optimizer, head_inputs, features):
     """Gradient hooks that hand finished buckets of the flat gradient to the optimiser's GradReducer while backward is still running:
     layer4 + predictor once every RoI pass's pooled input has its gradient, the RPN once the C4 feature map has its own."""
     reducer = getattr(optimizer, "reducer", None)
-    if reducer is None or not reducer.active:
+    final = getattr(optimizer, "bucket_final", None)    # FusedSGD: all-reduce of the bucket + (round 5) its early update
+    if reducer is None or final is None:
+        return
+    from ..solver.build import EARLY_SGD
+    if not (reducer.active or EARLY_SGD):
         return
     heads = [t for t in head_inputs if torch.is_tensor(t) and t.requires_grad]
     left = [len(heads)]
@@ -221,7 +225,7 @@ def _arm_overlap(optimizer, head_inputs, features):
     def head_done(g):
         left[0] -= 1
         if left[0] == 0:
-            reducer.reduce_bucket_async("roi_heads")
+            final("roi_heads")
         return None
 
     for t in heads:
@@ -229,8 +233,8 @@ def _arm_overlap(optimizer, head_inputs, features):
     f = features[0] if isinstance(features, (list, tuple)) else features
     if heads and torch.is_tensor(f) and f.requires_grad:
         def features_done(g):
-            reducer.reduce_bucket_async("roi_heads")   # (no-op when already sent)
-            reducer.reduce_bucket_async("rpn")
+            final("roi_heads")   # (no-op when already sent)
+            final("rpn")
             return None
         f.register_hook(features_done)
 

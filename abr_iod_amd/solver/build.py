@@ -12,8 +12,18 @@ import torch.distributed as dist
 
 from .. import ops
 from ..modeling.backbone.resnet import Conv2d, bump_trained_version
-from .grad_reducer import GradReducer
+from .grad_reducer import BUCKET_ORDER, GradReducer, bucket_of
 from .lr_scheduler import WarmupMultiStepLR
+
+# Round 5: the update of a gradient bucket (solver/grad_reducer.py: roi_heads, rpn, backbone) is applied AS SOON AS the bucket is final --
+# from the gradient hooks of engine/trainer.py::_arm_overlap, on a stream of its own behind the weight-gradient streams (and behind the bucket's
+# all-reduce under data parallelism) -- together with the preparation of the data derived from those weights for the NEXT step.  layer4 + predictor
+# and the RPN (75 % of the parameters, the largest derived data) are then updated and re-packed underneath the backbone's backward pass;
+# optimizer.step() is left with the backbone bucket.  Same kernels on the same values: the results do not change.
+# OPT-IN (ABR_EARLY_SGD=1): measured SLOWER in the step -- B = 4: 18.91 vs 18.24 ms, B = 2: 11.53 vs 10.89 ms (same session, two rounds each): the
+# hook issues its ~10 launches from the autograd thread in the middle of the backward pass (the dgrad chain's issue stalls behind them), and the
+# re-packing kernels then share the CUs with the backbone's backward instead of with the next step's prefetched forward.
+EARLY_SGD = os.environ.get("ABR_EARLY_SGD", "0") != "0"
 
 
 class FusedSGD(object):
@@ -53,6 +63,18 @@ class FusedSGD(object):
         self._steps = 0
         self._prep_plan = None
         self.reducer = GradReducer(self.flat.grads, self.flat.segments, side_streams=self._grad_writer_streams)
+        # per bucket: [(a, b, first segment, one past the last segment, segment ends relative to a)] -- the SGD kernel runs on sub-ranges
+        self._bucket_tables = {}
+        ends = [g["range"][1] for g in self.param_groups]
+        for name, ranges in self.reducer.buckets.items():
+            tabs = []
+            for a, b in ranges:
+                idx = [i for i, g in enumerate(self.param_groups) if a <= g["range"][0] and g["range"][1] <= b]
+                if idx:
+                    tabs.append((a, b, idx[0], idx[-1] + 1, torch.tensor([ends[i] - a for i in idx], dtype=torch.int64, device=dev)))
+            self._bucket_tables[name] = tabs
+        self._early_done = set()
+        self._early_stream_used = False
 
     @property
     def world_size(self):
@@ -85,6 +107,58 @@ class FusedSGD(object):
         self._main_stream = torch.cuda.current_stream() if self.flat.grads.is_cuda else None
         self.flat.zero_grad()
         self.reducer.begin()
+        self._early_done = set()
+        self._upload_lr()    # (the early bucket updates read it during backward; scheduler.step() runs after optimizer.step())
+
+    def _upload_lr(self):
+        lrs = [g["lr"] for g in self.param_groups]
+        if lrs != self._lr_host:  # only re-upload when the scheduler changed something
+            src = torch.tensor(lrs, dtype=torch.float32)
+            self._lr.copy_(src.pin_memory() if self._lr.is_cuda else src, non_blocking=True)  # pageable source = host stall
+            self._lr_host = lrs
+
+    def _sgd_ranges(self, buckets):
+        for name in buckets:
+            for a, b, i0, i1, seg_end in self._bucket_tables[name]:
+                ops.sgd_momentum_(self.flat.params[a:b], self.flat.grads[a:b], self.momentum_buffer[a:b], seg_end, self._lr[i0:i1], self._wd[i0:i1],
+                                  self.momentum, gscale=1.0 / self.world_size, first_step=(self._steps == 0))
+
+    def bucket_final(self, name):
+        """Every kernel that writes gradient bucket `name` (and every earlier bucket of BUCKET_ORDER) has been ENQUEUED: send its all-reduce
+        (data parallelism) and, with EARLY_SGD, apply its update and prepare its derived data for the next step right now, on the early stream."""
+        self.reducer.reduce_bucket_async(name)
+        if not (EARLY_SGD and self.flat.grads.is_cuda and self._prep_stream and self._batch_prep and name != BUCKET_ORDER[-1]):
+            return
+        todo = [b for b in BUCKET_ORDER[: BUCKET_ORDER.index(name) + 1] if b not in self._early_done]
+        if not todo:
+            return
+        if self.reducer.active and not all(b in self.reducer._done for b in todo):
+            return   # (overlap of the exchange is off: the buckets go out from step(), and so do the updates)
+        from ..modeling.backbone.resnet import _PARAM_VERSION
+        plan = self._prep_plan
+        if plan is None or plan["signature"] != self._prep_signature():
+            plan = self._prep_plan = self._build_prep_plan()
+        cur = torch.cuda.current_stream()
+        early = ops.side_stream((self.flat.params.device.index, "early-sgd"))
+        early.wait_stream(cur)
+        for s in self._grad_writer_streams():
+            early.wait_stream(s)
+        with torch.cuda.stream(early), torch.no_grad():
+            if self.reducer.active:
+                for w in list(self.reducer._works):
+                    w.wait()               # the early stream waits for the buckets' all-reduces
+            self._sgd_ranges(todo)
+            for b in todo:
+                sub = plan["buckets"].get(b)
+                if sub is None:
+                    continue
+                for pb in sub["forward"]:
+                    pb.run()
+                sub["backward"].run()
+                for conv in sub["convs"]:
+                    conv._wt_version = _PARAM_VERSION[0] + 1   # (the version optimizer.step() is about to give the weights)
+        self._early_done.update(todo)
+        self._early_stream_used = True
 
     def all_reduce_grads(self):
         """DistributedDataParallel's job in the reference (train_incremental.py:231): sum the flat gradient over ranks -- the
@@ -97,14 +171,18 @@ class FusedSGD(object):
                                "build the optimizer after moving the model")
         ops.join_side_stream()  # weight gradients queued on the side stream (no-op when already joined after backward)
         self.all_reduce_grads()
-        lrs = [g["lr"] for g in self.param_groups]
-        if lrs != self._lr_host:  # only re-upload when the scheduler changed something
-            src = torch.tensor(lrs, dtype=torch.float32)
-            self._lr.copy_(src.pin_memory() if self._lr.is_cuda else src, non_blocking=True)  # pageable source = host stall
-            self._lr_host = lrs
-        n = self.flat.n_trainable
-        ops.sgd_momentum_(self.flat.params[:n], self.flat.grads, self.momentum_buffer, self._seg_end, self._lr, self._wd,
-                          self.momentum, gscale=1.0 / self.world_size, first_step=(self._steps == 0))
+        self._upload_lr()
+        early_done = set(self._early_done)
+        if early_done:
+            # the buckets updated from the gradient hooks: only the rest is left (the early stream is joined below, behind this kernel)
+            self._sgd_ranges([b for b in BUCKET_ORDER if b not in early_done])
+        else:
+            n = self.flat.n_trainable
+            ops.sgd_momentum_(self.flat.params[:n], self.flat.grads, self.momentum_buffer, self._seg_end, self._lr, self._wd,
+                              self.momentum, gscale=1.0 / self.world_size, first_step=(self._steps == 0))
+        if self._early_stream_used and self.flat.params.is_cuda:
+            torch.cuda.current_stream().wait_stream(ops.side_stream((self.flat.params.device.index, "early-sgd")))
+        self._early_done = set()
         self._steps += 1
         bump_trained_version()  # data derived from the optimised weights (dgrad copies, Winograd-domain weights) is stale now
         if self._prep_stream and self.flat.params.is_cuda and self._derived:
@@ -122,13 +200,28 @@ class FusedSGD(object):
                     plan = self._prep_plan
                     if plan is None or plan["signature"] != self._prep_signature():
                         plan = self._prep_plan = self._build_prep_plan()
-                    for b in plan["forward"]:    # forward halves, stage by stage
-                        b.run()
-                    for fn in plan["rest"]:
-                        fn()
-                    plan["backward"].run()
-                    for conv in plan["convs"]:
-                        conv._wt_version = _PARAM_VERSION[0]
+                    if early_done:
+                        for bname in BUCKET_ORDER:
+                            if bname in early_done or bname not in plan["buckets"]:
+                                continue
+                            for b in plan["buckets"][bname]["forward"]:
+                                b.run()
+                        for fn in plan["rest"]:
+                            fn()
+                        for bname in BUCKET_ORDER:
+                            if bname in early_done or bname not in plan["buckets"]:
+                                continue
+                            plan["buckets"][bname]["backward"].run()
+                            for conv in plan["buckets"][bname]["convs"]:
+                                conv._wt_version = _PARAM_VERSION[0]
+                    else:
+                        for b in plan["forward"]:    # forward halves, stage by stage
+                            b.run()
+                        for fn in plan["rest"]:
+                            fn()
+                        plan["backward"].run()
+                        for conv in plan["convs"]:
+                            conv._wt_version = _PARAM_VERSION[0]
                 else:
                     for m in self._derived:
                         m.prepare_derived()
@@ -146,9 +239,12 @@ class FusedSGD(object):
 
     def _build_prep_plan(self):
         groups, rest = [], []
+        names = {id(m): n for n, m in self.model.named_modules()}
+        per_bucket = {}
         for m in self._derived:
             if hasattr(m, "prep_entries"):
                 ent = list(m.prep_entries())
+                per_bucket.setdefault(bucket_of(names.get(id(m), "") + "."), []).extend(ent)
                 key = self._derived_group.get(id(m), "")
                 if not groups or groups[-1][0] != key:
                     groups.append((key, []))
@@ -162,7 +258,16 @@ class FusedSGD(object):
                    for _, ent in groups]
         backward = ops.PreparedBatch([(conv.weight.detach(), scale, conv.dgrad_buffer(), stride, pad, math, conv.version)
                                       for conv, scale, stride, pad, math in allent])
-        return dict(signature=self._prep_signature(), forward=forward, rest=rest, backward=backward, convs=[e[0] for e in allent])
+        # the same tables cut by gradient bucket, for the early updates: `nxt` = the version the weights get at the END of the current step
+        buckets = {}
+        for bname, ent in per_bucket.items():
+            early = bname != BUCKET_ORDER[-1]
+            ver = (lambda c: (lambda: c.version() + 2)) if early else (lambda c: c.version)
+            buckets[bname] = dict(
+                forward=[ops.PreparedBatch([(conv.weight.detach(), None, None, stride, pad, math, ver(conv)) for conv, _, stride, pad, math in ent])],
+                backward=ops.PreparedBatch([(conv.weight.detach(), scale, conv.dgrad_buffer(), stride, pad, math, ver(conv)) for conv, scale, stride, pad, math in ent]),
+                convs=[e[0] for e in ent])
+        return dict(signature=self._prep_signature(), forward=forward, rest=rest, backward=backward, convs=[e[0] for e in allent], buckets=buckets)
 
     def _reference_params(self):
         """(name, parameter, offset into the flat buffer, Conv2d module or None) for every trainable tensor, in the
