@@ -123,6 +123,7 @@ _SIGS = {
     "abr_avgpool_forward": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "abr_avgpool_backward": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "abr_avgpool_relu_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "abr_avgpool_relu_backward_amax": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, C.c_uint32, _vp]),
     "abr_channel_mean": (_i, [_vp, _i64, _i, _vp, _vp]),
     "abr_relu_backward": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "abr_add_inplace": (_i, [_vp, _vp, _i64, _vp]),

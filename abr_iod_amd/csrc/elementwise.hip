@@ -137,8 +137,10 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 
 // the same through the ReLU that produced y (the pooled tensor): gx = y > 0 ? g / HW : 0 -- the pooling's and the ReLU's backward in one pass
 // over the [N, HW, C] tensor instead of a write + (two reads + a write)
+// amax (optional): max |gx| into that amax word (the f16x3 consumers of gx -- layer4's last dgrad and weight gradient -- read it)
 __global__ __launch_bounds__(256) void avgpool_bwd_masked_kernel(const float* __restrict__ g, const float* __restrict__ y, int64_t N, int HW, int C,
-                                                                  float* __restrict__ gx) {
+                                                                  float* __restrict__ gx, unsigned long long* amax, unsigned epoch) {
+    unsigned am = 0;
     const int cv = C / 4;
     const int64_t total = N * HW * cv;
     const float inv = 1.f / (float)HW;
@@ -150,7 +152,11 @@ __global__ __launch_bounds__(256) void avgpool_bwd_masked_kernel(const float* __
         v.x = yv.x > 0.f ? v.x * inv : 0.f; v.y = yv.y > 0.f ? v.y * inv : 0.f;
         v.z = yv.z > 0.f ? v.z * inv : 0.f; v.w = yv.w > 0.f ? v.w * inv : 0.f;
         reinterpret_cast<float4*>(gx)[i] = v;
+        if (amax)
+            am = max(max(am, max(__float_as_uint(v.x) & 0x7FFFFFFFu, __float_as_uint(v.y) & 0x7FFFFFFFu)),
+                     max(__float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu));
     }
+    if (amax) abr::h3_amax_emit(amax, epoch, am);
 }
 
 // out may alias g (in place): no __restrict__ on those two
@@ -307,14 +313,19 @@ extern "C" int abr_avgpool_backward(const float* g, int N, int HW, int C, float*
     return ABR_OK;
 }
 
-extern "C" int abr_avgpool_relu_backward(const float* g, const float* y, int N, int HW, int C, float* gx, void* stream) {
+extern "C" int abr_avgpool_relu_backward_amax(const float* g, const float* y, int N, int HW, int C, float* gx, uint64_t* amax, uint32_t amax_epoch,
+                                              void* stream) {
     ABR_REQUIRE(N >= 0 && HW > 0 && C % 4 == 0, "avgpool_relu_backward: bad args");
     if (N == 0) return ABR_OK;
     ABR_REQUIRE(g && y && gx, "avgpool_relu_backward: null pointer");
     const int64_t total = (int64_t)N * HW * (C / 4);
-    avgpool_bwd_masked_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 8192), 256, 0, abr::as_stream(stream)>>>(g, y, N, HW, C, gx);
+    avgpool_bwd_masked_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 8192), 256, 0, abr::as_stream(stream)>>>(
+        g, y, N, HW, C, gx, reinterpret_cast<unsigned long long*>(amax), amax_epoch);
     ABR_CHECK_LAUNCH("avgpool_relu_backward");
     return ABR_OK;
+}
+extern "C" int abr_avgpool_relu_backward(const float* g, const float* y, int N, int HW, int C, float* gx, void* stream) {
+    return abr_avgpool_relu_backward_amax(g, y, N, HW, C, gx, nullptr, 0, stream);
 }
 
 extern "C" int abr_relu_backward(const float* g, const float* y, int64_t n, float* out, void* stream) {

@@ -182,7 +182,7 @@ class _PredictorFn(Function):
         gx = None
         if ctx.need_dx:
             gp = ops.conv_forward(g, pred.fused_dgrad_weight(), 1, 0).view(K_, -1)
-            gx = from_nhwc(ops.avgpool_backward(gp, ctx.xshape, relu_of=ctx.relu_of))
+            gx = from_nhwc(ops.avgpool_backward(gp, ctx.xshape, relu_of=ctx.relu_of, emit_amax=True))   # (amax word for layer4's f16x3 backward)
             if ctx.relu_of is not None:
                 # "layer4's final ReLU mask is already applied" travels as a TOKEN bound to this very storage and version: if the autograd
                 # engine accumulates another consumer's gradient into the tensor (in place: the version moves; out of place: a new tensor

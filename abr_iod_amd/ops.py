@@ -758,7 +758,7 @@ def avgpool_forward(x):
     return out
 
 
-def avgpool_backward(g, shape, relu_of=None):
+def avgpool_backward(g, shape, relu_of=None, emit_amax=False):
     """g [N, C] -> [N, H, W, C] / (H*W); relu_of = the pooled tensor itself when it is a ReLU's output: that ReLU's backward rides along
     (gx = relu_of > 0 ? g / HW : 0) and the caller's gradient is already masked"""
     g = L.f32c(g)
@@ -767,7 +767,12 @@ def avgpool_backward(g, shape, relu_of=None):
     HW = gx.numel() // (N * Ch) if N else 1
     if relu_of is not None:
         assert tuple(relu_of.shape) == tuple(shape) and relu_of.is_contiguous()
-        L.check(L.lib().abr_avgpool_relu_backward(L.ptr(g), L.ptr(relu_of), N, HW, Ch, L.ptr(gx), L.stream()), "avgpool_relu_backward")
+        if emit_amax and H3_TAGS:
+            aw, ae = amax_new()
+            L.check(L.lib().abr_avgpool_relu_backward_amax(L.ptr(g), L.ptr(relu_of), N, HW, Ch, L.ptr(gx), aw, ae, L.stream()), "avgpool_relu_backward")
+            amax_tag(gx, aw, ae)
+        else:
+            L.check(L.lib().abr_avgpool_relu_backward(L.ptr(g), L.ptr(relu_of), N, HW, Ch, L.ptr(gx), L.stream()), "avgpool_relu_backward")
     else:
         L.check(L.lib().abr_avgpool_backward(L.ptr(g), N, HW, Ch, L.ptr(gx), L.stream()), "avgpool_backward")
     return gx

@@ -373,6 +373,8 @@ int abr_avgpool_forward(const float* x, int N, int HW, int C, float* out, void* 
 int abr_avgpool_backward(const float* g, int N, int HW, int C, float* gx, void* stream);
 /* the same fused with the backward of the ReLU that produced the pooled tensor y [N, HW, C]: gx = y > 0 ? g / HW : 0 */
 int abr_avgpool_relu_backward(const float* g, const float* y, int N, int HW, int C, float* gx, void* stream);
+/* ... which also writes max |gx| into an amax word (abr_h3_amax_alloc) for the f16x3 convs that consume gx; amax == NULL: as above */
+int abr_avgpool_relu_backward_amax(const float* g, const float* y, int N, int HW, int C, float* gx, uint64_t* amax, uint32_t amax_epoch, void* stream);
 /* out[row] = mean_c x[row, c] for x [rows, C] -- per-(RoI, bin) channel mean of NHWC pooled features
  * (tools/prototype_box_selection.py:84 `torch.mean(roi_align_features, dim=1)`) */
 int abr_channel_mean(const float* x, int64_t rows, int C, float* out, void* stream);
