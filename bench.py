@@ -72,12 +72,17 @@ def _pmc_traffic(kernel):
     import glob
     prefix = {"conv_igemm_kernel<128,128>": "conv_igemm_kernel<128, 128,", "conv_wgrad_kernel": "conv_wgrad_kernel<",
               "conv_igemm_x6_kernel<128,128>": "conv_igemm_x6_kernel<128, 128,", "conv_igemm_x6_kernel<128,64>": "conv_igemm_x6_kernel<128, 64,",
-              "conv_igemm_x6_kernel<64,64>": "conv_igemm_x6_kernel<64, 64,", "conv_wgrad_x6_kernel": "conv_wgrad_x6_kernel",
+              "conv_igemm_x6_kernel<64,64>": "conv_igemm_x6_kernel<64, 64,", "conv_wgrad_x6_kernel": "conv_wgrad_x6_kernel<6>",
+              "conv_wgrad_x6_kernel<3>": "conv_wgrad_x6_kernel<3>",
               "conv_igemm_x6w_kernel<128,128>": "conv_igemm_x6w_kernel<128, 128,", "conv_igemm_x6w_kernel<128,64>": "conv_igemm_x6w_kernel<128, 64,",
               "conv_igemm_x6w_kernel<64,64>": "conv_igemm_x6w_kernel<64, 64,",
+              "conv_igemm_x6w_kernel<128,128,NP=3>": "conv_igemm_x6w_kernel<128, 128,", "conv_igemm_x6w_kernel<128,64,NP=3>": "conv_igemm_x6w_kernel<128, 64,",
+              "conv_igemm_x6w_kernel<64,64,NP=3>": "conv_igemm_x6w_kernel<64, 64,",
               "conv_igemm_kernel<64,64>": "conv_igemm_kernel<64, 64,", "conv_igemm_kernel<128,64>": "conv_igemm_kernel<128, 64, 4, 1, false"}.get(kernel)
+    # template instances of the weights-direct kernel end in their product count: ", 6>" (bf16x6), ", 3>" (f16x3), ", 1>" (bf16)
+    suffix = ", 3>" if "NP=3" in kernel else (", 6>" if "_x6w_" in kernel else "")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-        hits = [v for k, v in json.load(open(f))["kernels"].items() if prefix and k.startswith(prefix)]
+        hits = [v for k, v in json.load(open(f))["kernels"].items() if prefix and k.startswith(prefix) and k.endswith(suffix)]
         n_l = sum(v["launches"] for v in hits)
         if n_l:
             return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n_l), os.path.relpath(f, ROOT)

@@ -3,7 +3,7 @@ box-rehearsal data path (mixup + mosaic from a rehearsal memory, voc_abr.py:555-
 (a mosaic canvas is mean(w,h)^2 -> 600x600 after the resize, voc_abr.py:712-714, next to 600x800 / 600x1000 images, zero-padded by
 to_image_list as image_list.py:50-68 does), through the full-width R50-C4 at the benchmark's RoI counts, in
 
-  * the default arithmetic (fp32 tensors, bf16x6 contractions): C4 features against the torch-CPU oracle on the same padded batch at
+  * the default arithmetic (fp32 tensors, f16x3 contractions since round 5): C4 features against the torch-CPU oracle on the same padded batch at
     the north-star tolerance, a whole training step with finite losses and a moving update, and
   * cfg.DTYPE = "bfloat16" (the "bf16 MFMA backbone" the config names): every backbone stage, teacher-forced on the oracle's own stage
     input, against oracle/torch_ref.py::bottleneck(bf16=True), and a whole step whose losses track the default arithmetic's.
@@ -109,7 +109,7 @@ def test_configs4_default_arithmetic_features_and_step(abr_batch):
     images, targets, kinds = abr_batch
     cfg_s, cfg_t, ms, mt = _models("float32")
     assert ms.roi_heads.box.predictor.num_classes == 11 and mt.roi_heads.box.predictor.num_classes == 16
-    assert all(m.math == ops.MATH_BF16X6 for m in mt.modules() if hasattr(m, "math"))
+    assert all(m.math == ops.MATH_F16X3 for m in mt.modules() if hasattr(m, "math"))
     with torch.no_grad():
         feats, _ = mt.backbone(images.tensors)
     assert tuple(feats[0].shape) == (3, 1024, 38, 63)

@@ -16,11 +16,17 @@ timeout 300 python bench.py --image-size 800x1333 --steps 10 > $O/${R}_bench_800
 timeout 300 python bench.py --task 10-5 --mosaic-squares --steps 20 > $O/${R}_bench_10-5_mosaic_squares.jsonl 2>/dev/null
 timeout 300 python bench.py --task 10-5 --mosaic-squares --math bf16 --steps 20 --no-kernel-timing > $O/${R}_bench_10-5_mosaic_squares_bf16_backbone.jsonl 2>/dev/null
 timeout 300 python bench.py --share-frozen-prefix $B > $O/${R}_bench_shared_frozen_prefix.jsonl 2>/dev/null
+timeout 300 python bench.py --math bf16x6 $B > $O/${R}_bench_bf16x6.jsonl 2>/dev/null
 # the per-rank workloads of BASELINE configs[3] / configs[4] (8 ranks x batch 2) on ONE GPU: what the first scaling run is divided by
 timeout 300 python bench.py --task 10-10 --batch-per-gpu 2 $B > $O/${R}_bench_10-10_b2.jsonl 2>/dev/null
 timeout 300 python bench.py --task 10-5 --batch-per-gpu 2 --mosaic-squares --steps 20 > $O/${R}_bench_10-5_b2_mosaic_squares.jsonl 2>/dev/null
 # main-stream timeline of the un-profiled step (events, no tracer) at B = 4 and B = 2
 ( timeout 200 python tools/step_marks.py; timeout 200 python tools/step_marks.py --batch-per-gpu 2 ) 2>&1 | grep -v amdgpu > $O/${R}_step_marks.txt
+# gates of the arithmetic switch (round 5): conv fuzz in every arithmetic, soak (bit-identical revisits), unusual batches
+( timeout 700 python tools/conv_fuzz.py --cases 2000 2>&1 | grep -v amdgpu | tail -15 ) > $O/${R}_conv_fuzz_2000.txt
+( timeout 400 python tools/soak.py --steps 600 2>&1 | grep -v amdgpu ) > $O/${R}_soak_600_steps.txt
+( timeout 300 python tools/edge_steps.py 2>&1 | grep -v amdgpu | tail -15 ) > $O/${R}_edge_steps.txt
+( timeout 300 python -m pytest tests/test_gpu_f16x3_admission.py tests/test_gpu_x6_admission.py -q -s -p no:cacheprovider 2>&1 | grep -E "ulp|passed|failed|inspected" | grep -v amdgpu ) > $O/${R}_admission_f16x3_and_bf16x6.txt
 # parity evidence: the full-size golden / oracle comparisons with their measured numbers (losses, proposal match, worst max-rel / rel-L2 of the 52
 # gradients per configuration and arithmetic) -- with -q alone the printed worst values are lost
 ( timeout 1500 python -m pytest tests/test_gpu_e2e_full_golden.py tests/test_gpu_e2e.py tests/test_gpu_e2e_golden.py tests/test_gpu_configs4_whole.py -q -s -p no:cacheprovider 2>&1 \
@@ -40,17 +46,12 @@ rm -rf gpurun_out/prof_ser
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_ser -o s -- python3 $OLDPWD/bench.py --steps 5 --warmup 2 $B --no-serialised-leg --fold-streams > $OLDPWD/$O/${R}_serialised_streams_bench.jsonl 2>/dev/null )
 cp gpurun_out/prof_ser/s_kernel_stats.csv $O/${R}_serialised_streams_kernel_stats.csv 2>/dev/null
 # per-shape table, HBM-bound kernels, ROIAlign L1 / L2 counters, main-loop labs
-timeout 600 python tools/conv_breakdown.py --target-tf 200 2>&1 | grep -v amdgpu.ids > $O/${R}_conv_shapes_bf16x6.txt
-timeout 600 python tools/conv_breakdown.py --batch 2 --target-tf 200 2>&1 | grep -v amdgpu.ids > $O/${R}_conv_shapes_bf16x6_b2.txt
+timeout 600 python tools/conv_breakdown.py --target-tf 400 2>&1 | grep -v amdgpu.ids > $O/${R}_conv_shapes_f16x3.txt
+timeout 600 python tools/conv_breakdown.py --batch 2 --target-tf 400 2>&1 | grep -v amdgpu.ids > $O/${R}_conv_shapes_f16x3_b2.txt
 timeout 600 python tools/microbench.py --only nothing 2>/dev/null > $O/${R}_microbench_hbm_kernels.txt
 timeout 600 bash tools/pmc_roialign.sh > $O/pmc_roialign.log 2>&1; [ -f gpurun_out/pmc_roialign.json ] && cp gpurun_out/pmc_roialign.json $O/${R}_pmc_roialign.json
-( echo "# tools/x6lab/plab.hip: conv_igemm_x6w_kernel<128,128,1,4>'s loop with the ACTIVATION operand pre-split too (fragment-ordered planes by LDS-DMA) vs the library loop"
-  timeout 250 tools/x6lab/plab ) > $O/${R}_x6lab_a_planes_lds_dma.txt 2>&1
-( echo "# tools/x6lab/flab.hip: forward (conv_igemm_x6w_kernel<128,128>) main loop with ONE ingredient removed per row (results wrong, time only)"
-  timeout 250 tools/x6lab/flab
-  echo
-  echo "# tools/x6lab/wlab.hip: weight-gradient (conv_wgrad_x6_kernel) main loop, the same; 'producer / consumer' = 512-thread variant with loader waves"
-  timeout 250 tools/x6lab/wlab ) > $O/${R}_x6lab_knockouts.txt 2>&1
+( echo "# tools/x6lab/hlab.hip: two-term fp16 split with three products (f16x3) in the weights-direct loop vs the library bf16x6 loop; error vs float64 at 2048 outputs; two timing rounds"
+  timeout 250 tools/x6lab/hlab ) > $O/${R}_x6lab_f16x3.txt 2>&1
 fi
 if [ "$PART" = all ] || [ "$PART" = 3 ]; then
 timeout 1500 bash tools/pmc_mfma.sh > $O/pmc_mfma.log 2>&1
