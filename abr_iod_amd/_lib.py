@@ -71,6 +71,8 @@ _SIGS = {
     "abr_loss_sum_backward": (_i, [_vp, _i, _vp, _vp, _vp]),
     "abr_gather_proposals": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "abr_h3_amax_alloc": (_i, [_vp, _vp]),
+    "abr_h3_amax_alloc_block": (_i, [_i, _vp, _vp]),
+    "abr_stream_wait_stream": (_i, [_vp, _vp]),
     "abr_h3_amax": (_i, [_vp, _i64, _vp, C.c_uint32, _vp]),
     "abr_h3_range_stats": (_i, [_vp, _i, _vp]),
     "abr_h3_range_stats_to_device": (_i, [_vp, _i, _vp]),

@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include <functional>
+#include <vector>
 
 #include "abr_iod_hip.h"
 
@@ -136,7 +137,7 @@ void* derived_cached(const void* w, int kind, size_t bytes, int64_t version, hip
 // The same in two halves, for fills that are launched together (abr_conv_prepare_batch): derived_acquire returns the entry's buffer and, when the
 // entry does not hold `version` yet, a token (the refill is already ordered behind the entry's readers); the caller fills every such buffer on `st`
 // and then hands the tokens to derived_commit, which records the fill events.  Entries with a pending token are never evicted.
-void* derived_acquire(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, void** token);
+void* derived_acquire(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, void** token, std::vector<hipStream_t>* waited = nullptr);
 void derived_commit(void* const* tokens, int n, hipStream_t st);
 // the fill did NOT happen (an error between acquire and commit): the entries hold no version and are evictable / refillable again
 void derived_abandon(void* const* tokens, int n);

@@ -318,6 +318,19 @@ AmaxRef h3_amax_alloc() {
     // word carries no epoch); 2^32 allocations ~ 10^7 training steps
     return AmaxRef{g_amax_ring + c % ABR_H3_AMAX_RING, (unsigned)(c + 1)};
 }
+// n consecutive allocations: the block's first is an ordinary allocation (which also makes the ring); the rest follow it unless another thread
+// allocated in between (then the block restarts at the current count and that first allocation is simply not used)
+bool h3_amax_alloc_block(int n, unsigned long long** base, uint64_t* first_count) {
+    const AmaxRef r = h3_amax_alloc();
+    if (!r.word) return false;
+    std::lock_guard<std::mutex> g(g_amax_mu);
+    uint64_t first = (uint64_t)r.epoch - 1;
+    if (g_amax_count != first + 1) first = g_amax_count;
+    g_amax_count = first + (uint64_t)n;
+    *base = g_amax_ring;
+    *first_count = first;
+    return true;
+}
 int h3_amax_reduce(const float* x, int64_t n, AmaxRef ref, hipStream_t st) {
     if (!ref.word) return 1;
     const int64_t blocks = std::min<int64_t>(std::max<int64_t>((n / 4 + 255) / 256, 1), 2048);
@@ -342,6 +355,25 @@ extern "C" int abr_h3_amax_alloc(uint64_t** word_out, uint32_t* epoch_out) {
     ABR_REQUIRE(r.word, "h3_amax_alloc: no device memory");
     *word_out = reinterpret_cast<uint64_t*>(r.word);
     *epoch_out = r.epoch;
+    return ABR_OK;
+}
+extern "C" int abr_h3_amax_alloc_block(int n, uint64_t** ring_base_out, uint64_t* first_count_out) {
+    ABR_REQUIRE(ring_base_out && first_count_out && n > 0 && n <= ABR_H3_AMAX_RING / 16, "h3_amax_alloc_block: bad args");
+    unsigned long long* base = nullptr;
+    ABR_REQUIRE(abr::h3_amax_alloc_block(n, &base, first_count_out), "h3_amax_alloc_block: no device memory");
+    *ring_base_out = reinterpret_cast<uint64_t*>(base);
+    return ABR_OK;
+}
+// one event per signalling stream, re-recorded by every call: hipStreamWaitEvent waits for the record that precedes it, later records do not move it
+extern "C" int abr_stream_wait_stream(void* waiter, void* signaller) {
+    static std::mutex mu;
+    static std::map<hipStream_t, hipEvent_t> events;
+    hipStream_t w = abr::as_stream(waiter), s = abr::as_stream(signaller);
+    if (w == s) return ABR_OK;
+    std::lock_guard<std::mutex> g(mu);
+    hipEvent_t& ev = events[s];
+    if (!ev) ABR_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "stream_wait_stream: no event");
+    ABR_REQUIRE(hipEventRecord(ev, s) == hipSuccess && hipStreamWaitEvent(w, ev, 0) == hipSuccess, "stream_wait_stream: record / wait failed");
     return ABR_OK;
 }
 extern "C" int abr_h3_range_stats(uint64_t* out_host, int reset, void* stream) {

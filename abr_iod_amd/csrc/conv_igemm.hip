@@ -410,7 +410,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
                     v.z = __float_as_uint(acc[i][j][4 * c + 2]); v.w = __float_as_uint(acc[i][j][4 * c + 3]);
                     __builtin_amdgcn_raw_buffer_store_b128(v, rws, (int)(my_off + (unsigned)((i * TN + j) * 4 + c) * 4096u), 0, kCoherent);
                 }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // = wait for this wave's stores; no cache maintenance
+        // every write-through store of this wave has landed before the ticket is taken.  The explicit wait matters: a workgroup-scope release
+        // alone need not drain vmcnt (all waves of a workgroup share one L1), and with 16 short units per tile the last arrival then read partials
+        // still in flight (round 5: wrong sums in 7-65 % of a tiny model's outputs, run to run).  No cache maintenance: sc0|sc1 on both sides.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         __shared__ int s_last;
         const int st = unit / p.split;  // index of this split tile
@@ -426,9 +430,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p, const fl
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int q = 0; q < p.split; q++) {  // fixed order 0..split-1: the same sum whoever arrives last
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(base + (unsigned)q * kPart + (unsigned)((i * TN + j) * 4 + c) * 4096u), 0, kCoherent);
-                        sum.x += __uint_as_float(v.x); sum.y += __uint_as_float(v.y); sum.z += __uint_as_float(v.z); sum.w += __uint_as_float(v.w);
+                    for (int q0 = 0; q0 < p.split; q0 += 4) {  // fixed order 0..split-1: the same sum whoever arrives last; four partials in flight per round
+                        u32x4 v[4];                            // (one load per iteration waited for each in turn: 16 partials = 16 round trips past the L2)
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int q = q0 + u < p.split ? q0 + u : p.split - 1;
+                            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rws, (int)(base + (unsigned)q * kPart + (unsigned)((i * TN + j) * 4 + c) * 4096u), 0, kCoherent);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (q0 + u < p.split) {
+                                sum.x += __uint_as_float(v[u].x); sum.y += __uint_as_float(v[u].y); sum.z += __uint_as_float(v[u].z); sum.w += __uint_as_float(v[u].w);
+                            }
                     }
                     acc[i][j][4 * c] = sum.x; acc[i][j][4 * c + 1] = sum.y; acc[i][j][4 * c + 2] = sum.z; acc[i][j][4 * c + 3] = sum.w;
                 }
@@ -1963,6 +1976,20 @@ static void dispatch_igemm(const ConvP& p, const float* x, const float* w, float
     const int64_t wgs128 = take_split128 ? best_nfull + (t128 - best_nfull) * best_s : t128;
     static const int sb_maxk = getenv("ABR_IGEMM_SB_MAXK") ? atoi(getenv("ABR_IGEMM_SB_MAXK")) : 512;
     const bool sb = sb_mode >= 0 ? sb_mode != 0 : (p.K <= sb_maxk || (wgs128 > 2 * cus && wgs128 <= 3 * cus) || take_split128);
+    // Small grid + long K (the predictor FCs: 2304 x 108 x 2048 is 72 tiles of 64 x 64 walking 64 k-tiles each, 256 x 80 x 2048 is 8): EVERY tile
+    // split along K over enough workgroups to cover the chip about twice, >= 4 k-tiles per unit; the partial sums meet in the last arrival in
+    // index order (deterministic).  Narrow outputs only (Cout <= 128): wider small-grid GEMMs keep the sequential-K kernel, whose error is the
+    // yardstick of the arithmetic admission tests (tests/test_gpu_*_admission.py: "2x the fp32-MFMA kernel's").  Measured (tools/dbg/fc_time.py, back-to-back calls): 50.3 -> 21.9 us and 48.9 -> 15.6 us; error vs float64 4.5 -> 1.1 units of 2^-24 sum|x||w| (shorter chains).  ABR_IGEMM_FC_SPLIT=0: off.
+    const char* fc_env = getenv("ABR_IGEMM_FC_SPLIT");   // (read per call: a test takes the sequential-K kernel's error as its yardstick)
+    const bool fc_split = !(fc_env && atoi(fc_env) == 0);
+    if (fc_split && !small_c && nb == 1 && p.Cout <= 128 && t64 * 2 <= cus && nk >= 16 && t64 <= kMaxSplitTiles) {
+        int sp = (int)std::min<int64_t>(nk / 4, std::max<int64_t>(2, 2 * cus / t64));   // (2 or 8 k-tiles per unit, one cover of the chip, double-buffered LDS: all within +-2 us)
+        sp = (int)std::min<int64_t>(sp, kMaxSplitUnits / t64);
+        if (sp >= 2) {
+            launch<64, 64, 2, 2, false, true>(p, x, w, out, st, abr::PROF_IGEMM_64x64, 0, sp);
+            return;
+        }
+    }
     if (small_c) {
         launch<128, 64, 4, 1, true, true>(p, x, w, out, st, abr::PROF_IGEMM_SMALLC);
     } else if (rule128 || take_split128) {
@@ -2417,6 +2444,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
     PrepTables& T = g_prep_tables[st];
     std::vector<abr::PrepJob> tj, uj, pj, hj;    // transposes, Winograd weight transforms, bf16x3 packings, f16x3 packings
     std::vector<void*> tokens;
+    std::vector<hipStream_t> waited;              // reader streams this call's stream is already ordered behind (derived_acquire)
     // every early return between the acquires below and derived_commit releases the tokens (entries left pending would never be evictable and
     // would repack on every later call)
     struct TokenGuard {
@@ -2449,8 +2477,8 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
             const bool h3 = math == ABR_MATH_F16X3;
             if (!(((math == ABR_MATH_BF16X6 && direct_on) || h3) && Cout % 32 == 0 && Cin % 4 == 0)) return 1;
             void* tok = nullptr;
-            void* planes = h3 ? abr::derived_acquire(w, abr::DERIVED_WINO_U_H3_PLANES, (size_t)h3_packed_bytes((int64_t)36 * Cout, Cin), ver, st, &tok)
-                              : abr::derived_acquire(w, abr::DERIVED_WINO_U_X6_PLANES, (size_t)x6_packed_bytes((int64_t)36 * Cout, Cin), ver, st, &tok);
+            void* planes = h3 ? abr::derived_acquire(w, abr::DERIVED_WINO_U_H3_PLANES, (size_t)h3_packed_bytes((int64_t)36 * Cout, Cin), ver, st, &tok, &waited)
+                              : abr::derived_acquire(w, abr::DERIVED_WINO_U_X6_PLANES, (size_t)x6_packed_bytes((int64_t)36 * Cout, Cin), ver, st, &tok, &waited);
             if (!planes) return 1;
             if (!tok) return 0;   // already there
             tokens.push_back(tok);
@@ -2468,7 +2496,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
         if (math == ABR_MATH_F16X3) {
             if (!(Cin % BKX == 0 && h3_planes_bytes(Cout, K) < (int64_t)0xFFFFFFF0)) return 0;
             void* tok = nullptr;
-            void* planes = abr::derived_acquire(w, abr::DERIVED_H3_PLANES, (size_t)h3_packed_bytes(Cout, K), ver, st, &tok);
+            void* planes = abr::derived_acquire(w, abr::DERIVED_H3_PLANES, (size_t)h3_packed_bytes(Cout, K), ver, st, &tok, &waited);
             if (!planes) return 1;
             if (tok) { tokens.push_back(tok); add_pack_h3(w, Cout, K, planes); }
             return 0;
@@ -2476,7 +2504,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
         if ((math == ABR_MATH_BF16X6 || (math == ABR_MATH_BF16 && Cin % BKH == 0)) && direct_on && Cin % BKX == 0 &&
             x6_packed_bytes(Cout, K) < (int64_t)0xFFFFFFF0) {   // (the bf16 mode reads plane 0 of the same packed planes)
             void* tok = nullptr;
-            void* planes = abr::derived_acquire(w, abr::DERIVED_X6_PLANES, (size_t)x6_packed_bytes(Cout, K), ver, st, &tok);
+            void* planes = abr::derived_acquire(w, abr::DERIVED_X6_PLANES, (size_t)x6_packed_bytes(Cout, K), ver, st, &tok, &waited);
             if (!planes) return 1;
             if (tok) { tokens.push_back(tok); add_pack(w, Cout, K, planes); }
             return 0;

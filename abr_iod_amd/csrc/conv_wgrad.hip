@@ -146,7 +146,11 @@ __device__ __forceinline__ void wgrad_finish(const WgP& p, f32x16 (&acc)[2][2], 
                 const u32x4 v = {__float_as_uint(a[4 * c]), __float_as_uint(a[4 * c + 1]), __float_as_uint(a[4 * c + 2]), __float_as_uint(a[4 * c + 3])};
                 __builtin_amdgcn_raw_buffer_store_b128(v, rws, (int)(my_off + (unsigned)(t * 4 + c) * 4096u), 0, kCoherent);
             }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // = wait for this wave's stores
+        // every write-through store of this wave has landed before the ticket is taken.  The explicit wait matters: a workgroup-scope release
+        // alone need not drain vmcnt (all waves of a workgroup share one L1), and with 16 short units per tile the last arrival then read partials
+        // still in flight (round 5: wrong sums in 7-65 % of a tiny model's outputs, run to run).  No cache maintenance: sc0|sc1 on both sides.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         __shared__ int s_last;
         if (tid == 0) s_last = atomicAdd(p.tickets + gtile, 1u) == (unsigned)p.splits - 1u;

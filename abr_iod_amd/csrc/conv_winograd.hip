@@ -514,7 +514,9 @@ size_t dcache_limit() {
 }  // namespace
 
 // (mutex held) the entry for (w, kind) with a buffer of `bytes`; *needs_fill = it does not hold `version`; a refill is ordered behind the readers
-static DEntry* dcache_acquire_locked(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, bool* needs_fill) {
+// `waited` (a batch of acquires on one host thread, abr_conv_prepare_batch): streams `st` was already ordered behind DURING this batch -- one event per
+// reader stream and batch instead of one per reader stream and entry (~150 event create / record / wait / destroy rounds per training step)
+static DEntry* dcache_acquire_locked(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, bool* needs_fill, std::vector<hipStream_t>* waited = nullptr) {
     DEntry& e = g_dcache[std::make_pair(w, kind)];
     e.last_use = ++g_dcache_clock;
     if (e.buf && e.bytes != bytes) dcache_drop(e);   // the address now holds a different weight tensor
@@ -534,9 +536,11 @@ static DEntry* dcache_acquire_locked(const void* w, int kind, size_t bytes, int6
         if (!e.filled) (void)hipEventCreateWithFlags(&e.filled, hipEventDisableTiming);
     }
     if (e.version == version && !e.pending) {
-        if (st != e.stream) {
+        if (st != e.stream && std::find(e.readers.begin(), e.readers.end(), st) == e.readers.end()) {
+            // first use of this fill on stream st: wait for it once -- st's later calls are ordered behind this wait by the stream itself
+            // (`readers` is cleared by every refill)
             (void)hipStreamWaitEvent(st, e.filled, 0);
-            if (std::find(e.readers.begin(), e.readers.end(), st) == e.readers.end()) e.readers.push_back(st);
+            e.readers.push_back(st);
         }
         *needs_fill = false;
         return &e;
@@ -546,6 +550,10 @@ static DEntry* dcache_acquire_locked(const void* w, int kind, size_t bytes, int6
     if (e.stream && e.stream != st) users.push_back(e.stream);
     for (hipStream_t r : users) {
         if (r == st) continue;
+        if (waited) {
+            if (std::find(waited->begin(), waited->end(), r) != waited->end()) continue;
+            waited->push_back(r);
+        }
         hipEvent_t ev = nullptr;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamSynchronize(r); continue; }
         (void)hipEventRecord(ev, r);
@@ -572,11 +580,11 @@ void* derived_cached(const void* w, int kind, size_t bytes, int64_t version, hip
     return e->buf;
 }
 
-void* derived_acquire(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, void** token) {
+void* derived_acquire(const void* w, int kind, size_t bytes, int64_t version, hipStream_t st, void** token, std::vector<hipStream_t>* waited) {
     std::lock_guard<std::mutex> lock(g_dcache_mu);
     *token = nullptr;
     bool needs_fill = false;
-    DEntry* e = dcache_acquire_locked(w, kind, bytes, version, st, &needs_fill);
+    DEntry* e = dcache_acquire_locked(w, kind, bytes, version, st, &needs_fill, waited);
     if (!e) return nullptr;
     if (needs_fill) {
         e->pending = version;

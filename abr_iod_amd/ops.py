@@ -6,6 +6,7 @@ abr_iod_amd/layers and abr_iod_amd/modeling and are built from these.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -217,12 +218,29 @@ _amax_count = [0]
 amax_reductions = [0, 0]   # (calls, bytes) of amax_compute: operands whose producer did not emit an amax word (bench.py reports them per step)
 
 
+_AMAX_BLOCK = 512
+_amax_block = {"it": iter(()), "base": 0}
+_amax_lock = threading.Lock()
+
+
 def amax_new():
-    """a fresh amax word of the library's ring: (address, epoch)"""
-    w, e = C.c_void_p(0), C.c_uint32(0)
-    L.check(L.lib().abr_h3_amax_alloc(C.byref(w), C.byref(e)), "h3_amax_alloc")
+    """a fresh amax word of the library's ring: (address, epoch).  Words come in blocks of _AMAX_BLOCK consecutive allocations
+    (abr_h3_amax_alloc_block) handed out here: one library call per block instead of one per tensor (~200 per training step)."""
+    try:
+        c = next(_amax_block["it"])       # (atomic under the GIL: the forward pass and autograd's thread both allocate)
+    except StopIteration:
+        with _amax_lock:
+            try:
+                c = next(_amax_block["it"])
+            except StopIteration:
+                base, first = C.c_void_p(0), C.c_uint64(0)
+                L.check(L.lib().abr_h3_amax_alloc_block(_AMAX_BLOCK, C.byref(base), C.byref(first)), "h3_amax_alloc_block")
+                _amax_block["base"] = int(base.value)
+                it = iter(range(int(first.value), int(first.value) + _AMAX_BLOCK))
+                c = next(it)
+                _amax_block["it"] = it
     _amax_count[0] += 1
-    return int(w.value), int(e.value)
+    return _amax_block["base"] + (c % _AMAX_RING) * 8, (c + 1) & 0xFFFFFFFF
 
 
 def amax_tag(t, word, epoch, stream=None):
@@ -360,25 +378,44 @@ class X6RangeWatch(object):
         return seen
 
 
+_desc_templates = {}
+
+
 def conv_desc(x_shape, w_shape, stride, pad, scale=None, bias=None, residual=None, mask=None, relu=False,
               out_hw=None, out_stride=(1, 1), math=MATH_F32):
-    B, H, W, Cin = x_shape
-    Cout, R, S, Cin2 = w_shape
-    if Cin != Cin2:
-        raise RuntimeError(f"conv: input has {Cin} channels, weight expects {Cin2}")
-    Ho = (H + 2 * pad - R) // stride + 1
-    Wo = (W + 2 * pad - S) // stride + 1
-    d = L.ConvDesc()
-    d.B, d.H, d.W, d.Cin, d.Cout, d.R, d.S = B, H, W, Cin, Cout, R, S
-    d.stride, d.pad, d.Ho, d.Wo = stride, pad, Ho, Wo
-    d.scale, d.bias, d.residual, d.mask = L.ptr(scale), L.ptr(bias), L.ptr(residual), L.ptr(mask)
-    d.relu = int(relu)
-    if out_hw is None:
-        d.out_H, d.out_W, d.out_sh, d.out_sw = Ho, Wo, 1, 1
-    else:
-        d.out_H, d.out_W = out_hw
-        d.out_sh, d.out_sw = out_stride
-    d.math = int(math)
+    """abr_conv_desc of a conv.  The geometry part is built once per distinct (shapes, stride, pad, epilogue flags, math) and kept as a
+    byte image: a call copies it and fills in the pointers (the field-by-field build costs 4.7 us, ~300 descriptors per training step)."""
+    key = (x_shape, w_shape, stride, pad, relu, out_hw, out_stride, math)
+    tmpl = _desc_templates.get(key)
+    if tmpl is None:
+        B, H, W, Cin = x_shape
+        Cout, R, S, Cin2 = w_shape
+        if Cin != Cin2:
+            raise RuntimeError(f"conv: input has {Cin} channels, weight expects {Cin2}")
+        Ho = (H + 2 * pad - R) // stride + 1
+        Wo = (W + 2 * pad - S) // stride + 1
+        d = L.ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.R, d.S = B, H, W, Cin, Cout, R, S
+        d.stride, d.pad, d.Ho, d.Wo = stride, pad, Ho, Wo
+        d.relu = int(relu)
+        if out_hw is None:
+            d.out_H, d.out_W, d.out_sh, d.out_sw = Ho, Wo, 1, 1
+        else:
+            d.out_H, d.out_W = out_hw
+            d.out_sh, d.out_sw = out_stride
+        d.math = int(math)
+        if len(_desc_templates) > 8192:     # (ragged batches: every image size brings its own set)
+            _desc_templates.clear()
+        tmpl = _desc_templates[key] = bytes(d)
+    d = L.ConvDesc.from_buffer_copy(tmpl)
+    if scale is not None:
+        d.scale = scale.data_ptr()
+    if bias is not None:
+        d.bias = bias.data_ptr()
+    if residual is not None:
+        d.residual = residual.data_ptr()
+    if mask is not None:
+        d.mask = mask.data_ptr()
     return d
 
 
@@ -544,7 +581,7 @@ def conv_cache_bytes():
     return int(L.lib().abr_conv_cache_bytes())
 
 
-def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino_v=None, amax_refs=None):
+def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino_v=None, amax_refs=None, stream=None):
     """dw [Cout,R,S,Cin] += scale * gy^T im2col(x) (fp32 atomics; caller zeroes dw once per step).  MATH_F16X3: the amax words of x and
     gy come from their tags (else the library reduces the operand first); amax_refs = ((word, epoch) of x, of gy) taken by the caller on
     the stream that produced the operands (conv_wgrad_async)."""
@@ -562,7 +599,7 @@ def conv_wgrad(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino_v=Non
                 d.x_amax, d.x_amax_epoch = amax_of(amax_compute(xc))
             if not d.gy_amax:
                 d.gy_amax, d.gy_amax_epoch = amax_of(amax_compute(gyc))
-    L.check(L.lib().abr_conv_wgrad(C.byref(d), L.ptr(xc), L.ptr(gyc), L.ptr(dw), L.stream()), "conv_wgrad")
+    L.check(L.lib().abr_conv_wgrad(C.byref(d), L.ptr(xc), L.ptr(gyc), L.ptr(dw), L.stream() if stream is None else stream), "conv_wgrad")
     return dw
 
 
@@ -600,10 +637,10 @@ def prep_wait():
     """make the current stream see the last weight preparation (no-op once per stream and preparation)"""
     ev = _prep["event"]
     if ev is not None:
-        cur = torch.cuda.current_stream()
-        if cur.cuda_stream not in _prep["waited"]:
-            cur.wait_event(ev)
-            _prep["waited"].add(cur.cuda_stream)
+        raw = L.stream()      # (torch.cuda.current_stream() builds a Stream object: ~9 us, and every dgrad call comes through here)
+        if raw not in _prep["waited"]:
+            torch.cuda.current_stream().wait_event(ev)
+            _prep["waited"].add(raw)
 
 
 def side_stream(key):
@@ -625,10 +662,17 @@ def mark_overlap(on):
 # Winograd inverse transform adds with a plain read-modify-write -- stream order keeps those two apart.
 WGRAD_STREAMS = max(1, int(os.environ.get("ABR_WGRAD_STREAMS", "2")))
 _wg_owner = {}
+_wg_keep = []    # operands of the weight gradients queued on side streams since the last join
+
+
+_wgrad_keys = {}
 
 
 def _wgrad_stream(dev, i):
-    return side_stream(dev if i == 0 else (dev, "wgrad%d" % i))
+    key = _wgrad_keys.get((dev, i))
+    if key is None:
+        key = _wgrad_keys[(dev, i)] = dev if i == 0 else (dev, "wgrad%d" % i)
+    return side_stream(key)
 
 
 def join_side_stream():
@@ -643,6 +687,7 @@ def join_side_stream():
             s = _side_streams.get(dev if i == 0 else (dev, "wgrad%d" % i))
             if s is not None:
                 torch.cuda.current_stream().wait_stream(s)
+    del _wg_keep[:]      # (after the waits: see conv_wgrad_async)
 
 
 # The side stream ends a backward pass behind the main one (the dgrad chain of the last stage is short, its weight gradients are not):
@@ -656,7 +701,6 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino
     """conv_wgrad on the side stream.  Only for use inside an autograd backward (the join is an engine callback)."""
     if not WGRAD_SIDE_STREAM:
         return conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v)
-    cur = torch.cuda.current_stream()
     owner = _wg_owner.get(dw.data_ptr())
     if owner is None:
         owner = _wg_owner[dw.data_ptr()] = len(_wg_owner) % WGRAD_STREAMS
@@ -679,13 +723,16 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino
         if amax_of(gy)[0] is None:
             amax_compute(gy)
         refs = (amax_of(x), amax_of(gy))
-    side.wait_stream(cur)  # x, gy (and the zeroed gradient buffer) are produced on the current stream
-    with torch.cuda.stream(side):
-        conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v, amax_refs=refs)
-    if wino_v is not None:
-        wino_v.record_stream(side)
-    x.record_stream(side)  # the caching allocator must not recycle them for the main stream while the side kernel reads
-    gy.record_stream(side)
+    # x, gy (and the zeroed gradient buffer) are produced on the current stream: the side stream is ordered behind it, and the launch names the
+    # side stream itself (side.wait_stream(cur) + `with torch.cuda.stream(side)` cost ~30 us of Python per gradient, ~60 gradients per step)
+    raw = side.cuda_stream
+    L.check(L.lib().abr_stream_wait_stream(raw, L.stream()), "stream_wait_stream")
+    conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v, amax_refs=refs, stream=raw)
+    # The caching allocator must not recycle the operands for the main stream while the side kernel still reads them: they are kept alive until
+    # the join (join_side_stream: the main stream waits for the side streams, THEN the references go), so their blocks return to the main
+    # stream's pool ordered behind the gradients.  (tensor.record_stream did the same at ~2 us per call plus an event per block at free time,
+    # three tensors per gradient.)
+    _wg_keep.append((x, gy, wino_v))
     return dw
 
 

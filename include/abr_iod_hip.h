@@ -49,6 +49,9 @@ int abr_device_info(int32_t* out_host);
  * fwd/bwd, 7 igemm bf16, 8 wgrad bf16 / bf16x6, 9 / 10 / 11 the bf16x6 implicit GEMM's 128x128 / 128x64 / 64x64 tile instances, 12 / 13 / 14 the same tiles of its weights-direct form.  Synchronises on the recorded events and stops profiling. */
 int abr_prof_begin(void);
 int abr_prof_mark_overlap(int on);
+/* Order everything queued on `waiter` from now on behind everything queued on `signaller` so far (an event recorded on `signaller`, waited for by
+ * `waiter`: torch's side.wait_stream(cur) in ONE call of ~2 us instead of ~15 us of Python -- the training step orders ~60 weight gradients so). */
+int abr_stream_wait_stream(void* waiter, void* signaller);
 /* bit id set = time that kernel (default all); every_nth = n > 1: bracket launch i of a kernel in step s iff (i + s) % n == 0 (an
  * event pair costs a ~6 us pipeline bubble per launch).  The caller marks step boundaries with abr_prof_step_begin(); over n
  * consecutive steps every launch position of the step's fixed launch sequence is sampled exactly once. */
@@ -295,6 +298,9 @@ typedef struct {
  * ABR_H3_AMAX_RING allocations; by then its tensor must be gone (a reader naming an older epoch raises ABR_H3_FLAG_STALE). */
 #define ABR_H3_AMAX_RING 65536
 int abr_h3_amax_alloc(uint64_t** word_out, uint32_t* epoch_out);
+/* n consecutive allocations at once (a host wrapper hands them out itself: one library call per n tensors instead of one per tensor):
+ * allocation k of the block (0 <= k < n) is word ring_base + (first_count + k) % ABR_H3_AMAX_RING with epoch (uint32_t)(first_count + k + 1). */
+int abr_h3_amax_alloc_block(int n, uint64_t** ring_base_out, uint64_t* first_count_out);
 /* Range statistics of the f16x3 kernels since the last reset: out_host[0] = operand elements seen more than 18 binades below their tensor's amax
  * (non-zero), out_host[1] = operand elements inspected (every element of an activation / gradient operand once per GEMM).  Synchronises `stream`. */
 int abr_h3_range_stats(uint64_t* out_host, int reset, void* stream);

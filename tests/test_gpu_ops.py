@@ -618,6 +618,39 @@ def test_conv_split_k_equals_unsplit(tmp_path):
         np.testing.assert_allclose(b, a, rtol=2e-5, atol=2e-5 * float(np.abs(a).max()))
 
 
+@pytest.mark.parametrize("M,N,K,k", [(2304, 108, 2048, 1), (256, 80, 2048, 1), (300, 64, 576, 3), (1000, 84, 4096, 1)])
+def test_conv_small_grid_split_k_hand_off_under_uneven_load(M, N, K, k):
+    """Small grid + long K (the predictor FCs): every 64 x 64 tile is split along K over up to 16 workgroups whose partial sums meet in the
+    last arrival (conv_igemm.hip, dispatch_igemm).  The hand-off is checked the way it fails: back-to-back launches with fresh data while
+    another stream keeps part of the chip busy, EVERY output word against float64 and against a repeat of the same call (the round-5 bug --
+    the ticket taken before the partial stores had drained -- showed as wrong sums in a few per cent of the words, run to run)."""
+    from abr_iod_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    side = torch.cuda.Stream()
+    big_a = torch.randn(4096, 4096, device="cuda", generator=g)
+    Cin = K // (k * k)
+    hw = int(round(M ** 0.5)) if k == 3 else 1
+    rows = hw * hw if k == 3 else M
+    for it in range(12):
+        x = torch.randn((1, hw, hw, Cin) if k == 3 else (M, 1, 1, Cin), device="cuda", generator=g)
+        w = torch.randn(N, k, k, Cin, device="cuda", generator=g) * 0.05
+        b = torch.randn(N, device="cuda", generator=g)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(1 + it % 3):
+                big_a @ big_a          # uneven load: some compute units are busy, some are not
+        y1 = ops.conv_forward(x, w, 1, k // 2, bias=b)
+        y2 = ops.conv_forward(x, w, 1, k // 2, bias=b)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2)
+        xn = x.permute(0, 3, 1, 2).double().cpu()
+        wn = w.permute(0, 3, 1, 2).double().cpu()
+        ref = torch.nn.functional.conv2d(xn, wn, b.double().cpu(), padding=k // 2).permute(0, 2, 3, 1).reshape(rows, N)
+        bound = torch.nn.functional.conv2d(xn.abs(), wn.abs(), padding=k // 2).permute(0, 2, 3, 1).reshape(rows, N)
+        err = ((y1.reshape(rows, N).double().cpu() - ref).abs() / bound).max().item()
+        assert err <= 8 * 2.0 ** -24, (it, err * 2 ** 24)   # units of 2^-24 sum|x||w| (measured: <= 1.2)
+
+
 @pytest.mark.parametrize("shape", [(2, 13, 18, 256, 128), (3, 4, 4, 512, 512), (1, 38, 63, 256, 256), (2, 8, 8, 1024, 160)])
 def test_conv3x3_winograd_matches_torch(shape):
     """Wide stride-1 pad-1 3x3 convs take the Winograd F(4x4,3x3) path (conv_winograd.hip + 36 batched MFMA GEMMs).  Against
@@ -757,7 +790,12 @@ def test_conv_bf16x6_mode_is_fp32_accurate(case):
     tol = 5e-5 if (k == 3 and Cin >= 128) else 1e-5   # Winograd-domain GEMMs carry the transforms' fp32 rounding, as in fp32 mode
     got = ops.conv_forward(xg, wg, s, p, math=ops.MATH_BF16X6).permute(0, 3, 1, 2)
     assert close(got, yr.detach(), tol)
-    f32 = ops.conv_forward(xg, wg, s, p).permute(0, 3, 1, 2)
+    import os
+    os.environ["ABR_IGEMM_FC_SPLIT"] = "0"   # the yardstick is the fp32 MFMA kernel's SEQUENTIAL chain over K (the split-K form it takes on
+    try:                                      # small grids since round 5 has shorter chains and a smaller error than any sequential kernel)
+        f32 = ops.conv_forward(xg, wg, s, p).permute(0, 3, 1, 2)
+    finally:
+        del os.environ["ABR_IGEMM_FC_SPLIT"]
     err6 = (got.cpu().double() - yr.detach()).norm().item(); err32 = (f32.cpu().double() - yr.detach()).norm().item()
     assert err6 < 1.5 * err32 + 1e-12, (err6, err32)     # never meaningfully worse than the fp32 MFMA chain
     dw = torch.zeros_like(wg)
