@@ -832,10 +832,6 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
     // lifts the kernel's own rate 132 -> 148 TF-eq, so it is ON by default since round 3.
     static const bool occ2 = !(getenv("ABR_WGRAD_OCC2") && atoi(getenv("ABR_WGRAD_OCC2")) == 0);
     static const int occ2_min_stages = getenv("ABR_WGRAD_OCC2_MINSTAGES") ? atoi(getenv("ABR_WGRAD_OCC2_MINSTAGES")) : 64;
-    // ABR_WGRAD_WGS_PER_CU = k > 1: small-output gradients (few tiles, long M) are split until k workgroups per CU are resident
-    // (never below 6 stages = 192 rows per workgroup): a lone 256-thread workgroup per CU leaves three quarters of the wave slots
-    // empty and cannot overlap its own fetch / split / MFMA / atomic phases
-    static const int per_cu = getenv("ABR_WGRAD_WGS_PER_CU") ? atoi(getenv("ABR_WGRAD_WGS_PER_CU")) : 1;
     const int max_splits = std::max(1, (m_tiles + 7) / 8);
     int splits = 1;
     double best = -1.0;
@@ -849,11 +845,6 @@ static void launch_wgrad(WgP p, const float* x, const float* gy, float* dw, void
                                                    // atomics epilogue: take two when each still gets >= 64 stages (head 1x1s: +11..15 %)
         eff -= 0.0002 * sp;                        // tie-break: fewer partial sums
         if (eff > best) { best = eff; splits = sp; }
-    }
-    if (per_cu > 1 && (long)tiles * splits < (long)per_cu * cus) {
-        const int want = (int)(((long)per_cu * cus + tiles - 1) / tiles);
-        const int cap = std::max(1, m_tiles / 6);
-        splits = std::max(splits, std::min(want, cap));
     }
     if (p.overwrite) splits = 1;  // one workgroup per output tile owns it: no zero-fill, no atomics
     p.splits = splits;

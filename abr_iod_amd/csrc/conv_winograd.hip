@@ -393,12 +393,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_inverse_kernel(const float* __
 }
 
 inline unsigned grid_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 32768); }
-// with an amax word to feed: fewer, longer-lived workgroups (the kernels are grid-stride loops), so that the block-wide max + the look at the
-// word at the end of every workgroup is paid ~2000 times per launch, not 30000 (measured: +4-7 us on a 17 us transform)
-inline unsigned grid_for(int64_t n, bool amax) {
-    static const int cap = getenv("ABR_WINO_AMAX_GRID") ? atoi(getenv("ABR_WINO_AMAX_GRID")) : 32768;   // (measured: a 2048 cap changes nothing in the step: 18.62 vs 18.56 ms)
-    return amax ? (unsigned)std::min<int64_t>((n + 255) / 256, cap) : grid_for(n);
-}
+inline unsigned grid_for(int64_t n, bool) { return grid_for(n); }   // (a smaller grid for the launches that feed an amax word changed nothing: 18.62 vs 18.56 ms)
 
 }  // namespace
 

@@ -45,21 +45,11 @@ PIPELINE_SOURCE = os.environ.get("ABR_PIPELINE_SOURCE", "1") != "0"
 # the next batch's source-model prefetch right behind the current batch's head pass on the source stream (-0.39 ms per step against issuing it
 # before the backward pass): see train_step
 EARLY_PREFETCH = os.environ.get("ABR_EARLY_PREFETCH", "1") != "0"
-# ... but ISSUED by the host only after the target's critical path (RoI targets, ROIAlign, layer4, predictor) is queued: the ~100 launches of the
-# prefetch cost the host 2-4 ms, during which the main stream sat idle behind the finished proposal selection (kernel trace, round 4); the
-# source stream is ordered behind an event recorded BEFORE that critical path, so the prefetch kernels still start as soon as they are issued
-PREFETCH_AFTER_CRITICAL = os.environ.get("ABR_PREFETCH_AFTER_CRITICAL", "0") != "0"   # (measured: 22.99 vs 22.83 ms with it: the un-profiled host is not what the main stream waits for)
 # Opt-in (off by default, and off in bench.py's headline): when the source and the target model hold IDENTICAL frozen stem / layer1 weights
 # (the reference's setup: both are loaded from the same checkpoint and FREEZE_CONV_BODY_AT = 2 never lets them move), that prefix is the same
 # function of the same batch in both models -- compute it once per batch and feed both.  Verified by comparing the tensors, never assumed.
 SHARE_FROZEN_PREFIX = [os.environ.get("ABR_SHARE_FROZEN_PREFIX", "0") != "0"]
 JOINT_ROI_PASS = os.environ.get("ABR_JOINT_ROI", "1") != "0"
-# The RPN's backward pass (loss kernels, the fused 1x1 heads, the 3x3 conv: ~0.5 ms of dgrad on the main stream + ~0.4 ms of weight gradients on
-# theirs) issued INSIDE the forward pass, in the hole where the main stream waits for the target's proposal selection (top-k + NMS: 0.9 ms at
-# B = 4, 1.9 ms at B = 2 -- tools/step_marks.py; with the joint RoI pass nothing else is left to put there).  Its gradient at the C4 feature map is
-# parked and added when the main backward pass reaches the feature map.  Needs the gradient buffers zeroed at the START of the step.
-EARLY_RPN_BACKWARD = os.environ.get("ABR_EARLY_RPN_BACKWARD", "0") != "0"
-
 
 class TrainerState(object):
     """What one (source, target) training pair carries from step to step: the work prefetched for the next batch and the bf16x6 range
@@ -239,20 +229,6 @@ def _arm_overlap(optimizer, head_inputs, features):
         f.register_hook(features_done)
 
 
-def _early_rpn_backward(begun):
-    """Run the backward pass of the RPN losses now (see EARLY_RPN_BACKWARD).  Returns True when it did."""
-    st = begun["rpn"]
-    live = [v for v in st["losses"].values() if torch.is_tensor(v) and v.requires_grad]
-    feats = begun["features"][0]
-    if not live or not (torch.is_tensor(feats) and feats.requires_grad):
-        return False
-    total = live[0] if len(live) == 1 else torch.stack([v.reshape(()) for v in live]).sum()
-    (g_feat,) = torch.autograd.grad(total, [feats])     # weight gradients land in the flat gradient buffer as a side effect of the conv Functions
-    st["losses"] = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in st["losses"].items()}
-    feats.register_hook(lambda g: g + g_feat)           # the RPN's share joins the RoI heads' when the main backward pass gets here
-    return True
-
-
 def _join_source_stream(deferred):
     """make the current stream (and the caching allocator) see what the source model's stream produced"""
     src = deferred.pop("_stream", None)
@@ -275,10 +251,6 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
     soften_result = soften_proposal = roi_align_features_source = rpn_output_source = roi_align_features_target = None
     deferred = None
     second_done = False
-    early_zeroed = False
-    if EARLY_RPN_BACKWARD and torch.is_grad_enabled():
-        optimizer.zero_grad()      # (:142 moved up: the early RPN backward below accumulates into the gradient buffers before the main one)
-        early_zeroed = True
     target_prefix = None      # (event, frozen_prefix result) of the target's frozen stem / layer1 for THIS batch, computed during the previous step
     if need_source:
         with torch.no_grad():                                                                              # :82-86
@@ -313,8 +285,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
 
     prefetched_now = [False]
 
-    def enqueue_prefetch(after=None):
-        """`after`: an event of the current stream that already covers whatever produced next_images (default: everything queued so far)"""
+    def enqueue_prefetch():
         if prefetched_now[0]:
             return
         prefetched_now[0] = True
@@ -327,10 +298,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
             from .. import ops
             cur = torch.cuda.current_stream()
             src = ops.side_stream((cur.device.index, "source-model"))
-            if after is not None:
-                src.wait_event(after)
-            else:
-                src.wait_stream(cur)   # next_images may have been produced on the current stream (async upload, device-side padding / augmentation)
+            src.wait_stream(cur)       # next_images may have been produced on the current stream (async upload, device-side padding / augmentation)
             tstate = trainer_state(model_target)
             shared = None
             if (SHARE_FROZEN_PREFIX[0] and PIPELINE_TARGET_FROZEN and hasattr(model_target, "prefetch_frozen")
@@ -393,18 +361,11 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         if src is not None:
             src_done = torch.cuda.Event()
             src_done.record(src)      # the source's results for THIS batch are complete here, whatever is queued on its stream afterwards
-        pre_critical = None
         if EARLY_PREFETCH and src is not None:
             # the next batch's source-model prefetch goes onto the source stream behind the head pass just queued there: it has nothing to
             # wait for and the device has the proposal selection's wait to fill
-            if PREFETCH_AFTER_CRITICAL:
-                pre_critical = torch.cuda.Event()
-                pre_critical.record()          # (issued below, once the target's critical path is in the queue)
-            else:
-                enqueue_prefetch()
+            enqueue_prefetch()
         ready = getattr(soften_proposal[0], "_roi_ready", None) if (EARLY_SECOND_PASS and src is not None and soften_proposal) else None
-        if early_zeroed:
-            _early_rpn_backward(begun)
         joint_ov = JOINT_ROI_PASS and need_source and bool(soften_proposal) and hasattr(model_target.roi_heads, "forward_joint")
         if joint_ov:
             # ABR_JOINT_ROI in the overlapped step: the 64 distillation RoIs per image ride along with the 512 detection RoIs through ONE
@@ -434,8 +395,6 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         if not joint_ov:
             loss_dict_target, feature_target, _, _, rpn_output_target, target_proposals, det_pooled, target_soften_results = \
                 model_target.forward_finish(begun)                                                         # :89-90 (second half)
-        if pre_critical is not None:
-            enqueue_prefetch(after=pre_critical)
         if src is not None:       # everything the source stream produced becomes visible to the main stream here
             cur = torch.cuda.current_stream()
             cur.wait_event(src_done)
@@ -488,8 +447,7 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
     enqueue_prefetch()
     if terms[0][0].is_cuda:
         _ops.mark("losses done (backward starts)")
-    if not early_zeroed:
-        optimizer.zero_grad()                                                                              # :142
+    optimizer.zero_grad()                                                                                  # :142
     # tensors whose gradients together say "every kernel of layer4's + the predictor's backward is queued": the pooled inputs of the RoI passes
     # (the joint pass has ONE pooled input for both RoI sets; its distillation-RoI output gets ARD's gradient much earlier and must not count)
     head_inputs = [det_pooled] if getattr(det_pooled, "_abr_joint_pool", False) else [det_pooled, roi_align_features_target if need_source else None]

@@ -690,13 +690,6 @@ def join_side_stream():
     del _wg_keep[:]      # (after the waits: see conv_wgrad_async)
 
 
-# The side stream ends a backward pass behind the main one (the dgrad chain of the last stage is short, its weight gradients are not):
-# the last WGRAD_MAIN_TAIL weight gradients of a backward pass (counted against the previous pass's total) are issued on the main
-# stream instead, which would otherwise idle until the join.
-WGRAD_MAIN_TAIL = int(os.environ.get("ABR_WGRAD_MAIN_TAIL", "0"))
-_wg_seq = {"n": 0, "last_total": 0}
-
-
 def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino_v=None):
     """conv_wgrad on the side stream.  Only for use inside an autograd backward (the join is an engine callback)."""
     if not WGRAD_SIDE_STREAM:
@@ -707,12 +700,8 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino
     side = _wgrad_stream(x.device.index, owner)
     if not _join_pending[0]:
         _join_pending[0] = True
-        _wg_seq["last_total"], _wg_seq["n"] = _wg_seq["n"], 0
         L.lib().abr_prof_mark_overlap(1)  # from here to the join, main-stream launches share the device with the side stream
         torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
-    _wg_seq["n"] += 1
-    if WGRAD_MAIN_TAIL and _wg_seq["last_total"] and _wg_seq["n"] > _wg_seq["last_total"] - WGRAD_MAIN_TAIL:
-        return conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v)   # (same stream as its producers: nothing to order)
     refs = None
     if math == MATH_F16X3 and H3_TAGS and x.is_contiguous() and gy.is_contiguous():
         # operands without an amax word get one HERE, on the stream that produced them: the dgrad that follows on this stream shares gy's, and

@@ -22,6 +22,10 @@ timeout 300 python bench.py --task 10-10 --batch-per-gpu 2 $B > $O/${R}_bench_10
 timeout 300 python bench.py --task 10-5 --batch-per-gpu 2 --mosaic-squares --steps 20 > $O/${R}_bench_10-5_b2_mosaic_squares.jsonl 2>/dev/null
 # main-stream timeline of the un-profiled step (events, no tracer) at B = 4 and B = 2
 ( timeout 200 python tools/step_marks.py; timeout 200 python tools/step_marks.py --batch-per-gpu 2 ) 2>&1 | grep -v amdgpu > $O/${R}_step_marks.txt
+# is the host the bottleneck?  issue time against device time per batch size, and the host floor (every kernel short)
+( timeout 300 python tools/dbg/host_time.py 2>&1 | grep "B ="; FLOOR_PROFILE=0 timeout 200 python tools/dbg/host_floor.py 2>&1 | grep floor ) > $O/${R}_host_time.txt
+( echo "# tools/dbg/fc_time.py: predictor FCs, all tiles split along K (default), then ABR_IGEMM_FC_SPLIT=0"; timeout 200 python tools/dbg/fc_time.py 2>&1 | grep " x "
+  ABR_IGEMM_FC_SPLIT=0 timeout 200 python tools/dbg/fc_time.py 2>&1 | grep " x " ) > $O/${R}_fc_split_k.txt
 # gates of the arithmetic switch (round 5): conv fuzz in every arithmetic, soak (bit-identical revisits), unusual batches
 ( timeout 700 python tools/conv_fuzz.py --cases 2000 2>&1 | grep -v amdgpu | tail -15 ) > $O/${R}_conv_fuzz_2000.txt
 ( timeout 400 python tools/soak.py --steps 600 2>&1 | grep -v amdgpu ) > $O/${R}_soak_600_steps.txt
@@ -50,6 +54,7 @@ timeout 600 python tools/conv_breakdown.py --target-tf 400 2>&1 | grep -v amdgpu
 timeout 600 python tools/conv_breakdown.py --batch 2 --target-tf 400 2>&1 | grep -v amdgpu.ids > $O/${R}_conv_shapes_f16x3_b2.txt
 timeout 600 python tools/microbench.py --only nothing 2>/dev/null > $O/${R}_microbench_hbm_kernels.txt
 timeout 600 bash tools/pmc_roialign.sh > $O/pmc_roialign.log 2>&1; [ -f gpurun_out/pmc_roialign.json ] && cp gpurun_out/pmc_roialign.json $O/${R}_pmc_roialign.json
+( echo "# tools/dbg/wino_time.sh: rocprofv3 kernel stats of the Winograd path, one 3x3 shape of the step per run (20 calls each)"; timeout 900 bash tools/dbg/wino_time.sh 2>&1 ) > $O/${R}_winograd_path_kernels.txt
 ( echo "# tools/x6lab/hlab.hip: two-term fp16 split with three products (f16x3) in the weights-direct loop vs the library bf16x6 loop; error vs float64 at 2048 outputs; two timing rounds"
   timeout 250 tools/x6lab/hlab ) > $O/${R}_x6lab_f16x3.txt 2>&1
 fi
