@@ -14,10 +14,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _work(seed, dev_stream, out, errors, barrier, rounds):
+def _work(seed, dev_stream, out, errors, barrier, rounds, math="bf16x6"):
     try:
         from abr_iod_amd import ops
-        X6 = ops.MATH_BF16X6
+        X6 = {"bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3}[math]   # (f16x3: amax words from the shared ring, allocated by every thread at once)
         g = torch.Generator(device="cuda").manual_seed(seed)
         with torch.cuda.stream(dev_stream):
             x = torch.randn(2, 20, 24, 128, device="cuda", generator=g)
@@ -42,7 +42,8 @@ def _work(seed, dev_stream, out, errors, barrier, rounds):
 
 
 @pytest.mark.timeout(300)
-def test_library_calls_from_concurrent_threads_match_serial():
+@pytest.mark.parametrize("math", ["bf16x6", "f16x3"])
+def test_library_calls_from_concurrent_threads_match_serial(math):
     from abr_iod_amd import ops
     n_threads, rounds = 4, 6
     ops.conv_cache_clear()
@@ -50,12 +51,12 @@ def test_library_calls_from_concurrent_threads_match_serial():
     ref, errors = {}, []
     one = threading.Barrier(1)
     for t in range(n_threads):
-        _work(t, torch.cuda.Stream(), ref, errors, one, rounds)
+        _work(t, torch.cuda.Stream(), ref, errors, one, rounds, math)
     assert not errors, errors
     ops.conv_cache_clear()
     got = {}
     barrier = threading.Barrier(n_threads)
-    threads = [threading.Thread(target=_work, args=(t, torch.cuda.Stream(), got, errors, barrier, rounds)) for t in range(n_threads)]
+    threads = [threading.Thread(target=_work, args=(t, torch.cuda.Stream(), got, errors, barrier, rounds, math)) for t in range(n_threads)]
     for th in threads:
         th.start()
     for th in threads:

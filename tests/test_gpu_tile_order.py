@@ -15,6 +15,7 @@ CHILD = r"""
 import hashlib, sys, torch
 sys.path.insert(0, %r)
 from abr_iod_amd import ops
+MATH = {"bf16x6": ops.MATH_BF16X6, "f16x3": ops.MATH_F16X3}[sys.argv[1]]
 g = torch.Generator(device="cuda").manual_seed(5)
 out = []
 ver = 900
@@ -22,11 +23,11 @@ for (M, N, K) in [(1000, 1280, 1024), (4096, 2048, 512), (777, 2048 + 96, 512), 
     x = torch.randn(1, 1, M, K, device="cuda", generator=g); w = torch.randn(N, 1, 1, K, device="cuda", generator=g) * 0.05
     res = torch.randn(1, 1, M, N, device="cuda", generator=g)
     ver += 1
-    out.append(ops.conv_forward(x, w, 1, 0, residual=res, relu=True, math=ops.MATH_BF16X6, w_version=ver))
+    out.append(ops.conv_forward(x, w, 1, 0, residual=res, relu=True, math=MATH, w_version=ver))
 for (B, H, W, C, N) in [(2, 19, 23, 1024, 1024 + 128), (40, 4, 4, 512, 512)]:                           # Winograd: 36 batched GEMMs
     x = torch.randn(B, H, W, C, device="cuda", generator=g); w = torch.randn(N, 3, 3, C, device="cuda", generator=g) * 0.02
     ver += 1
-    out.append(ops.conv_forward(x, w, 1, 1, relu=True, math=ops.MATH_BF16X6, w_version=ver))
+    out.append(ops.conv_forward(x, w, 1, 1, relu=True, math=MATH, w_version=ver))
 assert ops.x6_range_flags(reset=False) == 0
 h = hashlib.sha256()
 for t in out:
@@ -37,14 +38,15 @@ print("DIGEST", h.hexdigest())
 
 
 @pytest.mark.timeout(600)
-def test_outputs_do_not_depend_on_the_tile_order():
+@pytest.mark.parametrize("math", ["bf16x6", "f16x3"])
+def test_outputs_do_not_depend_on_the_tile_order(math):
     digests = {}
     for setting in ("0", None, "1", "3", "4", "7"):
         env = dict(os.environ)
         env.pop("ABR_X6_NGROUP", None)
         if setting is not None:
             env["ABR_X6_NGROUP"] = setting
-        r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        r = subprocess.run([sys.executable, "-c", CHILD, math], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
         assert r.returncode == 0, (setting, (r.stdout + r.stderr)[-2000:])
         digests[setting] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1]
     assert len(set(digests.values())) == 1, digests
