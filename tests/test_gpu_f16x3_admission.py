@@ -255,6 +255,65 @@ def test_non_finite_operands_raise_the_flag_and_poison_their_outputs():
     assert ops.x6_range_flags(reset=True) & ops.X6_FLAG_NONFINITE
 
 
+def test_amax_words_come_in_blocks_and_never_collide():
+    """ops.amax_new hands out the words of abr_h3_amax_alloc_block's blocks (one library call per 512 tensors); single allocations made by the
+    library in between (abr_h3_amax_alloc: the Winograd path's V / M words) must neither reuse a block's words nor its epochs, also across a block
+    boundary and from several host threads at once"""
+    import ctypes as C
+    import threading
+    from abr_iod_amd import ops, _lib as L
+    seen, lock = set(), threading.Lock()
+
+    def take(n, single_every):
+        got = []
+        for i in range(n):
+            got.append(ops.amax_new())
+            if i % single_every == 0:
+                w, e = C.c_void_p(0), C.c_uint32(0)
+                L.check(L.lib().abr_h3_amax_alloc(C.byref(w), C.byref(e)), "h3_amax_alloc")
+                got.append((int(w.value), int(e.value)))
+        with lock:
+            for g in got:
+                assert g not in seen, g
+                seen.add(g)
+    threads = [threading.Thread(target=take, args=(700, 7 + t)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    words = {}
+    for w, e in seen:
+        assert e != 0 and w % 8 == 0
+        words.setdefault(w, set()).add(e)
+    assert len(seen) >= 4 * 700
+    # within one pass of the ring (65536 words, far more than taken here) an address is handed out once
+    assert all(len(es) == 1 for es in words.values())
+    base = min(words)
+    assert max(words) - base < 65536 * 8
+
+
+def test_stream_wait_stream_orders_the_waiter_behind_the_signaller():
+    """abr_stream_wait_stream(waiter, signaller) = torch's waiter.wait_stream(signaller): a consumer queued on the waiter afterwards sees what the
+    signaller had queued before (a long chain of dependent kernels), repeatedly and in both directions"""
+    from abr_iod_amd import _lib as L
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.zeros(1 << 22, device="cuda")
+    torch.cuda.synchronize()
+    for it in range(20):
+        s1, s2 = (a, b) if it % 2 == 0 else (b, a)
+        with torch.cuda.stream(s1):
+            for _ in range(30):
+                x.add_(1.0)              # 30 dependent passes over 16 MB: the signaller is busy for a while
+        L.check(L.lib().abr_stream_wait_stream(s2.cuda_stream, s1.cuda_stream), "stream_wait_stream")
+        with torch.cuda.stream(s2):
+            y = x.clone()                # must see all 30 additions of this round
+            x.add_(0.0)                  # (keeps the next round's writes behind this read through the same ordering call)
+        L.check(L.lib().abr_stream_wait_stream(s1.cuda_stream, s2.cuda_stream), "stream_wait_stream")
+        s2.synchronize()
+        assert float(y.min()) == float(y.max()) == 30.0 * (it + 1), it
+    torch.cuda.synchronize()
+
+
 def test_stale_amax_word_raises_the_flag():
     """a consumer told an epoch its amax word does not carry (the plumbing bug the epochs exist to catch)"""
     import ctypes as C
