@@ -12,7 +12,7 @@
 // Rows of the table: the library's bf16x6 loop; f16x3 with the in-kernel split; f16x3 with A as pre-split fragment-ordered planes by LDS-DMA
 // (what a producer epilogue / a Winograd transform could write at no extra traffic); knock-outs (MFMAs only).
 //
-//   hipcc --offload-arch=gfx950 -O3 -o hlab hlab.hip && ./hlab [M N K]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -o hlab hlab.hip && ./hlab [M N K]
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // ------------------------------------------------------------------------------------------------------------------------- f16x3, in-kernel split
 // KO: 0 = full; 1 = MFMAs only (no loads / split / LDS; results wrong)
 // PF: B fragments prefetched PF tiles ahead (1 = the library's distance)
-template <int OCC, int KO, int PF>
+// DB: 0 = one LDS buffer, two barriers per k-tile (the library's loop); 1 = two LDS buffers, ONE barrier per k-tile; 2 = A fetched TWO k-tiles
+// ahead (two register sets), one LDS buffer
+template <int OCC, int KO, int PF, int DB = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_h3(const float* __restrict__ A, const u32x4* __restrict__ Bp,
                                                                                             float* __restrict__ C, int M, int N, int K,
                                                                                             const float* __restrict__ a_scale, const float* __restrict__ sn) {
@@ -225,25 +227,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     unsigned ao[4];
     for (int i = 0; i < 4; i++) ao[i] = ((m0 + srow + 32 * i) * K + kq * 4) * 4u;
     const unsigned bo = (unsigned)((((size_t)(n0 / 32 + wave) * KS) * 2 * 64 + lane) * 16);
-    u32x4 ra[4];
+    u32x4 ra[4], rb2[4];
     u32x4 fbr[PF][2][2];   // [tile slot][step][plane]
-    auto load_a = [&](int kt) {
+    int abuf = 0;          // DB == 1: the LDS buffer compute_tile reads
+    auto load_into = [&](u32x4 (&r)[4], int kt) {
         if (KO) return;
 #pragma unroll
-        for (int i = 0; i < 4; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)ao[i], kt * BKX * 4, 0);
+        for (int i = 0; i < 4; i++) r[i] = __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)ao[i], kt * BKX * 4, 0);
     };
-    auto store_a = [&]() {
+    auto load_a = [&](int kt) { load_into(ra, kt); };
+    auto store_from = [&](const u32x4 (&r)[4], int buf) {
         if (KO) return;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            _Float16* dst = As + (srow + 32 * i) * LDX + kq * 4;
+            _Float16* dst = As + buf * (2 * BM * LDX) + (srow + 32 * i) * LDX + kq * 4;
             uint2 o0, o1;
-            split_pair_h3(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y), inv, o0.x, o1.x);
-            split_pair_h3(__uint_as_float(ra[i].z), __uint_as_float(ra[i].w), inv, o0.y, o1.y);
+            split_pair_h3(__uint_as_float(r[i].x), __uint_as_float(r[i].y), inv, o0.x, o1.x);
+            split_pair_h3(__uint_as_float(r[i].z), __uint_as_float(r[i].w), inv, o0.y, o1.y);
             *reinterpret_cast<uint2*>(dst) = o0;
             *reinterpret_cast<uint2*>(dst + BM * LDX) = o1;
         }
     };
+    auto store_a = [&]() { store_from(ra, 0); };
     auto load_b = [&]<int SL>(int kt, int u) {
         if (KO) return;
         const int ks = kt * 2 + u;
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
                 for (int pl = 0; pl < 2; pl++) {
                     if (KO) { const u32x4 t = {(unsigned)(lane + i), (unsigned)pl, 5u, 7u}; fa[i][pl] = *reinterpret_cast<const f16x8*>(&t); }
-                    else fa[i][pl] = *reinterpret_cast<const f16x8*>(af + pl * BM * LDX + i * 32 * LDX + u * 16);
+                    else fa[i][pl] = *reinterpret_cast<const f16x8*>(af + (DB == 1 ? abuf * (2 * BM * LDX) : 0) + pl * BM * LDX + i * 32 * LDX + u * 16);
                 }
 #pragma unroll
             for (int pl = 0; pl < 2; pl++) fb[pl] = *reinterpret_cast<const f16x8*>(&fbr[SL][u][pl]);
@@ -294,7 +299,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         store_a();
         if (!KO) __syncthreads();
     };
-    if (PF == 1) {
+    if constexpr (DB == 1) {           // two LDS buffers: tile kt + 1 is stored into the other buffer right behind tile kt's MFMAs, one barrier per tile
+        for (int kt = 0; kt + 1 < nk; kt++) {
+            load_a(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile.template operator()<0>(kt);
+            store_from(ra, abuf ^ 1);
+            __syncthreads();
+            abuf ^= 1;
+        }
+        compute_tile.template operator()<0>(nk - 1);
+    } else if constexpr (DB == 2) {    // A two tiles ahead: ra carries tile kt + 1 (requested one tile ago), rb2 is requested for kt + 2 now
+        if (nk > 1) load_into(rb2, 1);
+        int kt = 0;
+        while (true) {
+            // LDS = tile kt; rb2 = tile kt + 1 in flight
+            if (kt + 2 < nk) load_into(ra, kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile.template operator()<0>(kt);
+            if (kt + 1 >= nk) break;
+            __syncthreads();
+            store_from(rb2, 0);
+            __syncthreads();
+            kt++;
+            if (kt + 2 < nk) load_into(rb2, kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile.template operator()<0>(kt);
+            if (kt + 1 >= nk) break;
+            __syncthreads();
+            store_from(ra, 0);
+            __syncthreads();
+            kt++;
+        }
+    } else if (PF == 1) {
         for (int kt = 0; kt + 1 < nk; kt++) body.template operator()<0>(kt);
         compute_tile.template operator()<0>(nk - 1);
     } else {   // two k-tiles per trip: the fragment slots are compile-time
@@ -426,7 +463,10 @@ static float time_it(const char* name, void (*launch)(Ctx*), Ctx* c, double flop
 }
 #define GRID(c) ((c->M / BM) * (c->N / BN))
 static void l_x6(Ctx* c) { k_x6<<<GRID(c), 256, sizeof(__bf16) * 3 * BM * LDX>>>(c->A, c->Bp3, c->C, c->M, c->N, c->K); }
-template <int OCC, int KO, int PF> static void l_h3(Ctx* c) { k_h3<OCC, KO, PF><<<GRID(c), 256, 2 * 2 * BM * LDX>>>(c->A, c->Bp2, c->C, c->M, c->N, c->K, c->a_scale, c->sn); }
+template <int OCC, int KO, int PF, int DB = 0> static void l_h3(Ctx* c) {
+    if (DB == 1) hipFuncSetAttribute(reinterpret_cast<const void*>(k_h3<OCC, KO, PF, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 2 * BM * LDX);
+    k_h3<OCC, KO, PF, DB><<<GRID(c), 256, (DB == 1 ? 2 : 1) * 2 * 2 * BM * LDX>>>(c->A, c->Bp2, c->C, c->M, c->N, c->K, c->a_scale, c->sn);
+}
 template <int S, int OCC> static void l_dma(Ctx* c) { k_h3_dma<S, OCC><<<GRID(c), 256, 2 * 4 * S * 2 * 1024>>>(c->Ap2, c->Bp2, c->C, c->M, c->N, c->K, c->a_scale, c->sn); }
 
 // data: 0 = uniform(-1, 1) (the other labs' operands); 1 = N(0,1)-ish x 2^U(-6, 6) per element (wide range inside every reduction)
@@ -465,6 +505,9 @@ static void run_shape(int M, int N, int K, int kind) {
     const V vs[] = {{"bf16x6 library loop (3 w/SIMD)", l_x6},
                     {"f16x3 in-kernel split, 3 w/SIMD, B 1 tile ahead", l_h3<3, 0, 1>},
                     {"f16x3 in-kernel split, 4 w/SIMD, B 1 tile ahead", l_h3<4, 0, 1>},
+                    {"f16x3 split, two LDS buffers, one barrier per tile, 3 w", l_h3<3, 0, 1, 1>},
+                    {"f16x3 split, A two k-tiles ahead, 3 w/SIMD", l_h3<3, 0, 1, 2>},
+                    {"f16x3 split, A two k-tiles ahead, 2 w/SIMD", l_h3<2, 0, 1, 2>},
                     {"f16x3 A planes by LDS-DMA, 32-k tiles, 3 w/SIMD", l_dma<2, 3>},
                     {"f16x3 A planes by LDS-DMA, 32-k tiles, 4 w/SIMD", l_dma<2, 4>},
                     {"f16x3 A planes by LDS-DMA, 64-k tiles, 2 w/SIMD", l_dma<4, 2>},
