@@ -459,13 +459,22 @@ def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, ma
             out = _empty((d.B, d.Ho, d.Wo, d.Cout), xc)
     if emit_amax is None:
         emit_amax = math == MATH_F16X3
-    emit_amax = bool(emit_amax) and H3_TAGS and (fresh or out is residual) and d.out_sh == 1 and d.out_sw == 1
+    # a strided scatter (the dgrad of a stride-2 1x1 conv: rows land on every out_sh-th pixel of a zeroed tensor) writes every non-zero element of
+    # its result, so its epilogue's amax IS the tensor's -- in the fresh pass, and in a second pass that adds into exactly that tensor
+    strided = d.out_sh != 1 or d.out_sw != 1
+    if strided:
+        covers = fresh or (out is residual and getattr(out, "_abr_scatter", None) == (out.data_ptr(), d.out_sh, d.out_sw))
+    else:
+        covers = fresh or out is residual
+    emit_amax = bool(emit_amax) and H3_TAGS and covers
     if emit_amax:
         ow, oe = amax_new()
         d.out_amax, d.out_amax_epoch = ow, oe
     L.check(L.lib().abr_conv_forward(C.byref(d), L.ptr(xc), L.ptr(w), L.ptr(out), L.stream()), "conv_forward")
     if emit_amax:
         amax_tag(out, ow, oe)
+    if strided and fresh:
+        out._abr_scatter = (out.data_ptr(), d.out_sh, d.out_sw)   # (zero everywhere but the pixels this geometry writes)
     return out
 
 

@@ -206,6 +206,23 @@ def test_amax_from_the_producers_tag_equals_amax_reduced_by_the_library(monkeypa
         y_lib = ops.conv_forward(h2.clone(), w2, 1, 1, math=ops.MATH_F16X3)
         monkeypatch.setattr(ops, "H3_TAGS", True)
         assert torch.equal(y_tag, y_lib)
+    # the strided scatter of a stride-2 1x1 conv's dgrad (rows on the even pixels of a zeroed tensor) carries its amax too, in the fresh pass and in
+    # the second pass that adds the downsample branch's gradient into the same tensor: a consumer gives the same bits either way
+    g1, g2 = rn(2, 12, 10, 256), rn(2, 12, 10, 128)
+    wt1, wt2 = rn(64, 1, 1, 256) / 16, rn(64, 1, 1, 128) / 11
+    ops.amax_compute(g1); ops.amax_compute(g2)
+    gx = ops.conv_forward(g1, wt1, 1, 0, out_hw=(24, 20), out_stride=(2, 2), math=ops.MATH_F16X3)
+    w_first = ops.amax_of(gx)[0]
+    assert w_first is not None
+    ops.conv_forward(g2, wt2, 1, 0, residual=gx, out=gx, out_hw=(24, 20), out_stride=(2, 2), math=ops.MATH_F16X3)
+    assert ops.amax_of(gx)[0] not in (None, w_first)
+    w3 = rn(64, 1, 1, 64) / 8
+    y_tag = ops.conv_forward(gx, w3, 1, 0, math=ops.MATH_F16X3)
+    y_red = ops.conv_forward(gx.clone(), w3, 1, 0, math=ops.MATH_F16X3)
+    assert torch.equal(y_tag, y_red)
+    other = torch.zeros_like(gx)        # a scatter into a tensor this geometry did not zero-fill gets no tag
+    ops.conv_forward(g2, wt2, 1, 0, residual=other, out=other, out_hw=(24, 20), out_stride=(2, 2), math=ops.MATH_F16X3)
+    assert ops.amax_of(other)[0] is None
     # an in-place write through torch invalidates the tag (the tensor's version moves)
     h = ops.conv_forward(x, w1, 1, 0, math=ops.MATH_F16X3)
     assert ops.amax_of(h)[0] is not None
