@@ -28,6 +28,7 @@ timeout 300 python bench.py --task 10-5 --batch-per-gpu 2 --mosaic-squares --ste
   ABR_IGEMM_FC_SPLIT=0 timeout 200 python tools/dbg/fc_time.py 2>&1 | grep " x " ) > $O/${R}_fc_split_k.txt
 # gates of the arithmetic switch (round 5): conv fuzz in every arithmetic, soak (bit-identical revisits), unusual batches
 ( timeout 700 python tools/conv_fuzz.py --cases 2000 2>&1 | grep -v amdgpu | tail -15 ) > $O/${R}_conv_fuzz_2000.txt
+( timeout 1200 python tools/detect_fuzz.py --cases 1000 2>&1 | grep -v amdgpu | tail -12 ) > $O/${R}_detect_fuzz_1000.txt
 ( timeout 400 python tools/soak.py --steps 600 2>&1 | grep -v amdgpu ) > $O/${R}_soak_600_steps.txt
 ( timeout 300 python tools/edge_steps.py 2>&1 | grep -v amdgpu | tail -15 ) > $O/${R}_edge_steps.txt
 ( timeout 300 python -m pytest tests/test_gpu_f16x3_admission.py tests/test_gpu_x6_admission.py -q -s -p no:cacheprovider 2>&1 | grep -E "ulp|passed|failed|inspected" | grep -v amdgpu ) > $O/${R}_admission_f16x3_and_bf16x6.txt
