@@ -315,7 +315,9 @@ class StemWithFixedBatchNorm(nn.Module):
         """x: [B,3,H,W] plain NCHW image batch -> logical [B,64,H/4,W/4]"""
         xh = ops.nchw_to_nhwc(x.contiguous(), cpad=4) if x.shape[1] == 3 else as_nhwc(x)
         s, b = self.bn1.scale_bias()
-        y = ops.conv_forward(xh, self.conv1.weight, 2, 3, scale=s, bias=b, relu=True)
+        # (the stem runs on the fp32 MFMA kernel; its epilogue still writes the output's amax word for layer1's f16x3 convs: the pooled tensor
+        #  inherits it as a bound instead of being reduced again)
+        y = ops.conv_forward(xh, self.conv1.weight, 2, 3, scale=s, bias=b, relu=True, emit_amax=True)
         return from_nhwc(ops.maxpool3x3s2(y))
 
 

@@ -790,7 +790,7 @@ def maxpool3x3s2(x):
     B, H, W, Ch = x.shape
     out = _empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Ch), x)
     L.check(L.lib().abr_maxpool3x3s2(L.ptr(x), B, H, W, Ch, L.ptr(out), L.stream()), "maxpool")
-    return out
+    return amax_carry_bound(out, x)   # (every input pixel lies in some window: max |pooled| <= max |x|, equal for a ReLU's output)
 
 
 def avgpool_forward(x):

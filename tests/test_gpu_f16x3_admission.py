@@ -272,6 +272,30 @@ def test_non_finite_operands_raise_the_flag_and_poison_their_outputs():
     assert ops.x6_range_flags(reset=True) & ops.X6_FLAG_NONFINITE
 
 
+def test_the_fp32_stem_hands_its_amax_on():
+    """the stem conv runs on the fp32 MFMA kernel; asked to, its epilogue writes the output's amax word all the same, and the max-pooled copy
+    inherits the tag (layer1's f16x3 convs then need no reduction pass over the pooled tensor)"""
+    import ctypes
+    from abr_iod_amd import ops
+    rn, _ = _gen(9)
+    x = rn(2, 64, 80, 4)
+    ws = rn(64, 7, 7, 4) / 14
+    y = ops.conv_forward(x, ws, 2, 3, relu=True, emit_amax=True)
+    w, e = ops.amax_of(y)
+    assert w is not None
+    host = ctypes.c_uint64(0)
+    torch.cuda.synchronize()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemcpy(ctypes.byref(host), ctypes.c_void_p(w), 8, 2) == 0   # hipMemcpyDeviceToHost
+    assert (int(host.value) >> 32) == e
+    assert torch.tensor([int(host.value) & 0xFFFFFFFF], dtype=torch.int64).to(torch.int32).view(torch.float32).item() == float(y.abs().max())
+    p = ops.maxpool3x3s2(y)
+    assert ops.amax_of(p) == ops.amax_of(y)
+    w1 = rn(64, 1, 1, 64) / 8
+    assert torch.equal(ops.conv_forward(p, w1, 1, 0, math=ops.MATH_F16X3), ops.conv_forward(p.clone(), w1, 1, 0, math=ops.MATH_F16X3))
+
+
 def test_amax_words_come_in_blocks_and_never_collide():
     """ops.amax_new hands out the words of abr_h3_amax_alloc_block's blocks (one library call per 512 tensors); single allocations made by the
     library in between (abr_h3_amax_alloc: the Winograd path's V / M words) must neither reuse a block's words nor its epochs, also across a block
