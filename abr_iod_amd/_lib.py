@@ -38,6 +38,15 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ConvOp(C.Structure):
+    """abr_conv_op (include/abr_iod_hip.h): one entry of abr_conv_run's table."""
+
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("desc", ConvDesc), ("a", _vp), ("b", _vp), ("out", _vp), ("stream", _vp), ("other", _vp)]
+
+
+OP_FORWARD, OP_WGRAD, OP_STREAM_WAIT = 0, 1, 2
+
+
 class PrepItem(C.Structure):
     """abr_prep_item (include/abr_iod_hip.h section 3): one tensor of abr_conv_prepare_batch."""
 
@@ -60,6 +69,7 @@ _SIGS = {
     "abr_prof_step_begin": (_i, []),
     "abr_conv_prepare_weights": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "abr_conv_prepare_batch": (_i, [_vp, _i, _vp]),
+    "abr_conv_run": (_i, [_vp, _i]),
     "abr_conv_cache_clear": (_i, []),
     "abr_conv_cache_drop_range": (_i, [_vp, _i64]),
     "abr_conv_cache_bytes": (_i64, []),

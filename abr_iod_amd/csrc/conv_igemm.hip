@@ -2577,6 +2577,22 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
     return ABR_OK;
 }
 
+extern "C" int abr_conv_run(const abr_conv_op* ops, int n) {
+    ABR_REQUIRE(n >= 0 && (n == 0 || ops), "conv_run: bad args");
+    for (int i = 0; i < n; i++) {
+        const abr_conv_op& o = ops[i];
+        int rc;
+        switch (o.kind) {
+            case ABR_OP_FORWARD: rc = abr_conv_forward(&o.desc, o.a, o.b, o.out, o.stream); break;
+            case ABR_OP_WGRAD: rc = abr_conv_wgrad(&o.desc, o.a, o.b, o.out, o.stream); break;
+            case ABR_OP_STREAM_WAIT: rc = abr_stream_wait_stream(o.stream, o.other); break;
+            default: ABR_REQUIRE(false, "conv_run: unknown op kind");
+        }
+        if (rc != ABR_OK) return rc;
+    }
+    return ABR_OK;
+}
+
 extern "C" int abr_conv_cache_clear(void) {
     abr::derived_cache_clear();
     return ABR_OK;

@@ -109,6 +109,118 @@ def _grad_buf(p):
     return p.grad
 
 
+# Round 5: one library call per bottleneck pass.  The four convs of a block's forward pass cost ~12 us of interpreter / binding time EACH
+# (tools/dbg/host_segments.py: at B = 1 the step is the host's issue time); their descriptors, weights and FrozenBN vectors do not change from
+# step to step, so a block keeps, per (input shape, stride, arithmetic), a table of abr_conv_op with all of that filled in (`_FwdPlan`) and
+# writes only this call's pointers and amax words before ONE abr_conv_run.  Same kernels, same arguments: bit-identical to the per-conv path,
+# which stays for everything the tables do not cover (ABR_BLOCK_PLANS=0: always).
+BLOCK_PLANS = os.environ.get("ABR_BLOCK_PLANS", "1") != "0"
+
+
+class _FwdPlan(object):
+    """the no-backward forward pass of one Bottleneck (conv1 [+ downsample] -> conv2 -> conv3 + identity) as an abr_conv_run table"""
+
+    def __init__(self, blk, x_shape, s):
+        L = ops.L
+        B, H, W, Cin = x_shape
+        self.blk, self.math = blk, blk.math
+        ds = blk.downsample
+        convs = [(blk.conv1, blk.bn1, s, 0, True)] + ([(ds[0], ds[1], s, 0, False)] if ds is not None else []) + \
+                [(blk.conv2, blk.bn2, 1, 1, True), (blk.conv3, blk.bn3, 1, 0, True)]
+        self.n = len(convs)
+        self.arr = (L.ConvOp * self.n)()
+        self.ptr = ops.C.cast(self.arr, ops.C.c_void_p)
+        self.has_ds = ds is not None
+        self.fused, self.wptr, self.convs = [], [], []
+        shape = tuple(x_shape)
+        shapes = []
+        for i, (conv, bn, st, pad, relu) in enumerate(convs):
+            if conv is blk.conv2:
+                in_shape = shapes[0]          # conv1's output
+            elif conv is blk.conv3:
+                in_shape = shapes[-1]         # conv2's output
+            else:
+                in_shape = shape              # conv1 and the downsample branch read x
+            sb = bn.scale_bias()
+            d = ops.conv_desc(in_shape, conv.weight.shape, st, pad, sb[0], sb[1], None, None, relu, math=self.math)
+            op = self.arr[i]
+            op.kind = L.OP_FORWARD
+            op.desc = d
+            op.b = conv.weight.data_ptr()
+            self.fused.append((bn, sb))
+            self.wptr.append((conv, conv.weight.data_ptr()))
+            self.convs.append(conv)
+            shapes.append((d.B, d.Ho, d.Wo, d.Cout))
+        self.shapes = shapes
+        i1, i2, i3 = 0, self.n - 2, self.n - 1
+        n1, n2 = _numel(shapes[i1]), _numel(shapes[i2])
+        nd = _numel(shapes[1]) if self.has_ds else 0
+        self.off = (0, n1, n1 + n2)            # o1, o2, identity branch inside the temporaries' buffer (floats)
+        self.tmp_floats = n1 + n2 + nd
+        self.out_shape = shapes[i3]
+        self.h3 = self.math == ops.MATH_F16X3
+
+    def valid(self):
+        blk = self.blk
+        if blk.math != self.math:
+            return False
+        for bn, sb in self.fused:
+            if bn._fused is not sb:
+                return False
+        for conv, p in self.wptr:
+            if conv.weight.data_ptr() != p:
+                return False
+        return True
+
+    def run(self, x):
+        arr, n = self.arr, self.n
+        st = ops.L.stream()
+        tmp = torch.empty(self.tmp_floats, dtype=torch.float32, device=x.device)
+        out = torch.empty(self.out_shape, dtype=torch.float32, device=x.device)
+        base, xp = tmp.data_ptr(), x.data_ptr()
+        o1, o2 = base + 4 * self.off[0], base + 4 * self.off[1]
+        idt = base + 4 * self.off[2] if self.has_ds else xp
+        i2, i3 = n - 2, n - 1
+        a0 = arr[0]
+        a0.a, a0.out, a0.stream = xp, o1, st
+        a0.desc.w_version = self.convs[0].version()
+        if self.has_ds:
+            a1 = arr[1]
+            a1.a, a1.out, a1.stream = xp, idt, st
+            a1.desc.w_version = self.convs[1].version()
+        a2, a3 = arr[i2], arr[i3]
+        a2.a, a2.out, a2.stream = o1, o2, st
+        a2.desc.w_version = self.convs[i2].version()
+        a3.a, a3.out, a3.stream = o2, out.data_ptr(), st
+        a3.desc.residual = idt
+        a3.desc.w_version = self.convs[i3].version()
+        if self.h3:
+            xw, xe = ops.amax_of(x)
+            if xw is None:
+                xw, xe = ops.amax_of(ops.amax_compute(x))
+            w1, e1 = ops.amax_new()
+            w2, e2 = ops.amax_new()
+            w3, e3 = ops.amax_new()
+            d0, d2, d3 = a0.desc, a2.desc, a3.desc
+            d0.x_amax, d0.x_amax_epoch, d0.out_amax, d0.out_amax_epoch = xw, xe, w1, e1
+            if self.has_ds:
+                d1 = arr[1].desc
+                d1.x_amax, d1.x_amax_epoch = xw, xe
+            d2.x_amax, d2.x_amax_epoch, d2.out_amax, d2.out_amax_epoch = w1, e1, w2, e2
+            d3.x_amax, d3.x_amax_epoch, d3.out_amax, d3.out_amax_epoch = w2, e2, w3, e3
+        ops.L.check(ops.L.lib().abr_conv_run(self.ptr, n), "conv_run (bottleneck forward)")
+        if self.h3:
+            ops.amax_tag(out, w3, e3)
+        return out
+
+
+def _numel(shape):
+    n = 1
+    for v in shape:
+        n *= v
+    return n
+
+
 class Bottleneck(nn.Module):
     """resnet.py:242-346 (BottleneckWithFixedBatchNorm :371-395): 1x1(stride) -> 3x3 -> 1x1 (+identity / 1x1(stride) downsample) -> ReLU."""
 
@@ -164,6 +276,16 @@ class Bottleneck(nn.Module):
     # x, returns NHWC tensors.  `stride` may be overridden to 1 when the caller already sub-sampled (bin_step=2 ROIAlign)
     def fwd(self, x, save, stride=None):
         s = self.stride if stride is None else stride
+        if (not save and BLOCK_PLANS and ops.H3_TAGS and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+                and not (self.math == ops.MATH_BF16X6 and ops.FUSE_TAIL64 and self.conv2.weight.shape[0] == 64)):
+            plans = self.__dict__.setdefault("_fwd_plans", {})
+            key = (x.shape, s, self.math)
+            plan = plans.get(key)
+            if plan is None or not plan.valid():
+                if len(plans) > 32:       # (ragged batches: every image size brings its own tables)
+                    plans.clear()
+                plan = plans[key] = _FwdPlan(self, x.shape, s)
+            return plan.run(x), None
         s1, b1 = self.bn1.scale_bias()
         s2, b2 = self.bn2.scale_bias()
         s3, b3 = self.bn3.scale_bias()

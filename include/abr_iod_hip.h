@@ -336,6 +336,29 @@ typedef struct abr_prep_item {
     int64_t w_version;
 } abr_prep_item;
 int abr_conv_prepare_batch(const abr_prep_item* items_host, int n, void* stream);
+
+/* A table of conv calls in ONE library call (round 5: the host side of a bottleneck's forward or backward pass is four to ten of the calls above,
+ * ~12 us of interpreter and binding time each; a host wrapper keeps the table of a (block, input shape) with everything that does not change from
+ * step to step filled in and writes only this step's pointers).  Ops run in table order, each on ITS stream:
+ *   ABR_OP_FORWARD      abr_conv_forward(&desc, a = x, b = w, out, stream)
+ *   ABR_OP_WGRAD        abr_conv_wgrad(&desc, a = x, b = gy, out = dw, stream)
+ *   ABR_OP_STREAM_WAIT  abr_stream_wait_stream(stream, other)            -- `stream` waits for what `other` has queued so far
+ * Stops at the first failing op and returns its status (abr_last_error names it).  The reference's counterpart: one cuDNN call per conv from
+ * ATen, driven by the Python of modeling/backbone/resnet.py:327-346. */
+#define ABR_OP_FORWARD 0
+#define ABR_OP_WGRAD 1
+#define ABR_OP_STREAM_WAIT 2
+typedef struct abr_conv_op {
+    int32_t kind;
+    int32_t reserved;
+    abr_conv_desc desc;
+    const float* a;
+    const float* b;
+    float* out;
+    void* stream;
+    void* other;
+} abr_conv_op;
+int abr_conv_run(const abr_conv_op* ops, int n);
 /* The library keeps this derived data per (weight address, kind, w_version) -- 36/9 of each wide 3x3 weight, 1.5x of every other bf16x6 weight.  The cache is bounded
  * (least-recently-used entries go when it exceeds ABR_WINO_CACHE_MB, default 4096); abr_conv_cache_clear drops every entry after waiting
  * for the streams that use them (call it when a model's parameter storage is released or rebuilt), abr_conv_cache_bytes reports its size. */

@@ -1021,3 +1021,41 @@ def test_avgpool_backward_fused_with_the_relu_of_its_input():
     assert torch.equal(got, want)
     ref = (g.view(37, 1, 1, 64) / 16.0).expand(37, 4, 4, 64) * (y > 0)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6", "f32"])
+def test_bottleneck_forward_table_equals_the_per_conv_calls(math, monkeypatch):
+    """One abr_conv_run per bottleneck forward (resnet.py::_FwdPlan: the block's four abr_conv_op with everything constant filled in once) against
+    the four conv_forward calls it replaces: same kernels, same arguments -> bit-identical outputs and an equally valid amax tag; with and without
+    a downsample branch, stride 1 / 2, a second input shape, and after the weights moved (new version: the table is still valid, its planes are not)"""
+    from abr_iod_amd import ops
+    from abr_iod_amd.modeling.backbone import resnet as R
+    m = {"f16x3": ops.MATH_F16X3, "bf16x6": ops.MATH_BF16X6, "f32": ops.MATH_F32}[math]
+    torch.manual_seed(11)
+    for cin, cb, cout, stride in ((256, 128, 512, 2), (512, 128, 512, 1), (64, 64, 256, 1)):
+        blk = R.Bottleneck(cin, cb, cout, stride).cuda()
+        blk.math = m
+        for bn in (blk.bn1, blk.bn2, blk.bn3) + ((blk.downsample[1],) if blk.downsample is not None else ()):
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1); bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.invalidate()
+        R.bump_param_version()
+        with torch.no_grad():
+            for shape in ((2, 20, 24, cin), (1, 9, 13, cin)):
+                x = torch.randn(shape, device="cuda")
+                monkeypatch.setattr(R, "BLOCK_PLANS", False)
+                ref, _ = blk.fwd(x, False)
+                monkeypatch.setattr(R, "BLOCK_PLANS", True)
+                for rep in range(2):
+                    got, saved = blk.fwd(x, False)
+                    assert saved is None and torch.equal(got, ref), (math, cin, shape, rep)
+                    assert (ops.amax_of(got)[0] is not None) == (m == ops.MATH_F16X3)
+            if not (m == ops.MATH_BF16X6 and cb == 64):
+                assert len(blk.__dict__.get("_fwd_plans", {})) == 2
+            blk.conv2.weight.mul_(1.5)          # the weights move (as after an optimiser step): new version, same table
+            R.bump_param_version()
+            x = torch.randn(2, 20, 24, cin, device="cuda")
+            monkeypatch.setattr(R, "BLOCK_PLANS", False)
+            ref, _ = blk.fwd(x, False)
+            monkeypatch.setattr(R, "BLOCK_PLANS", True)
+            got, _ = blk.fwd(x, False)
+            assert torch.equal(got, ref)
+    assert ops.x6_range_flags(reset=True) == 0
