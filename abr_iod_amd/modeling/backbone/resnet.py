@@ -314,6 +314,8 @@ class Bottleneck(nn.Module):
         s2, _ = self.bn2.scale_bias()
         s3, _ = self.bn3.scale_bias()
         g = gout if g_masked else ops.relu_backward(gout, out, inplace=g_owned)   # through the block's final ReLU
+        if BLOCK_PLANS:
+            return self._bwd_pairs(x, o1, o2, s, v2, g, need_dx, mask_dx, s1, s2, s3)
         ops.conv_wgrad_async(o2, g, _grad_buf(self.conv3.weight), 1, 0, scale=s3, math=self.math)
         g2 = self._dgrad(g, self.conv3, s3, 0, mask=o2)    # dgrad + ReLU mask of o2
         ops.conv_wgrad_async(o1, g2, _grad_buf(self.conv2.weight), 1, 1, scale=s2, math=self.math, wino_v=v2)
@@ -337,6 +339,42 @@ class Bottleneck(nn.Module):
         if ds is not None:
             self._dgrad(g, ds[0], sd, 0, residual=gx, out=gx, out_hw=(H, W), out_stride=(s, s))
         return gx
+
+
+def _bwd_pairs(self, x, o1, o2, s, v2, g, need_dx, mask_dx, s1, s2, s3):
+    """Bottleneck.bwd with ONE library call per conv (ops.conv_backward: the weight gradient on its side stream + the input gradient on this one):
+    the same launches with the same arguments as the per-call form; on every stream the same order except that a downsample branch's weight
+    gradient now precedes conv1's (independent buffers)."""
+    m = self.math
+    c1, c2, c3 = self.conv1, self.conv2, self.conv3
+    g2 = ops.conv_backward(o2, g, _grad_buf(c3.weight), c3.dgrad_weight(s3), 1, 0, scale=s3, math=m, w_version=c3.version(), mask=o2)
+    g1 = ops.conv_backward(o1, g2, _grad_buf(c2.weight), c2.dgrad_weight(s2), 1, 1, scale=s2, math=m, w_version=c2.version(), wino_v=v2, mask=o1)
+    ds = self.downsample
+    sd = ds[1].scale_bias()[0] if ds is not None else None
+    if not need_dx:
+        ops.conv_backward(x, g1, _grad_buf(c1.weight), None, s, 0, scale=s1, math=m, dgrad=False)
+        if ds is not None:
+            ops.conv_backward(x, g, _grad_buf(ds[0].weight), None, s, 0, scale=sd, math=m, dgrad=False)
+        return None
+    if s == 1:
+        if ds is not None:
+            gx = ops.conv_backward(x, g, _grad_buf(ds[0].weight), ds[0].dgrad_weight(sd), s, 0, scale=sd, math=m, w_version=ds[0].version())
+            return ops.conv_backward(x, g1, _grad_buf(c1.weight), c1.dgrad_weight(s1), s, 0, scale=s1, math=m, w_version=c1.version(),
+                                     residual=gx, out=gx, mask=mask_dx)
+        return ops.conv_backward(x, g1, _grad_buf(c1.weight), c1.dgrad_weight(s1), s, 0, scale=s1, math=m, w_version=c1.version(),
+                                 residual=g, mask=mask_dx)
+    # stride-2 1x1 convs: gradient rows land on the even pixels of a zeroed tensor
+    B, H, W, _ = x.shape
+    assert mask_dx is None, "stride-2 blocks open a stage: their input is not a block output of the same stage"
+    gx = ops.conv_backward(x, g1, _grad_buf(c1.weight), c1.dgrad_weight(s1), s, 0, scale=s1, math=m, w_version=c1.version(),
+                           out_hw=(H, W), out_stride=(s, s))
+    if ds is not None:
+        ops.conv_backward(x, g, _grad_buf(ds[0].weight), ds[0].dgrad_weight(sd), s, 0, scale=sd, math=m, w_version=ds[0].version(),
+                          residual=gx, out=gx, out_hw=(H, W), out_stride=(s, s))
+    return gx
+
+
+Bottleneck._bwd_pairs = _bwd_pairs
 
 
 class _StageFn(Function):

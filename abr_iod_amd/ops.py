@@ -734,6 +734,111 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino
     return dw
 
 
+# ---- one library call for a conv's whole backward pass (round 5): the weight gradient on its side stream and the input gradient on the current
+# stream are the per-conv calls above (conv_wgrad_async + conv_forward on the dgrad copy) -- ~40 us of interpreter / binding time together,
+# ~40 convs per step.  The three-entry abr_conv_run table [side stream waits for this one, weight gradient, input gradient] of a (weight, shapes,
+# geometry) is kept with everything constant filled in; a call writes this step's pointers and amax words.  Same kernels, same arguments,
+# same order on each stream: bit-identical to the two calls.
+_bwd_plans = {}
+
+
+def conv_backward(x, gy, dw, wt, stride, pad, scale=None, math=MATH_F32, w_version=0, wino_v=None, dgrad=True, mask=None, residual=None,
+                  out=None, out_hw=None, out_stride=(1, 1)):
+    """dw += scale * gy^T im2col(x) on dw's side stream, and (dgrad) returns dL/dx = conv(gy, wt, stride 1, pad R-1-pad) with the epilogue
+    options of conv_forward (mask / residual / out / the strided scatter of a stride-2 conv).  x, gy contiguous NHWC fp32; wt = the flipped,
+    scaled dgrad copy [Cin,R,S,Cout] of the weight whose gradient buffer dw is.  Only inside an autograd backward (see conv_wgrad_async)."""
+    if not (WGRAD_SIDE_STREAM and H3_TAGS and x.is_contiguous() and gy.is_contiguous() and x.dtype == _f32 and gy.dtype == _f32):
+        conv_wgrad_async(x, gy, dw, stride, pad, scale=scale, math=math, wino_v=wino_v)
+        if not dgrad:
+            return None
+        return conv_forward(gy, wt, 1, dw.shape[1] - 1 - pad, mask=mask, residual=residual, out=out, out_hw=out_hw, out_stride=out_stride,
+                            math=math, w_version=w_version)
+    key = (dw.data_ptr(), x.shape, gy.shape, stride, pad, math, dgrad, out_hw, out_stride, wino_v is not None)
+    plan = _bwd_plans.get(key)
+    wtp = wt.data_ptr() if dgrad else 0
+    scp = scale.data_ptr() if scale is not None else 0
+    if plan is None or plan[2] != wtp or plan[3] != scp:
+        if len(_bwd_plans) > 4096:
+            _bwd_plans.clear()
+        arr = (L.ConvOp * 3)()
+        arr[0].kind = L.OP_STREAM_WAIT
+        arr[1].kind = L.OP_WGRAD
+        arr[1].desc = conv_desc(x.shape, dw.shape, stride, pad, scale=scale, math=math)
+        arr[1].out = dw.data_ptr()
+        if dgrad:
+            arr[2].kind = L.OP_FORWARD
+            arr[2].desc = conv_desc(gy.shape, wt.shape, 1, dw.shape[1] - 1 - pad, out_hw=out_hw, out_stride=out_stride, math=math)
+            arr[2].b = wtp
+        owner = _wg_owner.get(dw.data_ptr())
+        if owner is None:
+            owner = _wg_owner[dw.data_ptr()] = len(_wg_owner) % WGRAD_STREAMS
+        plan = _bwd_plans[key] = (arr, C.cast(arr, C.c_void_p), wtp, scp, owner, (scale, dw))
+    arr, ptr, _, _, owner, _ = plan
+    side = _wgrad_stream(x.device.index, owner).cuda_stream
+    if not _join_pending[0]:
+        _join_pending[0] = True
+        L.lib().abr_prof_mark_overlap(1)
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+    main = L.stream()
+    h3 = math == MATH_F16X3
+    xp, gp = x.data_ptr(), gy.data_ptr()
+    a0, a1 = arr[0], arr[1]
+    a0.stream, a0.other = side, main
+    a1.a, a1.b, a1.stream = xp, gp, side
+    d1 = a1.desc
+    d1.wino_v = wino_v.data_ptr() if wino_v is not None else None
+    if h3:
+        # operands without an amax word get one here, on the stream that produced them (see conv_wgrad_async)
+        gw, ge = amax_of(gy)
+        if gw is None:
+            gw, ge = amax_of(amax_compute(gy))
+        if wino_v is None:
+            xw, xe = amax_of(x)
+            if xw is None:
+                xw, xe = amax_of(amax_compute(x))
+        else:
+            xw, xe = amax_of(x)     # (the kept V carries its own word inside the library; x's, when there, is passed as the per-conv call does)
+        d1.x_amax, d1.x_amax_epoch, d1.gy_amax, d1.gy_amax_epoch = xw, (xe if xw is not None else 0), gw, ge
+    n_ops = 2
+    res = None
+    if dgrad:
+        n_ops = 3
+        a2 = arr[2]
+        d2 = a2.desc
+        fresh = out is None
+        if fresh:
+            if out_hw is not None:
+                out = torch.zeros((d2.B, d2.out_H, d2.out_W, d2.Cout), dtype=_f32, device=x.device)
+            else:
+                out = torch.empty((d2.B, d2.Ho, d2.Wo, d2.Cout), dtype=_f32, device=x.device)
+        a2.a, a2.out, a2.stream = gp, out.data_ptr(), main
+        d2.residual = residual.data_ptr() if residual is not None else None
+        d2.mask = mask.data_ptr() if mask is not None else None
+        d2.w_version = int(w_version)
+        emit = False
+        if h3:
+            strided = d2.out_sh != 1 or d2.out_sw != 1
+            if strided:
+                emit = fresh or (out is residual and getattr(out, "_abr_scatter", None) == (out.data_ptr(), d2.out_sh, d2.out_sw))
+            else:
+                emit = fresh or out is residual
+            d2.x_amax, d2.x_amax_epoch = gw, ge
+            if emit:
+                ow, oe = amax_new()
+                d2.out_amax, d2.out_amax_epoch = ow, oe
+            else:
+                d2.out_amax, d2.out_amax_epoch = None, 0
+        res = out
+    L.check(L.lib().abr_conv_run(ptr, n_ops), "conv_run (conv backward)")
+    if dgrad:
+        if emit:
+            amax_tag(out, ow, oe)
+        if fresh and out_hw is not None and (d2.out_sh != 1 or d2.out_sw != 1):
+            out._abr_scatter = (out.data_ptr(), d2.out_sh, d2.out_sw)
+    _wg_keep.append((x, gy, wino_v))
+    return res
+
+
 def pack_weights(w, out=None):
     """w [Cout,R,S,Cin] (or any [rows, K] fp32 matrix, K % 16 == 0) -> its fragment-packed exact bf16x3 planes (uint8 buffer of
     abr_conv_packed_bytes bytes) for conv_forward(..., math=MATH_BF16X6, w_planes=): the weights-direct bf16x6 kernel loads weight

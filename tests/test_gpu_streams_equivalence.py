@@ -102,3 +102,18 @@ def test_joint_roi_pass_equals_two_passes(width):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (l_j, l_2)
     rel = float((p_j - p_2).norm() / p_2.norm())
     assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("width", ["tiny", "full"])
+def test_one_call_per_bottleneck_pass_equals_the_per_conv_calls(width, monkeypatch):
+    """ABR_BLOCK_PLANS (round 5): the bottlenecks' no-backward forward passes as one abr_conv_run each and every conv's backward pass (weight
+    gradient on its side stream + input gradient) as one abr_conv_run -- the same launches with the same arguments, so four overlapped training
+    steps leave BIT-IDENTICAL parameters and losses with the tables on and off"""
+    from abr_iod_amd.modeling.backbone import resnet
+    ov = TINY if width == "tiny" else TINY[8:]
+    monkeypatch.setattr(resnet, "BLOCK_PLANS", True)
+    p_on, l_on = _run(True, ov, joint=True)
+    monkeypatch.setattr(resnet, "BLOCK_PLANS", False)
+    p_off, l_off = _run(True, ov, joint=True)
+    assert l_on == l_off, (l_on, l_off)
+    assert torch.equal(p_on, p_off), float((p_on - p_off).abs().max())
