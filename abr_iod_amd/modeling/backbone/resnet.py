@@ -120,8 +120,9 @@ BLOCK_PLANS = os.environ.get("ABR_BLOCK_PLANS", "1") != "0"
 class _FwdPlan(object):
     """the no-backward forward pass of one Bottleneck (conv1 [+ downsample] -> conv2 -> conv3 + identity) as an abr_conv_run table"""
 
-    def __init__(self, blk, x_shape, s):
+    def __init__(self, blk, x_shape, s, save=False):
         L = ops.L
+        self.save = save
         B, H, W, Cin = x_shape
         self.blk, self.math = blk, blk.math
         ds = blk.downsample
@@ -155,10 +156,20 @@ class _FwdPlan(object):
         i1, i2, i3 = 0, self.n - 2, self.n - 1
         n1, n2 = _numel(shapes[i1]), _numel(shapes[i2])
         nd = _numel(shapes[1]) if self.has_ds else 0
-        self.off = (0, n1, n1 + n2)            # o1, o2, identity branch inside the temporaries' buffer (floats)
-        self.tmp_floats = n1 + n2 + nd
+        if save:   # o1, o2 are kept for the backward pass (tensors of their own); only the identity branch is a temporary
+            self.off = (0, 0, 0)
+            self.tmp_floats = nd
+            self.o1_shape, self.o2_shape = shapes[i1], shapes[i2]
+            # the Winograd-domain input of conv2, kept for its weight gradient (ops.wino_v_alloc)
+            self.v_floats = 0
+            if ops.KEEP_WINO_V and blk.conv2.weight.requires_grad:
+                self.v_floats = int(L.lib().abr_conv_wino_v_floats(ops.C.byref(self.arr[i2].desc)))
+        else:
+            self.off = (0, n1, n1 + n2)        # o1, o2, identity branch inside the temporaries' buffer (floats)
+            self.tmp_floats = n1 + n2 + nd
         self.out_shape = shapes[i3]
         self.h3 = self.math == ops.MATH_F16X3
+        self.s = s
 
     def valid(self):
         blk = self.blk
@@ -175,12 +186,21 @@ class _FwdPlan(object):
     def run(self, x):
         arr, n = self.arr, self.n
         st = ops.L.stream()
-        tmp = torch.empty(self.tmp_floats, dtype=torch.float32, device=x.device)
-        out = torch.empty(self.out_shape, dtype=torch.float32, device=x.device)
-        base, xp = tmp.data_ptr(), x.data_ptr()
-        o1, o2 = base + 4 * self.off[0], base + 4 * self.off[1]
-        idt = base + 4 * self.off[2] if self.has_ds else xp
+        f32, dev = torch.float32, x.device
+        tmp = torch.empty(self.tmp_floats, dtype=f32, device=dev) if self.tmp_floats else None
+        out = torch.empty(self.out_shape, dtype=f32, device=dev)
+        base, xp = (tmp.data_ptr() if tmp is not None else 0), x.data_ptr()
         i2, i3 = n - 2, n - 1
+        v2 = None
+        if self.save:
+            t1, t2 = torch.empty(self.o1_shape, dtype=f32, device=dev), torch.empty(self.o2_shape, dtype=f32, device=dev)
+            o1, o2 = t1.data_ptr(), t2.data_ptr()
+            if self.v_floats:
+                v2 = torch.empty(self.v_floats, dtype=f32, device=dev)
+            arr[i2].desc.wino_v = v2.data_ptr() if v2 is not None else None
+        else:
+            o1, o2 = base + 4 * self.off[0], base + 4 * self.off[1]
+        idt = base + 4 * self.off[2] if self.has_ds else xp
         a0 = arr[0]
         a0.a, a0.out, a0.stream = xp, o1, st
         a0.desc.w_version = self.convs[0].version()
@@ -211,7 +231,12 @@ class _FwdPlan(object):
         ops.L.check(ops.L.lib().abr_conv_run(self.ptr, n), "conv_run (bottleneck forward)")
         if self.h3:
             ops.amax_tag(out, w3, e3)
-        return out
+        if not self.save:
+            return out, None
+        if self.h3:
+            ops.amax_tag(t1, w1, e1)
+            ops.amax_tag(t2, w2, e2)
+        return out, (x, t1, t2, out, self.s, v2)
 
 
 def _numel(shape):
@@ -276,16 +301,17 @@ class Bottleneck(nn.Module):
     # x, returns NHWC tensors.  `stride` may be overridden to 1 when the caller already sub-sampled (bin_step=2 ROIAlign)
     def fwd(self, x, save, stride=None):
         s = self.stride if stride is None else stride
-        if (not save and BLOCK_PLANS and ops.H3_TAGS and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
-                and not (self.math == ops.MATH_BF16X6 and ops.FUSE_TAIL64 and self.conv2.weight.shape[0] == 64)):
+        if (BLOCK_PLANS and ops.H3_TAGS and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+                and (save or not (self.math == ops.MATH_BF16X6 and ops.FUSE_TAIL64 and self.conv2.weight.shape[0] == 64))):
             plans = self.__dict__.setdefault("_fwd_plans", {})
-            key = (x.shape, s, self.math)
+            keep_v = bool(save and ops.KEEP_WINO_V and self.conv2.weight.requires_grad)
+            key = (x.shape, s, self.math, save, keep_v)
             plan = plans.get(key)
             if plan is None or not plan.valid():
                 if len(plans) > 32:       # (ragged batches: every image size brings its own tables)
                     plans.clear()
-                plan = plans[key] = _FwdPlan(self, x.shape, s)
-            return plan.run(x), None
+                plan = plans[key] = _FwdPlan(self, x.shape, s, save)
+            return plan.run(x)
         s1, b1 = self.bn1.scale_bias()
         s2, b2 = self.bn2.scale_bias()
         s3, b3 = self.bn3.scale_bias()
