@@ -9,6 +9,7 @@ import sys
 
 import torch
 
+os.environ["ABR_BLOCK_PLANS"] = "0"   # this tool times the per-conv host calls: the bottlenecks' op tables (abr_conv_run) would bypass its hooks
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from abr_iod_amd import ops  # noqa: E402
 from abr_iod_amd.engine import train_step  # noqa: E402
