@@ -10,6 +10,7 @@ import sys
 import torch
 
 os.environ["ABR_BLOCK_PLANS"] = "0"   # this tool times the per-conv host calls: the bottlenecks' op tables (abr_conv_run) would bypass its hooks
+os.environ["ABR_WGRAD_STREAM"] = "0"  # ... and brackets every call with events on the CURRENT stream: weight gradients must run there too
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from abr_iod_amd import ops  # noqa: E402
 from abr_iod_amd.engine import train_step  # noqa: E402
