@@ -16,10 +16,10 @@ from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batc
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--math", default="bf16x6")
+ap.add_argument("--math", default=None, choices=[None, "f32", "bf16x6", "f16x3"], help="contraction arithmetic (default: the library's default, f16x3)")
 a = ap.parse_args()
-if a.math == "f32":
-    os.environ["ABR_CONV_MATH"] = "f32"
+if a.math:
+    os.environ["ABR_CONV_MATH"] = a.math
 cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, ims_per_batch=4)
 _, model = build_models(cfg_s, cfg_t, seed=0)
 model.eval()
@@ -57,5 +57,5 @@ torch.cuda.synchronize()
 dev_ms = sum(x.elapsed_time(y) for x, y in ev) / len(ev)
 print(json.dumps({"metric": "test-time images/sec (R50-C4 Faster R-CNN, eval mode)", "value": round(a.batch * a.iters / dt, 2), "unit": "img/s",
                   "ms_per_batch": round(1e3 * dt / a.iters, 3), "batch": a.batch, "device_ms_per_batch_forward_only": round(dev_ms, 3),
-                  "detections_per_image": round(n_det / (a.batch * a.iters), 1), "math": a.math, "data": "synthetic 600x1000, random-init weights",
+                  "detections_per_image": round(n_det / (a.batch * a.iters), 1), "math": getattr(model, "conv_math", a.math), "data": "synthetic 600x1000, random-init weights",
                   "config": {"workload": "TEST.IMS_PER_BATCH 8, PRE/POST_NMS_TOP_N_TEST 6000/1000, DETECTIONS_PER_IMG 100 (configs/voc/15-5/*RB_Target_model.yaml)"}}))

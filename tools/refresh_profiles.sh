@@ -17,6 +17,7 @@ timeout 300 python bench.py --task 10-5 --mosaic-squares --steps 20 > $O/${R}_be
 timeout 300 python bench.py --task 10-5 --mosaic-squares --math bf16 --steps 20 --no-kernel-timing > $O/${R}_bench_10-5_mosaic_squares_bf16_backbone.jsonl 2>/dev/null
 timeout 300 python bench.py --share-frozen-prefix $B > $O/${R}_bench_shared_frozen_prefix.jsonl 2>/dev/null
 timeout 300 python bench.py --math bf16x6 $B > $O/${R}_bench_bf16x6.jsonl 2>/dev/null
+timeout 300 python tools/bench_eval.py 2>/dev/null | tail -1 > $O/${R}_bench_eval.jsonl
 # the per-rank workloads of BASELINE configs[3] / configs[4] (8 ranks x batch 2) on ONE GPU: what the first scaling run is divided by
 timeout 300 python bench.py --task 10-10 --batch-per-gpu 2 $B > $O/${R}_bench_10-10_b2.jsonl 2>/dev/null
 timeout 300 python bench.py --task 10-5 --batch-per-gpu 2 --mosaic-squares --steps 20 > $O/${R}_bench_10-5_b2_mosaic_squares.jsonl 2>/dev/null
