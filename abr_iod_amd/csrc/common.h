@@ -11,6 +11,11 @@
 
 namespace abr {
 
+// ReLU as torch computes it (at::relu = clamp_min(0): NaN in, NaN out).  fmaxf / v_max_f32 return the OTHER operand for a NaN, which would turn a
+// diverged activation into a clean zero and hide it from the loss and from the range guard; the reference's run shows NaN (modeling/backbone/resnet.py:339-346).
+__device__ __forceinline__ float relu_f(const float v) { return v < 0.f ? 0.f : v; }
+
+
 void set_error(const char* fmt, ...);
 
 #define ABR_REQUIRE(cond, ...)                 \

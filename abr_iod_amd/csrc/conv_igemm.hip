@@ -169,7 +169,7 @@ __device__ __forceinline__ unsigned epilogue_rows(const ConvP& p, f32x16 (&acc)[
                     const float4 rr = make_float4(rr_.x, rr_.y, rr_.z, rr_.w);
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
-                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (p.relu) { v.x = abr::relu_f(v.x); v.y = abr::relu_f(v.y); v.z = abr::relu_f(v.z); v.w = abr::relu_f(v.w); }
                 if (p.mask) {
                     typedef float nt4m __attribute__((ext_vector_type(4)));
                     const nt4m mm_ = __builtin_nontemporal_load(reinterpret_cast<const nt4m*>(p.mask + row_off + ncol));
@@ -187,7 +187,7 @@ __device__ __forceinline__ unsigned epilogue_rows(const ConvP& p, f32x16 (&acc)[
                     if (ncol + e >= p.Cout) break;
                     float t = vv[e];
                     if (p.residual) t += p.residual[row_off + ncol + e];
-                    if (p.relu) t = fmaxf(t, 0.f);
+                    if (p.relu) t = abr::relu_f(t);
                     if (p.mask) t = p.mask[row_off + ncol + e] > 0.f ? t : 0.f;
                     o[e] = t;
                     amax_bits = max(amax_bits, __float_as_uint(t) & 0x7FFFFFFFu);
@@ -673,185 +673,9 @@ int launch_bf16(const ConvP& p, const float* x, const float* w, float* out, hipS
 constexpr int BKX = 32;
 constexpr int LDX = BKX + 8;   // LDS row pitch in bf16 elements (80 B)
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_x6_kernel(const ConvP p, const float* __restrict__ x_, const float* __restrict__ w_,
-                                                             float* __restrict__ out_) {
-    const float* x = x_;
-    const float* w = w_;
-    float* out = out_;
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int NA = BM / 32, NB = BN / 32;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    abr::prof_stamp_begin(p.prof_ts);
-    __bf16* As = reinterpret_cast<__bf16*>(smem);  // [3][BM][LDX]
-    __bf16* Bs = As + 3 * BM * LDX;                // [3][BN][LDX]
-
-    int tile = (int)abr::xcd_remap(blockIdx.x, gridDim.x);
-    if (p.nbatch > 1) {
-        const int bt = tile / p.tiles_pb;
-        tile -= bt * p.tiles_pb;
-        x += bt * p.a_bs; w += bt * p.w_bs; out += bt * p.o_bs;
-    }
-    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    // A thread stores 8 B per plane at (row * 80 + kq * 8) B.  ds_write_b64 is served in groups of 16 consecutive lanes over 32 banks: with rows
-    // (s, s + 1) in a group the two 64 B runs start 20 dwords apart and share 4 banks (every store took 2 LDS cycles per group: 25 - 33 % of all LDS
-    // cycles, SQ_LDS_BANK_CONFLICT of profiles/r03_pmc_mfma.json).  Rows (s, s + 4) start 80 dwords = 16 banks apart: conflict-free.  Lane bit 3
-    // therefore carries row bit 2 and lane bit 5 row bit 0; each 8-lane set still fetches one 128 B row segment, the fragment reads do not change.
-    const int kq = tid & 7, srow = ((tid >> 3) & ~5) | (((tid >> 3) & 1) << 2) | ((tid >> 5) & 1);
-
-    constexpr unsigned kOOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, p.w_bytes, 0x00020000);
-    int a_hi0[NA], a_wi0[NA], a_off0[NA];
-    bool a_ok[NA];
-#pragma unroll
-    for (int i = 0; i < NA; i++) {
-        const int m = m0 + srow + 32 * i;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
-        unsigned b, rem, ho, wo;
-        p.d_howo.divmod((unsigned)mm, b, rem);
-        p.d_wo.divmod(rem, ho, wo);
-        a_hi0[i] = (int)ho * p.stride - p.pad;
-        a_wi0[i] = (int)wo * p.stride - p.pad;
-        a_off0[i] = (((int)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + kq * 4;
-    }
-    unsigned b_off0[NB];   // weights: slot i = row srow + 32 i, 16 B = 4 k
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        const int n = n0 + srow + 32 * i;
-        b_off0[i] = n < p.Cout ? (unsigned)(n * p.K + kq * 4) * 4u : kOOB;
-    }
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    // TWO tiles in flight: a k-tile is only 48 MFMAs (~1500 cycles) per wave, well under the latency of the loads, so tile kt+2 is
-    // requested before tile kt is multiplied and is split / parked in LDS one iteration later (register sets alternate by parity)
-    u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
-    auto load_tile = [&](int kt, u32x4 (&ra)[NA], u32x4 (&rb)[NB], bool valid) {
-        const int k0 = kt * BKX;
-        unsigned rs, c0, r, s;
-        p.d_cin.divmod((unsigned)k0, rs, c0);
-        p.d_s.divmod(rs, r, s);
-        const int delta = ((int)r * p.W + (int)s) * p.Cin + (int)c0;
-#pragma unroll
-        for (int i = 0; i < NA; i++) {
-            const int hi = a_hi0[i] + (int)r, wi = a_wi0[i] + (int)s;
-            const bool ok = valid & a_ok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(a_off0[i] + delta) * 4u : kOOB), 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; i++) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(valid ? b_off0[i] : kOOB), k0 * 4, 0);
-    };
-    // Range guard of the exact split (abr_x6_range_flags, include/abr_iod_hip.h): every operand element is inspected ONCE per GEMM --
-    // the A rows by the workgroups of the first n-tile column, the weights by those of the first m-tile row (a workgroup-uniform
-    // branch; the other workgroups pay nothing).  bmin: smallest (bits << 1) - 1 seen (zero wraps to 0xFFFFFFFF and never wins);
-    // nonfin: x * 0 summed (NaN as soon as any element is inf or NaN).
-    const bool chk_a = p.x6_flags && tile_n == 0, chk_b = p.x6_flags && tile_m == 0;
-    unsigned bmin = 0xFFFFFFFFu;
-    float nonfin = 0.f;
-    auto inspect = [&](const u32x4 v) {
-        const unsigned b0 = (v.x << 1) - 1u, b1 = (v.y << 1) - 1u, b2 = (v.z << 1) - 1u, b3 = (v.w << 1) - 1u;
-        bmin = min(min(bmin, min(b0, b1)), min(b2, b3));
-        nonfin = fmaf(__uint_as_float(v.x), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.y), 0.f, nonfin);
-        nonfin = fmaf(__uint_as_float(v.z), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.w), 0.f, nonfin);
-    };
-    // exact three-way split of four fp32 values into bf16 planes
-    auto split_store = [](const u32x4 v, __bf16* dst, int plane_stride) {
-        uint2 o0, o1, o2;
-        x6_split4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), o0, o1, o2);
-        *reinterpret_cast<uint2*>(dst) = o0;
-        *reinterpret_cast<uint2*>(dst + plane_stride) = o1;
-        *reinterpret_cast<uint2*>(dst + 2 * plane_stride) = o2;
-    };
-    auto store_tile = [&](u32x4 (&ra)[NA], u32x4 (&rb)[NB]) {
-        if (chk_a) {
-#pragma unroll
-            for (int i = 0; i < NA; i++) inspect(ra[i]);
-        }
-        if (chk_b) {
-#pragma unroll
-            for (int i = 0; i < NB; i++) inspect(rb[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < NA; i++) split_store(ra[i], As + (srow + 32 * i) * LDX + kq * 4, BM * LDX);
-#pragma unroll
-        for (int i = 0; i < NB; i++) split_store(rb[i], Bs + (srow + 32 * i) * LDX + kq * 4, BN * LDX);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    const int l31 = lane & 31, lh = lane >> 5;
-    const __bf16* a_frag = As + (wm * (TM * 32) + l31) * LDX + lh * 8;
-    const __bf16* b_frag = Bs + (wn * (TN * 32) + l31) * LDX + lh * 8;
-    auto compute_tile = [&]() {
-#pragma unroll
-        for (int u = 0; u < BKX / 16; u++) {
-            bf16x8 fa[TM][3], fb[TN][3];
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int pl = 0; pl < 3; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * BM * LDX + i * 32 * LDX + u * 16);
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-#pragma unroll
-                for (int pl = 0; pl < 3; pl++) fb[j][pl] = *reinterpret_cast<const bf16x8*>(b_frag + pl * BN * LDX + j * 32 * LDX + u * 16);
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) {   // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-                }
-        }
-    };
-
-    const int nk = p.K / BKX;
-    {
-        load_tile(0, ra0, rb0, true);
-        load_tile(1, ra1, rb1, nk > 1);
-        store_tile(ra0, rb0);
-        __syncthreads();
-        int kt = 0;
-        for (; kt + 2 < nk; kt += 2) {   // LDS holds tile kt, set 1 holds tile kt+1 (possibly still in flight), set 0 is free
-            load_tile(kt + 2, ra0, rb0, true);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_tile();
-            __syncthreads();
-            store_tile(ra1, rb1);
-            __syncthreads();
-            load_tile(kt + 3, ra1, rb1, kt + 3 < nk);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_tile();
-            __syncthreads();
-            store_tile(ra0, rb0);
-            __syncthreads();
-        }
-        if (kt + 1 < nk) {   // one more tile, waiting in set 1
-            compute_tile();
-            __syncthreads();
-            store_tile(ra1, rb1);
-            __syncthreads();
-        }
-    }
-    compute_tile();
-    if (chk_a | chk_b) abr::x6_report(bmin, nonfin, p.x6_flags);
-    __syncthreads();  // the epilogue reuses the operand LDS
-    const unsigned ob = epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out);
-    if (p.out_amax) abr::h3_amax_emit(p.out_amax, p.out_epoch, ob);
-    abr::prof_stamp_end(p.prof_ts);
-}
+// (rounds 1-5 also carried conv_igemm_x6_kernel, which split the WEIGHT tile in every workgroup, for calls without packed planes, and the opt-in
+//  intra-workgroup split-K conv_igemm_x6wk_kernel; round 6 retired both: a call without planes packs them into stream scratch first -- same
+//  products in the same order, bit-identical results -- and every bf16x6 / f16x3 / bf16 contraction runs on the weights-direct kernel below.)
 
 // ------------------------------------------------------------------------------------------------------------------------
 // bf16x6 with the WEIGHT operand fed straight from global memory into the MFMA registers (conv_igemm_x6w_kernel).
@@ -1097,179 +921,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     abr::prof_stamp_end(p.prof_ts);
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// conv_igemm_x6wk_kernel: the weights-direct bf16x6 GEMM for SMALL grids with LONG K (layer3's conv1 and the dgrad of its conv3: 9576 x 256 x
-// 1024 = 600 tiles of 64 x 64 on 256 CUs, 32 k-tiles each).  Such a launch is a handful of workgroups per CU walking a long chain of k-tiles,
-// every link of it a global load -> split -> LDS -> barrier -> MFMA round trip of ~1.4 us against 0.2 us of MFMA work (52 us per conv, a
-// quarter of the MFMA-bound time).  Here the FOUR WAVES of a workgroup split K instead of the tile: wave w owns k-tiles w, w + 4, ... of the whole
-// 64 x 64 tile (2 x 2 accumulators), with its own operand planes in LDS (15 KB) -- so the main loop has NO workgroup barrier at all (a wave
-// reading what it wrote needs only its own lgkmcnt), the chain is a quarter as long, and four independent chains share each SIMD set.  The four
-// partial tiles meet in LDS once, wave w adds the partials of block w in wave order (fixed order: deterministic) and runs the usual epilogue.
-// PLAIN addressing only (1x1, stride 1, no padding).  Summation order differs from the k-sequential kernels by the 4-way interleave.
-// ------------------------------------------------------------------------------------------------------------------------
-constexpr size_t kX6wkLds = 4 * 16384;
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_igemm_x6wk_kernel(const ConvP p, const float* __restrict__ x,
-                                                                                                       float* __restrict__ out) {
-    constexpr int BM = 64, NA = 8;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    abr::prof_stamp_begin(p.prof_ts);
-    const int tile = (int)abr::xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char* region = reinterpret_cast<char*>(smem) + wave * 16384;          // this wave's 16 KB: operand planes [3][64][LDX], later partials / staging
-    __bf16* As = reinterpret_cast<__bf16*>(region);
-    const int kq = lane & 7, t8 = lane >> 3;
-    const int srow = (t8 & ~5) | ((t8 & 1) << 2) | ((t8 >> 2) & 1);       // conflict-free ds_write_b64 rows (see the x6w kernel)
-    constexpr unsigned kOOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_planes), 0, p.wp_bytes, 0x00020000);
-    unsigned a_voff[NA];
-#pragma unroll
-    for (int i = 0; i < NA; i++) {
-        const int m = m0 + srow + 8 * i;
-        a_voff[i] = m < p.M ? (unsigned)(m * p.Cin + kq * 4) * 4u : kOOB;
-    }
-    const int KS = p.K / 16;
-    unsigned bo[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int nb = n0 / 32 + j;
-        bo[j] = nb < p.wp_nblocks ? (unsigned)(((size_t)nb * KS * 3 * 64 + lane) * 16) : kOOB;
-    }
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 ra[NA];
-    u32x4 fbr[2][2][3];
-    auto load_a = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < NA; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)a_voff[i], kt * BKX * 4, 0);
-    };
-    auto load_b = [&](int kt, int u) {
-        const int ks = kt * 2 + u;
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) fbr[u][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rwp, (int)bo[j], (ks * 3 + pl) * 1024, 0);
-    };
-    const bool chk_a = p.x6_flags && tile_n == 0;
-    unsigned bmin = 0xFFFFFFFFu;
-    float nonfin = 0.f;
-    auto store_a = [&]() {
-        if (chk_a) {
-#pragma unroll
-            for (int i = 0; i < NA; i++) {
-                const u32x4 v = ra[i];
-                const unsigned b0 = (v.x << 1) - 1u, b1 = (v.y << 1) - 1u, b2 = (v.z << 1) - 1u, b3 = (v.w << 1) - 1u;
-                bmin = min(min(bmin, min(b0, b1)), min(b2, b3));
-                nonfin = fmaf(__uint_as_float(v.x), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.y), 0.f, nonfin);
-                nonfin = fmaf(__uint_as_float(v.z), 0.f, nonfin); nonfin = fmaf(__uint_as_float(v.w), 0.f, nonfin);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NA; i++) {
-            const u32x4 v = ra[i];
-            __bf16* dst = As + (srow + 8 * i) * LDX + kq * 4;
-            uint2 o0, o1, o2;
-            x6_split4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), o0, o1, o2);
-            *reinterpret_cast<uint2*>(dst) = o0;
-            *reinterpret_cast<uint2*>(dst + BM * LDX) = o1;
-            *reinterpret_cast<uint2*>(dst + 2 * BM * LDX) = o2;
-        }
-    };
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const __bf16* a_frag = As + l31 * LDX + lh * 8;
-    const int nk = p.K / BKX;
-    constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
-    auto compute_tile = [&](int kt_next) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            bf16x8 fa[2][3], fb[2][3];
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int pl = 0; pl < 3; pl++) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * BM * LDX + i * 32 * LDX + u * 16);
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int pl = 0; pl < 3; pl++) fb[j][pl] = *reinterpret_cast<const bf16x8*>(&fbr[u][j][pl]);
-#pragma unroll
-            for (int t = 0; t < 6; t++)
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa[t]], fb[j][pb[t]], acc[i][j], 0, 0, 0);
-            if (kt_next < nk) load_b(kt_next, u);
-            if (u == 0) __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // this wave's k-tiles: wave, wave + 4, ...  (LDS traffic of one wave is ordered: the fragment reads behind the stores need no barrier, only the
-    // wave's own lgkmcnt, which the compiler tracks; the stores of tile t + 4 behind the reads of tile t likewise)
-    int kt = wave;
-    if (kt < nk) {
-        load_b(kt, 0);
-        load_b(kt, 1);
-        load_a(kt);
-        store_a();
-        for (; kt + 4 < nk; kt += 4) {
-            load_a(kt + 4);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_tile(kt + 4);
-            store_a();
-        }
-        compute_tile(nk);
-    }
-    if (chk_a) abr::x6_report(bmin, nonfin, p.x6_flags);
-    // ---- the four partial tiles meet: every wave parks its accumulators in its own region (lane-linear: conflict-free), wave w adds block w's
-    float* part = reinterpret_cast<float*>(region);
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) part[((i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
-    __syncthreads();
-    f32x16 sum[1][1];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        float v = smem[(0 * 4096) + (wave * 16 + r) * 64 + lane];
-        v += smem[(1 * 4096) + (wave * 16 + r) * 64 + lane];
-        v += smem[(2 * 4096) + (wave * 16 + r) * 64 + lane];
-        v += smem[(3 * 4096) + (wave * 16 + r) * 64 + lane];
-        sum[0][0][r] = v;
-    }
-    __syncthreads();   // every partial has been read: the regions become the epilogue's staging
-    const unsigned ob = epilogue_rows<1, 1>(p, sum, reinterpret_cast<float*>(region), m0 + (wave >> 1) * 32, n0 + (wave & 1) * 32, lane, out);
-    if (p.out_amax) abr::h3_amax_emit(p.out_amax, p.out_epoch, ob);
-    abr::prof_stamp_end(p.prof_ts);
-}
-
-static int launch_x6wk(const ConvP& p, const float* x, float* out, hipStream_t st) {
-    ConvP q = p;
-    q.tiles_m = (p.M + 63) / 64;
-    q.tiles_n = (p.Cout + 63) / 64;
-    q.tiles_pb = q.tiles_m * q.tiles_n;
-    q.nbatch = 1;
-    q.n_full = q.tiles_pb; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
-    q.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_x6wk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX6wkLds);
-        attr_set = true;
-    }
-    q.prof_ts = abr::prof_stamp_slot(abr::PROF_X6W_64x64, 2.0 * (double)p.M * (double)p.Cout * (double)p.K);
-    abr::prof_add_bytes(abr::PROF_X6W_64x64, 4.0 * (double)p.M * p.K + 6.0 * (double)p.Cout * p.K +
-                                                 4.0 * (double)p.M * p.Cout * (1.0 + (p.residual ? 1.0 : 0.0) + (p.mask ? 1.0 : 0.0)));
-    conv_igemm_x6wk_kernel<<<(unsigned)q.tiles_pb, 256, kX6wkLds, st>>>(q, x, out);
-    return 0;
-}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Fused TAIL of a 64-wide bottleneck that has no backward pass (the frozen stem's layer1, run by BOTH models every step):
@@ -1447,7 +1098,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 float v0 = acc[i][r] * sc + bi, v1 = acc[i][r + 1] * sc + bi;
-                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                if (p.relu) { v0 = abr::relu_f(v0); v1 = abr::relu_f(v1); }
                 if (q.x6_flags) {   // conv3's operand: inspected once, as the stand-alone launch's first n-tile column does
                     const unsigned b0 = (__float_as_uint(v0) << 1) - 1u, b1 = (__float_as_uint(v1) << 1) - 1u;
                     bmin2 = min(bmin2, min(b0, b1));
@@ -1519,7 +1170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                 float4 v = *reinterpret_cast<const float4*>(ep + row * EP + c4);
                 v.x = v.x * sc4.x + bi4.x; v.y = v.y * sc4.y + bi4.y; v.z = v.z * sc4.z + bi4.z; v.w = v.w * sc4.w + bi4.w;
                 if (q.residual) { v.x += res[i][it].x; v.y += res[i][it].y; v.z += res[i][it].z; v.w += res[i][it].w; }
-                if (q.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (q.relu) { v.x = abr::relu_f(v.x); v.y = abr::relu_f(v.y); v.z = abr::relu_f(v.z); v.w = abr::relu_f(v.w); }
                 if (m < q.M) *reinterpret_cast<float4*>(out + (size_t)m * q.Cout + ncol) = v;
             }
         }
@@ -1717,29 +1368,6 @@ int launch_x6w(const ConvP& p, const float* x, float* out, hipStream_t st) {
                         : (p.nprod == 3 ? launch_x6w_np<BM, BN, WM, WN, 3>(p, x, out, st) : launch_x6w_np<BM, BN, WM, WN, 6>(p, x, out, st));
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_x6(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
-    ConvP q = p;
-    q.tiles_m = (p.M + BM - 1) / BM;
-    q.tiles_n = (p.Cout + BN - 1) / BN;
-    q.tiles_pb = q.tiles_m * q.tiles_n;
-    if (q.nbatch < 1) q.nbatch = 1;
-    q.n_full = q.tiles_pb * q.nbatch; q.split = 1; q.ws = nullptr; q.cnt = nullptr;
-    q.x6_flags = abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr;
-    constexpr size_t lds_op = sizeof(__bf16) * 3 * (BM + BN) * LDX;
-    constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
-    const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
-    auto kern = conv_igemm_x6_kernel<BM, BN, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    constexpr int prof_id = BM == 128 ? (BN == 128 ? abr::PROF_X6_128x128 : abr::PROF_X6_128x64) : abr::PROF_X6_64x64;   // one row per template instance
-    q.prof_ts = abr::prof_stamp_slot(prof_id, 2.0 * (double)p.M * (double)p.Cout * (double)p.K * q.nbatch);
-    kern<<<(unsigned)(q.tiles_pb * q.nbatch), 256, lds, st>>>(q, x, w, out);
-    return 0;
-}
 
 // split-K scratch: partial tiles (64 KB each for 128x128) + tickets, one set per stream (streams may run convs concurrently)
 struct SplitWs { float* ws = nullptr; int* cnt = nullptr; };
@@ -2024,15 +1652,13 @@ static void dispatch_igemm_bf16(const ConvP& p, const float* x, const float* w, 
     }
 }
 
-// bf16x6 math mode (fp32-accurate): same tile rules as the bf16 mode.  With packed weight planes (p.w_planes: the caller's, or the
-// library's per-version cache) the weights-direct kernel runs, else the kernel that splits the weight tile in every workgroup.
-static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {
+// The split arithmetics (bf16x6, f16x3, and bf16 as their one-product form): same tile rules as the bf16 mode.  p.w_planes -- the caller's, the
+// library's per-version cache, or planes packed into stream scratch for a one-off call -- is never null here: the weights-direct kernel is the only one.
+static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* /*w*/, float* out, hipStream_t st) {
     const int cus = num_cus();
     const int64_t nb = p.nbatch > 1 ? p.nbatch : 1;
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * nb;
     const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64) * nb;
-    static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
-    const bool wd = p.w_planes != nullptr && (direct_on || p.nprod == 3);   // (f16x3 has no in-kernel weight split: always weights-direct)
     static const int force = getenv("ABR_X6_TILE") ? atoi(getenv("ABR_X6_TILE")) : 0;   // experiments: 1 = 128x128, 2 = 128x64, 3 = 64x64
     static const int force_maxk = getenv("ABR_X6_TILE_MAXK") ? atoi(getenv("ABR_X6_TILE_MAXK")) : 1 << 30;
     // Short-K convs (K <= 256: the 1x1 convs of layer1-3 and their dgrads) take 64x64 tiles whatever the grid size: alone they are
@@ -2048,31 +1674,13 @@ static void dispatch_igemm_x6(const ConvP& p, const float* x, const float* w, fl
     else if (p.Cout > 64 && t128 * 10 >= (int64_t)t128_min10 * cus) tile = 1;
     else if (t12864 * 10 >= (int64_t)t12864_min10 * cus || p.Cout <= 64) tile = 2;
     else tile = 3;
-    // small grid + long K + plain addressing: the intra-workgroup split-K form (conv_igemm_x6wk_kernel).  OPT-IN (ABR_X6_SPLITK=1, read per call):
-    // stand-alone it wins on grids of up to two tiles per CU, inside the training step it changes nothing (B = 2: 13.04 vs 13.04 ms, B = 4: 22.55 vs
-    // 22.50 ms) and its summation order differs from every other bf16x6 kernel's in the last bits -- not worth a default.
-    const char* sk_env = getenv("ABR_X6_SPLITK");
-    const bool splitk_on = sk_env && atoi(sk_env) != 0;
-    static const int splitk_mink = getenv("ABR_X6_SPLITK_MINK") ? atoi(getenv("ABR_X6_SPLITK_MINK")) : 512;
-    if (wd && splitk_on && p.nprod == 6 && nb == 1 && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && !p.scatter && p.K >= splitk_mink &&
-        p.K % BKX == 0 && (int64_t)((p.M + 63) / 64) * ((p.Cout + 63) / 64) <= 2L * cus) {
-        // (measured, tools/dbg/splitk_time.py: 4788x256x1024 36.9 -> 31.7 us, 2048x512x2048 47.4 -> 36.8, 4096x512x2048 60.9 -> 56.4, 9576x76x1024
-        //  31.8 -> 28.3; from ~2.3 tiles per CU on -- 9576x256x1024: 45.0 -> 47.3 -- the k-sequential kernels win: those launches are bound by
-        //  VALU + MFMA issue per SIMD (a 64-wide tile splits every A element once per 64 columns), not by the length of the chain)
-        launch_x6wk(p, x, out, st);
-        return;
-    }
-    if (wd) {
+    {
         // Wave layouts chosen so that every weight fragment (global -> registers) is fetched by as few waves as possible: the 128x128 tile as four
         // waves of 128 x 32 (2x2 waves of 64 x 64 fetched each fragment twice; the A fragments, LDS reads, double instead: +1.3 % alone, -0.19 ms
         // per step), the 128x64 tile as 2x2 waves of 64 x 32 (4x1 waves of 32 x 64 fetched each four times: +4.7 % alone, -0.12 ms per step)
         if (tile == 1) launch_x6w<128, 128, 1, 4>(p, x, out, st);
         else if (tile == 2) launch_x6w<128, 64, 2, 2>(p, x, out, st);
         else launch_x6w<64, 64, 2, 2>(p, x, out, st);
-    } else {
-        if (tile == 1) launch_x6<128, 128, 2, 2>(p, x, w, out, st);
-        else if (tile == 2) launch_x6<128, 64, 4, 1>(p, x, w, out, st);
-        else launch_x6<64, 64, 2, 2>(p, x, w, out, st);
     }
 }
 
@@ -2087,18 +1695,17 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
     // 36 * Cout rows pack as ONE matrix whose 32-row blocks never straddle two batches), fed to the weights-direct kernel.
     // f16x3: the same with two fp16 planes and one scale per row of U (h3_pack_kernel); without a weight version U is transformed and packed
     // into scratch on every call.
-    static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
-    const bool h3 = p.math == ABR_MATH_F16X3;
-    if (h3 && p.Cout % 32 != 0) return false;
+    const bool h3 = p.math == ABR_MATH_F16X3, x6 = p.math == ABR_MATH_BF16X6;
+    if ((h3 || x6) && p.Cout % 32 != 0) return false;
     const void* Up = nullptr;
-    if (p.math == ABR_MATH_BF16X6 && p.w_version && direct_on && p.Cout % 32 == 0) {
+    if (x6 && p.w_version) {
         Up = abr::derived_cached(w, abr::DERIVED_WINO_U_X6_PLANES, (size_t)x6_packed_bytes((int64_t)36 * p.Cout, p.Cin), p.w_version, st, [&](void* buf) {
             float* Uf = abr::wino_ws(st, nU);   // fp32 U in this stream's scratch, consumed by the pack launch right behind it
             if (!Uf || abr::wino_weight_transform(w, p.Cout, p.Cin, Uf, st)) return 1;
             return x6_pack(Uf, (int64_t)36 * p.Cout, p.Cin, buf, st);
         });
     }
-    const size_t h3_up_floats = h3 ? (size_t)h3_packed_bytes((int64_t)36 * p.Cout, p.Cin) / 4 : 0;
+    const size_t h3_up_floats = h3 ? (size_t)h3_packed_bytes((int64_t)36 * p.Cout, p.Cin) / 4 : (x6 ? (size_t)x6_packed_bytes((int64_t)36 * p.Cout, p.Cin) / 4 : 0);
     if (h3 && p.w_version) {
         Up = abr::derived_cached(w, abr::DERIVED_WINO_U_H3_PLANES, h3_up_floats * 4, p.w_version, st, [&](void* buf) {
             float* Uf = abr::wino_ws(st, nU);
@@ -2109,16 +1716,16 @@ static bool wino_conv(const ConvP& p, const float* x, const float* w, float* out
     }
     float* Uc = (!Up && !h3 && p.w_version) ? abr::wino_u_cached(w, p.Cout, p.Cin, p.w_version, st) : nullptr;
     const bool have_u = Uc || Up;
-    const size_t h3_extra = (h3 && !Up) ? h3_up_floats : 0;   // f16x3 without a version: fp32 U AND its planes live in scratch
+    const size_t h3_extra = ((h3 || x6) && !Up) ? h3_up_floats : 0;   // split arithmetics without a version: fp32 U AND its planes live in scratch
     float* ws = abr::wino_ws(st, (p.v_out ? 0 : nV) + (have_u ? 0 : nU) + nM + h3_extra);
     if (!ws) return false;
     float* V = p.v_out ? p.v_out : ws;
     float* U = Uc ? Uc : ws + (p.v_out ? 0 : nV);
     float* Mm = ws + (p.v_out ? 0 : nV) + (have_u ? 0 : nU);
     if (!have_u && abr::wino_weight_transform(w, p.Cout, p.Cin, U, st)) return false;
-    if (h3 && !Up) {
+    if ((h3 || x6) && !Up) {
         void* planes = Mm + nM;
-        if (h3_pack(U, (int64_t)36 * p.Cout, p.Cin, planes, st)) return false;
+        if (h3 ? h3_pack(U, (int64_t)36 * p.Cout, p.Cin, planes, st) : x6_pack(U, (int64_t)36 * p.Cout, p.Cin, planes, st)) return false;
         Up = planes;
     }
     abr::AmaxRef v_ref{nullptr, 0};
@@ -2224,7 +1831,7 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
         // Round 4: with a weight version the bf16 mode runs on the weights-direct kernels of the default arithmetic, single product (NP = 1): plane 0
         // of the packed weights (the cache entry bf16x6 uses) IS bf16(w), the first plane of the activation split IS bf16(x).  3x3 convs stay
         // direct (a Winograd transform of rounded operands is a different, less accurate function than the mode's definition).
-        static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
+        constexpr bool direct_on = true;   // (ABR_X6_WEIGHTS_DIRECT=0, the in-kernel weight split, was retired in round 6)
         static const bool bf16_wd = !(getenv("ABR_BF16_WEIGHTS_DIRECT") && atoi(getenv("ABR_BF16_WEIGHTS_DIRECT")) == 0);
         const void* planes = d->w_planes;
         if (!planes && p.w_version && direct_on && bf16_wd && p.Cin % BKX == 0)
@@ -2266,6 +1873,11 @@ extern "C" int abr_conv_forward(const abr_conv_desc* d, const float* x, const fl
         // weights-direct kernel: the packed planes of (w, w_version) come from the library's cache (filled here on a miss: one small launch)
         if (!p.w_planes && p.w_version)
             p.w_planes = abr::derived_cached(w, abr::DERIVED_X6_PLANES, p.wp_bytes, p.w_version, st, [&](void* buf) { return x6_pack(w, d->Cout, p.K, buf, st); });
+        if (!p.w_planes) {   // a one-off call: planes into this stream's scratch (the in-kernel weight split of rounds 1-5 made the same three terms)
+            void* scratch = abr::wino_ws(st, (size_t)p.wp_bytes / 4 + 1);
+            ABR_REQUIRE(scratch && x6_pack(w, d->Cout, p.K, scratch, st) == 0, "conv_forward (bf16x6): no memory for the weight planes");
+            p.w_planes = scratch;
+        }
         dispatch_igemm_x6(p, x, w, out, st);
     } else {
         dispatch_igemm(p, x, w, out, st);
@@ -2341,7 +1953,7 @@ extern "C" int abr_conv_prepare_weights(const float* w, int Cout, int R, int S, 
     ABR_REQUIRE(w && w_version != 0, "conv_prepare_weights: needs a weight pointer and a non-zero w_version");
     ABR_REQUIRE(Cout > 0 && R > 0 && S > 0 && Cin > 0, "conv_prepare_weights: bad shape");
     hipStream_t st = abr::as_stream(stream);
-    static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
+    constexpr bool direct_on = true;   // (ABR_X6_WEIGHTS_DIRECT=0, the in-kernel weight split, was retired in round 6)
     const int K = R * S * Cin;
     // the same predicate as abr_conv_forward's Winograd branch (residual / scatter never occur on the convs that prepare)
     if (wino_min_c() > 0 && math != ABR_MATH_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && Cin % BK == 0 && Cout % 4 == 0 &&
@@ -2439,7 +2051,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
     ABR_REQUIRE(n >= 0 && (n == 0 || items), "conv_prepare_batch: bad args");
     if (n == 0) return ABR_OK;
     hipStream_t st = abr::as_stream(stream);
-    static const bool direct_on = !(getenv("ABR_X6_WEIGHTS_DIRECT") && atoi(getenv("ABR_X6_WEIGHTS_DIRECT")) == 0);
+    constexpr bool direct_on = true;   // (ABR_X6_WEIGHTS_DIRECT=0, the in-kernel weight split, was retired in round 6)
     std::lock_guard<std::mutex> lock(g_prep_mu);
     PrepTables& T = g_prep_tables[st];
     std::vector<abr::PrepJob> tj, uj, pj, hj;    // transposes, Winograd weight transforms, bf16x3 packings, f16x3 packings

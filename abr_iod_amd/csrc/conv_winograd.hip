@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
                 for (int e = 0; e < V; e++) {
                     v.v[e] = y[j].v[e] * sc.v[e] + bi.v[e];
-                    if (relu) v.v[e] = fmaxf(v.v[e], 0.f);
+                    if (relu) v.v[e] = abr::relu_f(v.v[e]);
                 }
                 if (mask) {
 #pragma unroll

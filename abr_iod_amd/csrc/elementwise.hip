@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
                 const int wi = wo * 2 - 1 + dx;
                 if ((unsigned)wi >= (unsigned)W) continue;
                 const float4 v = reinterpret_cast<const float4*>(x)[(((size_t)b * H + hi) * W + wi) * cv + c];
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                // (torch's max_pool2d keeps a NaN: `val > max || isnan(val)`, aten/src/ATen/native/cuda/DilatedMaxPool2d.cu; fmaxf would drop it)
+                m.x = (v.x > m.x || v.x != v.x) ? v.x : m.x; m.y = (v.y > m.y || v.y != v.y) ? v.y : m.y;
+                m.z = (v.z > m.z || v.z != v.z) ? v.z : m.z; m.w = (v.w > m.w || v.w != v.w) ? v.w : m.w;
             }
         }
         reinterpret_cast<float4*>(out)[i] = m;

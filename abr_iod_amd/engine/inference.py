@@ -14,18 +14,78 @@ from ..data.datasets.evaluation import evaluate
 from ..utils.comm import get_world_size, is_main_process, synchronize
 
 
-def compute_on_dataset(model, data_loader, device, timer=None):
+# The fp32-accurate split arithmetics have a DOMAIN: f16x3 keeps only an absolute accuracy of 2^-40 amax for operand elements more
+# than 18 binades below their tensor's amax, and both splits turn an inf / nan operand into NaN.  The kernels count / flag such operands; the
+# training loop polls those words (engine/trainer.py::_x6_guard) -- and so does this loop: a batch whose operands left the domain is RE-RUN in the
+# next arithmetic down (f16x3 -> bf16x6 -> fp32 MFMA), so no detection handed to the metric was computed outside it.  The read is synchronous and
+# per batch: the detections are copied to the host per batch anyway.  ABR_EVAL_GUARD=0: off.
+EVAL_GUARD = os.environ.get("ABR_EVAL_GUARD", "1") != "0"
+
+
+class EvalRangeGuard(object):
+    """`forward(images)` = model(images) under the range guard; `.stats` = what it saw (bench_eval.py prints it)."""
+
+    def __init__(self, model, log=None):
+        from .. import ops
+        self.ops, self.model = ops, model
+        self.log = log or logging.getLogger("maskrcnn_benchmark_target_model.inference")
+        self.stats = {"batches": 0, "reruns": 0, "small": 0, "seen": 0, "max_small_fraction": 0.0, "flags": 0}
+        self.limit = float(os.environ.get("ABR_H3_MAX_SMALL_FRACTION", "0.05"))
+        self._clean = False
+
+    def active(self):
+        return EVAL_GUARD and getattr(self.model, "conv_math", None) in ("f16x3", "bf16x6") and hasattr(self.model, "set_conv_math")
+
+    def forward(self, images):
+        ops, model = self.ops, self.model
+        if not self.active() or not (images.tensors if hasattr(images, "tensors") else images).is_cuda:
+            return model(images)
+        if not self._clean:      # whatever an earlier phase of the process (training steps) left in the words is not this batch's
+            ops.x6_range_flags(reset=True)
+            ops.h3_range_stats(reset=True)
+            self._clean = True
+        for _attempt in range(3):
+            out = model(images)
+            math = model.conv_math
+            flags = ops.x6_range_flags(reset=True)       # (synchronises the stream: the batch's kernels have all reported)
+            small, seen = ops.h3_range_stats(reset=True) if math == "f16x3" else (0, 0)
+            st = self.stats
+            st["batches"] += 1
+            st["flags"] |= flags
+            st["small"] += small
+            st["seen"] += seen
+            frac = small / seen if seen else 0.0
+            st["max_small_fraction"] = max(st["max_small_fraction"], frac)
+            if flags & ops.H3_FLAG_STALE:
+                raise RuntimeError("f16x3: a kernel was handed an amax word that did not carry the epoch it was told (a host plumbing bug, not data)")
+            if flags & ops.X6_FLAG_NONFINITE:
+                nxt = "f32"
+                why = "an inf / nan operand"
+            elif math == "f16x3" and frac > self.limit:
+                nxt = "bf16x6"
+                why = "{:.1%} of the operand elements more than 18 binades below their tensor's amax (limit {:.1%})".format(frac, self.limit)
+            else:
+                return out
+            self.log.warning("eval range guard: {} in the {} arithmetic -- switching the model to {} and re-running the batch".format(why, math, nxt))
+            model.set_conv_math(nxt)
+            st["reruns"] += 1
+        return out
+
+
+def compute_on_dataset(model, data_loader, device, timer=None, guard=None):
     """-> ({image id: BoxList on cpu}, {image id: background BoxList})  (inference.py:43-109).
     Batches are (images, targets, img_ids) or the reference's 4-tuple (images, targets, proposals, img_ids)."""
     model.eval()
     results, results_background = {}, {}
+    if guard is None:
+        guard = EvalRangeGuard(model)
     for batch in data_loader:
         images, img_ids = batch[0], batch[-1]
         if hasattr(images, "to"):
             images = images.to(device)
         with torch.no_grad():
             t0 = time.perf_counter()
-            output, _features, background = model(images)
+            output, _features, background = guard.forward(images)
             if timer is not None:
                 torch.cuda.synchronize()
                 timer["total"] = timer.get("total", 0.0) + time.perf_counter() - t0

@@ -14,6 +14,7 @@ hand-scheduled: dgrad is the same kernel on a flipped/transposed weight copy wit
 fused in the epilogue, wgrad accumulates atomically into the flat gradient buffer.  Activations are NHWC.
 """
 import os
+import threading
 from collections import namedtuple
 
 import torch
@@ -170,6 +171,9 @@ class _FwdPlan(object):
         self.out_shape = shapes[i3]
         self.h3 = self.math == ops.MATH_F16X3
         self.s = s
+        # the table is mutable: two host threads running the same model (threaded inference) must not rewrite each other's pointers while
+        # abr_conv_run -- which releases the GIL -- still walks them
+        self.lock = threading.Lock()
 
     def valid(self):
         blk = self.blk
@@ -184,6 +188,10 @@ class _FwdPlan(object):
         return True
 
     def run(self, x):
+        with self.lock:
+            return self._run(x)
+
+    def _run(self, x):
         arr, n = self.arr, self.n
         st = ops.L.stream()
         f32, dev = torch.float32, x.device

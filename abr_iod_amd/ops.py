@@ -277,9 +277,12 @@ def amax_carry_bound(dst, src):
 
 
 def amax_drop(t):
-    """t was written in place by a raw kernel: whatever tag it carried no longer describes it"""
+    """t was written in place by a raw kernel: whatever tag it carried no longer describes it (nor does the "zero except the pixels of a
+    strided scatter" mark: add_ fills the holes, and scale_ by inf / nan would too)"""
     if getattr(t, "_abr_amax", None) is not None:
         t._abr_amax = None
+    if getattr(t, "_abr_scatter", None) is not None:
+        t._abr_scatter = None
     return t
 
 
@@ -473,6 +476,8 @@ def conv_forward(x, w, stride=1, pad=0, scale=None, bias=None, residual=None, ma
     L.check(L.lib().abr_conv_forward(C.byref(d), L.ptr(xc), L.ptr(w), L.ptr(out), L.stream()), "conv_forward")
     if emit_amax:
         amax_tag(out, ow, oe)
+    elif not fresh:
+        amax_drop(out)     # a raw kernel moves neither data_ptr nor _version: whatever word `out` carried no longer bounds its values
     if strided and fresh:
         out._abr_scatter = (out.data_ptr(), d.out_sh, d.out_sw)   # (zero everywhere but the pixels this geometry writes)
     return out
@@ -671,7 +676,16 @@ def mark_overlap(on):
 # Winograd inverse transform adds with a plain read-modify-write -- stream order keeps those two apart.
 WGRAD_STREAMS = max(1, int(os.environ.get("ABR_WGRAD_STREAMS", "2")))
 _wg_owner = {}
-_wg_keep = []    # operands of the weight gradients queued on side streams since the last join
+_wg_keep = {}    # {raw handle of the stream that produced them: [operands of the weight gradients queued on side streams since that stream's last join]}
+_wg_lock = threading.Lock()
+
+
+def _wg_hold(main, item):
+    lst = _wg_keep.get(main)
+    if lst is None:
+        with _wg_lock:
+            lst = _wg_keep.setdefault(main, [])
+    lst.append(item)
 
 
 _wgrad_keys = {}
@@ -696,7 +710,11 @@ def join_side_stream():
             s = _side_streams.get(dev if i == 0 else (dev, "wgrad%d" % i))
             if s is not None:
                 torch.cuda.current_stream().wait_stream(s)
-    del _wg_keep[:]      # (after the waits: see conv_wgrad_async)
+    # (after the waits: see conv_wgrad_async.)  Only the operands that belong to THIS stream go: another host thread's backward pass on another
+    # stream has not waited for its side kernels yet, and its blocks would return to a pool whose stream is not ordered behind them.
+    lst = _wg_keep.get(L.stream()) if torch.cuda.is_available() else None
+    if lst:
+        del lst[:]
 
 
 def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino_v=None):
@@ -711,11 +729,14 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino
         _join_pending[0] = True
         L.lib().abr_prof_mark_overlap(1)  # from here to the join, main-stream launches share the device with the side stream
         torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+    # The operands are made contiguous, and their amax words reduced, HERE -- on the stream that produced them and before the side stream's wait is
+    # recorded: a copy or a reduction issued after that event would not be ordered before the side stream's kernel.  The copies are what the
+    # kernel reads, so they are what is kept alive until the join.
+    x, gy = L.f32c(x), L.f32c(gy)
     refs = None
-    if math == MATH_F16X3 and H3_TAGS and x.is_contiguous() and gy.is_contiguous():
-        # operands without an amax word get one HERE, on the stream that produced them: the dgrad that follows on this stream shares gy's, and
-        # the side stream (ordered behind this point by wait_stream) is handed both -- a word reduced on the side stream would not be ordered
-        # before this stream's later readers
+    if math == MATH_F16X3 and H3_TAGS:
+        # operands without an amax word get one on this stream: the dgrad that follows here shares gy's, and the side stream (ordered behind
+        # this point by the wait below) is handed both -- a word reduced on the side stream would not be ordered before this stream's later readers
         if wino_v is None and amax_of(x)[0] is None:
             amax_compute(x)
         if amax_of(gy)[0] is None:
@@ -724,13 +745,14 @@ def conv_wgrad_async(x, gy, dw, stride=1, pad=0, scale=None, math=MATH_F32, wino
     # x, gy (and the zeroed gradient buffer) are produced on the current stream: the side stream is ordered behind it, and the launch names the
     # side stream itself (side.wait_stream(cur) + `with torch.cuda.stream(side)` cost ~30 us of Python per gradient, ~60 gradients per step)
     raw = side.cuda_stream
-    L.check(L.lib().abr_stream_wait_stream(raw, L.stream()), "stream_wait_stream")
+    main = L.stream()
+    L.check(L.lib().abr_stream_wait_stream(raw, main), "stream_wait_stream")
     conv_wgrad(x, gy, dw, stride, pad, scale, math, wino_v, amax_refs=refs, stream=raw)
     # The caching allocator must not recycle the operands for the main stream while the side kernel still reads them: they are kept alive until
     # the join (join_side_stream: the main stream waits for the side streams, THEN the references go), so their blocks return to the main
     # stream's pool ordered behind the gradients.  (tensor.record_stream did the same at ~2 us per call plus an event per block at free time,
     # three tensors per gradient.)
-    _wg_keep.append((x, gy, wino_v))
+    _wg_hold(main, (x, gy, wino_v))
     return dw
 
 
@@ -772,8 +794,13 @@ def conv_backward(x, gy, dw, wt, stride, pad, scale=None, math=MATH_F32, w_versi
         owner = _wg_owner.get(dw.data_ptr())
         if owner is None:
             owner = _wg_owner[dw.data_ptr()] = len(_wg_owner) % WGRAD_STREAMS
-        plan = _bwd_plans[key] = (arr, C.cast(arr, C.c_void_p), wtp, scp, owner, (scale, dw))
-    arr, ptr, _, _, owner, _ = plan
+        plan = _bwd_plans[key] = (arr, C.cast(arr, C.c_void_p), wtp, scp, owner, (scale, dw), threading.Lock())
+    arr, ptr, _, _, owner, _, lock = plan
+    with lock:     # (the table is shared by every host thread that runs this conv's backward pass; abr_conv_run releases the GIL)
+        return _conv_backward_run(arr, ptr, owner, x, gy, dw, math, wino_v, dgrad, mask, residual, out, out_hw, w_version)
+
+
+def _conv_backward_run(arr, ptr, owner, x, gy, dw, math, wino_v, dgrad, mask, residual, out, out_hw, w_version):
     side = _wgrad_stream(x.device.index, owner).cuda_stream
     if not _join_pending[0]:
         _join_pending[0] = True
@@ -833,9 +860,11 @@ def conv_backward(x, gy, dw, wt, stride, pad, scale=None, math=MATH_F32, w_versi
     if dgrad:
         if emit:
             amax_tag(out, ow, oe)
+        elif not fresh:
+            amax_drop(out)
         if fresh and out_hw is not None and (d2.out_sh != 1 or d2.out_sw != 1):
             out._abr_scatter = (out.data_ptr(), d2.out_sh, d2.out_sw)
-    _wg_keep.append((x, gy, wino_v))
+    _wg_hold(main, (x, gy, wino_v))
     return res
 
 

@@ -323,6 +323,10 @@ def main():
                     help="BASELINE.json configs[4]'s shape variety: every second step runs a batch of SQUARE images (min(H,W) on a side), as the "
                          "mosaic canvases of the box-rehearsal data path are (voc_abr.py:712-714: mean(w,h)^2 -> ~600x600 after the resize); aspect "
                          "grouping keeps each batch homogeneous (data/build.py:93-100).  Informational (the metric's batches are all 600x1000)")
+    ap.add_argument("--batch-pool", type=int, default=4,
+                    help="number of DISTINCT synthetic batches the timed region rotates over (same geometry, same config; other images, other numbers "
+                         "of ground-truth boxes -> other matches, other NMS survivor counts, other sampled RoIs).  1 = the single repeated batch of "
+                         "rounds 1-5, which the default run still reports as `single_batch_informational`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the short informational re-run on the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -406,6 +410,12 @@ def main():
     images, targets = synthetic_batch(B, IH, IW, seed=42 + rank,           # each rank its own shard of the global batch
                                       label_range=(n_old_cls + 1, n_old_cls + n_new_cls + 1))
     batches = [(images, targets)]
+    # the headline rotates over a pool of distinct batches: 1-5, 1-3, 1-8 and 1-12 ground-truth boxes per image (VOC trainval averages ~2.4 objects
+    # per image, up to ~40), each rank its own images
+    POOL_MAX_BOXES = (5, 3, 8, 12, 2, 6, 10, 4)
+    for j in range(1, max(1, a.batch_pool)):
+        batches.append(synthetic_batch(B, IH, IW, seed=42 + rank + 1009 * j, label_range=(n_old_cls + 1, n_old_cls + n_new_cls + 1),
+                                       max_boxes=POOL_MAX_BOXES[j % len(POOL_MAX_BOXES)]))
     if a.mosaic_squares:
         side = min(IH, IW)
         batches.append(synthetic_batch(B, side, side, seed=1042 + rank, label_range=(n_old_cls + 1, n_old_cls + n_new_cls + 1)))
@@ -483,6 +493,20 @@ def main():
                                                                          "sustained_clock_ghz", "frac_at_sustained_clock") if k in x}
                                       for x in srows},
                           "note": "every stream of the step folded into one, every conv launch timed (informational re-run behind the timed region)"}
+    single = None
+    if len(batches) > 1 and a.batch_pool > 1 and not a.mosaic_squares and world == 1:
+        # AFTER the timed region, never part of `value`: rounds 1-5's workload -- ONE batch repeated (constant NMS survivor counts, steady allocator)
+        SB = 10
+        for _ in range(2):
+            train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t, next_images=images)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(SB):
+            train_step(model_source, model_target, images, targets, optimizer, scheduler, cfg_t, next_images=images)
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        single = {"value": round(B * SB / e1, 3), "unit": "img/s", "ms_per_step": round(1e3 * e1 / SB, 3), "steps": SB,
+                  "note": "informational: the same step on ONE repeated batch (the workload rounds 1-5 reported); not the reported value"}
     rccl_ranks = 1
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -517,6 +541,8 @@ def main():
                                         else "not the metric's geometry (BASELINE.json: 600x1000 batches): GFLOP / roofline figures per image do not apply",
                        "shared_frozen_prefix": bool(a.share_frozen_prefix),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "math": a.math,
+                       "batch_pool": {"distinct_batches": len(batches), "gt_boxes_per_image": [[len(t) for t in tg] for _, tg in batches],
+                                      "note": "the timed region visits them in turn (step i runs batch i mod n, the next one prefetched)"},
                        "rccl_ranks": rccl_ranks, "collective": "RCCL all-reduce of the flat gradient, 3 buckets, 2 under backward" if world > 1 else None,
                        "gradient_exchange": optimizer.reducer.describe() if world > 1 else None,
                        "gflop_per_img_algorithmic": GFLOP_PER_IMG_ARD if standard else None},
@@ -524,6 +550,8 @@ def main():
             "conv_math_at_end": getattr(model_target, "conv_math", None),   # "f32" here = the range guard took the run off the bf16x6 kernels
             "math": a.math,
         }
+        if single is not None:
+            out["single_batch_informational"] = single
         if a.math in ("bf16x6", "f16x3"):
             from abr_iod_amd import ops as _o
             fl = _o.x6_range_flags(reset=False)

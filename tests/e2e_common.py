@@ -111,16 +111,17 @@ def oracle_full_size_step(g, name, sd_s, sd_t, images, with_grad=True, H=600, W=
         fh, fw = ft.shape[-2:]
         anchors, vis = O.grid_anchors(O.cell_anchors(), fh, fw, 16, (H, W))
         n = anchors.shape[0]
-        gts = [g["gt0"], g["gt1"]]
-        labs, tgts, posm, negm = [], [], torch.zeros(2, n, dtype=torch.bool), torch.zeros(2, n, dtype=torch.bool)
-        for i in range(2):
+        NB = int(g["batch"]) if "batch" in g else 2
+        gts = [g[f"gt{i}"] for i in range(NB)]
+        labs, tgts, posm, negm = [], [], torch.zeros(NB, n, dtype=torch.bool), torch.zeros(NB, n, dtype=torch.bool)
+        for i in range(NB):
             lab, tgt, _ = R.rpn_prepare_targets(anchors, vis, gts[i])
             labs.append(torch.from_numpy(lab)); tgts.append(torch.from_numpy(tgt))
             posm[i, torch.from_numpy(g[f"rpn_pos{i}"]).long()] = True
             negm[i, torch.from_numpy(g[f"rpn_neg{i}"]).long()] = True
         lo, lb = R.rpn_loss(obj, reg, torch.stack(labs), torch.stack(tgts), posm, negm)
         rois, labels, rts = [], [], []
-        for i in range(2):
+        for i in range(NB):
             boxes = g[f"tgt_props{i}"]
             m = O.matcher(O.box_iou(gts[i], boxes), 0.5, 0.5, False)
             lab = g[f"gt_labels{i}"][np.clip(m, 0, None)].astype(np.int64)
@@ -137,7 +138,7 @@ def oracle_full_size_step(g, name, sd_s, sd_t, images, with_grad=True, H=600, W=
             with torch.no_grad():
                 fs = ms.backbone(images)
                 rois64 = torch.from_numpy(np.concatenate([np.concatenate([np.full((64, 1), i, np.float32), g[f"src_top128_{i}"][g[f"soften_sel{i}"]]], 1)
-                                                          for i in range(2)]))
+                                                          for i in range(NB)]))
                 ps, zs, bs = ms.box_head(fs, rois64)
             pt, zt, bt = mt.box_head(ft, rois64)
             k_all = zt.shape[1]

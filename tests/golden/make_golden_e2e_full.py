@@ -14,6 +14,7 @@ its outputs: the 4 detector losses, ID and ARD losses, and spot values of the C4
 The reference cannot run backward on CPU (csrc/ROIAlign.h:44), so no gradients.
 
     python tests/golden/make_golden_e2e_full.py [15-5|10-10|10-5|finetune ...]
+    python tests/golden/make_golden_e2e_full.py 15-5@4      (B = 4, the benchmarked batch -> e2e_full_15-5_b4.npz)
 """
 import os
 import random
@@ -63,7 +64,7 @@ def load(model, sd):
     model.load_state_dict(sd, strict=False)
 
 
-def main(name):
+def main(name, B=B):
     task, dist_type, feat, alpha, beta, gamma, label_range, n_old = CONFIGS[name]
     torch.set_num_threads(8)
     yaml = f"configs/voc/{task}/e2e_faster_rcnn_R_50_C4_4x_{'RB_' if needs_source(name) else ''}Target_model.yaml"
@@ -97,7 +98,7 @@ def main(name):
         return pos, neg
     BalancedPositiveNegativeSampler.__call__ = rec
 
-    out = {"config": np.array(name), "image_seed": np.array(42)}
+    out = {"config": np.array(name), "image_seed": np.array(42), "batch": np.array(B)}
     torch.manual_seed(11)
     random.seed(5)
     t0 = time.time()
@@ -126,7 +127,7 @@ def main(name):
         pre = mt.rpn.box_selector_train(anchors, rpn_out_t[0], rpn_out_t[1], targets)   # the post-NMS (+GT) lists the box head sampled from
     print(name, "reference forward: %.1f s" % (time.time() - t0))
     tdraws = draws[n_draws0:]
-    assert len(tdraws) == 2, len(tdraws)
+    assert len(tdraws) == 2, len(tdraws)   # (one RPN draw, one box-head draw; each a per-image list)
     (rpn_pos, rpn_neg), (head_pos, head_neg) = tdraws
     for i in range(B):
         out[f"rpn_pos{i}"] = torch.nonzero(rpn_pos[i]).squeeze(1).numpy().astype(np.int32)
@@ -138,13 +139,13 @@ def main(name):
         out[f"gt_labels{i}"] = targets[i].get_field("labels").numpy()
     f = feat_t[0]
     out["feat_t_absmax"] = np.array(float(f.abs().max()))
-    out["feat_t_spot"] = f[:, ::97, ::7, ::11].numpy()                    # [2, 11, 6, 6]
+    out["feat_t_spot"] = f[:, ::97, ::7, ::11].numpy()                    # [B, 11, 6, 6]
     out["rpn_obj_spot"] = rpn_out_t[0][0][:, :, ::5, ::9].numpy()         # [2, 15, 8, 7]
     out["rpn_obj_absmax"] = np.array(float(rpn_out_t[0][0].abs().max()))
     out["det_logits_head"] = soft_res[0][:16].numpy()
     for k, v in loss_dict.items():
         out[k] = np.array(float(v))
-    path = os.path.join(HERE, f"e2e_full_{name}.npz")
+    path = os.path.join(HERE, f"e2e_full_{name}.npz" if B == 2 else f"e2e_full_{name}_b{B}.npz")
     np.savez_compressed(path, **out)
     print({k: float(out[k]) for k in out if k.startswith("loss")}, "file KB", os.path.getsize(path) / 1e3)
     BalancedPositiveNegativeSampler.__call__ = orig
@@ -152,4 +153,8 @@ def main(name):
 
 if __name__ == "__main__":
     for nm in (sys.argv[1:] or ["15-5"]):
-        main(nm)
+        if "@" in nm:
+            nm, b = nm.split("@")
+            main(nm, int(b))
+        else:
+            main(nm)

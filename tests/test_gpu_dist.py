@@ -250,3 +250,117 @@ def test_two_ranks_one_image_each_equal_one_rank_two_images():
     relp = float(np.linalg.norm(p0 - p_single) / np.linalg.norm(p_single - p_before.cpu().numpy()))
     print("parameter update rel-L2 difference", relp)
     assert relp < 2e-5, relp
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# FOUR ranks on the one GPU whose steps differ in everything the exchange must not depend on: which gradient hooks
+# fire, whether the rank has a source model at all, how many images it holds.  solver/grad_reducer.py promises the SAME collective sequence
+# on every rank whatever its local state; here the sequence each rank really issued is recorded and compared, and the exchanged gradient
+# must be the sum of the four local gradients, element for element.
+#   rank 0  ARD + ID step, hooks armed                                   (the benchmark's step)
+#   rank 1  the same with the overlap switched off: NO hook sends, everything leaves from optimizer.step()
+#   rank 2  finetune-shaped step: no source model, no second RoI pass, no distillation terms (one pooled input instead of two / a joint one)
+#   rank 3  ARD + ID step on TWO images
+UNEVEN_MODES = ("ard", "ard-no-overlap", "finetune", "ard-two-images")
+
+
+def _uneven_rank_worker(rank, world, port, out):
+    import random
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    mode = UNEVEN_MODES[rank]
+    from abr_iod_amd.engine import train_step
+    from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
+    from abr_iod_amd.solver import grad_reducer
+    from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer
+    tiny = ["MODEL.RESNETS.STEM_OUT_CHANNELS", 16, "MODEL.RESNETS.RES2_OUT_CHANNELS", 32, "MODEL.RESNETS.WIDTH_PER_GROUP", 8,
+            "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 128]
+    if mode == "finetune":
+        cfg_s, cfg_t = make_cfgs("15-5", dist_type="l2", feat="no", alpha=0.0, beta=0.0, gamma=0.0, overrides=tiny)
+    else:
+        cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, overrides=tiny)
+    images, targets = synthetic_batch(2 if mode == "ard-two-images" else 1, 160, 224, seed=20 + rank)
+    if mode == "ard-no-overlap":
+        grad_reducer.OVERLAP = False
+
+    def models():
+        ms, mt = build_models(cfg_s, cfg_t, seed=0)          # the same target weights on every rank (the finetune target has the same 21-class head)
+        return (None if mode == "finetune" else ms), mt
+
+    # (a) the LOCAL gradient of the step, exchange switched off; the draws are recorded and replayed in (b)
+    ms, mt = models()
+    opt = make_optimizer(cfg_t, mt); sch = make_lr_scheduler(cfg_t, opt)
+    opt.reducer.reduce_bucket_async = lambda name: None
+    opt.reducer.finish = lambda: None
+    opt.reducer.begin = lambda: None
+    torch.manual_seed(3 + rank); random.seed(3 + rank)
+    real_all_reduce = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: None                 # (the range guard's flag exchange too: phase (a) is a local run)
+    try:
+        train_step(ms, mt, images, targets, opt, sch, cfg_t)
+    finally:
+        dist.all_reduce = real_all_reduce
+    torch.cuda.synchronize()
+    g_local = mt.flat.grads.clone().cpu().numpy()
+    ev_rpn, ev_box = mt.rpn.loss_evaluator, mt.roi_heads.box.loss_evaluator
+    pos, samp = ev_rpn.last_sampled
+    draws = ((pos[pos >= 0].clone(), samp[samp >= 0].clone()), [t[t >= 0].clone() for t in ev_box.last_sampled_inds],
+             [list(s) for s in ms.last_soften_indices] if ms is not None else None)
+
+    # (b) the exchanged step, every collective this rank issues logged as (dtype, elements, offset inside its storage, reduce op)
+    ms, mt = models()
+    opt = make_optimizer(cfg_t, mt); sch = make_lr_scheduler(cfg_t, opt)
+    assert opt.reducer.active and opt.world_size == world
+    issued = []
+
+    def logged_all_reduce(t, op=dist.ReduceOp.SUM, *a, **k):
+        issued.append((str(t.dtype), int(t.numel()), int(t.storage_offset()) if t.numel() > 1 else -1, str(op)))
+        return real_all_reduce(t, op, *a, **k)
+    dist.all_reduce = logged_all_reduce
+    grad_reducer.dist.all_reduce = logged_all_reduce
+    hook_sends = []
+    inner = opt.reducer.reduce_bucket_async
+    opt.reducer.reduce_bucket_async = lambda name: (hook_sends.append(name), inner(name))
+    mt.rpn.loss_evaluator.inject_sampled, mt.roi_heads.box.loss_evaluator.inject_sampled_inds = draws[0], draws[1]
+    if ms is not None:
+        ms.inject_soften_indices = draws[2]
+    train_step(ms, mt, images, targets, opt, sch, cfg_t)
+    torch.cuda.synchronize()
+    out.put((rank, mode, issued, hook_sends, g_local, mt.flat.grads.cpu().numpy(), mt.flat.params.detach().cpu().numpy(),
+             [(b, by, w) for b, by, w in opt.reducer.last_issue], int(mt.flat.n_trainable)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(420)
+def test_four_ranks_with_uneven_hook_firing_issue_one_collective_sequence():
+    import numpy as np
+    import torch.multiprocessing as mp
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from e2e_common import run_ranks
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    got = sorted(run_ranks(ctx, _uneven_rank_worker, [(r, world, port) for r in range(world)], timeout=360), key=lambda t: t[0])
+    seqs = [g[2] for g in got]
+    for r in range(1, world):
+        assert seqs[r] == seqs[0], "rank {} ({}) issued {} but rank 0 issued {}".format(r, got[r][1], seqs[r], seqs[0])
+    # three gradient ranges (roi_heads, rpn, backbone) in BUCKET_ORDER, float32, sum -- whatever the hooks did
+    fl = [s for s in seqs[0] if s[0] == "torch.float32" and s[1] > 1]
+    assert len(fl) >= 3 and sum(s[1] for s in fl) == got[0][8], (fl, got[0][8])     # every trainable element in exactly one range
+    # the ISSUE POINTS differ, as intended: rank 0 sent two buckets from hooks, rank 1 none
+    where = {g[1]: [w for _, _, w in g[7]] for g in got}
+    assert where["ard"][:2] == ["backward-hook", "backward-hook"] and where["ard"][2] == "optimizer.step", where
+    assert where["ard-no-overlap"] == ["optimizer.step"] * 3, where
+    # every rank holds the same gradient, and it is the sum of the four local ones: each element reduced exactly once
+    for g in got[1:]:
+        assert np.array_equal(g[5], got[0][5]) and np.array_equal(g[6], got[0][6])
+    want = got[0][4].astype(np.float64) + got[1][4] + got[2][4] + got[3][4]
+    have = got[0][5].astype(np.float64)
+    assert np.isfinite(have).all() and float(np.abs(have).max()) > 0
+    err = float(np.abs(have - want).max()) / float(np.abs(want).max())
+    print("4 uneven ranks: exchanged gradient vs the sum of the local ones, max-abs / max", err, " issue points", where)
+    assert err <= 1e-6, err            # (gloo's reduction order over four ranks is its own: fp32 rounding of a 4-term sum)

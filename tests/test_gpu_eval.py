@@ -166,3 +166,62 @@ def test_inference_loop_to_map(tmp_path):
     preds = torch.load(str(tmp_path / "predictions.pth"), weights_only=False)
     assert len(preds) == 6 and all(p.bbox.device.type == "cpu" and p.has_field("scores") and p.has_field("labels") for p in preds)
     assert (tmp_path / "result.txt").exists()
+
+
+def _tiny_eval_model():
+    from abr_iod_amd.engine.synthetic import build_models, make_cfgs
+    tiny = ["MODEL.RESNETS.STEM_OUT_CHANNELS", 16, "MODEL.RESNETS.RES2_OUT_CHANNELS", 32, "MODEL.RESNETS.WIDTH_PER_GROUP", 8,
+            "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 128, "MODEL.RPN.PRE_NMS_TOP_N_TEST", 300, "MODEL.RPN.POST_NMS_TOP_N_TEST", 150]
+    cfg_s, cfg_t = make_cfgs("15-5", dist_type="id", feat="ard", alpha=0.5, beta=1.0, gamma=1.0, overrides=tiny)
+    _, mt = build_models(cfg_s, cfg_t, seed=0, need_source=False)
+    mt.eval()
+    return mt
+
+
+def test_eval_range_guard_in_domain_batch_stays_on_f16x3():
+    """The test loop polls the split arithmetic's range words per batch (engine/inference.py::EvalRangeGuard): an ordinary batch is inside
+    f16x3's domain -- no flag, a small-element share far below the limit, one forward per batch, same detections as the bare model call."""
+    from abr_iod_amd.engine.inference import EvalRangeGuard
+    from abr_iod_amd.engine.synthetic import synthetic_batch
+    mt = _tiny_eval_model()
+    if mt.conv_math != "f16x3":
+        pytest.skip("default arithmetic is not f16x3 in this environment")
+    images, _ = synthetic_batch(2, 160, 224, seed=3)
+    g = EvalRangeGuard(mt)
+    with torch.no_grad():
+        want, _, _ = mt(images)
+        got, _, _ = g.forward(images)
+    assert mt.conv_math == "f16x3" and g.stats["reruns"] == 0 and g.stats["batches"] == 1 and g.stats["flags"] == 0
+    assert g.stats["seen"] > 0 and g.stats["max_small_fraction"] < 0.05
+    for a, b in zip(want, got):
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
+
+
+def test_eval_range_guard_reruns_out_of_domain_batches():
+    """(a) a batch whose small-element share exceeds the limit (forced here by a limit below zero: the share of a seeded Gaussian-like batch is
+    data, not a constant) is re-run in bf16x6 (exact split, no amax domain) and its detections equal a bf16x6 model's; (b) an inf pixel -> the
+    fp32 MFMA kernels.  A warning each time."""
+    from abr_iod_amd.engine.inference import EvalRangeGuard
+    from abr_iod_amd.engine.synthetic import synthetic_batch
+    mt = _tiny_eval_model()
+    if mt.conv_math != "f16x3":
+        pytest.skip("default arithmetic is not f16x3 in this environment")
+    images, _ = synthetic_batch(2, 160, 224, seed=4)
+    g = EvalRangeGuard(mt)
+    g.limit = -1.0
+    with torch.no_grad():
+        got, _, _ = g.forward(images)
+    assert g.stats["reruns"] == 1 and g.stats["batches"] == 2 and mt.conv_math == "bf16x6", g.stats
+    ref = _tiny_eval_model()
+    ref.set_conv_math("bf16x6")
+    with torch.no_grad():
+        want, _, _ = ref(images)
+    for a, b in zip(want, got):
+        assert torch.equal(a.bbox, b.bbox)
+    bad = images.clone()
+    bad[0, 0, 5, 5] = float("inf")
+    with torch.no_grad():
+        g.forward(bad)
+    assert mt.conv_math == "f32" and g.stats["flags"] & 2
+    # from here on the guard has nothing left to watch
+    assert not g.active()

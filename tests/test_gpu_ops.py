@@ -874,15 +874,10 @@ def test_bf16x6_packed_weight_planes_are_exact_and_give_identical_results():
         sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
         res = torch.randn(B, (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1, Cout, device="cuda", generator=g) if k == 1 and s == 1 else None
         kw = dict(scale=sc, relu=True, residual=res, math=ops.MATH_BF16X6)
-        want = ops.conv_forward(x, w, s, p, **kw)                                                  # weight tile split per workgroup
+        want = ops.conv_forward(x, w, s, p, **kw)                                                  # no planes, no version: packed into stream scratch per call
         got = ops.conv_forward(x, w, s, p, w_planes=ops.pack_weights(w), **kw)
 
         def same(a, b, M, N, K):
-            # small grid + long K + plain 1x1: the weights-direct path is the intra-workgroup split-K kernel (conv_igemm_x6wk_kernel, round 4), whose
-            # four interleaved partial sums differ from the k-sequential kernels in the last bits only
-            import os as _os
-            if _os.environ.get("ABR_X6_SPLITK", "0") != "0" and k == 1 and s == 1 and K >= 512 and ((M + 63) // 64) * ((N + 63) // 64) <= 2 * 256:
-                return bool((a - b).abs().max() <= 4e-6 * max(1.0, float(b.abs().max())))
             return torch.equal(a, b)
         M_ = B * ((H + 2 * p - k) // s + 1) * ((W + 2 * p - k) // s + 1)
         assert same(got, want, M_, Cout, Cin * k * k)
@@ -901,54 +896,6 @@ def test_bf16x6_packed_weight_planes_are_exact_and_give_identical_results():
     w[3, 0, 0, 5] = 2.0 ** -120
     ops.pack_weights(w)
     assert ops.x6_range_flags() & ops.X6_FLAG_TINY
-
-
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 38, 63, 1024, 256), (2, 38, 63, 1024, 256), (2, 38, 63, 1024, 76), (1, 19, 23, 512, 64), (4, 38, 63, 2048, 512)])
-def test_bf16x6_intra_workgroup_split_k(B, H, W, Cin, Cout):
-    """conv_igemm_x6wk_kernel (small grid, long K, plain 1x1: layer3's conv1 / the dgrad of its conv3 / the fused RPN heads): the four waves of a
-    workgroup take k-tiles w, w + 4, ... of the whole 64 x 64 tile and the partial tiles are added in wave order.  fp32-accurate like the
-    k-sequential kernels (float64 on a sample of outputs, the bound of test_conv_bf16x6_mode_is_fp32_accurate), deterministic, epilogue
-    (scale, bias, residual, ReLU, ragged Cout and M) intact."""
-    from abr_iod_amd import ops
-    g = torch.Generator(device="cuda").manual_seed(B * 100 + Cout)
-    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
-    w = torch.randn(Cout, 1, 1, Cin, device="cuda", generator=g) / Cin ** 0.5
-    sc, bi = torch.rand(Cout, device="cuda", generator=g) + 0.5, torch.randn(Cout, device="cuda", generator=g) * 0.1
-    res = torch.randn(B, H, W, Cout, device="cuda", generator=g)
-    ver = 300000 + B * 1000 + Cout
-    ops.conv_cache_clear()
-    import os
-    seq = ops.conv_forward(x, w, 1, 0, scale=sc, bias=bi, residual=res, relu=True, math=ops.MATH_BF16X6, w_version=ver)   # the default (k-sequential) kernel
-    old = os.environ.get("ABR_X6_SPLITK")
-    os.environ["ABR_X6_SPLITK"] = "1"          # opt-in, read by the library on every call
-    try:
-        y = ops.conv_forward(x, w, 1, 0, scale=sc, bias=bi, residual=res, relu=True, math=ops.MATH_BF16X6, w_version=ver)
-        assert torch.equal(y, ops.conv_forward(x, w, 1, 0, scale=sc, bias=bi, residual=res, relu=True, math=ops.MATH_BF16X6, w_version=ver))
-    finally:
-        if old is None:
-            os.environ.pop("ABR_X6_SPLITK", None)
-        else:
-            os.environ["ABR_X6_SPLITK"] = old
-    assert float((y - seq).abs().max()) <= 4e-6 * max(1.0, float(seq.abs().max()))     # the two summation orders agree to the last bits
-    if ((B * H * W + 63) // 64) * ((Cout + 63) // 64) <= 2 * 256:
-        assert not torch.equal(y, seq) or Cin <= 128                                       # (it really was the other kernel)
-    ref = torch.relu((x.double().reshape(-1, Cin) @ w.double().reshape(Cout, Cin).t()) * sc.double() + bi.double() + res.double().reshape(-1, Cout))
-    err = (y.double().reshape(-1, Cout) - ref).abs().max().item()
-    assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
-    assert ops.x6_range_flags(reset=False) == 0
-
-
-def test_bf16x6_in_kernel_split_fallback_passes_the_same_parity_tests():
-    """ABR_X6_WEIGHTS_DIRECT=0 keeps every bf16x6 conv on the kernel that splits the weight tile in each workgroup (what runs whenever a
-    caller passes neither planes nor a w_version).  It is a process-wide switch: run the step-level parity test in a child process."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_e2e.py::test_train_step_losses_and_grads_vs_oracle", "-x", "-q", "-p",
-                        "no:cacheprovider", "-k", "15-5-bf16x6"], cwd=root, env=dict(os.environ, ABR_X6_WEIGHTS_DIRECT="0"),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_winograd_weight_cache_follows_w_version():

@@ -29,13 +29,19 @@ def _close(a, b, tol=1e-4):
     return abs(a - b) <= tol * max(1.0, abs(b))
 
 
-def test_oracle_reproduces_reference_full_size_step(gold):
+import pytest
+
+
+@pytest.mark.parametrize("fixture", ["15-5", "15-5_b4"])
+def test_oracle_reproduces_reference_full_size_step(gold, fixture):
+    """(`15-5_b4`: the same configuration at B = 4, the benchmarked batch)"""
     from abr_iod_amd.engine.synthetic import synthetic_batch
-    name = "15-5"
-    g = gold("e2e_full_" + name)
+    name = fixture.split("_b")[0]
+    g = gold("e2e_full_" + fixture)
+    NB = int(g["batch"]) if "batch" in g else 2
     _, dist_type, _, alpha, beta, gamma, label_range, n_old = CONFIGS[name]
     sd_s, sd_t, _, _, _, _ = regenerated_state_dicts(name)
-    images, _ = synthetic_batch(2, H, W, seed=int(g["image_seed"]), label_range=label_range, device="cpu")
+    images, _ = synthetic_batch(NB, H, W, seed=int(g["image_seed"]), label_range=label_range, device="cpu")
     torch.set_num_threads(8)
     mt, ms = RefModel(sd_t, trainable_prefixes=()), RefModel(sd_s, trainable_prefixes=())
     with torch.no_grad():
@@ -48,16 +54,16 @@ def test_oracle_reproduces_reference_full_size_step(gold):
         assert (fh, fw) == (38, 63)
         anchors, vis = O.grid_anchors(O.cell_anchors(), fh, fw, 16, (H, W))
         assert anchors.shape[0] == 35910
-        gts = [g["gt0"], g["gt1"]]
+        gts = [g[f"gt{i}"] for i in range(NB)]
         # proposals: 12000 -> NMS -> 2000 (+GT).  fp32 re-association (oneDNN here vs oneDNN there is identical; this guards the logic)
-        props = R.rpn_post_process(obj, reg, [anchors] * 2, [(H, W)] * 2, 12000, 2000, gt_boxes=gts)
-        for i in range(2):   # as sets (e2e_common.match_fraction): the losses below use the reference's own lists
+        props = R.rpn_post_process(obj, reg, [anchors] * NB, [(H, W)] * NB, 12000, 2000, gt_boxes=gts)
+        for i in range(NB):   # as sets (e2e_common.match_fraction): the losses below use the reference's own lists
             assert abs(props[i][0].shape[0] - g[f"tgt_props{i}"].shape[0]) <= 2
             assert match_fraction(g[f"tgt_props{i}"], props[i][0]) >= 0.98, match_fraction(g[f"tgt_props{i}"], props[i][0])
         # RPN loss with the reference's sampler draw
         n = anchors.shape[0]
-        labs, tgts, posm, negm = [], [], torch.zeros(2, n, dtype=torch.bool), torch.zeros(2, n, dtype=torch.bool)
-        for i in range(2):
+        labs, tgts, posm, negm = [], [], torch.zeros(NB, n, dtype=torch.bool), torch.zeros(NB, n, dtype=torch.bool)
+        for i in range(NB):
             lab, tgt, _ = R.rpn_prepare_targets(anchors, vis, gts[i])
             labs.append(torch.from_numpy(lab)); tgts.append(torch.from_numpy(tgt))
             posm[i, torch.from_numpy(g[f"rpn_pos{i}"]).long()] = True
@@ -66,7 +72,7 @@ def test_oracle_reproduces_reference_full_size_step(gold):
         assert _close(float(lo), float(g["loss_objectness"])) and _close(float(lb), float(g["loss_rpn_box_reg"]))
         # box head on the reference's sampled proposals
         rois, labels, rts = [], [], []
-        for i in range(2):
+        for i in range(NB):
             boxes = g[f"tgt_props{i}"]
             m = O.matcher(O.box_iou(gts[i], boxes), 0.5, 0.5, False)
             lab = g[f"gt_labels{i}"][np.clip(m, 0, None)].astype(np.int64)
@@ -83,7 +89,7 @@ def test_oracle_reproduces_reference_full_size_step(gold):
         assert _close(float(lc), float(g["loss_classifier"])) and _close(float(lbox), float(g["loss_box_reg"]))
         # distillation pass on the reference's 64 picks of its top-128
         rois64 = torch.from_numpy(np.concatenate([np.concatenate([np.full((64, 1), i, np.float32), g[f"src_top128_{i}"][g[f"soften_sel{i}"]]], 1)
-                                                  for i in range(2)]))
+                                                  for i in range(NB)]))
         ps, zs, bs = ms.box_head(fs, rois64)
         pt, zt, bt = mt.box_head(ft, rois64)
         np.testing.assert_allclose(zs[:8].numpy(), g["soften_scores_head"], rtol=1e-4, atol=1e-5)
