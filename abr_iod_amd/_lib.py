@@ -151,6 +151,12 @@ _SIGS = {
     "abr_match_encode": (_i, [_vp, _i, _vp, _vp, _i, _vp, _f, _f, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "abr_sample_pos_neg": (_i, [_vp, _i, _i, _i, _i64, _i, _i, C.c_uint64, _i, _i64, _vp, _vp, _vp, _vp]),
     "abr_sgd_momentum": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _f, _f, _i, _vp]),
+    "abr_comm_rccl_version": (_i, []),
+    "abr_comm_unique_id": (_i, [_vp]),
+    "abr_comm_init": (_i, [_i, _i, _vp, C.POINTER(_vp)]),
+    "abr_comm_info": (_i, [_vp, _vp]),
+    "abr_comm_destroy": (_i, [_vp]),
+    "abr_allreduce_flat": (_i, [_vp, _vp, _vp, _i, _vp]),
 }
 
 # every symbol include/abr_iod_hip.h declares (tests/test_abi.py checks the library exports them all)

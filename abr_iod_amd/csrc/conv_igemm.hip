@@ -106,7 +106,13 @@ struct ConvP {
 
 // Returns the bits of max |value stored| by this thread (for the output's amax word).  wsc / sa (f16x3): per-column scales of the packed weight
 // planes and the A operand's scale -- both powers of two, multiplied into the column scale, so the result equals scaling the accumulators first.
-template <int TM, int TN>
+// PF (the weights-direct kernels; round 6): the residual / mask rows of a 32-row block are REQUESTED before the block's accumulators go through LDS, so
+// their L2 / HBM latency runs under the transposition instead of in front of every store: the epilogue of a tile with a fused residual or mask was a
+// chain of TM x (load -> wait -> store) round trips during which the workgroup holds a third of its CU.  Stand-alone (tools/dbg/igemm_probe.py,
+// profiles/r06_igemm_epilogue_prefetch.txt): 36864x2048x512 + residual 306 -> 290 us, + residual + mask 350 -> 333, 9576x1024x256 45 -> 41, 37500x512x128
+// 64 -> 58, 150000x256x64 104 -> 91; step 17.65 / 17.60 -> 17.49 / 17.52 ms.  (Two register sets -- block i + 1 requested before block i's stores --
+// spill at three waves per SIMD.  A start-up skew of the first 768 workgroups, meant to keep a CU's three workgroups in different phases, LOST 0.1-0.2 ms.)
+template <int TM, int TN, bool PF = false>
 __device__ __forceinline__ unsigned epilogue_rows(const ConvP& p, f32x16 (&acc)[TM][TN], float* ep, int m_base, int n_base, int lane,
                                                   float* __restrict__ out, const float* __restrict__ wsc = nullptr, const float sa = 1.f) {
     unsigned amax_bits = 0;
@@ -137,43 +143,62 @@ __device__ __forceinline__ unsigned epilogue_rows(const ConvP& p, f32x16 (&acc)[
                 }
             }
     }
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    constexpr int NIT = 32 / RPI;
+    constexpr bool PRE = PF && NIT <= 4;
+    auto row_offset = [&](int m) -> size_t {
+        if (p.scatter) {
+            unsigned b, rem, ho, wo;
+            p.d_howo.divmod((unsigned)m, b, rem);
+            p.d_wo.divmod(rem, ho, wo);
+            return (((size_t)b * p.out_H + (size_t)ho * p.out_sh) * p.out_W + (size_t)wo * p.out_sw) * p.Cout;
+        }
+        return (size_t)m * p.Cout;
+    };
+    nt4 rr[1][PRE ? NIT : 1], mk[1][PRE ? NIT : 1];
+    auto request = [&](int i, int buf) {   // the residual / mask rows of block i into register set `buf`
+        if constexpr (PRE) {
+            if (!vec_ok) return;
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int m = m_base + i * 32 + it * RPI + lane / LPR;
+                if (m >= p.M) continue;
+                const size_t ro = row_offset(m) + ncol;
+                if (p.residual) rr[buf][it] = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(p.residual + ro));
+                if (p.mask) mk[buf][it] = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(p.mask + ro));
+            }
+        }
+    };
 #pragma unroll
     for (int i = 0; i < TM; i++) {
+        if constexpr (PRE) request(i, 0);
 #pragma unroll
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 ep[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + j * 32 + l31] = acc[i][j][r];
 #pragma unroll 4
-        for (int it = 0; it < 32 / RPI; it++) {
+        for (int it = 0; it < NIT; it++) {
             const int row = it * RPI + lane / LPR;
             const int m = m_base + i * 32 + row;
             if (m >= p.M || ncol >= p.Cout) continue;
-            size_t row_off;
-            if (p.scatter) {
-                unsigned b, rem, ho, wo;
-                p.d_howo.divmod((unsigned)m, b, rem);
-                p.d_wo.divmod(rem, ho, wo);
-                row_off = (((size_t)b * p.out_H + (size_t)ho * p.out_sh) * p.out_W + (size_t)wo * p.out_sw) * p.Cout;
-            } else {
-                row_off = (size_t)m * p.Cout;
-            }
+            const size_t row_off = row_offset(m);
             float4 v = *reinterpret_cast<const float4*>(ep + row * EP + c4);
             if (wsc) { v.x *= lo4.x; v.y *= lo4.y; v.z *= lo4.z; v.w *= lo4.w; }
             v.x = v.x * sc4.x + bi4.x; v.y = v.y * sc4.y + bi4.y; v.z = v.z * sc4.z + bi4.z; v.w = v.w * sc4.w + bi4.w;
             float* o = out + row_off + ncol;
             if (vec_ok) {
                 if (p.residual) {
-                    typedef float nt4 __attribute__((ext_vector_type(4)));
-                    const nt4 rr_ = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(p.residual + row_off + ncol));
-                    const float4 rr = make_float4(rr_.x, rr_.y, rr_.z, rr_.w);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    nt4 rr_;
+                    if constexpr (PRE) rr_ = rr[0][it];
+                    else rr_ = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(p.residual + row_off + ncol));
+                    v.x += rr_.x; v.y += rr_.y; v.z += rr_.z; v.w += rr_.w;
                 }
                 if (p.relu) { v.x = abr::relu_f(v.x); v.y = abr::relu_f(v.y); v.z = abr::relu_f(v.z); v.w = abr::relu_f(v.w); }
                 if (p.mask) {
-                    typedef float nt4m __attribute__((ext_vector_type(4)));
-                    const nt4m mm_ = __builtin_nontemporal_load(reinterpret_cast<const nt4m*>(p.mask + row_off + ncol));
-                    const float4 mm = make_float4(mm_.x, mm_.y, mm_.z, mm_.w);
+                    nt4 mm;
+                    if constexpr (PRE) mm = mk[0][it];
+                    else mm = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(p.mask + row_off + ncol));
                     v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f; v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
                 }
                 *reinterpret_cast<float4*>(o) = v;
@@ -916,7 +941,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     __syncthreads();  // the epilogue reuses the operand LDS
     const float* wsc = nullptr;
     if constexpr (H3) wsc = p.w_scales + (p.nbatch > 1 ? (size_t)wsc_bt * p.Cout : 0);
-    const unsigned ob = epilogue_rows<TM, TN>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out, wsc, sa);
+    const unsigned ob = epilogue_rows<TM, TN, true>(p, acc, smem + wave * (32 * (TN * 32 + EPAD)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, out, wsc, sa);
     if (p.out_amax) abr::h3_amax_emit(p.out_amax, p.out_epoch, ob);
     abr::prof_stamp_end(p.prof_ts);
 }
@@ -1317,6 +1342,15 @@ static int h3_pack(const float* w, int64_t rows, int K, void* planes, hipStream_
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int32_t info[3];
+        n = abr_device_info(info) == ABR_OK ? info[0] : 256;
+    }
+    return n;
+}
+
 template <int BM, int BN, int WM, int WN, int NP>
 int launch_x6w_np(const ConvP& p, const float* x, float* out, hipStream_t st) {
     ConvP q = p;
@@ -1338,7 +1372,6 @@ int launch_x6w_np(const ConvP& p, const float* x, float* out, hipStream_t st) {
     }
     q.x6_flags = (NP != 1 && abr::x6_guard_enabled()) ? abr::x6_flags_ptr() : nullptr;   // (rounding to bf16 is defined for every finite value: no guard)
     q.h3_stats = (NP == 3 && q.x6_flags) ? abr::h3_stats_ptr() : nullptr;
-    if (q.h3_stats) abr::h3_stats_inspected((double)q.tiles_m * BM * (double)p.K * q.nbatch);   // (the first n-tile column's workgroups inspect their A rows)
     constexpr size_t lds_op = sizeof(__bf16) * (NP == 1 ? 1 : (NP == 3 ? 2 : 3)) * BM * LDX;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
     const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;
@@ -1552,15 +1585,6 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
 }
 
 }  // namespace
-
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int32_t info[3];
-        n = abr_device_info(info) == ABR_OK ? info[0] : 256;
-    }
-    return n;
-}
 
 // tile configuration + launch for one (possibly batched) implicit GEMM described by p
 static void dispatch_igemm(const ConvP& p, const float* x, const float* w, float* out, hipStream_t st) {

@@ -146,7 +146,8 @@ class FusedSGD(object):
         with torch.cuda.stream(early), torch.no_grad():
             if self.reducer.active:
                 for w in list(self.reducer._works):
-                    w.wait()               # the early stream waits for the buckets' all-reduces
+                    if w is not None:      # (None = a bucket-end marker)
+                        w.wait()           # the early stream waits for the buckets' all-reduces
             self._sgd_ranges(todo)
             for b in todo:
                 sub = plan["buckets"].get(b)

@@ -263,6 +263,23 @@ def launch_ranks(n):
     return rc or max((abs(p.returncode or 0) for p in procs), default=0)
 
 
+def pin_rank_to_cores(local_rank, local_world):
+    """Give this rank process its own contiguous slice of the host cores it may run on (os.sched_setaffinity); returns the slice or None when the
+    platform has no affinity call or the slice would be empty.  Must run before the GPU runtime starts its helper threads."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity") or os.environ.get("ABR_PIN_RANKS", "1") == "0":
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // local_world
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return [mine[0], mine[-1]]
+    except OSError:
+        return None
+
+
 def fold_streams(on, optimizer):
     """Fold every HIP stream of the step into the current one (or restore the defaults): weight gradients, the source model, proposal
     selection, the cross-step prefetches and the weight preparation all run in issue order -- the step `roofline.serialised` times.
@@ -283,6 +300,13 @@ def fold_streams(on, optimizer):
      ops.WGRAD_SIDE_STREAM, rpn.PROPOSALS_SIDE_STREAM, prep) = optimizer._folded_saved
     if prep is not None:
         optimizer._prep_stream = prep
+
+
+def rccl_summary(optimizer):
+    from abr_iod_amd import _lib
+    from abr_iod_amd.solver.grad_reducer import rccl_debug_summary
+    return {"rccl_version": int(_lib.lib().abr_comm_rccl_version()),
+            "log": rccl_debug_summary(os.environ.get("NCCL_DEBUG_FILE", "")) if os.environ.get("NCCL_DEBUG_FILE") else []}
 
 
 def read_prof(_lib):
@@ -345,6 +369,11 @@ def main():
     ap.add_argument("--share-frozen-prefix", action="store_true",
                     help="(informational, never the headline) compute the frozen stem + layer1 ONCE per batch for the source and the target model when "
                          "their frozen weights compare equal (engine/trainer.py::SHARE_FROZEN_PREFIX); the reference computes them in both models")
+    ap.add_argument("--allreduce-backend", choices=["torch", "abr"], default=os.environ.get("ABR_ALLREDUCE_BACKEND", "torch"),
+                    help="who issues the gradient all-reduces: torch.distributed under backend nccl (= RCCL; default) or the library's own RCCL communicator "
+                         "(abr_allreduce_flat, csrc/comm.hip)")
+    ap.add_argument("--no-rccl-debug", dest="rccl_debug", action="store_false",
+                    help="--gpus N > 1: do not switch on rank 0's NCCL_DEBUG=INFO log (INIT,TUNING) that config.gradient_exchange_rccl summarises")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher self-test: start the ranks, form the process group (gloo when there is no GPU), all-reduce a 1 per rank, print the count")
     ap.add_argument("--inject-failure", type=int, default=-1,
@@ -353,6 +382,16 @@ def main():
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus))
+    pinned = None
+    if a.gpus > 1:
+        # BEFORE anything touches the GPU (or imports torch: its thread pools inherit the mask): each rank issues ~500 launches per step from one
+        # Python thread plus autograd's; eight such pairs migrating over each other's cores is the one host effect a single-GPU box cannot show
+        pinned = pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+        if int(os.environ.get("RANK", "0")) == 0 and a.rccl_debug:
+            # what RCCL chose (channels, rings / trees, algorithm + protocol per message size) goes to a file that config.gradient_exchange_rccl quotes
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/abr_rccl_%p.log")
 
     import torch
     import torch.distributed as dist
@@ -406,6 +445,9 @@ def main():
     model_source, model_target = build_models(cfg_s, cfg_t, seed=0)       # same seed on every rank = broadcast weights
     optimizer = make_optimizer(cfg_t, model_target)
     scheduler = make_lr_scheduler(cfg_t, optimizer)
+    if world > 1:
+        optimizer.reducer.backend = a.allreduce_backend
+        optimizer.reducer.measure = True      # per-bucket wait of the main stream for the exchange (events; every rank alike)
     IH, IW = (int(v) for v in a.image_size.lower().split("x"))
     images, targets = synthetic_batch(B, IH, IW, seed=42 + rank,           # each rank its own shard of the global batch
                                       label_range=(n_old_cls + 1, n_old_cls + n_new_cls + 1))
@@ -545,6 +587,8 @@ def main():
                                       "note": "the timed region visits them in turn (step i runs batch i mod n, the next one prefetched)"},
                        "rccl_ranks": rccl_ranks, "collective": "RCCL all-reduce of the flat gradient, 3 buckets, 2 under backward" if world > 1 else None,
                        "gradient_exchange": optimizer.reducer.describe() if world > 1 else None,
+                       "gradient_exchange_rccl": (rccl_summary(optimizer) if world > 1 else None),
+                       "host_cores_of_rank0": pinned,
                        "gflop_per_img_algorithmic": GFLOP_PER_IMG_ARD if standard else None},
             "final_losses": {k: round(float(v.detach()), 5) for k, v in loss_dict.items()},
             "conv_math_at_end": getattr(model_target, "conv_math", None),   # "f32" here = the range guard took the run off the bf16x6 kernels

@@ -549,6 +549,26 @@ int abr_img_fill_u8(uint8_t* dst, int64_t n, int value, void* stream);
 int abr_img_normalize_to_batch(const uint8_t* src, int h, int w, int flip, int to_bgr255, const float* mean3_host,
                                const float* std3_host, float* out_slot, int HP, int WP, void* stream);
 
+/* =====================================================================================================
+ * 8. Data-parallel gradient exchange: what DistributedDataParallel's reducer does for the reference
+ *    between backward and optimizer.step() (tools/train_incremental.py:231-235; reduce in maskrcnn_benchmark/engine/trainer.py:15-37),
+ *    as an in-place sum all-reduce of element ranges of the FLAT fp32 gradient buffer over RCCL (csrc/comm.hip).  One process per GPU.
+ *    librccl.so.1 is loaded at first use (a copy the process already holds is reused).  Rendezvous: rank 0 calls abr_comm_unique_id and
+ *    distributes the 128 bytes out of band; every rank then calls abr_comm_init (collective) on its own device.
+ * ===================================================================================================== */
+/* RCCL's version code (ncclGetVersion), 0 when librccl cannot be loaded */
+int abr_comm_rccl_version(void);
+/* id128_host: 128 bytes (ncclUniqueId) */
+int abr_comm_unique_id(void* id128_host);
+/* *comm_out = a communicator of `world` ranks on the CURRENT device (hipSetDevice first); collective over the ranks */
+int abr_comm_init(int world, int rank, const void* id128_host, void** comm_out);
+/* out[0] = ranks, out[1] = this rank, out[2] = device ordinal the communicator was created on */
+int abr_comm_info(void* comm, int32_t* out_host);
+int abr_comm_destroy(void* comm);
+/* flat[a_i : b_i) = sum over ranks, in place, for the n_ranges ranges ranges_host = {a_0, b_0, a_1, b_1, ...} (element offsets, HOST array):
+ * ONE RCCL group enqueued on `stream`; returns without synchronising.  Every rank must pass the same ranges in the same order. */
+int abr_allreduce_flat(void* comm, float* flat, const int64_t* ranges_host, int n_ranges, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,10 @@ def _free_port():
     return p
 
 
-def test_single_rank_rccl_step_equals_local_step():
+@pytest.mark.parametrize("backend", ["torch", "abr"])
+def test_single_rank_rccl_step_equals_local_step(backend):
+    """backend "torch": torch.distributed.all_reduce under "nccl" (= RCCL); "abr": the library's own communicator and abr_allreduce_flat
+    (csrc/comm.hip), one RCCL group per bucket on the reducer's stream."""
     from abr_iod_amd.engine import train_step
     from abr_iod_amd.engine.synthetic import build_models, make_cfgs, synthetic_batch
     from abr_iod_amd.solver.build import make_lr_scheduler, make_optimizer
@@ -35,6 +38,8 @@ def test_single_rank_rccl_step_equals_local_step():
         ms, mt = build_models(cfg_s, cfg_t, seed=0)
         opt = make_optimizer(cfg_t, mt)
         opt.force_all_reduce = collective
+        opt.reducer.backend = backend
+        opt.reducer.measure = collective
         sent, inner = [], opt.reducer.reduce_bucket_async
         opt.reducer.reduce_bucket_async = lambda name: (sent.append((name, name in opt.reducer._done)), inner(name))
         sch = make_lr_scheduler(cfg_t, opt)
@@ -45,6 +50,11 @@ def test_single_rank_rccl_step_equals_local_step():
         if collective:  # the trainer's gradient hooks sent the RoI-head bucket, then the RPN bucket, DURING each backward pass
             first = [name for name, already in sent if not already]
             assert first == ["roi_heads", "rpn"] * 3, sent
+            d = opt.reducer.describe()
+            assert [r["bucket"] for r in d] == ["roi_heads", "rpn", "backbone"] and all(r["backend"] == backend for r in d)
+            waits = [r["main_stream_wait_ms_cumulative"] for r in d]
+            assert all(w >= 0.0 for w in waits) and waits == sorted(waits), waits      # measured, cumulative in issue order
+            opt.reducer.close()
         else:
             assert sent == []
         return mt.flat.params.clone()
@@ -59,6 +69,39 @@ def test_single_rank_rccl_step_equals_local_step():
     assert torch.isfinite(with_rccl).all()
     # atomically accumulated weight gradients make two runs differ in the last bits; the collective adds nothing on top
     assert float((with_rccl - local).norm() / local.norm()) < 1e-5
+
+
+def test_allreduce_flat_abi_single_rank():
+    """abr_comm_* / abr_allreduce_flat straight through the C ABI: a one-rank communicator on this GPU, ranges summed in place (= unchanged),
+    ranges outside the list untouched, bad ranges refused; include/abr_iod_hip.h section 8."""
+    import ctypes as C
+    from abr_iod_amd import _lib as L
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    lib = L.lib()
+    assert lib.abr_comm_rccl_version() >= 20000
+    idb = C.create_string_buffer(128)
+    L.check(lib.abr_comm_unique_id(C.cast(idb, C.c_void_p)), "comm_unique_id")
+    assert any(idb.raw)
+    comm = C.c_void_p()
+    L.check(lib.abr_comm_init(1, 0, C.cast(idb, C.c_void_p), C.byref(comm)), "comm_init")
+    try:
+        info = (C.c_int32 * 3)()
+        L.check(lib.abr_comm_info(comm, C.cast(info, C.c_void_p)), "comm_info")
+        assert list(info) == [1, 0, torch.cuda.current_device()]
+        g = torch.Generator(device="cuda").manual_seed(0)
+        buf = torch.randn(1 << 20, device="cuda", generator=g)
+        want = buf.clone()
+        ranges = (C.c_int64 * 6)(0, 1000, 5000, 5000, 70000, 1 << 20)      # (the middle range is empty)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        L.check(lib.abr_allreduce_flat(comm, buf.data_ptr(), C.cast(ranges, C.c_void_p), 3, side.cuda_stream), "allreduce_flat")
+        side.synchronize()
+        assert torch.equal(buf, want)
+        bad = (C.c_int64 * 2)(10, 5)
+        assert lib.abr_allreduce_flat(comm, buf.data_ptr(), C.cast(bad, C.c_void_p), 1, side.cuda_stream) == -1
+        assert b"range 0" in lib.abr_last_error()
+    finally:
+        L.check(lib.abr_comm_destroy(comm), "comm_destroy")
 
 
 def _two_rank_worker(rank, world, port, out):
