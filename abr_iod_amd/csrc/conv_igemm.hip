@@ -1372,6 +1372,7 @@ int launch_x6w_np(const ConvP& p, const float* x, float* out, hipStream_t st) {
     }
     q.x6_flags = (NP != 1 && abr::x6_guard_enabled()) ? abr::x6_flags_ptr() : nullptr;   // (rounding to bf16 is defined for every finite value: no guard)
     q.h3_stats = (NP == 3 && q.x6_flags) ? abr::h3_stats_ptr() : nullptr;
+    if (q.h3_stats) abr::h3_stats_inspected((double)q.tiles_m * BM * (double)p.K * q.nbatch);   // (the first n-tile column's workgroups inspect their A rows)
     constexpr size_t lds_op = sizeof(__bf16) * (NP == 1 ? 1 : (NP == 3 ? 2 : 3)) * BM * LDX;
     constexpr size_t lds_ep = sizeof(float) * 4 * 32 * (BN / WN + EPAD);
     const size_t lds = lds_op > lds_ep ? lds_op : lds_ep;

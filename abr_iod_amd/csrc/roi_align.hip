@@ -171,130 +171,6 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------
-// NHWC forward with REGISTER REUSE of shared taps (round 6).  The reference's association order fixes 4 tap vectors per sample (16 per output
-// for a 2 x 2 sample grid, 64 for 4 x 4), and that tap traffic through the vector L1 -- not HBM -- bounds the kernel above.
-// But neighbouring samples of a bin read the SAME cells: sample spacing is bin / grid <= 1 cell, so along a sample row the left tap pair of
-// sample ix is the right pair of ix - 1 (or the same pair), and a sample row's upper pair is the previous row's lower pair (or the same pair):
-// a gh x gw grid touches <= (gh + 1)(gw + 1) distinct cells, not 4 gh gw.  Each thread keeps, per sample column ix < 4, the four vectors of the
-// last sample it evaluated there together with their flat indices; a tap whose index equals a cached one is taken from the register (the value
-// IS the value a load would return), everything else is loaded.  Same products, same order: bit-identical to the kernel above
-// (tests/test_gpu_ops.py, test_gpu_vs_reference_csrc.py, the detection fuzz).  RoIs with more than 4 sample columns or more samples than one
-// table chunk take the plain loop.
-// ---------------------------------------------------------------------------------------------------
-#pragma clang fp contract(off)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void roi_align_fwd_nhwc_reuse(const float* __restrict__ feat, const float* __restrict__ rois,
-                                                                int K, int C, int H, int W, float scale, int PH, int PW,
-                                                                int sr, int step, int PHo, int PWo, int bpb, int tx,
-                                                                int blocks_per_roi, int cslices, float* __restrict__ out) {
-    __shared__ int4 s_idx[256];
-    __shared__ float4 s_w[256];
-    const unsigned nblk = gridDim.x;
-    const unsigned bid = cslices > 1 ? blockIdx.x / (unsigned)cslices : abr::xcd_remap(blockIdx.x, nblk);
-    const int slice = cslices > 1 ? (int)(blockIdx.x % (unsigned)cslices) : 0;
-    const int n = bid / blocks_per_roi;
-    const int bin0 = (bid % blocks_per_roi) * bpb;
-    const int nbins = PHo * PWo;
-    const int tch = 256 / bpb;  // samples per chunk per bin
-
-    const RoiGeom g = roi_geom(rois + 5 * (size_t)n, scale, PH, PW, sr);
-    const int ns = g.gh * g.gw;
-    const float count = (float)ns;
-
-    const int bl = threadIdx.x / tx;  // local bin
-    const int cl = threadIdx.x % tx;  // channel lane
-    const int bin = bin0 + bl;
-    const bool bin_ok = bin < nbins;
-    const int cps = C / 4 / cslices;
-    const int cv_begin = slice * cps, cvecs = cv_begin + cps;
-    const float* fb = feat + (size_t)g.b * H * W * C;
-
-    const int eb = threadIdx.x / tch, es = threadIdx.x % tch;
-    const int ebin = bin0 + eb;
-    const int eph = (ebin / PWo) * step, epw = (ebin % PWo) * step;
-    const bool reuse = ns <= tch && g.gw <= 4;   // (uniform over the workgroup: one RoI)
-
-    for (int c0 = cv_begin; c0 < cvecs; c0 += tx) {
-        const int cv = c0 + cl;
-        const bool c_ok = bin_ok && cv < cvecs;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* fc = fb + cv * 4;
-        auto ld = [&](int p) { return *reinterpret_cast<const float4*>(fc + (size_t)p * C); };
-        auto fma4 = [&](const float4& w, const float4& a0, const float4& a1, const float4& a2, const float4& a3) {
-            acc.x += w.x * a0.x + w.y * a1.x + w.z * a2.x + w.w * a3.x;
-            acc.y += w.x * a0.y + w.y * a1.y + w.z * a2.y + w.w * a3.y;
-            acc.z += w.x * a0.z + w.y * a1.z + w.z * a2.z + w.w * a3.z;
-            acc.w += w.x * a0.w + w.y * a1.w + w.z * a2.w + w.w * a3.w;
-        };
-        for (int sb = 0; sb < ns; sb += tch) {
-            __syncthreads();
-            {
-                const int s = sb + es;
-                Tap t;
-                if (s < ns && ebin < nbins) {
-                    t = make_tap(g, H, W, eph, epw, s / g.gw, s % g.gw);
-                } else {
-                    t.p0 = t.p1 = t.p2 = t.p3 = -1;
-                    t.w0 = t.w1 = t.w2 = t.w3 = 0.f;
-                }
-                s_idx[threadIdx.x] = make_int4(t.p0, t.p1, t.p2, t.p3);
-                s_w[threadIdx.x] = make_float4(t.w0, t.w1, t.w2, t.w3);
-            }
-            __syncthreads();
-            if (!c_ok) continue;
-            if (!reuse) {
-                const int lim = min(tch, ns - sb);
-                for (int s = 0; s < lim; s++) {
-                    const int4 p = s_idx[bl * tch + s];
-                    if (p.x < 0) continue;
-                    const float4 w = s_w[bl * tch + s];
-                    const float4 v0 = ld(p.x), v1 = ld(p.y), v2 = ld(p.z), v3 = ld(p.w);
-                    fma4(w, v0, v1, v2, v3);
-                }
-                continue;
-            }
-            // cached per sample column: the four tap vectors of the last sample evaluated there.  Their flat indices are re-read from the table
-            // (the entry one row up / one column left): an entry that was rejected (-1) matches nothing, so a stale vector is never taken
-            float4 c0v[4], c1v[4], c2v[4], c3v[4];
-            const int4 none = make_int4(-2, -2, -2, -2);
-            for (int iy = 0; iy < g.gh; iy++) {
-#pragma unroll
-                for (int ix = 0; ix < 4; ix++) {
-                    if (ix >= g.gw) break;
-                    const int s = iy * g.gw + ix;
-                    const int4 p = s_idx[bl * tch + s];
-                    if (p.x < 0) continue;   // rejected sample: nothing read, nothing cached
-                    const float4 w = s_w[bl * tch + s];
-                    float4 v0, v1, v2, v3;
-                    int4 u = iy > 0 ? s_idx[bl * tch + s - g.gw] : none;       // the sample above: cache column ix holds it iff it was evaluated
-                    int4 l = ix > 0 ? s_idx[bl * tch + s - 1] : none;          // the sample to the left: cache column ix - 1, same condition
-                    if (u.x < 0) u = none;
-                    if (l.x < 0) l = none;
-                    // upper pair (p.x, p.y)
-                    if (p.x == u.x && p.y == u.y) { v0 = c0v[ix]; v1 = c1v[ix]; }                 // same cell row as the sample above
-                    else if (p.x == u.z && p.y == u.w) { v0 = c2v[ix]; v1 = c3v[ix]; }            // one cell row down: its lower pair
-                    else if (ix > 0 && p.x == l.x && p.y == l.y) { v0 = c0v[ix > 0 ? ix - 1 : 0]; v1 = c1v[ix > 0 ? ix - 1 : 0]; }   // same cells as the left sample
-                    else if (ix > 0 && p.x == l.y) { v0 = c1v[ix > 0 ? ix - 1 : 0]; v1 = ld(p.y); }                                   // one cell to the right of it
-                    else { v0 = ld(p.x); v1 = ld(p.y); }
-                    // lower pair (p.z, p.w)
-                    if (p.z == u.z && p.w == u.w) { v2 = c2v[ix]; v3 = c3v[ix]; }
-                    else if (ix > 0 && p.z == l.z && p.w == l.w) { v2 = c2v[ix > 0 ? ix - 1 : 0]; v3 = c3v[ix > 0 ? ix - 1 : 0]; }
-                    else if (ix > 0 && p.z == l.w) { v2 = c3v[ix > 0 ? ix - 1 : 0]; v3 = ld(p.w); }
-                    else if (p.z == p.x && p.w == p.y) { v2 = v0; v3 = v1; }                      // clamped at the last row: yh == yl
-                    else { v2 = ld(p.z); v3 = ld(p.w); }
-                    fma4(w, v0, v1, v2, v3);
-                    c0v[ix] = v0; c1v[ix] = v1; c2v[ix] = v2; c3v[ix] = v3;
-                }
-            }
-        }
-        if (c_ok) {
-            float4 o;
-            o.x = acc.x / count; o.y = acc.y / count; o.z = acc.z / count; o.w = acc.w / count;
-            *reinterpret_cast<float4*>(out + ((size_t)n * nbins + bin) * C + cv * 4) = o;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // NHWC backward: scatter (g*w_k)/count to the 4 taps with hardware fp32 atomics (global_atomic_add_f32).
 // ---------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
@@ -953,14 +829,8 @@ extern "C" int abr_roi_align_forward(const float* feat, const float* rois, int K
             const int cslices = (slice_on && (C / 4) % 8 == 0 && C / 4 / 8 >= 32 && (int64_t)H * W * C * 4 > (2 << 20)) ? 8 : 1;
             pick_shape(C / 4 / cslices, nbins, &tx, &bpb);
             const int bpr = (nbins + bpb - 1) / bpb;
-            // ABR_ROIALIGN_REUSE=0 (read per call): the plain tap loop
-            const char* ru = getenv("ABR_ROIALIGN_REUSE");
-            if (!(ru && atoi(ru) == 0))
-                roi_align_fwd_nhwc_reuse<<<(unsigned)(K * bpr * cslices), 256, 0, st>>>(feat, rois, K, C, H, W, scale, PH, PW, sr,
-                                                                                         bin_step, PHo, PWo, bpb, tx, bpr, cslices, out);
-            else
-                roi_align_fwd_nhwc<4><<<(unsigned)(K * bpr * cslices), 256, 0, st>>>(feat, rois, K, C, H, W, scale, PH, PW, sr,
-                                                                                      bin_step, PHo, PWo, bpb, tx, bpr, cslices, out);
+            roi_align_fwd_nhwc<4><<<(unsigned)(K * bpr * cslices), 256, 0, st>>>(feat, rois, K, C, H, W, scale, PH, PW, sr,
+                                                                                  bin_step, PHo, PWo, bpb, tx, bpr, cslices, out);
         } else {
             pick_shape(C, nbins, &tx, &bpb);
             const int bpr = (nbins + bpb - 1) / bpb;
