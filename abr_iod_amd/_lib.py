@@ -119,6 +119,7 @@ _SIGS = {
     "abr_img_blend_paste_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.c_double, _vp]),
     "abr_img_copy_rect_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "abr_img_fill_u8": (_i, [_vp, _i64, _i, _vp]),
+    "abr_img_color_jitter_u8": (_i, [_vp, _i, _i, _i, C.c_double, _vp, _vp]),
     "abr_img_normalize_to_batch": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _i, _i, _vp]),
     "abr_conv_forward": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "abr_conv_tail64_forward": (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),

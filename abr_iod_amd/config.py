@@ -83,6 +83,13 @@ _C.INPUT.MAX_SIZE_TRAIN = 1333
 _C.INPUT.PIXEL_MEAN = [102.9801, 115.9465, 122.7717]
 _C.INPUT.PIXEL_STD = [1.0, 1.0, 1.0]
 _C.INPUT.TO_BGR255 = True
+_C.INPUT.MIN_SIZE_TEST = 800
+_C.INPUT.MAX_SIZE_TEST = 1333
+_C.INPUT.FLIP_PROB_TRAIN = 0.5
+_C.INPUT.BRIGHTNESS = 0.0      # ColorJitter strengths (config/defaults.py:62-66; 0 in every configs/voc YAML)
+_C.INPUT.CONTRAST = 0.0
+_C.INPUT.SATURATION = 0.0
+_C.INPUT.HUE = 0.0
 
 _C.DATALOADER = CN()
 _C.DATALOADER.NUM_WORKERS = 4

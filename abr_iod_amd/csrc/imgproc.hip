@@ -117,6 +117,87 @@ __global__ __launch_bounds__(256) void normalize_kernel(const uint8_t* __restric
 
 inline unsigned grid_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 16384); }
 
+
+// ---- ColorJitter's pixel ops (transforms.py:132-150 -> torchvision -> Pillow), in place on a uint8 HWC RGB image.  Bit-exact restatements of
+// Pillow's C arithmetic (Blend.c; Convert.c rgb2l / rgb2hsv_row / hsv2rgb_row), pinned against Pillow by oracle/abr_data_ref.py's tests:
+//   blend(degenerate, image, f): float32, truncation; for f outside [0, 1] clipped to [0, 255] first
+//   brightness: degenerate = 0;  contrast: degenerate = int(mean(L) + 0.5) (one scalar per image, summed exactly in 64-bit integers by
+//   gray_sum_kernel and read from device memory: no host round trip);  saturation: degenerate = L of the pixel;  L = (19595 R + 38470 G + 7471 B + 2^15) >> 16
+//   hue: RGB -> HSV (float quotients; the sector offset and the fmod in double), H += shift (mod 256), HSV -> RGB (double products, C round())
+#pragma clang fp contract(off)
+__device__ __forceinline__ uint8_t pil_blend(const int in1, const int in2, const float alpha, const bool inside) {
+    const float t = (float)in1 + alpha * ((float)in2 - (float)in1);
+    if (inside) return (uint8_t)(int)t;
+    return t <= 0.f ? (uint8_t)0 : (t >= 255.f ? (uint8_t)255 : (uint8_t)(int)t);
+}
+__device__ __forceinline__ int pil_l(const int r, const int g, const int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+
+__global__ __launch_bounds__(256) void gray_sum_kernel(const uint8_t* __restrict__ img, int64_t npix, unsigned long long* __restrict__ sum) {
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x)
+        acc += (unsigned)pil_l(img[3 * i], img[3 * i + 1], img[3 * i + 2]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);   // (integer sum: exact, order-free)
+}
+
+// op: 0 brightness, 1 contrast (gray_sum holds the image's L sum), 2 saturation
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void color_blend_kernel(uint8_t* __restrict__ img, int64_t npix, int op, float factor,
+                                                          const unsigned long long* __restrict__ gray_sum) {
+    const bool inside = factor >= 0.f && factor <= 1.f;
+    int mean = 0;
+    if (op == 1) mean = (int)((double)*gray_sum / (double)npix + 0.5);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t* p = img + 3 * i;
+        const int r = p[0], g = p[1], b = p[2];
+        const int d = op == 0 ? 0 : (op == 1 ? mean : pil_l(r, g, b));
+        p[0] = pil_blend(d, r, factor, inside); p[1] = pil_blend(d, g, factor, inside); p[2] = pil_blend(d, b, factor, inside);
+    }
+}
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void hue_shift_kernel(uint8_t* __restrict__ img, int64_t npix, int shift) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t* px = img + 3 * i;
+        const int r = px[0], g = px[1], b = px[2];
+        const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+        int uh = 0, us = 0;
+        const int uv = maxc;
+        if (minc != maxc) {   // rgb2hsv_row
+            const float cr = (float)(maxc - minc);
+            const float s = cr / (float)maxc;
+            const float rc = (float)(maxc - r) / cr, gc = (float)(maxc - g) / cr, bc = (float)(maxc - b) / cr;
+            float h;
+            if (r == maxc) h = bc - gc;
+            else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+            else h = (float)(4.0 + (double)gc - (double)rc);
+            h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+            uh = (int)((double)h * 255.0); uh = uh < 0 ? 0 : (uh > 255 ? 255 : uh);
+            us = (int)((double)s * 255.0); us = us < 0 ? 0 : (us > 255 ? 255 : us);
+        }
+        uh = (uh + shift) & 255;
+        if (us == 0) { px[0] = px[1] = px[2] = (uint8_t)uv; continue; }   // hsv2rgb_row
+        const double hh = (double)(float)uh * 6.0 / 255.0;
+        const int sec = (int)floor(hh);
+        const double f = (double)(float)(hh - (double)(float)sec);
+        const double fs = (double)(float)((double)(float)us / 255.0);
+        const double vf = (double)(float)uv;
+        int pp = (int)round(vf * (1.0 - fs)), qq = (int)round(vf * (1.0 - fs * f)), tt = (int)round(vf * (1.0 - fs * (1.0 - f)));
+        pp = pp < 0 ? 0 : (pp > 255 ? 255 : pp); qq = qq < 0 ? 0 : (qq > 255 ? 255 : qq); tt = tt < 0 ? 0 : (tt > 255 ? 255 : tt);
+        int R, G, B;
+        switch (sec % 6) {
+            case 0: R = uv; G = tt; B = pp; break;
+            case 1: R = qq; G = uv; B = pp; break;
+            case 2: R = pp; G = uv; B = tt; break;
+            case 3: R = pp; G = qq; B = uv; break;
+            case 4: R = tt; G = pp; B = uv; break;
+            default: R = uv; G = pp; B = qq; break;
+        }
+        px[0] = (uint8_t)R; px[1] = (uint8_t)G; px[2] = (uint8_t)B;
+    }
+}
+
 }  // namespace
 
 extern "C" int abr_img_resample_u8(const uint8_t* src, int H, int W, uint8_t* dst, int OH, int OW, const int32_t* bounds_h,
@@ -185,5 +266,31 @@ extern "C" int abr_img_normalize_to_batch(const uint8_t* src, int h, int w, int 
                                                                                      mean3_host[2], std3_host[0], std3_host[1],
                                                                                      std3_host[2], out_slot, HP, WP);
     ABR_CHECK_LAUNCH("img_normalize");
+    return ABR_OK;
+}
+
+/* ColorJitter's pixel ops, in place (include/abr_iod_hip.h section 7).  op: 0 brightness, 1 contrast, 2 saturation (factor = the enhancement factor),
+ * 3 hue (factor = hue_factor in [-0.5, 0.5]).  scratch: 8 bytes of device memory (contrast's L sum). */
+extern "C" int abr_img_color_jitter_u8(uint8_t* img, int H, int W, int op, double factor, void* scratch8, void* stream) {
+    ABR_REQUIRE(H >= 0 && W >= 0 && op >= 0 && op <= 3, "img_color_jitter: bad args");
+    const int64_t npix = (int64_t)H * W;
+    if (npix == 0) return ABR_OK;
+    ABR_REQUIRE(img, "img_color_jitter: null pointer");
+    hipStream_t st = abr::as_stream(stream);
+    if (op == 3) {
+        ABR_REQUIRE(factor >= -0.5 && factor <= 0.5, "img_color_jitter: hue_factor (%g) is not in [-0.5, 0.5]", factor);
+        const int shift = ((int)(factor * 255.0) % 256 + 256) % 256;   // uint8(hue_factor * 255): truncation toward zero, modulo 256
+        hue_shift_kernel<<<grid_for(npix), 256, 0, st>>>(img, npix, shift);
+    } else {
+        ABR_REQUIRE(factor >= 0.0, "img_color_jitter: negative enhancement factor");
+        unsigned long long* sum = reinterpret_cast<unsigned long long*>(scratch8);
+        if (op == 1) {
+            ABR_REQUIRE(sum, "img_color_jitter: contrast needs 8 bytes of device scratch");
+            if (hipMemsetAsync(sum, 0, 8, st) != hipSuccess) { abr::set_error("img_color_jitter: memset failed"); return ABR_E_LAUNCH; }
+            gray_sum_kernel<<<grid_for(npix), 256, 0, st>>>(img, npix, sum);
+        }
+        color_blend_kernel<<<grid_for(npix), 256, 0, st>>>(img, npix, op, (float)factor, sum);
+    }
+    ABR_CHECK_LAUNCH("img_color_jitter");
     return ABR_OK;
 }

@@ -235,20 +235,58 @@ class Resize(object):
         return image, (target.resize((ow, oh)) if target is not None else None)
 
 
+class ColorJitter(object):
+    """transforms.py:132-150: torchvision.transforms.ColorJitter(brightness, contrast, saturation, hue) on a device image.  Strength v > 0 means a
+    factor drawn uniformly from [max(0, 1 - v), 1 + v] (hue: [-v, v], v <= 0.5); the active ops are applied in a shuffled order.  The draws follow
+    torchvision 0.2-0.4's `get_params` (the reference's era): one `random.uniform` per active op in the order brightness, contrast, saturation, hue,
+    then one `random.shuffle` -- Python's `random`, like the flip.  The pixel work is csrc/imgproc.hip (bit-exact against Pillow's ImageEnhance /
+    HSV conversions, which is what torchvision's PIL path calls).  All strengths 0 (every configs/voc YAML): the identity, nothing drawn."""
+
+    def __init__(self, brightness=None, contrast=None, saturation=None, hue=None):
+        def interval(v, name, center=1.0, bound=None, clip0=True):
+            v = float(v or 0.0)
+            if v < 0:
+                raise ValueError("If {} is a single number, it must be non negative.".format(name))
+            if v == 0:
+                return None
+            lo, hi = center - v, center + v
+            if clip0:
+                lo = max(lo, 0.0)
+            if bound is not None and not (bound[0] <= lo <= hi <= bound[1]):
+                raise ValueError("{} values should be between {}".format(name, bound))
+            return (lo, hi)
+        self.spec = [("brightness", interval(brightness, "brightness")), ("contrast", interval(contrast, "contrast")),
+                     ("saturation", interval(saturation, "saturation")), ("hue", interval(hue, "hue", 0.0, (-0.5, 0.5), False))]
+
+    def get_params(self):
+        ops_ = [(n, random.uniform(iv[0], iv[1])) for n, iv in self.spec if iv is not None]
+        random.shuffle(ops_)
+        return ops_
+
+    def __call__(self, image, target=None):
+        ops_ = self.get_params()
+        if ops_:
+            image = image.clone()       # (the dataset may hand out a cached device image)
+            for name, factor in ops_:
+                G.color_jitter_(image, name, factor)
+        return image, target
+
+
 class GPUTransform(object):
-    """build_transforms(cfg, is_train) (transforms/build.py:5-41) for device images: Resize -> RandomHorizontalFlip -> ToTensor ->
+    """build_transforms(cfg, is_train) (transforms/build.py:5-41) for device images: ColorJitter -> Resize -> RandomHorizontalFlip -> ToTensor ->
     Normalize.  The flip and the normalisation are deferred into the batching kernel, so this returns (resized uint8 image,
-    target, flip flag); `collate` finishes the job.  ColorJitter is the identity in every configs/voc YAML (all four strengths 0)."""
+    target, flip flag); `collate` finishes the job.  ColorJitter is the identity in every configs/voc YAML (all four strengths 0) and at test time."""
 
     def __init__(self, cfg, is_train=True):
-        if any(float(getattr(cfg.INPUT, k, 0.0) or 0.0) != 0.0 for k in ("BRIGHTNESS", "CONTRAST", "SATURATION", "HUE")):
-            raise NotImplementedError("ColorJitter strengths are 0 in every configs/voc YAML; non-zero jitter is not implemented")
+        j = [float(getattr(cfg.INPUT, k, 0.0) or 0.0) if is_train else 0.0 for k in ("BRIGHTNESS", "CONTRAST", "SATURATION", "HUE")]   # build.py:10-21
+        self.color_jitter = ColorJitter(*j)
         self.resize = Resize(cfg.INPUT.MIN_SIZE_TRAIN if is_train else cfg.INPUT.MIN_SIZE_TEST,
                              cfg.INPUT.MAX_SIZE_TRAIN if is_train else cfg.INPUT.MAX_SIZE_TEST)
         self.flip_prob = getattr(cfg.INPUT, "FLIP_PROB_TRAIN", 0.5) if is_train else 0
         self.mean, self.std, self.to_bgr255 = cfg.INPUT.PIXEL_MEAN, cfg.INPUT.PIXEL_STD, cfg.INPUT.TO_BGR255
 
     def __call__(self, image, target):
+        image, target = self.color_jitter(image, target)      # first, on the original-size image (build.py:28-30)
         image, target = self.resize(image, target)
         flip = random.random() < self.flip_prob
         if flip and target is not None:

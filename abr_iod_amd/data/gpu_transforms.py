@@ -78,3 +78,22 @@ def normalize_into(img, out_slot, mean, std, to_bgr255=True, flip=False):
     L.check(L.lib().abr_img_normalize_to_batch(L.ptr(img), h, w, int(bool(flip)), int(bool(to_bgr255)), m, s, L.ptr(out_slot), HP, WP,
                                                L.stream()), "img_normalize")
     return out_slot
+
+
+_JITTER_OPS = {"brightness": 0, "contrast": 1, "saturation": 2, "hue": 3}
+_jitter_scratch = {}
+
+
+def color_jitter_(img, op, factor):
+    """One ColorJitter op of torchvision's PIL path, in place on a device image (uint8 HWC RGB), bit-exact against Pillow:
+    F.adjust_brightness / adjust_contrast / adjust_saturation (= ImageEnhance: Image.blend with a degenerate image) and F.adjust_hue
+    (H byte shifted through Pillow's RGB <-> HSV conversions).  op: a name of _JITTER_OPS."""
+    L.require_cuda(img)
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or not img.is_contiguous():
+        raise ValueError("expected a contiguous uint8 HWC RGB device image")
+    scratch = _jitter_scratch.get(img.device)
+    if scratch is None:
+        scratch = _jitter_scratch[img.device] = torch.zeros(1, dtype=torch.int64, device=img.device)
+    L.check(L.lib().abr_img_color_jitter_u8(L.ptr(img), img.shape[0], img.shape[1], _JITTER_OPS[op], float(factor), L.ptr(scratch), L.stream()),
+            "img_color_jitter")
+    return img

@@ -544,6 +544,11 @@ int abr_img_blend_paste_u8(uint8_t* img, int H, int W, const uint8_t* crop, int 
 int abr_img_copy_rect_u8(uint8_t* dst, int DH, int DW, const uint8_t* src, int SH, int SW, int dx, int dy, int sx, int sy,
                          int rw, int rh, void* stream);
 int abr_img_fill_u8(uint8_t* dst, int64_t n, int value, void* stream);
+/* ColorJitter (transforms.py:132-150 -> torchvision.transforms.ColorJitter -> Pillow's ImageEnhance / HSV conversions), one op in place:
+ * op 0 brightness, 1 contrast, 2 saturation: img = Image.blend(degenerate, img, factor) with Pillow's float32 arithmetic (degenerate = black /
+ * the constant int(mean(L) + 0.5) / the pixel's L); op 3 hue: H += uint8(factor * 255) (mod 256) through Pillow's RGB <-> HSV conversions,
+ * factor in [-0.5, 0.5].  scratch8: 8 bytes of device memory (used by contrast). */
+int abr_img_color_jitter_u8(uint8_t* img, int H, int W, int op, double factor, void* scratch8, void* stream);
 /* one [3,HP,WP] fp32 slot of the batch tensor: (optional hflip) -> /255 -> [2,1,0]*255 (to_bgr255) -> (x-mean)/std, zeros outside
  * [h,w] (transforms.py:108-165 + to_image_list).  mean/std are HOST pointers to 3 floats. */
 int abr_img_normalize_to_batch(const uint8_t* src, int h, int w, int flip, int to_bgr255, const float* mean3_host,

@@ -130,3 +130,114 @@ def to_tensor_normalize(img, mean, std, to_bgr255=True, flip=False):
     mean_t = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
     std_t = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
     return ((t - mean_t) / std_t).numpy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# ColorJitter (maskrcnn_benchmark/data/transforms/transforms.py:132-150 -> torchvision.transforms.ColorJitter on PIL images: the first
+# transform of build.py:28-36, on the ORIGINAL-size image).  torchvision is not importable in this image; its PIL path is four calls into
+# Pillow -- ImageEnhance.Brightness / Contrast / Color (= Image.blend with a degenerate image) and an RGB -> HSV -> RGB round trip with the
+# hue byte shifted -- and Pillow IS here, so the functions below restate Pillow's C arithmetic (src/libImaging/Blend.c, Convert.c::rgb2l,
+# rgb2hsv_row, hsv2rgb_row) and tests/test_oracle_data.py pins them bit-exact against Pillow itself (the conversions over all 2^24 colours).
+def _blend_u8(in1, in2, alpha):
+    """Image.blend(im1, im2, alpha): float32 arithmetic, truncation; outside [0, 1] the result is clipped first (Blend.c)"""
+    al = np.float32(alpha)
+    t = in1.astype(np.float32) + al * (in2.astype(np.float32) - in1.astype(np.float32))
+    if 0.0 <= alpha <= 1.0:
+        return t.astype(np.int32).astype(np.uint8)
+    return np.where(t <= 0, 0, np.where(t >= 255, 255, t.astype(np.int32))).astype(np.uint8)
+
+
+def rgb_to_l(img):
+    """Image.convert("L"): ITU-R 601-2 luma in 16-bit fixed point (Convert.c rgb2l)"""
+    r, g, b = (img[..., c].astype(np.int64) for c in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def adjust_brightness(img, factor):
+    """F.adjust_brightness: ImageEnhance.Brightness(img).enhance(factor) = blend(black, img, factor)"""
+    return _blend_u8(np.zeros_like(img), img, factor)
+
+
+def adjust_contrast(img, factor):
+    """F.adjust_contrast: the degenerate image is the constant int(mean(L) + 0.5)"""
+    mean = int(float(rgb_to_l(img).astype(np.float64).sum() / (img.shape[0] * img.shape[1])) + 0.5)
+    return _blend_u8(np.full_like(img, mean), img, factor)
+
+
+def adjust_saturation(img, factor):
+    """F.adjust_saturation: ImageEnhance.Color, the degenerate image is convert("L").convert("RGB")"""
+    return _blend_u8(np.repeat(rgb_to_l(img)[..., None], 3, axis=2), img, factor)
+
+
+def rgb_to_hsv_u8(rgb):
+    """Image.convert("HSV") (Convert.c rgb2hsv_row: float quotients, the hue offset and the fmod in double, truncation)"""
+    r, g, b = (rgb[..., c].astype(np.int32) for c in range(3))
+    maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    cr = (maxc - minc).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = cr / maxc.astype(np.float32)
+        rc, gc, bc = ((maxc - c).astype(np.float32) / cr for c in (r, g, b))
+        h0 = (bc - gc).astype(np.float32)
+        h1 = (2.0 + rc.astype(np.float64) - bc.astype(np.float64)).astype(np.float32)
+        h2 = (4.0 + gc.astype(np.float64) - rc.astype(np.float64)).astype(np.float32)
+        h = np.where(r == maxc, h0, np.where(g == maxc, h1, h2))
+        hd = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)
+        uh = np.clip((hd.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
+        us = np.clip((s.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
+    gray = minc == maxc
+    return np.stack([np.where(gray, 0, uh), np.where(gray, 0, us), maxc], -1).astype(np.uint8)
+
+
+def hsv_to_rgb_u8(hsv):
+    """Image.convert("RGB") of an HSV image (Convert.c hsv2rgb_row: sector and remainder from (float)h * 6.0 / 255.0 in double, C round())"""
+    h, s, v = hsv[..., 0].astype(np.float32), hsv[..., 1], hsv[..., 2]
+    hh = h.astype(np.float64) * 6.0 / 255.0
+    i = np.floor(hh).astype(np.int32)
+    f = (hh - i.astype(np.float32).astype(np.float64)).astype(np.float32).astype(np.float64)
+    fs = (s.astype(np.float32).astype(np.float64) / 255.0).astype(np.float32).astype(np.float64)
+    vf = v.astype(np.float32).astype(np.float64)
+
+    def c_round(x):   # half away from zero
+        return np.where(x >= 0, np.floor(x + 0.5), np.ceil(x - 0.5)).astype(np.int32)
+    p, q, t = (np.clip(c_round(x), 0, 255) for x in (vf * (1.0 - fs), vf * (1.0 - fs * f), vf * (1.0 - fs * (1.0 - f))))
+    vi, k = v.astype(np.int32), i % 6
+    R, G, B = np.choose(k, [vi, q, p, p, t, vi]), np.choose(k, [t, vi, vi, q, p, p]), np.choose(k, [p, p, t, vi, vi, q])
+    gray = s == 0
+    return np.stack([np.where(gray, vi, R), np.where(gray, vi, G), np.where(gray, vi, B)], -1).astype(np.uint8)
+
+
+def hue_shift_u8(hue_factor):
+    """the byte torchvision adds to the H channel: uint8(hue_factor * 255) -- truncation toward zero, then modulo 256"""
+    return int(hue_factor * 255) % 256
+
+
+def adjust_hue(img, hue_factor):
+    """F.adjust_hue on a PIL image: H += uint8(hue_factor * 255) with wrap-around, S and V untouched"""
+    if not -0.5 <= hue_factor <= 0.5:
+        raise ValueError("hue_factor ({}) is not in [-0.5, 0.5].".format(hue_factor))
+    hsv = rgb_to_hsv_u8(img)
+    hsv[..., 0] = (hsv[..., 0].astype(np.int32) + hue_shift_u8(hue_factor)).astype(np.uint8)
+    return hsv_to_rgb_u8(hsv)
+
+
+def color_jitter_params(brightness, contrast, saturation, hue, rng):
+    """torchvision.transforms.ColorJitter of the reference's era (0.2-0.4: ColorJitter.get_params): the interval of each strength (None = off),
+    one `random.uniform` per active op in the order brightness, contrast, saturation, hue, then `random.shuffle` of the op list.
+    -> [(op name, factor)] in application order.  `rng`: the `random` module or a random.Random."""
+    def interval(v, center=1.0, clip0=True):
+        if v is None or v == 0:
+            return None
+        lo, hi = center - v, center + v
+        return (max(lo, 0.0) if clip0 else lo, hi)
+    spec = [("brightness", interval(brightness)), ("contrast", interval(contrast)), ("saturation", interval(saturation)),
+            ("hue", interval(hue, 0.0, False))]
+    ops_ = [(n, rng.uniform(iv[0], iv[1])) for n, iv in spec if iv is not None]
+    rng.shuffle(ops_)
+    return ops_
+
+
+def color_jitter_apply(img, ops_):
+    fn = {"brightness": adjust_brightness, "contrast": adjust_contrast, "saturation": adjust_saturation, "hue": adjust_hue}
+    for name, factor in ops_:
+        img = fn[name](img, factor)
+    return img

@@ -135,3 +135,67 @@ def test_transform_and_collate_vs_pillow_torch():
         assert tuple(images.image_sizes[i]) == (h.shape[1], h.shape[2])
     images32, _ = tf.collate(samples, size_divisible=32)
     assert images32.tensors.shape[2] % 32 == 0 and images32.tensors.shape[3] % 32 == 0
+
+
+def test_color_jitter_ops_bit_exact_vs_pillow_restatement():
+    """csrc/imgproc.hip's ColorJitter ops == the oracle's restatements of Pillow's ImageEnhance / HSV arithmetic (pinned against Pillow itself by
+    tests/test_oracle_data.py): brightness / contrast / saturation for factors inside and outside [0, 1], hue shifts with wrap-around, saturated and
+    black regions, a gray image (the hue of a gray pixel is 0 whatever the shift)."""
+    from abr_iod_amd.data import gpu_transforms as G
+    from oracle import abr_data_ref as R
+    rs = np.random.RandomState(5)
+    img = rs.randint(0, 256, (157, 211, 3), dtype=np.uint8)
+    img[:20] = 255
+    img[20:40] = 0
+    img[40:60] = rs.randint(0, 256, (20, 211, 1), dtype=np.uint8)      # gray band
+    fn = {"brightness": R.adjust_brightness, "contrast": R.adjust_contrast, "saturation": R.adjust_saturation, "hue": R.adjust_hue}
+    for op, factors in (("brightness", (0.0, 0.3, 1.0, 1.37, 2.5)), ("contrast", (0.0, 0.45, 1.0, 1.8)), ("saturation", (0.0, 0.7, 1.0, 1.6, 3.0)),
+                        ("hue", (-0.5, -0.23, 0.0, 0.004, 0.31, 0.5))):
+        for f in factors:
+            got = G.color_jitter_(G.to_device_u8(img), op, f).cpu().numpy()
+            want = fn[op](img, f)
+            assert np.array_equal(got, want), (op, f, int(np.abs(got.astype(int) - want.astype(int)).max()), int((got != want).sum()))
+    # every colour of a 64^3 sub-cube through the hue path (the conversions' branches: which channel is the maximum, all six sectors)
+    v = np.arange(0, 256, 4, dtype=np.uint8)
+    cube = np.ascontiguousarray(np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(512, 512, 3))
+    for f in (0.0, 0.17, -0.4):
+        assert np.array_equal(G.color_jitter_(G.to_device_u8(cube), "hue", f).cpu().numpy(), R.adjust_hue(cube, f)), f
+    with pytest.raises(RuntimeError):
+        G.color_jitter_(G.to_device_u8(img), "hue", 0.7)
+
+
+def test_color_jitter_transform_draws_and_order():
+    """data/abr.py::ColorJitter (transforms.py:132-150): factors drawn and ops shuffled as torchvision 0.2-0.4's get_params does, applied in that order;
+    GPUTransform applies it before the resize, only in training, and is the identity (same tensor object, nothing drawn) at zero strengths."""
+    from abr_iod_amd.data.abr import ColorJitter, GPUTransform
+    from abr_iod_amd.data.gpu_transforms import to_device_u8
+    from oracle import abr_data_ref as R
+    rs = np.random.RandomState(9)
+    img = rs.randint(0, 256, (120, 160, 3), dtype=np.uint8)
+    cj = ColorJitter(0.4, 0.3, 0.5, 0.1)
+    for seed in (1, 2, 3):
+        random.seed(seed)
+        want_ops = R.color_jitter_params(0.4, 0.3, 0.5, 0.1, random)
+        random.seed(seed)
+        dev = to_device_u8(img)
+        out, _ = cj(dev, None)
+        assert len(want_ops) == 4 and out is not dev and np.array_equal(dev.cpu().numpy(), img)     # the input image is not written
+        assert np.array_equal(out.cpu().numpy(), R.color_jitter_apply(img, want_ops)), (seed, want_ops)
+    base = dict(MIN_SIZE_TRAIN=(120,), MAX_SIZE_TRAIN=200, MIN_SIZE_TEST=120, MAX_SIZE_TEST=200, FLIP_PROB_TRAIN=0.0,
+                PIXEL_MEAN=[102.9801, 115.9465, 122.7717], PIXEL_STD=[1.0, 1.0, 1.0], TO_BGR255=True)
+    cfg0 = types.SimpleNamespace(INPUT=types.SimpleNamespace(BRIGHTNESS=0.0, CONTRAST=0.0, SATURATION=0.0, HUE=0.0, **base))
+    cfg1 = types.SimpleNamespace(INPUT=types.SimpleNamespace(BRIGHTNESS=0.2, CONTRAST=0.0, SATURATION=0.0, HUE=0.05, **base))
+    dev = to_device_u8(img)
+    state = random.getstate()
+    plain, _, _ = GPUTransform(cfg0, is_train=True)(dev, None)
+    assert np.array_equal(plain.cpu().numpy(), img)                       # 120x160 is already the target size: untouched
+    random.setstate(state)
+    random.seed(11)
+    ops_ = R.color_jitter_params(0.2, 0.0, 0.0, 0.05, random)
+    random.seed(11)
+    jit, _, _ = GPUTransform(cfg1, is_train=True)(dev, None)
+    assert [n for n, _ in sorted(ops_)] == ["brightness", "hue"] and np.array_equal(jit.cpu().numpy(), R.color_jitter_apply(img, ops_))
+    test_time, _, _ = GPUTransform(cfg1, is_train=False)(dev, None)       # build.py:15-21: no jitter at test time
+    assert np.array_equal(test_time.cpu().numpy(), img)
+    with pytest.raises(ValueError):
+        ColorJitter(hue=0.6)
