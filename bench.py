@@ -366,6 +366,7 @@ def main():
     ap.add_argument("--fold-streams", action="store_true",
                     help="run the whole benchmark with every HIP stream of the step folded into one (for a serialised-stream rocprofv3 profile)")
     ap.add_argument("--no-serialised-leg", action="store_true", help="skip the short serialised-stream re-run behind the timed region (roofline.serialised)")
+    ap.add_argument("--no-single-batch-leg", action="store_true", help="skip the short single-batch re-run behind the timed region (single_batch_informational)")
     ap.add_argument("--share-frozen-prefix", action="store_true",
                     help="(informational, never the headline) compute the frozen stem + layer1 ONCE per batch for the source and the target model when "
                          "their frozen weights compare equal (engine/trainer.py::SHARE_FROZEN_PREFIX); the reference computes them in both models")
@@ -536,7 +537,7 @@ def main():
                                       for x in srows},
                           "note": "every stream of the step folded into one, every conv launch timed (informational re-run behind the timed region)"}
     single = None
-    if len(batches) > 1 and a.batch_pool > 1 and not a.mosaic_squares and world == 1:
+    if len(batches) > 1 and a.batch_pool > 1 and not a.mosaic_squares and world == 1 and not a.no_single_batch_leg:
         # AFTER the timed region, never part of `value`: rounds 1-5's workload -- ONE batch repeated (constant NMS survivor counts, steady allocator)
         SB = 10
         for _ in range(2):

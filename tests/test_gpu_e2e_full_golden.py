@@ -22,7 +22,9 @@ H, W = 600, 1000
 # configurations whose full-size BACKWARD is compared with the oracle's autograd (a CPU forward + backward of the full-width model on two
 # images: 12 s on 8 cores)
 GRAD_CONFIGS = ("15-5", "10-10", "10-5", "finetune")
-GRAD_MAX_REL, GRAD_L2_REL = 3.5e-3, 1e-3
+# 2x the worst values measured over the five fixtures (profiles/r06_fullsize_parity.log: 9.2e-4 max-rel on layer3.0.downsample.0.weight in 10-5,
+# 2.3e-4 rel-L2 on layer2.0.conv1.weight in 15-5; bf16x6 in round 4: 1.1e-3 / 3.0e-4)
+GRAD_MAX_REL, GRAD_L2_REL = 2e-3, 5e-4
 
 
 def _close(a, b, tol=1e-4):
@@ -170,6 +172,5 @@ def test_full_size_step_matches_reference(gold, name):
     assert len(report) == 52, len(report)
     w1, w2 = max(report, key=lambda r: r[1]), max(report, key=lambda r: r[2])
     print(f"[{fixture}] full-size gradients vs oracle: worst max-rel {w1[1]:.2e} ({w1[0]}), worst l2-rel {w2[2]:.2e} ({w2[0]})")
-    # bounds = 2x the worst values measured over the five fixtures (profiles/r06_fullsize_parity.log names the tensors)
     for pname, rel, rel_l2 in report:
         assert rel <= GRAD_MAX_REL and rel_l2 <= GRAD_L2_REL, f"grad {pname}: max-rel {rel}, l2-rel {rel_l2}"

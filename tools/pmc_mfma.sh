@@ -5,7 +5,7 @@
 # Run on the GPU box from the repo root:  bash tools/pmc_mfma.sh  ->  gpurun_out/pmc_mfma.json  (copy to profiles/rNN_pmc_mfma.json)
 export TMPDIR=/tmp
 R=$(pwd)
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-alt-math --no-kernel-timing --no-serialised-leg"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-alt-math --no-kernel-timing --no-serialised-leg --no-single-batch-leg"
 PASS_A="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 PASS_B="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
 mkdir -p gpurun_out

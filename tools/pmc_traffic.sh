@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_$c -o b -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-math --no-kernel-timing --no-serialised-leg > gpurun_out/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_$c -o b -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-math --no-kernel-timing --no-serialised-leg --no-single-batch-leg > gpurun_out/pmc_$c.log 2>&1
 done
 python3 - <<'PY'
 import csv, collections, json
@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in agg.items():
         if "conv" in k or "roi_align" in k or "ard" in k or "sgd" in k or "wino" in k:
             raw.setdefault(k, {})[c] = (len(v), sum(v) / len(v))
-out = {"command": "tools/pmc_traffic.sh : rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-math --no-kernel-timing --no-serialised-leg",
+out = {"command": "tools/pmc_traffic.sh : rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-math --no-kernel-timing --no-serialised-leg --no-single-batch-leg",
        "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) coalesced reads -> x2 (MI355X_MICROARCH.md 'HBM'); "
                      "unit KB; WRITE_SIZE as reported. Calibrated on ard_bwd_kernel (algorithmic 102.8 MB read / 51.4 MB written at B=4).",
        "kernels": {}}

@@ -7,7 +7,7 @@ STEPS=${STEPS:-5}
 WARMUP=${WARMUP:-2}
 # --no-alt-math: without it bench.py appends 13 bf16x6 steps AFTER the timed region and every shared kernel's stats are polluted;
 # --no-cpu-baseline: the oracle leg is host work.  The program itself follows `--` (no env / bash -c hop under the profiler).
-ARGS="--steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-alt-math --no-serialised-leg $EXTRA_ARGS"
+ARGS="--steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-alt-math --no-serialised-leg --no-single-batch-leg $EXTRA_ARGS"
 mkdir -p gpurun_out
 rm -rf gpurun_out/prof_stats
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o b -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_bench.jsonl 2> $R/gpurun_out/prof_bench.err )

@@ -15,6 +15,7 @@ timeout 600 python bench.py > $O/${R}_bench_default.jsonl 2> $O/bench_default.er
 timeout 300 python bench.py --image-size 800x1333 --steps 10 > $O/${R}_bench_800x1333.jsonl 2>/dev/null
 timeout 300 python bench.py --task 10-5 --mosaic-squares --steps 20 > $O/${R}_bench_10-5_mosaic_squares.jsonl 2>/dev/null
 timeout 300 python bench.py --task 10-5 --mosaic-squares --math bf16 --steps 20 --no-kernel-timing > $O/${R}_bench_10-5_mosaic_squares_bf16_backbone.jsonl 2>/dev/null
+timeout 300 python bench.py --batch-pool 1 $B > $O/${R}_bench_single_batch.jsonl 2>/dev/null
 timeout 300 python bench.py --share-frozen-prefix $B > $O/${R}_bench_shared_frozen_prefix.jsonl 2>/dev/null
 timeout 300 python bench.py --math bf16x6 $B > $O/${R}_bench_bf16x6.jsonl 2>/dev/null
 timeout 300 python tools/bench_eval.py 2>/dev/null | tail -1 > $O/${R}_bench_eval.jsonl
@@ -49,7 +50,7 @@ cp gpurun_out/prof_bench.jsonl $O/${R}_bench_under_rocprof.jsonl
 [ -f gpurun_out/pmc_traffic.json ] && cp gpurun_out/pmc_traffic.json $O/${R}_pmc_traffic.json
 # every stream folded into one: the kernels' own durations as a kernel trace sees them
 rm -rf gpurun_out/prof_ser
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_ser -o s -- python3 $OLDPWD/bench.py --steps 5 --warmup 2 $B --no-serialised-leg --fold-streams > $OLDPWD/$O/${R}_serialised_streams_bench.jsonl 2>/dev/null )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_ser -o s -- python3 $OLDPWD/bench.py --steps 5 --warmup 2 $B --no-serialised-leg --no-single-batch-leg --fold-streams > $OLDPWD/$O/${R}_serialised_streams_bench.jsonl 2>/dev/null )
 cp gpurun_out/prof_ser/s_kernel_stats.csv $O/${R}_serialised_streams_kernel_stats.csv 2>/dev/null
 # per-shape table, HBM-bound kernels, ROIAlign L1 / L2 counters, main-loop labs
 timeout 600 python tools/conv_breakdown.py --target-tf 400 2>&1 | grep -v amdgpu.ids > $O/${R}_conv_shapes_f16x3.txt
