@@ -639,6 +639,7 @@ def main():
             _ops.conv_cache_clear()   # the library's per-weight Winograd-domain copies of the models just dropped
         print(json.dumps(out), flush=True)
     if world > 1:
+        optimizer.reducer.close()        # (the library's own communicator, when --allreduce-backend abr made one)
         dist.destroy_process_group()
 
 
