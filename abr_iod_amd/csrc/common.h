@@ -160,6 +160,8 @@ int prep_transpose_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStre
 int prep_pack_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);        // conv_igemm.hip
 int prep_pack_h3_multi(const PrepJob* jobs_dev, int njobs, int blocks, int scale_blocks, hipStream_t st);     // conv_igemm.hip (f16x3 planes: one workgroup per 32-row block)
 int prep_wino_u_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);      // conv_winograd.hip (C % 4 == 0 jobs only)
+// f16x3: w [N][3][3][C] -> packed planes + row scales of the Winograd-domain [36 N][C] matrix, U never written (N % 32 == 0, C % 64 == 0)
+int prep_wino_h3_direct_multi(const PrepJob* jobs_dev, int njobs, int pack_blocks, int scale_blocks, unsigned* flags, hipStream_t st);   // conv_winograd.hip
 __device__ __forceinline__ int prep_find_job(const PrepJob* jobs, int njobs, int block) {
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {

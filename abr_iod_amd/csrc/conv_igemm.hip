@@ -2079,7 +2079,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
     constexpr bool direct_on = true;   // (ABR_X6_WEIGHTS_DIRECT=0, the in-kernel weight split, was retired in round 6)
     std::lock_guard<std::mutex> lock(g_prep_mu);
     PrepTables& T = g_prep_tables[st];
-    std::vector<abr::PrepJob> tj, uj, pj, hj;    // transposes, Winograd weight transforms, bf16x3 packings, f16x3 packings
+    std::vector<abr::PrepJob> tj, uj, pj, hj, wj;    // transposes, Winograd weight transforms, bf16x3 packings, f16x3 packings, f16x3 Winograd weights straight to planes
     std::vector<void*> tokens;
     std::vector<hipStream_t> waited;              // reader streams this call's stream is already ordered behind (derived_acquire)
     // every early return between the acquires below and derived_commit releases the tokens (entries left pending would never be evictable and
@@ -2090,7 +2090,8 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
     } token_guard{tokens};
     std::vector<size_t> u_off;                    // per uj entry: offset (floats) of its U inside the scratch
     size_t u_total = 0;
-    int tb = 0, ub = 0, pb = 0, hb = 0, hsb = 0;  // workgroups of the launches (hsb: the f16x3 row-scale launch)
+    int tb = 0, ub = 0, pb = 0, hb = 0, hsb = 0, wb = 0, wsb = 0;  // workgroups of the launches (hsb: the f16x3 row-scale launch; wb / wsb: the direct Winograd pack / scale launches)
+    static const bool wino_direct = !(getenv("ABR_PREP_WINO_DIRECT") && atoi(getenv("ABR_PREP_WINO_DIRECT")) == 0);   // 0: through the fp32 U in the scratch (A/B)
     std::vector<int> h_scale_first;               // per hj entry: its first workgroup in the row-scale launch (stored in PrepJob::c once the sources are patched)
     auto add_pack_h3 = [&](const float* src, int64_t rows, int K, void* dst) {
         abr::PrepJob j{};
@@ -2119,6 +2120,14 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
             if (!planes) return 1;
             if (!tok) return 0;   // already there
             tokens.push_back(tok);
+            if (h3 && wino_direct && Cin % 64 == 0) {   // w -> planes, U never written (conv_winograd.hip: wino_h3_scales / wino_h3_pack)
+                abr::PrepJob j{};
+                j.src = w; j.dst = planes; j.a = Cout; j.b = Cin; j.gx = Cin / 64; j.gy = Cout / 32; j.first_block = wb; j.c = wsb;
+                wb += j.gx * j.gy;
+                wsb += Cout / 4;
+                wj.push_back(j);
+                return 0;
+            }
             abr::PrepJob j{};
             j.src = w; j.a = Cout; j.b = Cin; j.gx = (int)(((int64_t)Cout * (Cin / 4) + 255) / 256); j.gy = 1; j.first_block = ub;
             ub += j.gx;
@@ -2163,9 +2172,9 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
             if (derive(it.wt, it.Cin, it.R, it.S, it.Cout, 1, it.R - 1 - it.pad, it.math, it.w_version)) single_bwd.push_back(i);
         }
     }
-    const size_t njobs = tj.size() + uj.size() + pj.size() + hj.size();
+    const size_t njobs = tj.size() + uj.size() + pj.size() + hj.size() + wj.size();
     if (njobs) {
-        if (T.u_floats < u_total) {
+        if (u_total && T.u_floats < u_total) {
             if (T.u_scratch) { (void)hipStreamSynchronize(st); (void)hipFree(T.u_scratch); T.u_scratch = nullptr; T.u_floats = 0; }
             ABR_REQUIRE(hipMalloc(&T.u_scratch, u_total * sizeof(float)) == hipSuccess, "conv_prepare_batch: no memory for the Winograd-domain scratch");
             T.u_floats = u_total;
@@ -2185,6 +2194,7 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
         std::copy(uj.begin(), uj.end(), h + tj.size());
         std::copy(pj.begin(), pj.end(), h + tj.size() + uj.size());
         std::copy(hj.begin(), hj.end(), h + tj.size() + uj.size() + pj.size());
+        std::copy(wj.begin(), wj.end(), h + tj.size() + uj.size() + pj.size() + hj.size());
         ABR_REQUIRE(hipMemcpyAsync(d, h, njobs * sizeof(abr::PrepJob), hipMemcpyHostToDevice, st) == hipSuccess, "conv_prepare_batch: table upload failed");
         hipEvent_t up = nullptr;
         if (hipEventCreateWithFlags(&up, hipEventDisableTiming) == hipSuccess) {
@@ -2195,6 +2205,8 @@ extern "C" int abr_conv_prepare_batch(const abr_prep_item* items, int n, void* s
         bad |= abr::prep_wino_u_multi(d + tj.size(), (int)uj.size(), ub, st);
         bad |= abr::prep_pack_multi(d + tj.size() + uj.size(), (int)pj.size(), pb, st);
         bad |= abr::prep_pack_h3_multi(d + tj.size() + uj.size() + pj.size(), (int)hj.size(), hb, hsb, st);
+        bad |= abr::prep_wino_h3_direct_multi(d + tj.size() + uj.size() + pj.size() + hj.size(), (int)wj.size(), wb, wsb,
+                                              abr::x6_guard_enabled() ? abr::x6_flags_ptr() : nullptr, st);
         ABR_REQUIRE(!bad, "conv_prepare_batch: launch failed");
         abr::derived_commit(tokens.data(), (int)tokens.size(), st);
         token_guard.committed = true;

@@ -20,6 +20,7 @@
 #include <functional>
 #include <mutex>
 #include <utility>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -156,15 +157,51 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     if (amax) abr::h3_amax_emit(amax, epoch, am);
 }
 
-// G (6x3) on a 3-vector
-template <typename T>
-__device__ __forceinline__ void g6(const T g0, const T g1, const T g2, T& o0, T& o1, T& o2, T& o3, T& o4, T& o5) {
-    o0 = 0.25f * g0;
-    o1 = (-1.f / 6.f) * (g0 + g1 + g2);
-    o2 = (-1.f / 6.f) * (g0 - g1 + g2);
-    o3 = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-    o4 = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-    o5 = g2;
+// U = G g G^T, one row I of it (6 values), with EVERY rounding spelled out (contraction off, explicit fma): the same U has to come out of every
+// kernel that forms it -- the fp32 transforms (wino_weight_*_kernel) and the kernels that go from w straight to packed f16x3 planes
+// (wino_h3_*_multi_kernel) -- and left to itself the compiler fuses (1/24) a -+ (1/12) b + (1/6) c and the sums of products differently from one
+// kernel to the next (seen in round 6: planes differing in rows 24..35 between two kernels built from one expression).  The expressions are the
+// ones rounds 2-5's build evaluated (read off its code), so that every result of those rounds is reproduced bit for bit:
+//   G row 0: 1/4 a          rows 1, 2: -1/6 ((a +- b) + c)          rows 3, 4: fma(c, 1/6, fma(a, 1/24, +-(b / 12)))          row 5: c
+// along r (t = G g), then the same along q (u = t G^T), except that where t is itself a product k s (rows 0..2) the sums of u1 / u2 take the
+// second and third terms unrounded: fma(s2, k, fma(+-s1, k, t0)).
+template <int I, int V>
+__device__ __forceinline__ void wino_u_row(const vf<V> (&g)[3][3], vf<V> (&u)[6]) {
+#pragma clang fp contract(off)
+    constexpr float k6 = -1.f / 6.f, c24 = 1.f / 24.f, c12 = 1.f / 12.f, c6 = 1.f / 6.f;
+    constexpr float k = I == 0 ? 0.25f : k6;
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+        float t[3], s[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const float a = g[0][q].v[e], b = g[1][q].v[e], c = g[2][q].v[e];
+            if constexpr (I == 0) { s[q] = a; t[q] = 0.25f * a; }
+            else if constexpr (I == 1) { s[q] = (a + b) + c; t[q] = k6 * s[q]; }
+            else if constexpr (I == 2) { s[q] = (a - b) + c; t[q] = k6 * s[q]; }
+            else if constexpr (I == 3) { s[q] = 0.f; t[q] = __builtin_fmaf(c, c6, __builtin_fmaf(a, c24, b * c12)); }
+            else if constexpr (I == 4) { s[q] = 0.f; t[q] = __builtin_fmaf(c, c6, __builtin_fmaf(a, c24, -(b * c12))); }
+            else { s[q] = 0.f; t[q] = c; }
+        }
+        u[0].v[e] = 0.25f * t[0];
+        if constexpr (I < 3) {
+            u[1].v[e] = k6 * __builtin_fmaf(s[2], k, __builtin_fmaf(s[1], k, t[0]));
+            u[2].v[e] = k6 * __builtin_fmaf(s[2], k, __builtin_fmaf(-s[1], k, t[0]));
+        } else {
+            u[1].v[e] = k6 * ((t[0] + t[1]) + t[2]);
+            u[2].v[e] = k6 * ((t[0] - t[1]) + t[2]);
+        }
+        const float m = t[1] * c12;
+        u[3].v[e] = __builtin_fmaf(t[2], c6, __builtin_fmaf(t[0], c24, m));
+        u[4].v[e] = __builtin_fmaf(t[2], c6, __builtin_fmaf(t[0], c24, -m));
+        u[5].v[e] = t[2];
+    }
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, 5>)
+template <typename F>
+__device__ __forceinline__ void for_rows6(F&& f) {
+    f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{});
+    f(std::integral_constant<int, 3>{}); f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{});
 }
 
 // w [N][3][3][C] (OHWI) -> U [36][N][C]; V input channels per thread
@@ -182,16 +219,13 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
         for (int r = 0; r < 3; r++)
 #pragma unroll
             for (int q = 0; q < 3; q++) g[r][q] = vld<V>(w + ((n * 3 + r) * 3 + q) * C + c);
-        fv t[6][3];  // G g
-#pragma unroll
-        for (int q = 0; q < 3; q++) g6(g[0][q], g[1][q], g[2][q], t[0][q], t[1][q], t[2][q], t[3][q], t[4][q], t[5][q]);
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            fv u0, u1, u2, u3, u4, u5;
-            g6(t[i][0], t[i][1], t[i][2], u0, u1, u2, u3, u4, u5);
+        for_rows6([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            fv u[6];
+            wino_u_row<i>(g, u);
             float* o = U + ((int64_t)(6 * i) * N + n) * C + c;
-            vst(o, u0); vst(o + ps, u1); vst(o + 2 * ps, u2); vst(o + 3 * ps, u3); vst(o + 4 * ps, u4); vst(o + 5 * ps, u5);
-        }
+            vst(o, u[0]); vst(o + ps, u[1]); vst(o + 2 * ps, u[2]); vst(o + 3 * ps, u[3]); vst(o + 4 * ps, u[4]); vst(o + 5 * ps, u[5]);
+        });
     }
 }
 
@@ -213,16 +247,150 @@ __global__ __launch_bounds__(256) void wino_weight_multi_kernel(const abr::PrepJ
     for (int r = 0; r < 3; r++)
 #pragma unroll
         for (int q = 0; q < 3; q++) g[r][q] = vld<4>(w + ((n * 3 + r) * 3 + q) * C + c);
-    fv t[6][3];  // G g
-#pragma unroll
-    for (int q = 0; q < 3; q++) g6(g[0][q], g[1][q], g[2][q], t[0][q], t[1][q], t[2][q], t[3][q], t[4][q], t[5][q]);
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        fv u0, u1, u2, u3, u4, u5;
-        g6(t[i][0], t[i][1], t[i][2], u0, u1, u2, u3, u4, u5);
+    for_rows6([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        fv u[6];
+        wino_u_row<i>(g, u);
         float* o = U + ((int64_t)(6 * i) * N + n) * C + c;
-        vst(o, u0); vst(o + ps, u1); vst(o + 2 * ps, u2); vst(o + 3 * ps, u3); vst(o + 4 * ps, u4); vst(o + 5 * ps, u5);
+        vst(o, u[0]); vst(o + ps, u[1]); vst(o + 2 * ps, u[2]); vst(o + 3 * ps, u[3]); vst(o + 4 * ps, u[4]); vst(o + 5 * ps, u[5]);
+    });
+}
+
+// ---- f16x3: Winograd-domain weights straight into the packed planes (round 6) ---------------------------------------------------------------
+// abr_conv_prepare_batch used to go  w -> U (fp32, 4x the weights' size, written) -> row amax (U read) -> pack (U read again, planes written):
+// 3.4 GB of HBM traffic per optimiser step for the step's 20.6 M Winograd-domain weights and their dgrad copies, on a stream of its own but NOT
+// hidden -- with the preparation knocked out the step is 0.86 ms shorter (MEASUREMENTS.md).  The two kernels below never materialise U: pass A
+// computes every U row's amax from w (one wave per output channel), pass B recomputes U from a w tile staged in LDS and writes the two fp16 planes
+// in MFMA-fragment order directly.  w (1/4 of U) is read twice, the planes are written once.  Same G g G^T arithmetic (wino_u_row), same row scales,
+// same split as wino_weight_multi_kernel + h3_rowscale_multi_kernel + h3_pack_multi_kernel: bit-identical planes
+// (tests/test_gpu_prep_batch.py compares against the self-contained path).  jobs[j]: src = w [N][3][3][C], dst = planes of the [36 N][C] matrix with
+// its 36 N row scales behind them, a = N (% 32 == 0), b = C (% 64 == 0), c = first workgroup in the scale launch (N / 4 workgroups),
+// first_block / gx = C / 64 / gy = N / 32 in the pack launch.
+__device__ __forceinline__ int prep_find_job_by_c(const abr::PrepJob* jobs, int njobs, int block) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].c <= block) lo = mid; else hi = mid - 1;
     }
+    return lo;
+}
+__device__ __forceinline__ size_t h3_planes_bytes_of(int rows, int K) { return (size_t)((rows + 31) / 32 * 32) * (size_t)K * 4; }
+
+// pass A: the scale of every U row.  One WAVE per output channel n: its lanes walk the input channels (4 per lane, 256 per trip), keep the 36
+// running maxima of |U| in registers, reduce them across the wave once and lanes 0..35 write the rows' scales (h3_scales of the amax bits) behind the
+// planes -- no atomics, no zeroed scratch.  .c = the job's first workgroup in this launch (4 output channels per workgroup).
+__global__ __launch_bounds__(256, 3) void wino_h3_scales_multi_kernel(const abr::PrepJob* __restrict__ jobs, int njobs, unsigned* flags) {
+    typedef vf<4> fv;
+    const int j = prep_find_job_by_c(jobs, njobs, blockIdx.x);
+    const abr::PrepJob jb = jobs[j];
+    const float* w = jb.src;
+    const int N = jb.a, C = jb.b;
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)(blockIdx.x - jb.c) * 4 + (threadIdx.x >> 6);    // N % 32 == 0: always inside
+    float* scales = reinterpret_cast<float*>(reinterpret_cast<char*>(jb.dst) + h3_planes_bytes_of(36 * N, C));
+    unsigned mx[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) mx[k] = 0u;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int c = 4 * lane; c < C; c += 256) {
+        fv g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) g[r][q] = vld<4>(w + ((n * 3 + r) * 3 + q) * C + c);
+        for_rows6([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            fv u[6];
+            wino_u_row<i>(g, u);
+#pragma unroll
+            for (int jj = 0; jj < 6; jj++) mx[6 * i + jj] = vabs_max(mx[6 * i + jj], u[jj]);
+        });
+    }
+    // across the wave through LDS: [k][lane] written by everyone, row k read back by lane k (16 x 16 B)
+    __shared__ __attribute__((aligned(16))) unsigned red_[4][36][64];
+    unsigned (*red)[64] = red_[threadIdx.x >> 6];
+#pragma unroll
+    for (int k = 0; k < 36; k++) red[k][lane] = mx[k];
+    __builtin_amdgcn_wave_barrier();
+    unsigned mine = 0u;
+    if (lane < 36) {
+        const uint4* rowp = reinterpret_cast<const uint4*>(red[lane]);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint4 v = rowp[q];
+            mine = max(max(mine, max(v.x, v.y)), max(v.z, v.w));
+        }
+    }
+    if (lane < 36) {
+        float sc, inv;
+        abr::h3_scales(mine, sc, inv);
+        scales[(size_t)lane * N + n] = sc;
+        if (flags && (mine >> 23) >= 255u) atomicOr(flags, ABR_X6_FLAG_NONFINITE);
+    }
+}
+
+constexpr int kWhPitch = 9 * 64 + 4;                                  // floats per row of the staged w tile (+4: conflict-free ds_read_b128 over 32 rows)
+constexpr size_t kWhLds = sizeof(float) * 32 * kWhPitch;              // 74 240 B: two workgroups per CU
+
+__global__ __launch_bounds__(256) void wino_h3_pack_multi_kernel(const abr::PrepJob* __restrict__ jobs, int njobs) {
+    typedef vf<4> fv;
+    extern __shared__ __attribute__((aligned(16))) float wt_[];
+    const int j = abr::prep_find_job(jobs, njobs, blockIdx.x);
+    const abr::PrepJob jb = jobs[j];
+    const float* w = jb.src;
+    const int N = jb.a, C = jb.b;
+    const int lb = blockIdx.x - jb.first_block;
+    const int nblk = lb / jb.gx, kc = lb % jb.gx;                     // 32 output channels x 64 input channels
+    const int n0 = nblk * 32, k0 = kc * 64;
+    const int tid = threadIdx.x;
+    // the w tile [32 rows][9 taps][64 channels], coalesced (256 B per row and tap)
+#pragma unroll
+    for (int it = 0; it < 18; it++) {
+        const int f = tid + 256 * it, rt = f >> 4, c4 = (f & 15) * 4;
+        const int row = rt / 9, tap = rt - row * 9;
+        *reinterpret_cast<float4*>(wt_ + row * kWhPitch + tap * 64 + c4) =
+            *reinterpret_cast<const float4*>(w + (((int64_t)(n0 + row)) * 9 + tap) * C + k0 + c4);
+    }
+    __syncthreads();
+    // lane = (row, 8 consecutive channels): exactly the element set of its 16 B in a packed chunk (h3_pack_chunk's mapping)
+    const int wave = tid >> 6, lane = tid & 63, row = lane & 31, k8 = wave * 16 + (lane >> 5) * 8;
+    const float* src = wt_ + row * kWhPitch + k8;
+    fv gA[3][3], gB[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const float4 a = *reinterpret_cast<const float4*>(src + (r * 3 + q) * 64), b = *reinterpret_cast<const float4*>(src + (r * 3 + q) * 64 + 4);
+            gA[r][q] = {{a.x, a.y, a.z, a.w}};
+            gB[r][q] = {{b.x, b.y, b.z, b.w}};
+        }
+    uint4* planes = reinterpret_cast<uint4*>(jb.dst);
+    const float* scales = reinterpret_cast<const float*>(reinterpret_cast<const char*>(jb.dst) + h3_planes_bytes_of(36 * N, C));   // pass A's
+    const int ks = kc * 4 + wave, KS = C / 16;
+    auto emit = [&](int xi, const fv& uA, const fv& uB, float sc) {
+        const float inv = 1.f / sc;   // (a power of two: exact)
+        unsigned h0[4], h1[4];
+        abr::h3_split2(uA.v[0], uA.v[1], inv, h0[0], h1[0]);
+        abr::h3_split2(uA.v[2], uA.v[3], inv, h0[1], h1[1]);
+        abr::h3_split2(uB.v[0], uB.v[1], inv, h0[2], h1[2]);
+        abr::h3_split2(uB.v[2], uB.v[3], inv, h0[3], h1[3]);
+        const size_t nb = ((size_t)xi * N + n0) / 32;
+        const size_t ch = (nb * KS + ks) * 2;
+        planes[ch * 64 + lane] = make_uint4(h0[0], h0[1], h0[2], h0[3]);
+        planes[(ch + 1) * 64 + lane] = make_uint4(h1[0], h1[1], h1[2], h1[3]);
+    };
+    auto row_i = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        float sc[6];
+#pragma unroll
+        for (int jj = 0; jj < 6; jj++) sc[jj] = scales[(size_t)(6 * i + jj) * N + n0 + row];
+        fv uA[6], uB[6];
+        wino_u_row<i>(gA, uA);
+        wino_u_row<i>(gB, uB);
+#pragma unroll
+        for (int jj = 0; jj < 6; jj++) emit(6 * i + jj, uA[jj], uB[jj], sc[jj]);
+    };
+    for_rows6(row_i);
 }
 
 // A^T (4x6) on a 6-vector
@@ -423,6 +591,18 @@ int wino_input_transform(const float* x, int B, int H, int W, int C, float* V, h
 int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st) {
     if (C % 4 == 0) wino_weight_kernel<4><<<grid_for((int64_t)N * (C / 4)), 256, 0, st>>>(w, N, C, U);
     else wino_weight_kernel<2><<<grid_for((int64_t)N * (C / 2)), 256, 0, st>>>(w, N, C, U);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int prep_wino_h3_direct_multi(const PrepJob* jobs_dev, int njobs, int pack_blocks, int scale_blocks, unsigned* flags, hipStream_t st) {
+    if (njobs <= 0 || pack_blocks <= 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_h3_pack_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWhLds);
+        attr_set = true;
+    }
+    wino_h3_scales_multi_kernel<<<(unsigned)scale_blocks, 256, 0, st>>>(jobs_dev, njobs, flags);
+    wino_h3_pack_multi_kernel<<<(unsigned)pack_blocks, 256, kWhLds, st>>>(jobs_dev, njobs);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [  # (Cout, R, Cin, stride, pad, with scale)
     (256, 1, 64, 1, 0, True), (128, 3, 128, 1, 1, True), (512, 1, 256, 2, 0, False), (1024, 3, 1024, 1, 1, False),
-    (64, 3, 64, 1, 1, True), (76, 1, 1024, 1, 0, False), (512, 3, 512, 1, 1, True),
+    (64, 3, 64, 1, 1, True), (76, 1, 1024, 1, 0, False), (512, 3, 512, 1, 1, True), (256, 3, 256, 1, 1, True),
 ]
 
 
@@ -51,3 +51,22 @@ def test_batched_weight_preparation_equals_per_tensor_preparation(math_name):
     x = torch.randn(2, 20, 20, SHAPES[0][2], device="cuda")
     assert torch.equal(ops.conv_forward(x, ws[0], 1, 0, math=math, w_version=9001), ops.conv_forward(x, ws[0], 1, 0, math=math, w_version=0))
     assert torch.equal(wts[0], ops.conv_dgrad_weights(ws[0], scales[0]))
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_batched_winograd_preparation_reports_non_finite_weights(bad):
+    """f16x3, 3x3 stride 1: the batch goes from w straight to packed Winograd-domain planes (conv_winograd.hip: wino_h3_scales / wino_h3_pack); a
+    non-finite weight must raise the range guard's flag there as it does on the per-tensor way, and poison its output channel."""
+    from abr_iod_amd import ops
+    torch.manual_seed(1)
+    w = torch.randn(256, 3, 3, 256, device="cuda") * 0.05
+    w[5, 1, 1, 7] = bad
+    wt = torch.empty(256, 3, 3, 256, device="cuda")
+    ops.conv_cache_clear()
+    ops.x6_range_flags(reset=True)
+    ops.conv_prepare_batch([(w, None, wt, 1, 1, ops.MATH_F16X3, 4242)])
+    torch.cuda.synchronize()
+    assert ops.x6_range_flags(reset=True) & ops.X6_FLAG_NONFINITE
+    y = ops.conv_forward(torch.randn(1, 12, 12, 256, device="cuda"), w, 1, 1, math=ops.MATH_F16X3, w_version=4242)
+    assert bool((~torch.isfinite(y))[..., 5].all())
+    assert bool(torch.isfinite(y[..., :5]).all()) and bool(torch.isfinite(y[..., 6:]).all())
