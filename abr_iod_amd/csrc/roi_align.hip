@@ -480,11 +480,28 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
                                                                     int PHo, int PWo, const float* __restrict__ Wy,
                                                                     const float* __restrict__ Wx, const RoiRect* __restrict__ rect,
                                                                     const int32_t* __restrict__ lists, const int32_t* __restrict__ counts,
-                                                                    int cchunks, int accumulate, float* __restrict__ gfeat) {
+                                                                    int cchunks, int accumulate, float* __restrict__ gfeat, int n_xt, int B,
+                                                                    int xcd_map) {
     // (a workgroup of 8 x-tiles x 128 channels with the channel chunk chosen by XCD, like the forward kernel's slices, measured
     // slower: 1.29 vs 1.10 ms on 2048 large RoIs -- the x-tiles' re-reads of a RoI's gradient already hit in L2)
-    const int xt = blockIdx.x / cchunks, chunk = blockIdx.x % cchunks;
-    const int y = blockIdx.y, b = blockIdx.z;
+    int xt, chunk, y, b;
+    if (xcd_map) {
+        // round 6: 1-D grid of 8 x ceil(S / P) workgroups (S spatial tiles, P = 8 / cchunks XCDs per channel chunk).  Workgroup h runs on XCD
+        // h % 8: that XCD owns ONE channel chunk and a contiguous 1/P of the (image, row, x-tile) domain, walked x-tile first -- the ~15 tiles
+        // that read a RoI's gradient rows (neighbours in x and y) sit on one XCD and find them in ITS L2.  With the 3-D grid the x-tiles of a
+        // row alternated between two XCDs (n_xt cchunks = 32 workgroups per row): every gradient row was fetched from HBM twice (PMC 1.4-2.0x).
+        const unsigned h = blockIdx.x, xcd = h & 7u, i = h >> 3;
+        const unsigned P = 8u / (unsigned)cchunks, S = (unsigned)n_xt * (unsigned)H * (unsigned)B, Sp = (S + P - 1) / P;
+        chunk = (int)(xcd % (unsigned)cchunks);
+        const unsigned t = (xcd / (unsigned)cchunks) * Sp + i;
+        if (i >= Sp || t >= S) return;
+        xt = (int)(t % (unsigned)n_xt);
+        y = (int)((t / (unsigned)n_xt) % (unsigned)H);
+        b = (int)(t / ((unsigned)n_xt * (unsigned)H));
+    } else {
+        xt = blockIdx.x / cchunks; chunk = blockIdx.x % cchunks;
+        y = blockIdx.y; b = blockIdx.z;
+    }
     const int x0 = xt * kXT;
     const int ws = NS > 1 ? (int)(threadIdx.x >> 6) : 0;                       // which share of the list this wave walks
     const int cv = NS > 1 ? chunk * 64 + (int)(threadIdx.x & 63) : chunk * (int)blockDim.x + (int)threadIdx.x;
@@ -492,7 +509,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
     float4 acc[kXT];
 #pragma unroll
     for (int i = 0; i < kXT; i++) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int lid = (b * H + y) * (int)(gridDim.x / cchunks) + xt;
+    const int lid = (b * H + y) * n_xt + xt;
     const int32_t* row_list = lists + (size_t)lid * K;
     const int n_row = counts[lid];
     // Per list entry: wave-uniform data (the RoI index, its <= PO row weights for this feature row, its PWo x 8 column weights for these
@@ -968,21 +985,31 @@ extern "C" int abr_roi_align_backward_gather(const float* grad, const float* roi
     // ABR_ROIALIGN_BWD_SPLIT (default 4; 1 = round 3's one wave per list): waves per workgroup sharing a tile's RoI list (see the kernel)
     static const int ns = getenv("ABR_ROIALIGN_BWD_SPLIT") ? atoi(getenv("ABR_ROIALIGN_BWD_SPLIT")) : 4;
     const int rec = abr::prof_start(st, abr::PROF_ROIALIGN_BWD, 0.0);
+    // ABR_ROIALIGN_BWD_XCD (default 1; 0 = rounds 2-5's 3-D grid): channel chunk and spatial range of a workgroup chosen by the XCD it runs on
+    static const int xcd_on = getenv("ABR_ROIALIGN_BWD_XCD") ? atoi(getenv("ABR_ROIALIGN_BWD_XCD")) : 1;
+    auto grid_of = [&](int cchunks, int* xcd_map) {
+        *xcd_map = xcd_on && (cchunks == 1 || cchunks == 2 || cchunks == 4 || cchunks == 8) ? 1 : 0;
+        if (!*xcd_map) return dim3((unsigned)(n_xt * cchunks), (unsigned)H, (unsigned)B);
+        const int64_t P = 8 / cchunks, S = (int64_t)n_xt * H * B;
+        return dim3((unsigned)(8 * ((S + P - 1) / P)), 1u, 1u);
+    };
     if (ns == 4) {
         const int cchunks = (C / 4 + 63) / 64;
-        dim3 grid((unsigned)(n_xt * cchunks), (unsigned)H, (unsigned)B);
+        int xm = 0;
+        const dim3 grid = grid_of(cchunks, &xm);
         if (PHo <= 4 && PWo <= 4)
-            roi_align_bwd_gather_kernel<4, 4><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
+            roi_align_bwd_gather_kernel<4, 4><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat, n_xt, B, xm);
         else
-            roi_align_bwd_gather_kernel<8, 4><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
+            roi_align_bwd_gather_kernel<8, 4><<<grid, 256, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat, n_xt, B, xm);
     } else {
         const int TB = (tb == 64 || tb == 128 || tb == 256) ? tb : 64;
         const int cchunks = (C / 4 + TB - 1) / TB;
-        dim3 grid((unsigned)(n_xt * cchunks), (unsigned)H, (unsigned)B);
+        int xm = 0;
+        const dim3 grid = grid_of(cchunks, &xm);
         if (PHo <= 4 && PWo <= 4)
-            roi_align_bwd_gather_kernel<4><<<grid, TB, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
+            roi_align_bwd_gather_kernel<4><<<grid, TB, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat, n_xt, B, xm);
         else
-            roi_align_bwd_gather_kernel<8><<<grid, TB, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat);
+            roi_align_bwd_gather_kernel<8><<<grid, TB, 0, st>>>(grad, K, C, H, W, Wp, PHo, PWo, Wy, Wx, rect, lists, counts, cchunks, accumulate, gfeat, n_xt, B, xm);
     }
     abr::prof_stop(st, rec);
     ABR_CHECK_LAUNCH("roi_align_backward_gather");

@@ -125,6 +125,26 @@ def test_roi_align_full_size_properties():
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
 
 
+@pytest.mark.parametrize("B,H,W,Ch", [(3, 13, 21, 256), (1, 38, 63, 512), (4, 9, 17, 1024), (2, 7, 30, 2048), (2, 11, 9, 1536), (5, 5, 5, 64)])
+def test_roi_align_backward_gather_reaches_every_tile_under_the_xcd_mapping(B, H, W, Ch):
+    """The gather's workgroups take their (channel chunk, image, row, x-tile) from the XCD they run on (round 6; 1, 2, 4 or 8 chunks of 256
+    channels; any other count -- 1536 channels -- keeps the 3-D grid): odd extents, every chunk count, spatial tile counts that do not divide by
+    the XCDs per chunk.  A missed or doubled tile shows against the per-RoI atomic scatter form; bin_step = 2 too."""
+    from abr_iod_amd import ops
+    torch.manual_seed(B * 1000 + Ch)
+    K = 64 * B
+    x1 = torch.rand(K) * (W * 16 - 40); y1 = torch.rand(K) * (H * 16 - 40)
+    rois = torch.stack([torch.randint(0, B, (K,)).float(), x1, y1, x1 + 8 + torch.rand(K) * W * 10, y1 + 8 + torch.rand(K) * H * 10], 1).cuda()
+    rois[:, 3].clamp_(max=W * 16 - 1); rois[:, 4].clamp_(max=H * 16 - 1)
+    for step in (1, 2):
+        P = (7 + step - 1) // step
+        gy = torch.randn(K, P, P, Ch, device="cuda")
+        got = ops.roi_align_backward(gy, rois, 0.0625, 7, 7, 2, B, H, W, Ch, bin_step=step)
+        want = ops.roi_align_backward(gy, rois, 0.0625, 7, 7, 2, B, H, W, Ch, bin_step=step, method="scatter")
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-4 * float(want.abs().max())), (step, float((got - want).abs().max()))
+        assert torch.equal(got, ops.roi_align_backward(gy, rois, 0.0625, 7, 7, 2, B, H, W, Ch, bin_step=step))
+
+
 # ------------------------------------------------------------------------------------------ NMS
 def test_nms_golden_index_exact(gold, O):
     from abr_iod_amd import _C
