@@ -345,10 +345,6 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         _ops.mark("step: target forward_begin issued from here")
         begun = model_target.forward_begin(images, targets, rpn_output_source=rpn_output_source, prefix=prefix)   # :89-90 (first half)
         _ops.mark("target backbone + RPN head + RPN loss done")
-        if getattr(optimizer, "_deferred_prep", None) is not None:   # ABR_DEFER_DGRAD_PREP=1 (solver/build.py)
-            ev_prep = torch.cuda.Event()
-            ev_prep.record(torch.cuda.current_stream())
-            optimizer.run_deferred_prep(ev_prep)
         src = deferred.get("_stream") if SOURCE_HEAD_STREAM else None
         if src is not None:       # the source's head pass stays on its stream, next to the target's big RoI pass below
             deferred.pop("_stream")
@@ -449,8 +445,6 @@ def train_step(model_source, model_target, images, targets, optimizer, scheduler
         losses = faster_rcnn_losses + distillation_losses                                                  # :128
 
     enqueue_prefetch()
-    if getattr(optimizer, "_deferred_prep", None) is not None:   # (a path that did not issue it above)
-        optimizer.run_deferred_prep()
     if terms[0][0].is_cuda:
         _ops.mark("losses done (backward starts)")
     optimizer.zero_grad()                                                                                  # :142

@@ -24,9 +24,6 @@ from .lr_scheduler import WarmupMultiStepLR
 # hook issues its ~10 launches from the autograd thread in the middle of the backward pass (the dgrad chain's issue stalls behind them), and the
 # re-packing kernels then share the CUs with the backbone's backward instead of with the next step's prefetched forward.
 EARLY_SGD = os.environ.get("ABR_EARLY_SGD", "0") != "0"
-# experiment (round 6): the dgrad halves of the per-step weight preparation issued from inside the NEXT forward pass (behind the RPN head, next to the
-# matrix-bound RoI pass) instead of right after the SGD kernel, where they share HBM with the bandwidth-bound layer1-3 forward
-DEFER_DGRAD_PREP = os.environ.get("ABR_DEFER_DGRAD_PREP", "0") == "1"
 
 
 class FusedSGD(object):
@@ -223,32 +220,13 @@ class FusedSGD(object):
                             b.run()
                         for fn in plan["rest"]:
                             fn()
-                        if DEFER_DGRAD_PREP:
-                            self._deferred_prep = plan   # the dgrad halves: issued by the trainer from inside the next forward pass (run_deferred_prep)
-                        else:
-                            plan["backward"].run()
-                            for conv in plan["convs"]:
-                                conv._wt_version = _PARAM_VERSION[0]
+                        plan["backward"].run()
+                        for conv in plan["convs"]:
+                            conv._wt_version = _PARAM_VERSION[0]
                 else:
                     for m in self._derived:
                         m.prepare_derived()
             ops.prep_done(prep)
-
-    def run_deferred_prep(self, after_event=None):
-        """ABR_DEFER_DGRAD_PREP=1: the dgrad halves of the weight preparation (transposed copies and what derives from them, first read when
-        backward starts) left over by step(); `after_event`: a point of the calling stream they are to start behind.  No-op otherwise."""
-        plan, self._deferred_prep = getattr(self, "_deferred_prep", None), None
-        if plan is None:
-            return
-        from ..modeling.backbone.resnet import _PARAM_VERSION
-        prep = ops.side_stream((self.flat.params.device.index, "weight-prep"))
-        if after_event is not None:
-            prep.wait_event(after_event)
-        with torch.cuda.stream(prep), torch.no_grad():
-            plan["backward"].run()
-            for conv in plan["convs"]:
-                conv._wt_version = _PARAM_VERSION[0]
-        ops.prep_done(prep)
 
     def _prep_signature(self):
         """what the cached preparation tables were built from: the modules' entries (conv, FrozenBN scale tensor, geometry, math mode), the
