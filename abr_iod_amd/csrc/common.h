@@ -156,6 +156,10 @@ struct PrepJob {
     int gx, gy;           // the job's grid (x, y) as the single-job kernel would have it (z = blocks / (gx * gy))
     int first_block;
 };
+// tile edge of a transpose job: 64 (16 B accesses) when both channel counts are multiples of 4 and both tensors are 16 B aligned, else 32
+__host__ __device__ __forceinline__ int prep_transpose_tile(int Cout, int Cin, const void* w, const void* wt) {
+    return (((Cout | Cin) & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(wt)) & 15) == 0) ? 64 : 32;
+}
 int prep_transpose_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);   // conv_igemm.hip
 int prep_pack_multi(const PrepJob* jobs_dev, int njobs, int blocks, hipStream_t st);        // conv_igemm.hip
 int prep_pack_h3_multi(const PrepJob* jobs_dev, int njobs, int blocks, int scale_blocks, hipStream_t st);     // conv_igemm.hip (f16x3 planes: one workgroup per 32-row block)
