@@ -596,11 +596,10 @@ int wino_weight_transform(const float* w, int N, int C, float* U, hipStream_t st
 
 int prep_wino_h3_direct_multi(const PrepJob* jobs_dev, int njobs, int pack_blocks, int scale_blocks, unsigned* flags, hipStream_t st) {
     if (njobs <= 0 || pack_blocks <= 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;   // (several host threads may prepare weights: one attribute call, seen by all)
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_h3_pack_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWhLds);
-        attr_set = true;
-    }
+    });
     wino_h3_scales_multi_kernel<<<(unsigned)scale_blocks, 256, 0, st>>>(jobs_dev, njobs, flags);
     wino_h3_pack_multi_kernel<<<(unsigned)pack_blocks, 256, kWhLds, st>>>(jobs_dev, njobs);
     return hipGetLastError() == hipSuccess ? 0 : 1;
